@@ -1,0 +1,139 @@
+/*
+ * promptcache_hip.h -- C-ABI of the MI355X-native prompt-cache prefill path (libpromptcache_hip.so).
+ *
+ * The reference (yale-sys/prompt-cache) is pure Python with no FFI; the seam this library sits
+ * under is the `LanguageModel` adapter (promptcache/model/__init__.py:90-161) as consumed by
+ * `CacheEngine` (promptcache/cache_engine.py:331-522) and `GenerationEngine`
+ * (promptcache/generation_engine.py:61-209).  Each entry point below names the reference
+ * op sequence (file:line) it replaces.  See INTEGRATION.md for the ctypes binding.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocations);
+ *     tables marked "host" are small host arrays read during the call;
+ *   - `stream` is a hipStream_t passed as void*; nothing allocates, nothing synchronises, all
+ *     launches are asynchronous on `stream` (hipGraph-capturable);
+ *   - KV element type is IEEE fp16 (the reference stages KV as torch.half, cache_engine.py:105-106);
+ *   - return 0 on success, a negative code on error; pc_last_error_string() describes the last
+ *     error on the calling thread.
+ */
+#ifndef PROMPTCACHE_HIP_H
+#define PROMPTCACHE_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_OK 0
+#define PC_ERR_ARG (-1001)      /* bad argument (null pointer, unsupported head_dim, ...) */
+#define PC_ERR_BOUNDS (-1002)   /* a segment / append would run past the destination capacity */
+#define PC_ERR_WORKSPACE (-1003)/* workspace too small (query pc_attn_workspace_bytes) */
+#define PC_ERR_HIP(e) (-(int)(e)) /* -hipError_t from a launch */
+
+#define PC_ABI_VERSION 1
+
+int pc_version(void);
+const char* pc_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * pc_kv_gather -- replaces PromptCache.update's copy loop, cache_engine.py:135-151
+ *   (`tgt[:, st:ed, :].copy_(src)` x 2 x n_layers per segment) with ONE launch over a segment table.
+ *
+ *   seg_src[s]     device ptr to segment s's module KV, contiguous [n_layers][2][n_kv_heads][seg_len[s]][head_dim]
+ *                  (index 0 of the "2" axis = K, 1 = V)                                    (host array)
+ *   seg_len[s]     tokens in segment s                                                      (host array)
+ *   seg_dst_off[s] first token row of segment s in the staged buffer                        (host array)
+ *   dst            staged buffer [n_layers][2][n_kv_heads][max_ctx][head_dim] fp16 (cache_engine.py:104-107,
+ *                  all layers in one allocation; layer i's K plane is the reference's device_cache[i][0])
+ *   Segments with seg_dst_off + seg_len > max_ctx -> PC_ERR_BOUNDS (nothing is launched).
+ * ------------------------------------------------------------------------------------------- */
+int pc_kv_gather(const void* const* seg_src, const int32_t* seg_len, const int32_t* seg_dst_off,
+                 int32_t nseg, void* dst, int32_t n_layers, int32_t n_kv_heads, int32_t head_dim,
+                 int32_t max_ctx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pc_kv_slice_store -- replaces SchemaCache._process's slice-and-store, cache_engine.py:283-296
+ *   (`k_cache[j, :, st:ed, :]` per layer per TokenSequence, then `.cpu()`): the module KV stays in HBM.
+ *
+ *   src            the encode pass's KV arena [n_layers][2][n_kv_heads][src_cap][head_dim] (one batch row)
+ *   seg_src_off[s] first token row of segment s inside the arena (= position_ids.index(offset), :278)
+ *   seg_dst[s]     device ptr to the segment store, contiguous [n_layers][2][n_kv_heads][seg_len[s]][head_dim]
+ * ------------------------------------------------------------------------------------------- */
+int pc_kv_slice_store(const void* src, int32_t src_cap, const int32_t* seg_src_off, const int32_t* seg_len,
+                      void* const* seg_dst, int32_t nseg, int32_t n_layers, int32_t n_kv_heads,
+                      int32_t head_dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pc_rope_table -- replaces LlamaRotaryEmbedding's cos/sin table + the `cos[position_ids]` gather,
+ *   llama2.py:129-147 and :204-207.  Only the rows the supplied position ids select are produced
+ *   (fp32, angle = float(pos) * inv_freq, as the reference builds them before its dtype cast).
+ *
+ *   pos       int32 [n_tok]        position ids of the new tokens (arbitrary, gaps allowed)
+ *   inv_freq  fp32  [head_dim/2]   theta^(-2i/D), computed by the caller exactly as llama2.py:121
+ *   cs        fp32  [n_tok][head_dim/2][2]  (cos, sin) out
+ * ------------------------------------------------------------------------------------------- */
+int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs, int32_t n_tok, int32_t head_dim,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pc_rope_append -- replaces apply_rotary_pos_emb (llama2.py:202-210) on q and k plus the
+ *   `torch.cat([past, new], dim=2)` of llama2.py:361-364: q is rotated in place, rotated k and v are
+ *   written IN PLACE at token rows [past_len, past_len+q_len) of this layer's KV arena (the past is
+ *   not re-copied).
+ *
+ *   q      fp16 [B][q_len][H][D], token stride q_token_stride, batch stride q_batch_stride (elements)
+ *   k_new  fp16 [B][q_len][Hkv][D] (pre-RoPE), v_new likewise; strides kv_new_token_stride / _batch_stride
+ *   k_arena, v_arena  fp16 [B][Hkv][cap][D]: head stride arena_head_stride, batch stride arena_batch_stride
+ *   cs     from pc_rope_table, [B*q_len][D/2][2]
+ *   past_len_dev: optional device int32*; when non-null the kernel reads past_len from it (graph replay)
+ * ------------------------------------------------------------------------------------------- */
+int pc_rope_append(void* q, int64_t q_batch_stride, int64_t q_token_stride,
+                   const void* k_new, const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
+                   void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                   const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                   int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pc_attn_fwd -- replaces llama2.py:368-398: repeat_kv, QK^T/sqrt(D), + mask, softmax(fp32), PV,
+ *   transpose/reshape.  The mask of llama2.py:62-76 / :798-819 is implicit: new token i (input order)
+ *   sees every staged key j < past_len and new keys past_len + i' with i' <= i.  fp32 softmax and
+ *   accumulation, MFMA fp16 x fp16 -> fp32 for both contractions, flash-style (scores are never
+ *   materialised), split over the KV axis when (heads x q-blocks) cannot fill the chip.
+ *
+ *   q    fp16 [B][q_len][H][D]  RoPE applied;  k, v fp16 arena planes [B][Hkv][cap][D] holding
+ *        past_len + q_len valid rows;  out fp16 [B][q_len][H*D] (token stride out_token_stride).
+ *   workspace: >= pc_attn_workspace_bytes(...) bytes of device memory (split-KV partials).
+ *   past_len_dev: optional device int32* (graph replay; then `past_len` is the upper bound used
+ *        for sizing the launch).
+ * ------------------------------------------------------------------------------------------- */
+int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
+
+int pc_attn_fwd(const void* q, int64_t q_batch_stride, int64_t q_token_stride,
+                const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride,
+                void* out, int64_t out_batch_stride, int64_t out_token_stride,
+                int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
+                float softmax_scale, void* workspace, int64_t workspace_bytes,
+                const int32_t* past_len_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise / reduction pieces of the layer stack, fused for the small-q prefill (q_len rows):
+ *   pc_rmsnorm      -- LlamaRMSNorm.forward, llama2.py:103-108 (fp32 statistics)
+ *   pc_silu_mul     -- act_fn(gate) * up of LlamaMLP.forward, llama2.py:242
+ *   pc_embed_gather -- embed_tokens lookup, llama2.py:869
+ * ------------------------------------------------------------------------------------------- */
+int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32_t hidden, float eps,
+               int32_t x_is_f32, void* stream);
+int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, void* stream);
+int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,
+                    int32_t vocab, void* stream);
+
+/* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
+ * map the attention kernel relies on (see csrc/pc_probe.hip). */
+int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROMPTCACHE_HIP_H */

@@ -1,0 +1,310 @@
+// Prefill attention over a staged KV arena (flash-style, MFMA, wave64) for gfx950.
+//
+// Replaces  LlamaAttention.forward core   promptcache/model/llama2.py:368-398
+//             repeat_kv (:368-369), QK^T/sqrt(D) (:371), +mask (:384), softmax fp32 (:387), PV (:388),
+//             transpose/reshape (:396-398)
+//           _make_causal_mask / _prepare_decoder_attention_mask   llama2.py:62-76, :798-819  (implicit)
+//
+// Mask semantics (index order, NOT position order): new token i sees every staged key j < past_len and
+// the new keys past_len + i' with i' <= i.  Position ids only steer RoPE (pc_rope.hip).
+//
+// Formulation ("doubly swapped" so all softmax state is lane-local, no cross-lane P shuffles):
+//     S^T[key][q] = K[key][:] . Q[q][:]        mfma_f32_16x16x32_f16   A = K rows,   B = Q^T
+//     O^T[d][q]  += V^T[d][key] . P^T[key][q]  mfma_f32_16x16x32_f16   A = V^T,      B = P^T
+//   With the 16x16 C/D map (col = lane&15, row = 4*(lane>>4)+reg) a lane owns ONE query column n=lane&15:
+//   its 4 accumulator registers are 4 keys of that query (S^T) or 4 head-dims of that query (O^T), so the
+//   running max / sum / rescale never leave the lane group {n, n+16, n+32, n+48}.
+//   The P^T B-operand wants key slot (g, j), g = lane>>4; a lane's own S^T values of two adjacent 16-key
+//   blocks are keys {4g..4g+3} and {16+4g..16+4g+3}: we DEFINE slot (g, j<4) = key 4g+j, (g, j>=4) =
+//   key 16+4g+(j-4) and feed V^T with the same permutation, so P goes register -> MFMA directly.
+//   V^T fragments come from the row-major LDS V tile through ds_read_b64_tr_b16 (hardware transpose).
+//
+// Tiling: workgroup = 4 waves = 64 query rows (16 per wave) of one head; KV tile = 64 keys, loaded
+// cooperatively (16 B/lane, full 256-B rows -> coalesced) into LDS (K XOR-swizzled against the 16-way
+// ds_read_b128 bank conflict of a 256-B row stride).  When B*H*q-blocks cannot fill 256 CUs (cached
+// prefill: q_len ~ 10..50) the KV axis is split across workgroups and a second kernel merges the
+// (m, l, O) partials.
+//
+// Roofline: cached prefill (q << S) is HBM-bound on the K/V stream: bytes = 2*Hkv*(S+q)*D*2 per layer;
+// encode / no-cache (q = S) is MFMA-bound: flops = 4*H*D*q*(S + (q+1)/2) per layer.
+#include <hip/hip_fp16.h>
+
+#include "pc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTK = 64;        // keys per LDS tile
+constexpr int kThreads = 256;  // 4 waves
+constexpr int kQB = 64;        // query rows per workgroup
+constexpr int kMaxSplit = 32;
+constexpr float kNegBig = -1.0e30f;  // finite "-inf" for the running max
+
+struct AttnParams {
+    const _Float16* q; int64_t q_bs, q_ts;
+    const _Float16* k; const _Float16* v; int64_t kv_bs, kv_hs;
+    _Float16* out; int64_t o_bs, o_ts;
+    float* part_o; float* part_ml;
+    const int32_t* past_len_dev;
+    int32_t H, Hkv, q_len, past_len, nsplit;
+    float scale_log2;
+};
+
+__device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
+    // ds_read_b64_tr_b16: within a 16-lane group, lane i receives sub-element (i%4) of the 8 bytes
+    // addressed by lanes {i/4, 4+i/4, 8+i/4, 12+i/4} (verified by pc_probe_layouts on hardware).
+    s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p));
+    return __builtin_bit_cast(h4, r);
+}
+
+template <int D>
+__global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int KS = D / 32;   // MFMA k-steps across the head dim (QK^T)
+    constexpr int DB = D / 16;   // 16-wide head-dim blocks of O^T
+    constexpr int CPR = D / 8;   // 16-byte chunks per K/V row
+    constexpr int LPT = kTK * CPR / kThreads;  // 16-byte loads per thread per tile per tensor
+    static_assert(LPT >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[kTK * D];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[kTK * D];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int qblk = blockIdx.x, h = blockIdx.y;
+    const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
+    const int hkv = h / (p.H / p.Hkv);
+    const int q_len = p.q_len;
+    const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int kv_len = past_len + q_len;
+
+    // this split's key range (tile-aligned) clipped by what the workgroup can causally see
+    int kps = (kv_len + p.nsplit - 1) / p.nsplit;
+    kps = (kps + kTK - 1) / kTK * kTK;
+    const int ks0 = split * kps;
+    const int wg_rows_end = (qblk * kQB + kQB < q_len) ? qblk * kQB + kQB : q_len;
+    int kend = ks0 + kps;
+    kend = kend < kv_len ? kend : kv_len;
+    kend = kend < past_len + wg_rows_end ? kend : past_len + wg_rows_end;
+
+    const int qrow0 = qblk * kQB + wave * 16;
+    const int qi = qrow0 + n;                       // this lane's query row (new-token index)
+    const bool wave_active = qrow0 < q_len;         // wave-uniform
+    const int wave_rows_end = (qrow0 + 16 < q_len) ? qrow0 + 16 : q_len;
+    const int wave_vis_end = past_len + wave_rows_end;
+    const int row_vis_end = (qi < q_len) ? past_len + qi + 1 : 0;  // keys [0, row_vis_end) are visible
+
+    h8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[ks] = z;
+        if (wave_active && qi < q_len)
+            qf[ks] = *(const h8*)(p.q + b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 32 + g * 8);
+    }
+
+    f4 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { f4 z = {0.f, 0.f, 0.f, 0.f}; o[db] = z; }
+    float m_run = kNegBig, l_run = 0.f;
+
+    const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+    const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+
+    for (int key0 = ks0; key0 < kend; key0 += kTK) {
+        // ---- cooperative, coalesced tile load (zero-fill rows at/after kend: a garbage V row would
+        //      turn 0 * NaN into NaN in the PV MFMA) ----
+        u32x4 kr[LPT], vr[LPT];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int c = tid + i * kThreads;
+            const int row = c / CPR, col = c - row * CPR;
+            const int key = key0 + row;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            kr[i] = z; vr[i] = z;
+            if (key < kend) {
+                kr[i] = *(const u32x4*)(kbase + (int64_t)key * D + col * 8);
+                vr[i] = *(const u32x4*)(vbase + (int64_t)key * D + col * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int c = tid + i * kThreads;
+            const int row = c / CPR, col = c - row * CPR;
+            *(u32x4*)(Kl + row * D + ((col ^ (row & (CPR - 1))) << 3)) = kr[i];
+            *(u32x4*)(Vl + row * D + (col << 3)) = vr[i];
+        }
+        __syncthreads();
+
+        if (wave_active && key0 < wave_vis_end) {
+            // ---- S^T = K . Q^T : four 16-key blocks ----
+            float sv[4][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int row = kb * 16 + n;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int chunk = ks * 4 + g;
+                    const h8 a = *(const h8*)(Kl + row * D + ((chunk ^ (row & (CPR - 1))) << 3));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kb * 16 + g * 4 + r;
+                    const float s = (key < row_vis_end && key < kend) ? acc[r] * p.scale_log2 : -INFINITY;
+                    sv[kb][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);       // stays finite (m_run starts at -1e30)
+            const float alpha = exp2f(m_run - m_new);
+            float rs = 0.f;
+            h8 pb[2];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(sv[kb][r] - m_new);   // exp2(-inf) = 0 for masked keys
+                    rs += e;
+                    pb[kb >> 1][(kb & 1) * 4 + r] = (_Float16)e;
+                }
+            }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+            }
+            // ---- O^T += V^T . P^T : two 32-key steps x DB head-dim blocks ----
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const _Float16* vp = Vl + (t * 32 + g * 4 + (n >> 2)) * D + db * 16 + (n & 3) * 4;
+                    const h4 lo = lds_tr_read(vp);            // keys 32t + 4g + {0..3}
+                    const h4 hi = lds_tr_read(vp + 16 * D);   // keys 32t + 16 + 4g + {0..3}
+                    const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!(wave_active && qi < q_len)) return;
+    if (p.nsplit == 1) {
+        const float inv = 1.0f / l_run;
+        _Float16* op = p.out + b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + g * 4;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            h4 r = {(_Float16)(o[db][0] * inv), (_Float16)(o[db][1] * inv), (_Float16)(o[db][2] * inv),
+                    (_Float16)(o[db][3] * inv)};
+            *(h4*)(op + db * 16) = r;
+        }
+    } else {
+        const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
+        float* po = p.part_o + slot * D + g * 4;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *(f4*)(po + db * 16) = o[db];
+        if (g == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_run; }
+    }
+}
+
+// Merge split-KV partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i.
+template <int D>
+__global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                    _Float16* __restrict__ out, int64_t o_bs, int64_t o_ts, int H, int q_len,
+                                    int nsplit) {
+    const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const int64_t base = ((int64_t)b * H + h) * nsplit;
+    float mstar = kNegBig;
+    for (int s = 0; s < nsplit; ++s) mstar = fmaxf(mstar, part_ml[((base + s) * q_len + qi) * 2]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const int64_t slot = (base + s) * q_len + qi;
+        const float w = exp2f(part_ml[slot * 2] - mstar);
+        den += w * part_ml[slot * 2 + 1];
+        num += w * part_o[slot * D + d];
+    }
+    out[b * o_bs + (int64_t)qi * o_ts + (int64_t)h * D + d] = (_Float16)(num / den);
+}
+
+int choose_nsplit(int B, int H, int q_len, int kv_len) {
+    static const int forced = [] { const char* e = getenv("PC_ATTN_NSPLIT"); return e ? atoi(e) : 0; }();
+    const int nqblk = pc_ceil_div(q_len, kQB);
+    const int base = B * H * nqblk;
+    int ns = forced > 0 ? forced : 1024 / (base > 0 ? base : 1);  // aim at ~4 workgroups per CU
+    const int max_by_len = kv_len / (2 * kTK);                   // keep >= 2 tiles per split
+    if (ns > max_by_len) ns = max_by_len;
+    if (ns > kMaxSplit) ns = kMaxSplit;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+template <int D>
+int launch_attn(const AttnParams& p, int B, hipStream_t stream) {
+    dim3 grid(pc_ceil_div(p.q_len, kQB), p.H, B * p.nsplit);
+    hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(kThreads), 0, stream, p);
+    int rc = pc_check_launch("attn_fwd_kernel");
+    if (rc != PC_OK) return rc;
+    if (p.nsplit > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel<D>, dim3(p.q_len, p.H, B), dim3(D), 0, stream, p.part_o, p.part_ml,
+                           p.out, p.o_bs, p.o_ts, p.H, p.q_len, p.nsplit);
+        rc = pc_check_launch("attn_combine_kernel");
+    }
+    return rc;
+}
+
+}  // namespace
+
+PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max) {
+    if (B <= 0 || H <= 0 || D <= 0 || q_len <= 0) return 0;
+    const int ns = choose_nsplit(B, H, q_len, kv_len_max);
+    if (ns <= 1) return 0;
+    return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
+}
+
+PC_EXPORT int pc_attn_fwd(const void* q, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+                          const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
+                          int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
+                          int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
+                          int64_t workspace_bytes, const int32_t* past_len_dev, void* stream) {
+    PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
+               "pc_attn_fwd: bad sizes");
+    PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
+    if (q_len == 0) return PC_OK;
+    PC_REQUIRE(q && k && v && out, PC_ERR_ARG, "pc_attn_fwd: null pointer");
+    PC_REQUIRE(q_token_stride % 8 == 0 && kv_head_stride % 8 == 0 && out_token_stride % 4 == 0, PC_ERR_ARG,
+               "pc_attn_fwd: strides must keep 16-byte (q, kv) / 8-byte (out) alignment");
+    AttnParams p;
+    p.q = (const _Float16*)q; p.q_bs = q_batch_stride; p.q_ts = q_token_stride;
+    p.k = (const _Float16*)k; p.v = (const _Float16*)v; p.kv_bs = kv_batch_stride; p.kv_hs = kv_head_stride;
+    p.out = (_Float16*)out; p.o_bs = out_batch_stride; p.o_ts = out_token_stride;
+    p.past_len_dev = past_len_dev;
+    p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
+    p.part_o = nullptr; p.part_ml = nullptr;
+    if (p.nsplit > 1) {
+        const int64_t slots = (int64_t)B * H * p.nsplit * q_len;
+        const int64_t need = slots * (D + 2) * (int64_t)sizeof(float);
+        PC_REQUIRE(workspace && workspace_bytes >= need, PC_ERR_WORKSPACE,
+                   "pc_attn_fwd: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+        p.part_o = (float*)workspace;
+        p.part_ml = p.part_o + slots * D;
+    }
+    switch (D) {
+        case 32: return launch_attn<32>(p, B, (hipStream_t)stream);
+        case 64: return launch_attn<64>(p, B, (hipStream_t)stream);
+        default: return launch_attn<128>(p, B, (hipStream_t)stream);
+    }
+}

@@ -1,0 +1,180 @@
+// kv_copy: the module-KV gather (staging) and its inverse (slice-and-store), as ONE batched-memcpy
+// kernel over a segment table.
+//
+// Replaces  PromptCache.update      promptcache/cache_engine.py:135-151  (pc_kv_gather)
+//           SchemaCache._process    promptcache/cache_engine.py:283-296  (pc_kv_slice_store)
+//
+// Data layout in HBM (fp16 everywhere, D = head_dim):
+//   staged buffer / encode arena   [n_layers][2][n_kv_heads][cap][D]       plane p = (layer, k|v, head)
+//   segment store (module library) [n_layers][2][n_kv_heads][len_s][D]
+// Inside one plane the tokens of a segment are contiguous on both sides, so a (segment, plane) pair is
+// a flat copy of len_s*D*2 bytes; a segment contributes `planes` such runs whose bases advance by a
+// per-side plane stride.  The kernel is HBM-bound: algorithmic bytes = 2 * S * planes * D * 2
+// (read once + write once).
+//
+// Work decomposition: tile = <=16 KiB of one segment-plane (64 tokens at D=128); a workgroup owns one
+// tile index for PP consecutive planes.  Lanes move 16 B each (global_load/store_dwordx4, 1 KiB per
+// wave-instruction, fully coalesced); 8 loads are issued before the first store so each lane keeps
+// 128 B in flight.  Short segments (the 1-token whitespace runs between PML tags: 17 of the 25
+// segments of the persona prompt) fold several planes into one pass so no lane idles.
+#include "pc_common.h"
+
+namespace {
+
+constexpr int kMaxSeg = 40;          // descriptors per launch (kernarg-resident, 40 B each)
+constexpr int kTileBytes = 16384;    // per plane per workgroup
+constexpr int kPlanesPerWG = 8;
+constexpr int kUnroll = 8;
+constexpr int kThreads = 256;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct SegDesc {
+    const char* src;
+    char* dst;
+    int64_t src_plane_stride;  // bytes
+    int64_t dst_plane_stride;  // bytes
+    int32_t bytes_per_plane;
+    int32_t tile_start;        // first tile index of this segment in the launch
+};
+
+struct CopyArgs {
+    SegDesc seg[kMaxSeg];
+    int32_t nseg;
+    int32_t planes;
+};
+
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void kv_copy_kernel(const CopyArgs a) {
+    const int tile = blockIdx.x;
+    // Wave-uniform scan of the (<=40 entry) kernarg table: scalar loads, no divergence.
+    int s = 0;
+    for (int i = 1; i < a.nseg; ++i) s = (a.seg[i].tile_start <= tile) ? i : s;
+    const SegDesc d = a.seg[s];
+    const int64_t byte0 = (int64_t)(tile - d.tile_start) * kTileBytes;
+    int rem = d.bytes_per_plane - (int)byte0;
+    rem = rem > kTileBytes ? kTileBytes : rem;
+    const int nchunk = rem >> 4;  // 16-byte chunks in this tile, 1..1024
+
+    // Lane -> (plane-in-pass, chunk) with a power-of-two chunk width w >= min(nchunk, 256).
+    const int lg = nchunk >= kThreads ? 8 : (nchunk <= 1 ? 0 : 32 - __builtin_clz(nchunk - 1));
+    const int w = 1 << lg;
+    const int planes_per_pass = kThreads >> lg;
+    const int tid = threadIdx.x;
+    const int pl = tid >> lg;
+    const int c0 = tid & (w - 1);
+    const int nci = (nchunk + w - 1) >> lg;
+
+    const int p0 = blockIdx.y * kPlanesPerWG;
+    const int pend = (p0 + kPlanesPerWG < a.planes) ? p0 + kPlanesPerWG : a.planes;
+    const int npi = (pend - p0 + planes_per_pass - 1) / planes_per_pass;
+    const int niter = npi * nci;
+
+    int pi = 0, ci = 0;  // uniform counters: iteration k = pi * nci + ci
+    for (int k0 = 0; k0 < niter; k0 += kUnroll) {
+        u32x4 v[kUnroll];
+        int64_t doff[kUnroll];
+        bool ok[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int p = p0 + pi * planes_per_pass + pl;
+            const int c = c0 + ci * w;
+            ok[u] = (k0 + u < niter) && (p < pend) && (c < nchunk);
+            const int64_t inner = byte0 + (int64_t)c * 16;
+            doff[u] = (int64_t)p * d.dst_plane_stride + inner;
+            if (ok[u]) {
+                const u32x4* sp = (const u32x4*)(d.src + (int64_t)p * d.src_plane_stride + inner);
+                v[u] = NT ? __builtin_nontemporal_load(sp) : *sp;
+            }
+            if (++ci == nci) { ci = 0; ++pi; }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (ok[u]) {
+                u32x4* dp = (u32x4*)(d.dst + doff[u]);
+                if (NT) __builtin_nontemporal_store(v[u], dp); else *dp = v[u];
+            }
+        }
+    }
+}
+
+int launch_batches(SegDesc* descs, int nseg, int planes, hipStream_t stream) {
+    static const bool nt = [] { const char* e = getenv("PC_GATHER_NT"); return e && e[0] == '1'; }();
+    for (int base = 0; base < nseg; base += kMaxSeg) {
+        CopyArgs a;
+        const int n = (nseg - base < kMaxSeg) ? nseg - base : kMaxSeg;
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) {
+            a.seg[i] = descs[base + i];
+            a.seg[i].tile_start = tiles;
+            tiles += (a.seg[i].bytes_per_plane + kTileBytes - 1) / kTileBytes;
+        }
+        a.nseg = n;
+        a.planes = planes;
+        if (tiles == 0) continue;
+        dim3 grid(tiles, pc_ceil_div(planes, kPlanesPerWG));
+        if (nt) hipLaunchKernelGGL(kv_copy_kernel<true>, grid, dim3(kThreads), 0, stream, a);
+        else    hipLaunchKernelGGL(kv_copy_kernel<false>, grid, dim3(kThreads), 0, stream, a);
+        int rc = pc_check_launch("kv_copy_kernel");
+        if (rc != PC_OK) return rc;
+    }
+    return PC_OK;
+}
+
+}  // namespace
+
+PC_EXPORT int pc_kv_gather(const void* const* seg_src, const int32_t* seg_len, const int32_t* seg_dst_off,
+                           int32_t nseg, void* dst, int32_t n_layers, int32_t n_kv_heads, int32_t head_dim,
+                           int32_t max_ctx, void* stream) {
+    PC_REQUIRE(nseg >= 0 && n_layers > 0 && n_kv_heads > 0 && max_ctx > 0, PC_ERR_ARG, "pc_kv_gather: bad sizes");
+    PC_REQUIRE(head_dim > 0 && head_dim % 8 == 0, PC_ERR_ARG, "pc_kv_gather: head_dim must be a multiple of 8");
+    if (nseg == 0) return PC_OK;
+    PC_REQUIRE(seg_src && seg_len && seg_dst_off && dst, PC_ERR_ARG, "pc_kv_gather: null pointer");
+    const int64_t row = (int64_t)head_dim * 2;
+    SegDesc* descs = (SegDesc*)alloca(sizeof(SegDesc) * (size_t)nseg);
+    int n = 0;
+    for (int s = 0; s < nseg; ++s) {
+        PC_REQUIRE(seg_len[s] >= 0 && seg_dst_off[s] >= 0, PC_ERR_ARG, "pc_kv_gather: negative segment field");
+        PC_REQUIRE((int64_t)seg_dst_off[s] + seg_len[s] <= max_ctx, PC_ERR_BOUNDS,
+                   "pc_kv_gather: segment %d (off %d, len %d) exceeds max_ctx %d", s, seg_dst_off[s], seg_len[s], max_ctx);
+        if (seg_len[s] == 0) continue;
+        PC_REQUIRE(seg_src[s] != nullptr, PC_ERR_ARG, "pc_kv_gather: null segment %d", s);
+        PC_REQUIRE((int64_t)seg_len[s] * row < (1ll << 31), PC_ERR_ARG, "pc_kv_gather: segment too long");
+        SegDesc& d = descs[n++];
+        d.src = (const char*)seg_src[s];
+        d.dst = (char*)dst + (int64_t)seg_dst_off[s] * row;
+        d.bytes_per_plane = (int32_t)(seg_len[s] * row);
+        d.src_plane_stride = d.bytes_per_plane;
+        d.dst_plane_stride = (int64_t)max_ctx * row;
+        d.tile_start = 0;
+    }
+    return launch_batches(descs, n, n_layers * 2 * n_kv_heads, (hipStream_t)stream);
+}
+
+PC_EXPORT int pc_kv_slice_store(const void* src, int32_t src_cap, const int32_t* seg_src_off, const int32_t* seg_len,
+                                void* const* seg_dst, int32_t nseg, int32_t n_layers, int32_t n_kv_heads,
+                                int32_t head_dim, void* stream) {
+    PC_REQUIRE(nseg >= 0 && n_layers > 0 && n_kv_heads > 0 && src_cap > 0, PC_ERR_ARG, "pc_kv_slice_store: bad sizes");
+    PC_REQUIRE(head_dim > 0 && head_dim % 8 == 0, PC_ERR_ARG, "pc_kv_slice_store: head_dim must be a multiple of 8");
+    if (nseg == 0) return PC_OK;
+    PC_REQUIRE(src && seg_src_off && seg_len && seg_dst, PC_ERR_ARG, "pc_kv_slice_store: null pointer");
+    const int64_t row = (int64_t)head_dim * 2;
+    SegDesc* descs = (SegDesc*)alloca(sizeof(SegDesc) * (size_t)nseg);
+    int n = 0;
+    for (int s = 0; s < nseg; ++s) {
+        PC_REQUIRE(seg_len[s] >= 0 && seg_src_off[s] >= 0, PC_ERR_ARG, "pc_kv_slice_store: negative segment field");
+        PC_REQUIRE((int64_t)seg_src_off[s] + seg_len[s] <= src_cap, PC_ERR_BOUNDS,
+                   "pc_kv_slice_store: segment %d (off %d, len %d) exceeds arena rows %d", s, seg_src_off[s], seg_len[s], src_cap);
+        if (seg_len[s] == 0) continue;
+        PC_REQUIRE(seg_dst[s] != nullptr, PC_ERR_ARG, "pc_kv_slice_store: null segment %d", s);
+        PC_REQUIRE((int64_t)seg_len[s] * row < (1ll << 31), PC_ERR_ARG, "pc_kv_slice_store: segment too long");
+        SegDesc& d = descs[n++];
+        d.src = (const char*)src + (int64_t)seg_src_off[s] * row;
+        d.dst = (char*)seg_dst[s];
+        d.bytes_per_plane = (int32_t)(seg_len[s] * row);
+        d.src_plane_stride = (int64_t)src_cap * row;
+        d.dst_plane_stride = d.bytes_per_plane;
+        d.tile_start = 0;
+    }
+    return launch_batches(descs, n, n_layers * 2 * n_kv_heads, (hipStream_t)stream);
+}

@@ -1,0 +1,174 @@
+// Library plumbing (version, thread-local error string), the small elementwise / reduction pieces of the
+// layer stack, and the hardware-layout probe the GPU tests use to pin the two lane maps pc_attn.hip
+// depends on.
+//
+// Replaces  LlamaRMSNorm.forward       promptcache/model/llama2.py:103-108   (pc_rmsnorm)
+//           act_fn(gate) * up          promptcache/model/llama2.py:242       (pc_silu_mul)
+//           embed_tokens(input_ids)    promptcache/model/llama2.py:869       (pc_embed_gather)
+#include <hip/hip_fp16.h>
+#include <string.h>
+
+#include "pc_common.h"
+
+static thread_local char g_err[512] = "";
+
+void pc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+PC_EXPORT int pc_version(void) { return PC_ABI_VERSION; }
+PC_EXPORT const char* pc_last_error_string(void) { return g_err; }
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One workgroup (256 threads) per row; 8 elements (16 B of fp16 / 32 B of fp32) per lane per pass.
+// fp32 statistics; `out = weight * fp16(x * rsqrt(mean(x^2) + eps))` -- the reference multiplies the gain
+// AFTER casting the normalised value back to the input dtype (llama2.py:108).
+template <bool XF32>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ xin, const _Float16* __restrict__ w,
+                                                      _Float16* __restrict__ out, int hidden, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int nv = hidden >> 3;
+    float ss = 0.f;
+    for (int i = tid; i < nv; i += 256) {
+        if (XF32) {
+            const f4* p = (const f4*)((const float*)xin + (int64_t)row * hidden + i * 8);
+            const f4 a = p[0], b = p[1];
+            ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+        } else {
+            const h8 a = *(const h8*)((const _Float16*)xin + (int64_t)row * hidden + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += (float)a[e] * (float)a[e];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rs = rsqrtf(tot / (float)hidden + eps);
+    for (int i = tid; i < nv; i += 256) {
+        const h8 g = *(const h8*)(w + i * 8);
+        h8 o;
+        if (XF32) {
+            const f4* p = (const f4*)((const float*)xin + (int64_t)row * hidden + i * 8);
+            const f4 a = p[0], b = p[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = g[e] * (_Float16)(a[e] * rs);
+                o[e + 4] = g[e + 4] * (_Float16)(b[e] * rs);
+            }
+        } else {
+            const h8 a = *(const h8*)((const _Float16*)xin + (int64_t)row * hidden + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = g[e] * (_Float16)((float)a[e] * rs);
+        }
+        *(h8*)(out + (int64_t)row * hidden + i * 8) = o;
+    }
+}
+
+// gate_up: [rows][2*inter] (gate columns first, then up) -> out[rows][inter] = silu(gate) * up, fp32 math.
+__global__ __launch_bounds__(256) void silu_mul_kernel(const _Float16* __restrict__ gu, _Float16* __restrict__ out,
+                                                       int inter) {
+    const int row = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i * 8 >= inter) return;
+    const h8 gt = *(const h8*)(gu + (int64_t)row * 2 * inter + i * 8);
+    const h8 up = *(const h8*)(gu + (int64_t)row * 2 * inter + inter + i * 8);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (float)gt[e];
+        o[e] = (_Float16)((x / (1.0f + __expf(-x))) * (float)up[e]);
+    }
+    *(h8*)(out + (int64_t)row * inter + i * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void embed_gather_kernel(const _Float16* __restrict__ table,
+                                                           const int64_t* __restrict__ ids, _Float16* __restrict__ out,
+                                                           int hidden, int vocab) {
+    const int t = blockIdx.x;
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int i = threadIdx.x; i < (hidden >> 3); i += 256)
+        *(h8*)(out + (int64_t)t * hidden + i * 8) = *(const h8*)(table + id * hidden + i * 8);
+}
+
+// ---- layout probe -------------------------------------------------------------------------------------
+// out_mfma[lane*4+r]: D register r of lane for D = A.B with A[m][slot0] = m+1, B[slot0][n] = n+17 (all other
+//   k-slots zero) -> expected (row+1)*(col+17) with row = 4*(lane>>4)+r, col = lane&15 (asymmetric on purpose).
+// out_tr[0..255]:   ds_read_b64_tr_b16 with lane l addressing elements [4l, 4l+4) of an iota array.
+// out_tr[256..511]: the same with the attention kernel's addressing (row stride 128 elements).
+__global__ void probe_kernel(float* out_mfma, float* out_tr) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4096];
+    const int l = threadIdx.x, n = l & 15, g = l >> 4;
+    for (int i = l; i < 4096; i += 64) lds[i] = (_Float16)(float)(i & 2047);
+    __syncthreads();
+    h8 a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g == 0) { a[0] = (_Float16)(float)(n + 1); b[0] = (_Float16)(float)(n + 17); }
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) out_mfma[l * 4 + r] = acc[r];
+    s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lds + l * 4));
+    h4 h0 = __builtin_bit_cast(h4, t0);
+    for (int j = 0; j < 4; ++j) out_tr[l * 4 + j] = (float)h0[j];
+    s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4*)(lds + (g * 4 + (n >> 2)) * 128 + (n & 3) * 4));
+    h4 h1 = __builtin_bit_cast(h4, t1);
+    for (int j = 0; j < 4; ++j) out_tr[256 + l * 4 + j] = (float)h1[j];
+}
+
+}  // namespace
+
+PC_EXPORT int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32_t hidden, float eps,
+                         int32_t x_is_f32, void* stream) {
+    PC_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0, PC_ERR_ARG, "pc_rmsnorm: hidden must be a multiple of 8");
+    if (rows == 0) return PC_OK;
+    PC_REQUIRE(x && weight && out, PC_ERR_ARG, "pc_rmsnorm: null pointer");
+    if (x_is_f32)
+        hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x,
+                           (const _Float16*)weight, (_Float16*)out, hidden, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x,
+                           (const _Float16*)weight, (_Float16*)out, hidden, eps);
+    return pc_check_launch("rmsnorm_kernel");
+}
+
+PC_EXPORT int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, void* stream) {
+    PC_REQUIRE(rows >= 0 && inter > 0 && inter % 8 == 0, PC_ERR_ARG, "pc_silu_mul: inter must be a multiple of 8");
+    if (rows == 0) return PC_OK;
+    PC_REQUIRE(gate_up && out, PC_ERR_ARG, "pc_silu_mul: null pointer");
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(pc_ceil_div(inter / 8, 256), rows), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)gate_up, (_Float16*)out, inter);
+    return pc_check_launch("silu_mul_kernel");
+}
+
+PC_EXPORT int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,
+                              int32_t vocab, void* stream) {
+    PC_REQUIRE(n_tok >= 0 && hidden > 0 && hidden % 8 == 0 && vocab > 0, PC_ERR_ARG, "pc_embed_gather: bad sizes");
+    if (n_tok == 0) return PC_OK;
+    PC_REQUIRE(table && ids && out, PC_ERR_ARG, "pc_embed_gather: null pointer");
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(n_tok), dim3(256), 0, (hipStream_t)stream, (const _Float16*)table,
+                       ids, (_Float16*)out, hidden, vocab);
+    return pc_check_launch("embed_gather_kernel");
+}
+
+PC_EXPORT int pc_probe_layouts(float* out_mfma, float* out_tr, void* stream) {
+    PC_REQUIRE(out_mfma && out_tr, PC_ERR_ARG, "pc_probe_layouts: null pointer");
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_mfma, out_tr);
+    return pc_check_launch("probe_kernel");
+}

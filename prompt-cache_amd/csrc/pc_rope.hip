@@ -1,0 +1,111 @@
+// Position-id-aware RoPE and in-place KV append.
+//
+// Replaces  LlamaRotaryEmbedding._set_cos_sin_cache / forward   promptcache/model/llama2.py:129-147
+//           apply_rotary_pos_emb (cos[position_ids] gather)      promptcache/model/llama2.py:202-210
+//           torch.cat([past, new], dim=2) for K and V            promptcache/model/llama2.py:361-364
+//
+// The reference sizes its cos/sin table by max(position_ids)+1 (llama2.py:357) and gathers rows by the
+// supplied ids; here only the gathered rows are ever computed (pc_rope_table, once per forward, fp32),
+// and every layer applies them to q (in place) and k while writing k/v straight into rows
+// [past_len, past_len+q_len) of the layer's KV arena -- the staged past is never re-copied.
+//
+// Both kernels are tiny (q_len x (H+2*Hkv) x D elements) and launch-latency-bound.
+#include <hip/hip_fp16.h>
+
+#include "pc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ void rope_table_kernel(const int32_t* __restrict__ pos, const float* __restrict__ inv_freq,
+                                  float2* __restrict__ cs, int n_tok, int half_dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tok * half_dim) return;
+    const int t = i / half_dim, f = i - t * half_dim;
+    // angle = fp32(pos) * inv_freq, one fp32 rounding, as torch.einsum("i,j->ij", t, inv_freq) (llama2.py:133)
+    const float ang = __fmul_rn((float)pos[t], inv_freq[f]);
+    float s, c;
+    sincosf(ang, &s, &c);  // full-range argument reduction (positions reach 1e4 rad)
+    cs[i] = make_float2(c, s);
+}
+
+// One work item = 8 rotary pairs of one (token, head): 16 B from the low half + 16 B from the high half.
+// Items per token: H*D/16 for q, Hkv*D/16 for k, then Hkv*D/8 plain 16 B copies for v.
+__global__ __launch_bounds__(256) void rope_append_kernel(
+    _Float16* __restrict__ q, int64_t q_bs, int64_t q_ts,
+    const _Float16* __restrict__ k_new, const _Float16* __restrict__ v_new, int64_t n_bs, int64_t n_ts,
+    _Float16* __restrict__ k_arena, _Float16* __restrict__ v_arena, int64_t a_bs, int64_t a_hs,
+    const float2* __restrict__ cs, int H, int Hkv, int D, int q_len, int past_len,
+    const int32_t* __restrict__ past_len_dev) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (past_len_dev) past_len = *past_len_dev;
+    const int half = D >> 1;
+    const int cph = D >> 4;  // 8-pair chunks per head
+    const int nq = H * cph, nk = Hkv * cph, nv = Hkv * (D >> 3);
+    const float2* csr = cs + (int64_t)(b * q_len + t) * half;
+    for (int it = threadIdx.x; it < nq + nk + nv; it += blockDim.x) {
+        if (it < nq + nk) {
+            const bool is_q = it < nq;
+            const int j = is_q ? it : it - nq;
+            const int h = j / cph, c = j - h * cph;
+            const _Float16* src = is_q ? q + b * q_bs + t * q_ts + (int64_t)h * D
+                                       : k_new + b * n_bs + t * n_ts + (int64_t)h * D;
+            _Float16* dst = is_q ? q + b * q_bs + t * q_ts + (int64_t)h * D
+                                 : k_arena + b * a_bs + h * a_hs + (int64_t)(past_len + t) * D;
+            const h8 lo = *(const h8*)(src + c * 8);
+            const h8 hi = *(const h8*)(src + half + c * 8);
+            h8 olo, ohi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 w = csr[c * 8 + e];
+                const float x1 = (float)lo[e], x2 = (float)hi[e];
+                // q*cos + rotate_half(q)*sin  (llama2.py:208): low half pairs with -high, high with +low
+                olo[e] = (_Float16)(x1 * w.x - x2 * w.y);
+                ohi[e] = (_Float16)(x2 * w.x + x1 * w.y);
+            }
+            *(h8*)(dst + c * 8) = olo;
+            *(h8*)(dst + half + c * 8) = ohi;
+        } else {
+            const int j = it - nq - nk;
+            const int cpv = D >> 3;
+            const int h = j / cpv, c = j - h * cpv;
+            const h8 x = *(const h8*)(v_new + b * n_bs + t * n_ts + (int64_t)h * D + c * 8);
+            *(h8*)(v_arena + b * a_bs + h * a_hs + (int64_t)(past_len + t) * D + c * 8) = x;
+        }
+    }
+}
+
+}  // namespace
+
+PC_EXPORT int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs, int32_t n_tok, int32_t head_dim,
+                            void* stream) {
+    PC_REQUIRE(n_tok >= 0 && head_dim > 0 && head_dim % 2 == 0, PC_ERR_ARG, "pc_rope_table: bad sizes");
+    if (n_tok == 0) return PC_OK;
+    PC_REQUIRE(pos && inv_freq && cs, PC_ERR_ARG, "pc_rope_table: null pointer");
+    const int n = n_tok * (head_dim / 2);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(pc_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                       inv_freq, (float2*)cs, n_tok, head_dim / 2);
+    return pc_check_launch("rope_table_kernel");
+}
+
+PC_EXPORT int pc_rope_append(void* q, int64_t q_batch_stride, int64_t q_token_stride, const void* k_new,
+                             const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
+                             void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                             const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                             int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* stream) {
+    PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG, "pc_rope_append: bad sizes");
+    PC_REQUIRE(D > 0 && D % 16 == 0, PC_ERR_ARG, "pc_rope_append: head_dim must be a multiple of 16");
+    if (q_len == 0) return PC_OK;
+    PC_REQUIRE(q && k_new && v_new && k_arena && v_arena && cs, PC_ERR_ARG, "pc_rope_append: null pointer");
+    PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
+               "pc_rope_append: past_len %d + q_len %d exceeds arena rows %d", past_len, q_len, cap);
+    PC_REQUIRE(q_token_stride % 8 == 0 && kv_new_token_stride % 8 == 0 && arena_head_stride % 8 == 0, PC_ERR_ARG,
+               "pc_rope_append: strides must keep 16-byte alignment");
+    hipLaunchKernelGGL(rope_append_kernel, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream, (_Float16*)q,
+                       q_batch_stride, q_token_stride, (const _Float16*)k_new, (const _Float16*)v_new,
+                       kv_new_batch_stride, kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena,
+                       arena_batch_stride, arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len,
+                       past_len_dev);
+    return pc_check_launch("rope_append_kernel");
+}

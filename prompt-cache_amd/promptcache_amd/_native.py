@@ -1,0 +1,149 @@
+"""ctypes binding of ``libpromptcache_hip.so`` (C-ABI declared in ``include/promptcache_hip.h``).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+``RuntimeError`` is raised.  PyTorch-ROCm is used only for device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_LIB_NAME = "libpromptcache_hip.so"
+_lib: Optional[C.CDLL] = None
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_pi32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one
+SIGNATURES = {
+    "pc_version": (C.c_int, []),
+    "pc_last_error_string": (C.c_char_p, []),
+    "pc_kv_gather": (C.c_int, [C.POINTER(_vp), _pi32, _pi32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pc_kv_slice_store": (C.c_int, [_vp, _i32, _pi32, _pi32, C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp]),
+    "pc_rope_table": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
+                                 _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "pc_attn_workspace_bytes": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
+    "pc_attn_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+                              _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp]),
+    "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
+    "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
+}
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{_LIB_NAME} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the prompt-cache hot path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().pc_last_error_string()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# thin typed wrappers (tensor.data_ptr() + sizes; no torch types cross the ABI)
+# ------------------------------------------------------------------------------------------------
+
+def kv_gather(seg_ptrs: Sequence[int], seg_lens: Sequence[int], seg_dst_off: Sequence[int], dst,
+              n_layers: int, n_kv_heads: int, head_dim: int, max_ctx: int, stream: Optional[int] = None) -> None:
+    n = len(seg_ptrs)
+    a_ptr = (_vp * n)(*seg_ptrs)
+    a_len = (C.c_int32 * n)(*seg_lens)
+    a_off = (C.c_int32 * n)(*seg_dst_off)
+    rc = load().pc_kv_gather(a_ptr, a_len, a_off, n, dst.data_ptr(), n_layers, n_kv_heads, head_dim, max_ctx,
+                             current_stream() if stream is None else stream)
+    check(rc, "pc_kv_gather")
+
+
+def kv_slice_store(src, src_cap: int, seg_src_off: Sequence[int], seg_lens: Sequence[int], seg_dst_ptrs: Sequence[int],
+                   n_layers: int, n_kv_heads: int, head_dim: int, stream: Optional[int] = None) -> None:
+    n = len(seg_dst_ptrs)
+    a_off = (C.c_int32 * n)(*seg_src_off)
+    a_len = (C.c_int32 * n)(*seg_lens)
+    a_ptr = (_vp * n)(*seg_dst_ptrs)
+    rc = load().pc_kv_slice_store(src.data_ptr(), src_cap, a_off, a_len, a_ptr, n, n_layers, n_kv_heads, head_dim,
+                                  current_stream() if stream is None else stream)
+    check(rc, "pc_kv_slice_store")
+
+
+def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_rope_table(pos_i32.data_ptr(), inv_freq.data_ptr(), cs_out.data_ptr(), n_tok, head_dim,
+                              current_stream() if stream is None else stream)
+    check(rc, "pc_rope_table")
+
+
+def rope_append(q, q_bs, q_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs, B, H, Hkv, D, q_len,
+                past_len, cap, past_len_dev=None, stream: Optional[int] = None) -> None:
+    rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, k_new.data_ptr(), v_new.data_ptr(), n_bs, n_ts,
+                               k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, cs.data_ptr(), B, H, Hkv, D,
+                               q_len, past_len, cap, _ptr(past_len_dev),
+                               current_stream() if stream is None else stream)
+    check(rc, "pc_rope_append")
+
+
+def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) -> int:
+    return int(load().pc_attn_workspace_bytes(B, H, D, q_len, kv_len_max))
+
+
+def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
+             workspace=None, past_len_dev=None, stream: Optional[int] = None) -> None:
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    rc = load().pc_attn_fwd(q.data_ptr(), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, out.data_ptr(),
+                            o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, _ptr(workspace), ws_bytes,
+                            _ptr(past_len_dev), current_stream() if stream is None else stream)
+    check(rc, "pc_attn_fwd")
+
+
+def rmsnorm(x, weight, out, rows: int, hidden: int, eps: float, x_is_f32: bool, stream: Optional[int] = None) -> None:
+    rc = load().pc_rmsnorm(x.data_ptr(), weight.data_ptr(), out.data_ptr(), rows, hidden, eps, int(x_is_f32),
+                           current_stream() if stream is None else stream)
+    check(rc, "pc_rmsnorm")
+
+
+def silu_mul(gate_up, out, rows: int, inter: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_silu_mul(gate_up.data_ptr(), out.data_ptr(), rows, inter,
+                            current_stream() if stream is None else stream)
+    check(rc, "pc_silu_mul")
+
+
+def embed_gather(table, ids_i64, out, n_tok: int, hidden: int, vocab: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_embed_gather(table.data_ptr(), ids_i64.data_ptr(), out.data_ptr(), n_tok, hidden, vocab,
+                                current_stream() if stream is None else stream)
+    check(rc, "pc_embed_gather")
+
+
+def probe_layouts(out_mfma, out_tr, stream: Optional[int] = None) -> None:
+    rc = load().pc_probe_layouts(out_mfma.data_ptr(), out_tr.data_ptr(), current_stream() if stream is None else stream)
+    check(rc, "pc_probe_layouts")

@@ -1,0 +1,69 @@
+"""Model shape descriptions for the Llama-2-class adapters.
+
+The reference reads these from HF ``config.json`` via ``LlamaConfig`` (``promptcache/model/llama2.py:262-283``);
+the shape constants it quotes for its system benchmarks are at ``eval_sys.py:92-100``.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, asdict
+
+
+@dataclass
+class LlamaShape:
+    vocab_size: int = 32000
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_position_embeddings: int = 4096
+    initializer_range: float = 0.02
+    name: str = "llama"
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def kv_bytes_per_token(self) -> int:
+        """fp16 K+V bytes per token over all layers (7b = 524288)."""
+        return 2 * self.num_hidden_layers * self.num_key_value_heads * self.head_dim * 2
+
+    def to_dict(self):
+        return asdict(self)
+
+    @classmethod
+    def from_hf_dir(cls, path: str) -> "LlamaShape":
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        return cls(
+            vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+            intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
+            num_attention_heads=c["num_attention_heads"],
+            num_key_value_heads=c.get("num_key_value_heads", c["num_attention_heads"]),
+            rms_norm_eps=c.get("rms_norm_eps", 1e-5), rope_theta=c.get("rope_theta", 10000.0),
+            max_position_embeddings=c.get("max_position_embeddings", 4096),
+            name=os.path.basename(os.path.normpath(path)))
+
+
+SHAPES = {
+    # test-sized
+    "tiny": LlamaShape(vocab_size=1024, hidden_size=128, intermediate_size=344, num_hidden_layers=2,
+                       num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-6, name="tiny"),
+    # D=128 like the real models, GQA 2:1 so the head-broadcast index math is exercised
+    "mid": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1376, num_hidden_layers=3,
+                      num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid"),
+    # D=128, MHA, 2 layers at hidden 256 (cheap full-path checks)
+    "mid_mha": LlamaShape(vocab_size=2048, hidden_size=256, intermediate_size=688, num_hidden_layers=2,
+                          num_attention_heads=2, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid_mha"),
+    # BASELINE.json configs
+    "llama2-7b": LlamaShape(name="llama2-7b"),
+    "llama2-13b": LlamaShape(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40,
+                             num_attention_heads=40, num_key_value_heads=40, name="llama2-13b"),
+    "codellama-7b": LlamaShape(vocab_size=32016, rope_theta=1e6, max_position_embeddings=16384,
+                               name="codellama-7b"),
+}

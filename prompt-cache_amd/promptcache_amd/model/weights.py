@@ -1,0 +1,100 @@
+"""Weight sources for the Llama-2-class adapter.
+
+* ``make_weights_np``  -- seeded N(0, initializer_range) weights (the reference's ``_init_weights``,
+  ``promptcache/model/llama2.py:686-695``) drawn with numpy's PCG64 so the same numbers can be
+  produced in any process (tests, golden generation, the GPU box) and rounded to fp16.
+* ``load_hf_safetensors`` -- real checkpoints (HF layout) when a directory is available.
+* ``random_weights_device`` -- seeded weights drawn directly on the GPU at true shapes (bench).
+
+Key names: ``embed``, ``l{i}.ln1|wq|wk|wv|wo|ln2|gate|up|down``, ``norm``, ``lm_head``;
+linear weights are ``[out, in]`` (``nn.Linear`` layout).
+"""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Dict
+
+import numpy as np
+
+from .config import LlamaShape
+
+
+def weight_shapes(cfg: LlamaShape) -> Dict[str, tuple]:
+    hid, inter, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    shapes = {"embed": (cfg.vocab_size, hid)}
+    for i in range(cfg.num_hidden_layers):
+        shapes[f"l{i}.ln1"] = (hid,)
+        shapes[f"l{i}.wq"] = (H * D, hid)
+        shapes[f"l{i}.wk"] = (Hkv * D, hid)
+        shapes[f"l{i}.wv"] = (Hkv * D, hid)
+        shapes[f"l{i}.wo"] = (hid, H * D)
+        shapes[f"l{i}.ln2"] = (hid,)
+        shapes[f"l{i}.gate"] = (inter, hid)
+        shapes[f"l{i}.up"] = (inter, hid)
+        shapes[f"l{i}.down"] = (hid, inter)
+    shapes["norm"] = (hid,)
+    shapes["lm_head"] = (cfg.vocab_size, hid)
+    return shapes
+
+
+def make_weights_np(cfg: LlamaShape, seed: int = 0, scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """fp16 numpy weights.  Norm gains are 1 + 0.1*N(0,1) (not all-ones) so a test notices a
+    dropped or misapplied gain.  ``scale`` multiplies the linear-weight std (tests use >1 to make
+    the attention logits non-trivial at tiny hidden sizes)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in weight_shapes(cfg).items():
+        if len(shp) == 1:
+            w = 1.0 + 0.1 * rng.standard_normal(shp, dtype=np.float32)
+        else:
+            w = (cfg.initializer_range * scale) * rng.standard_normal(shp, dtype=np.float32)
+        out[name] = w.astype(np.float16)
+    return out
+
+
+_HF_MAP = {
+    "ln1": "input_layernorm.weight", "wq": "self_attn.q_proj.weight", "wk": "self_attn.k_proj.weight",
+    "wv": "self_attn.v_proj.weight", "wo": "self_attn.o_proj.weight",
+    "ln2": "post_attention_layernorm.weight", "gate": "mlp.gate_proj.weight",
+    "up": "mlp.up_proj.weight", "down": "mlp.down_proj.weight",
+}
+
+
+def load_hf_safetensors(path: str, cfg: LlamaShape, device, dtype):
+    """Read an HF Llama checkpoint directory (``*.safetensors``) into the key layout above."""
+    import torch
+    from safetensors import safe_open
+
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    raw = {}
+    for fn in files:
+        with safe_open(fn, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                raw[k] = f.get_tensor(k)
+    out = {"embed": raw["model.embed_tokens.weight"], "norm": raw["model.norm.weight"],
+           "lm_head": raw.get("lm_head.weight", raw["model.embed_tokens.weight"])}
+    for i in range(cfg.num_hidden_layers):
+        for short, hf in _HF_MAP.items():
+            out[f"l{i}.{short}"] = raw[f"model.layers.{i}.{hf}"]
+    return {k: v.to(device=device, dtype=dtype) for k, v in out.items()}
+
+
+def random_weights_device(cfg: LlamaShape, device, dtype, seed: int = 0):
+    """Seeded N(0, 0.02) weights generated on ``device`` (true-shape benchmarks: 7b = 13.5 GB fp16)."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    for name, shp in weight_shapes(cfg).items():
+        if len(shp) == 1:
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        else:
+            w = torch.empty(shp, device=device, dtype=torch.float32).normal_(0.0, cfg.initializer_range, generator=g)
+        out[name] = w.to(dtype)
+        del w
+    return out

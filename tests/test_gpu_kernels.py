@@ -1,0 +1,365 @@
+"""GPU parity tests for the HIP kernels, called through the C-ABI, checked against the numpy oracle.
+
+Bit-exact for the byte-moving kernels (gather / slice-store / V append); fp16-attention tolerance for
+RoPE and attention (tolerances written at each assert).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _n():
+    from promptcache_amd import _native
+    return _native
+
+
+# ---------------------------------------------------------------------------------------------------
+# hardware lane maps the attention kernel depends on
+# ---------------------------------------------------------------------------------------------------
+
+def test_probe_mfma_cd_layout_and_lds_transpose_read():
+    n = _n()
+    om = torch.zeros(256, device=DEV, dtype=torch.float32)
+    ot = torch.zeros(512, device=DEV, dtype=torch.float32)
+    n.probe_layouts(om, ot)
+    torch.cuda.synchronize()
+    om = om.cpu().numpy().reshape(64, 4)
+    ot = ot.cpu().numpy()
+    lane = np.arange(64)
+    nn, g = lane & 15, lane >> 4
+    # MFMA 16x16 C/D: col = lane&15, row = 4*(lane>>4)+reg ; D[m][n] = (m+1)*(n+17)
+    exp = np.stack([(4 * g + r + 1) * (nn + 17) for r in range(4)], axis=1).astype(np.float32)
+    np.testing.assert_array_equal(om, exp)
+    # ds_read_b64_tr_b16, contiguous addressing: lane i of group G receives lds[64G + 16j + i]
+    exp_tr = np.stack([64 * g + 16 * j + nn for j in range(4)], axis=1).astype(np.float32)
+    np.testing.assert_array_equal(ot[:256].reshape(64, 4), exp_tr)
+    # attention-kernel addressing: lane supplies (row 4G + i/4, cols 4(i%4)..) of a 128-wide tile,
+    # receives rows 4G + j at column i
+    exp_tr2 = np.stack([(4 * g + j) * 128 + nn for j in range(4)], axis=1).astype(np.float32)
+    np.testing.assert_array_equal(ot[256:].reshape(64, 4), exp_tr2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# kv_gather / kv_slice_store
+# ---------------------------------------------------------------------------------------------------
+
+def _rand_half(shape, rng):
+    # arbitrary bit patterns incl. NaN/Inf encodings: the copy must be a pure byte move
+    return torch.from_numpy(rng.integers(0, 65536, size=shape, dtype=np.uint16).view(np.float16))
+
+
+@pytest.mark.parametrize("L,Hkv,D,lens,max_ctx", [
+    (2, 4, 32, [5, 1, 1, 17, 1, 64, 65, 3], 200),
+    (3, 2, 128, [275, 1, 1, 1, 84, 1, 174, 256, 1], 900),
+    (1, 1, 64, [1], 1),
+    (2, 2, 128, [1] * 50 + [130], 256),          # > kMaxSeg descriptors -> several launches
+    (2, 3, 128, [0, 7, 0, 9], 16),                # empty segments are skipped
+])
+def test_kv_gather_bit_exact(L, Hkv, D, lens, max_ctx):
+    n = _n()
+    rng = np.random.default_rng(0)
+    segs = [_rand_half((L, 2, Hkv, ln, D), rng).to(DEV) for ln in lens]
+    dst = torch.zeros((L, 2, Hkv, max_ctx, D), dtype=torch.float16, device=DEV)
+    canary = _rand_half((L, 2, Hkv, max_ctx, D), rng).to(DEV)
+    dst.copy_(canary)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(int).tolist()
+    n.kv_gather([s.data_ptr() if s.numel() else 0 for s in segs], lens, offs, dst, L, Hkv, D, max_ctx)
+    torch.cuda.synchronize()
+    exp = canary.clone()
+    for s, o, ln in zip(segs, offs, lens):
+        exp[:, :, :, o:o + ln, :] = s
+    assert torch.equal(dst.view(torch.int16), exp.view(torch.int16))  # rows past S untouched
+
+
+def test_kv_gather_matches_oracle_rounding_and_layout():
+    """Oracle path: fp32 module KV rounded to fp16 by the staging copy (cache_engine.py:148-149)."""
+    n = _n()
+    rng = np.random.default_rng(1)
+    L, H, D, lens, max_ctx = 2, 4, 32, [9, 1, 30], 64
+    segs32 = [[(rng.standard_normal((H, ln, D), dtype=np.float32), rng.standard_normal((H, ln, D), dtype=np.float32))
+               for _ in range(L)] for ln in lens]
+    staged, S = orc.kv_gather(segs32, max_ctx)
+    segs_dev = [torch.from_numpy(np.stack([np.stack([kv[0], kv[1]]) for kv in seg]).astype(np.float16)).to(DEV)
+                for seg in segs32]
+    dst = torch.zeros((L, 2, H, max_ctx, D), dtype=torch.float16, device=DEV)
+    n.kv_gather([s.data_ptr() for s in segs_dev], lens, [0, 9, 10], dst, L, H, D, max_ctx)
+    torch.cuda.synchronize()
+    assert S == 40
+    for i in range(L):
+        np.testing.assert_array_equal(dst[i, 0, :, :S].cpu().numpy(), staged[i][0])
+        np.testing.assert_array_equal(dst[i, 1, :, :S].cpu().numpy(), staged[i][1])
+
+
+def test_kv_gather_errors():
+    n = _n()
+    seg = torch.zeros((1, 2, 1, 8, 32), dtype=torch.float16, device=DEV)
+    dst = torch.zeros((1, 2, 1, 8, 32), dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="exceeds max_ctx"):
+        n.kv_gather([seg.data_ptr()], [8], [1], dst, 1, 1, 32, 8)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        n.kv_gather([seg.data_ptr()], [8], [0], dst, 1, 1, 36, 8)
+    n.kv_gather([], [], [], dst, 1, 1, 32, 8)  # empty table is a no-op
+
+
+def test_slice_store_then_gather_round_trip():
+    """encode arena -> segment stores -> staged buffer reproduces the selected rows (any order)."""
+    n = _n()
+    rng = np.random.default_rng(2)
+    L, Hkv, D, cap = 2, 2, 128, 300
+    arena = _rand_half((L, 2, Hkv, cap, D), rng).to(DEV)
+    src_off = [0, 40, 41, 200, 299]
+    lens = [40, 1, 100, 99, 1]
+    stores = [torch.empty((L, 2, Hkv, ln, D), dtype=torch.float16, device=DEV) for ln in lens]
+    n.kv_slice_store(arena, cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
+    for s, o, ln in zip(stores, src_off, lens):
+        assert torch.equal(s.view(torch.int16), arena[:, :, :, o:o + ln].contiguous().view(torch.int16))
+    order = [3, 0, 4, 2, 1]
+    dst = torch.zeros((L, 2, Hkv, 256, D), dtype=torch.float16, device=DEV)
+    offs, o = [], 0
+    for i in order:
+        offs.append(o)
+        o += lens[i]
+    n.kv_gather([stores[i].data_ptr() for i in order], [lens[i] for i in order], offs, dst, L, Hkv, D, 256)
+    torch.cuda.synchronize()
+    exp = torch.cat([arena[:, :, :, src_off[i]:src_off[i] + lens[i]] for i in order], dim=3)
+    assert torch.equal(dst[:, :, :, :o].contiguous().view(torch.int16), exp.contiguous().view(torch.int16))
+
+
+# ---------------------------------------------------------------------------------------------------
+# RoPE table + rotate/append
+# ---------------------------------------------------------------------------------------------------
+
+def _inv_freq(D, theta):
+    # exactly the reference formula (llama2.py:121), evaluated by torch on the CPU
+    return 1.0 / (theta ** (torch.arange(0, D, 2).float() / D))
+
+
+@pytest.mark.parametrize("D,theta", [(32, 10000.0), (128, 10000.0), (128, 1e6)])
+def test_rope_table_matches_oracle(D, theta):
+    n = _n()
+    pos = np.array([0, 1, 2, 3, 1981, 1992, 4095, 8191, 9185, 16383, 7, 7], dtype=np.int32)
+    cs = torch.empty((len(pos), D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(torch.from_numpy(pos).to(DEV), _inv_freq(D, theta).to(DEV), cs, len(pos), D)
+    torch.cuda.synchronize()
+    cos, sin = orc.rope_cos_sin(pos[None], D, theta, _inv_freq(D, theta).numpy())
+    cs = cs.cpu().numpy()
+    # fp32 sincos of an fp32 angle: device libm vs numpy agree to a few ulp of 1.0
+    np.testing.assert_allclose(cs[..., 0], cos[0, :, :D // 2], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(cs[..., 1], sin[0, :, :D // 2], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,cap", [
+    (1, 4, 4, 32, 12, 40, 64), (2, 4, 2, 128, 5, 0, 8), (1, 32, 32, 128, 14, 100, 128), (1, 2, 2, 64, 1, 7, 8)])
+def test_rope_append_matches_oracle(B, H, Hkv, D, q_len, past, cap):
+    n = _n()
+    rng = np.random.default_rng(3)
+    W = (H + 2 * Hkv) * D
+    qkv = torch.from_numpy(rng.standard_normal((B, q_len, W), dtype=np.float32).astype(np.float16)).to(DEV)
+    qkv0 = qkv.clone()
+    pos = rng.integers(0, 5000, size=(B, q_len)).astype(np.int32)
+    cs = torch.empty((B * q_len, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(torch.from_numpy(pos.reshape(-1)).to(DEV), _inv_freq(D, 10000.0).to(DEV), cs, B * q_len, D)
+    arena = _rand_half((B, 2, Hkv, cap, D), np.random.default_rng(4)).to(DEV)
+    arena0 = arena.clone()
+    q = qkv[:, :, :H * D]
+    k = qkv[:, :, H * D:(H + Hkv) * D]
+    v = qkv[:, :, (H + Hkv) * D:]
+    n.rope_append(q, q_len * W, W, k, v, q_len * W, W, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, cs,
+                  B, H, Hkv, D, q_len, past, cap)
+    torch.cuda.synchronize()
+    cos, sin = orc.rope_cos_sin(pos, D, 10000.0, _inv_freq(D, 10000.0).numpy())
+    x = qkv0.float().cpu().numpy()
+    q_ref = orc.apply_rope(x[:, :, :H * D].reshape(B, q_len, H, D).transpose(0, 2, 1, 3), cos, sin)
+    k_ref = orc.apply_rope(x[:, :, H * D:(H + Hkv) * D].reshape(B, q_len, Hkv, D).transpose(0, 2, 1, 3), cos, sin)
+    q_got = qkv[:, :, :H * D].float().cpu().numpy().reshape(B, q_len, H, D).transpose(0, 2, 1, 3)
+    k_got = arena[:, 0, :, past:past + q_len].float().cpu().numpy()
+    # one fp16 rounding of an fp32 result: |err| <= 2^-11 * |x| (+ tiny sincos difference)
+    np.testing.assert_allclose(q_got, q_ref, atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(k_got, k_ref, atol=1e-3, rtol=1e-3)
+    # V is a pure copy; k/v columns of qkv untouched; arena rows outside [past, past+q) untouched
+    v_exp = qkv0[:, :, (H + Hkv) * D:].reshape(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    assert torch.equal(arena[:, 1, :, past:past + q_len].contiguous().view(torch.int16), v_exp.contiguous().view(torch.int16))
+    assert torch.equal(qkv[:, :, H * D:].view(torch.int16), qkv0[:, :, H * D:].view(torch.int16))
+    mask = torch.ones(cap, dtype=torch.bool)
+    mask[past:past + q_len] = False
+    mask = mask.to(DEV)
+    assert torch.equal(arena[:, :, :, mask].view(torch.int16), arena0[:, :, :, mask].view(torch.int16))
+
+
+def test_rope_append_bounds():
+    n = _n()
+    qkv = torch.zeros((1, 4, 3 * 32), dtype=torch.float16, device=DEV)
+    cs = torch.zeros((4, 16, 2), dtype=torch.float32, device=DEV)
+    arena = torch.zeros((1, 2, 1, 8, 32), dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="exceeds arena rows"):
+        n.rope_append(qkv, 0, 96, qkv, qkv, 0, 96, arena[:, 0], arena[:, 1], 0, 256, cs, 1, 1, 1, 32, 4, 5, 8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+
+def _run_attn(q, k, v, past, scale=None):
+    """q [B,q,H,D] fp16 cuda; k, v [B,Hkv,cap,D] fp16 cuda with past+q valid rows."""
+    n = _n()
+    B, ql, H, D = q.shape
+    Hkv, cap = k.shape[1], k.shape[2]
+    out = torch.full((B, ql, H * D), float("nan"), dtype=torch.float16, device=DEV)
+    ws_bytes = n.attn_workspace_bytes(B, H, D, ql, past + ql)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=DEV)
+    n.attn_fwd(q, ql * H * D, H * D, k, v, Hkv * cap * D, cap * D, out, ql * H * D, H * D, B, H, Hkv, D, ql, past,
+               (1.0 / np.sqrt(D)) if scale is None else scale, ws)
+    torch.cuda.synchronize()
+    return out, ws_bytes
+
+
+def _ref_attn(q, k, v, past):
+    B, ql, H, D = q.shape
+    Hkv = k.shape[1]
+    qn = q.float().cpu().numpy().transpose(0, 2, 1, 3)
+    kn = k[:, :, :past + ql].float().cpu().numpy()
+    vn = v[:, :, :past + ql].float().cpu().numpy()
+    o = orc.attention_core(qn, kn, vn, past, H // Hkv)
+    if ql == 1:  # oracle skips the mask for q_len==1 exactly as the reference; same thing here
+        pass
+    return o.transpose(0, 2, 1, 3).reshape(B, ql, H * D)
+
+
+ATTN_CASES = [
+    # B, H, Hkv, D, q_len, past
+    (1, 4, 4, 32, 12, 40),
+    (1, 4, 4, 32, 1, 0),
+    (1, 4, 4, 32, 16, 0),
+    (1, 4, 4, 32, 17, 3),
+    (2, 4, 2, 128, 12, 300),      # GQA + batch, split-KV
+    (1, 32, 32, 128, 12, 1725),   # persona cached prefill shape (one layer)
+    (1, 32, 32, 128, 14, 4390),   # game cached prefill shape
+    (1, 2, 2, 64, 50, 129),
+    (1, 2, 2, 128, 64, 0),
+    (1, 2, 2, 128, 65, 0),
+    (1, 4, 4, 128, 200, 77),      # several q blocks, causal diagonal inside tiles
+    (1, 2, 1, 128, 456, 0),       # encode regime (q = S)
+    (1, 8, 8, 128, 1, 1000),      # decode step
+    (1, 40, 40, 128, 30, 511),    # 13b head count
+]
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past", ATTN_CASES)
+def test_attn_matches_oracle(B, H, Hkv, D, q_len, past):
+    rng = np.random.default_rng(5)
+    cap = past + q_len + 3
+    q = torch.from_numpy(rng.standard_normal((B, q_len, H, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    k = torch.from_numpy(rng.standard_normal((B, Hkv, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((B, Hkv, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    # poison the rows past the valid range: they must never contribute (NaN would propagate)
+    k[:, :, past + q_len:] = float("nan")
+    v[:, :, past + q_len:] = float("nan")
+    out, _ = _run_attn(q, k, v, past)
+    ref = _ref_attn(q, k, v, past)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    # fp16 P (2^-11 relative per weight, averaged by the softmax) and fp16 output rounding of O(1) values
+    np.testing.assert_allclose(got, ref, atol=4e-3, rtol=1e-2)
+
+
+def test_attn_softmax_rescale_with_key_spike():
+    """Force the running max to jump late in the KV stream (online-softmax rescale path) and early
+    (later tiles contribute ~0): a spike row in K aligned with one query."""
+    rng = np.random.default_rng(6)
+    B, H, D, q_len, past = 1, 2, 128, 12, 700
+    cap = past + q_len
+    q = torch.from_numpy(rng.standard_normal((B, q_len, H, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    k = torch.from_numpy((0.3 * rng.standard_normal((B, H, cap, D), dtype=np.float32)).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((B, H, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    for spike_at in (650, 5):
+        k2 = k.clone()
+        k2[0, 0, spike_at] = q[0, 3, 0] * 2.0      # q.k ~ 2*|q|^2 = 256 -> scaled ~ 22 above the rest
+        out, _ = _run_attn(q, k2, v, past)
+        ref = _ref_attn(q, k2, v, past)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=4e-3, rtol=1e-2)
+
+
+def test_attn_index_order_mask_not_position_order():
+    """Permuting the *past* keys (with their values) must not change the output: every new token sees
+    all staged KV regardless of order (llama2.py:62-76 gives zeros over all past columns)."""
+    rng = np.random.default_rng(7)
+    B, H, D, q_len, past = 1, 4, 128, 9, 333
+    cap = past + q_len
+    q = torch.from_numpy(rng.standard_normal((B, q_len, H, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    k = torch.from_numpy(rng.standard_normal((B, H, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((B, H, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    out1, _ = _run_attn(q, k, v, past)
+    perm = torch.from_numpy(rng.permutation(past)).to(DEV)
+    k2, v2 = k.clone(), v.clone()
+    k2[:, :, :past] = k[:, :, perm]
+    v2[:, :, :past] = v[:, :, perm]
+    out2, _ = _run_attn(q, k2, v2, past)
+    np.testing.assert_allclose(out1.float().cpu().numpy(), out2.float().cpu().numpy(), atol=2e-3, rtol=0)
+
+
+def test_attn_full_size_property_uniform_values():
+    """BASELINE-size property check (13b heads, 8k staged keys): with all V rows equal to one vector the
+    output equals that vector for every query, whatever the scores are."""
+    rng = np.random.default_rng(8)
+    B, H, D, q_len, past = 1, 40, 128, 260, 8000
+    cap = past + q_len
+    q = torch.from_numpy(rng.standard_normal((B, q_len, H, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    k = torch.from_numpy(rng.standard_normal((B, H, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    vec = torch.from_numpy(rng.standard_normal((H, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    v = vec[None, :, None, :].expand(B, H, cap, D).contiguous()
+    out, _ = _run_attn(q, k, v, past)
+    exp = vec.reshape(1, 1, H * D).expand(B, q_len, H * D)
+    np.testing.assert_allclose(out.float().cpu().numpy(), exp.float().cpu().numpy(), atol=2e-3, rtol=2e-3)
+
+
+def test_attn_errors():
+    n = _n()
+    t = torch.zeros(4096, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        n.attn_fwd(t, 0, 96, t, t, 0, 96, t, 0, 96, 1, 1, 1, 96, 1, 0, 1.0)
+    with pytest.raises(RuntimeError, match="workspace"):
+        # long KV + tiny q -> split-KV needs a workspace
+        big = torch.zeros(2 * 2048 * 128, dtype=torch.float16, device=DEV)
+        n.attn_fwd(big, 0, 256, big, big, 0, 2048 * 128, big, 0, 256, 1, 2, 2, 128, 1, 2000, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# elementwise pieces
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,hidden,f32", [(12, 4096, True), (3, 128, False), (14, 5120, True), (1, 256, False)])
+def test_rmsnorm_matches_oracle(rows, hidden, f32):
+    n = _n()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((rows, hidden), dtype=np.float32) * 3
+    w = (1 + 0.1 * rng.standard_normal(hidden, dtype=np.float32)).astype(np.float16)
+    xd = torch.from_numpy(x if f32 else x.astype(np.float16)).to(DEV)
+    out = torch.empty((rows, hidden), dtype=torch.float16, device=DEV)
+    n.rmsnorm(xd, torch.from_numpy(w).to(DEV), out, rows, hidden, 1e-5, f32)
+    torch.cuda.synchronize()
+    ref = orc.rmsnorm(xd.float().cpu().numpy(), w.astype(np.float32), 1e-5)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=4e-3, rtol=4e-3)  # two fp16 roundings
+
+
+def test_silu_mul_and_embed():
+    n = _n()
+    rng = np.random.default_rng(10)
+    rows, inter = 5, 11008
+    gu = torch.from_numpy(rng.standard_normal((rows, 2 * inter), dtype=np.float32).astype(np.float16)).to(DEV)
+    out = torch.empty((rows, inter), dtype=torch.float16, device=DEV)
+    n.silu_mul(gu, out, rows, inter)
+    g = gu.float().cpu().numpy()
+    ref = orc.silu(g[:, :inter]) * g[:, inter:]
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3, rtol=2e-3)
+    table = torch.from_numpy(rng.standard_normal((100, 128), dtype=np.float32).astype(np.float16)).to(DEV)
+    ids = torch.tensor([0, 99, 5, 5, 42], dtype=torch.int64, device=DEV)
+    e = torch.empty((5, 128), dtype=torch.float16, device=DEV)
+    n.embed_gather(table, ids, e, 5, 128, 100)
+    torch.cuda.synchronize()
+    assert torch.equal(e, table[ids])

@@ -1,0 +1,78 @@
+"""Kernel micro-benchmarks (run on the GPU box): achieved GB/s of kv_gather, time and GB/s|TFLOP/s of
+attention at the BASELINE shapes.  HIP-event timing on torch's current stream (where the C-ABI launches)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "prompt-cache_amd"))
+from promptcache_amd import _native as n  # noqa: E402
+
+DEV = "cuda"
+PERSONA = [275, 1, 1, 1, 1, 1, 84, 1, 1, 174, 1, 1, 256, 1, 1, 155, 1, 1, 267, 1, 1, 265, 1, 1, 232]
+GAME = [306, 2, 2, 2, 2, 76, 800, 800, 800, 800, 800]
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def bench_gather(name, lens, L, Hkv, D, max_ctx):
+    segs = [torch.randn((L, 2, Hkv, ln, D), device=DEV).half() for ln in lens]
+    dst = torch.empty((L, 2, Hkv, max_ctx, D), dtype=torch.float16, device=DEV)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(int).tolist()
+    ptrs = [s.data_ptr() for s in segs]
+    S = sum(lens)
+    byts = 2 * S * L * 2 * Hkv * D * 2
+    med, best = timeit(lambda: n.kv_gather(ptrs, lens, offs, dst, L, Hkv, D, max_ctx))
+    # torch reference: one big D2D copy of the same byte count
+    a = torch.empty(byts // 4, dtype=torch.float16, device=DEV)
+    b = torch.empty_like(a)
+    cmed, _ = timeit(lambda: b.copy_(a))
+    print(f"gather {name}: S={S} nseg={len(lens)} bytes={byts/1e9:.3f} GB  med {med*1e3:.1f} us  "
+          f"{byts/med/1e6:.0f} GB/s (best {byts/best/1e6:.0f})  | torch D2D copy same bytes {byts/cmed/1e6:.0f} GB/s")
+
+
+def bench_attn(name, H, Hkv, D, q_len, past):
+    cap = past + q_len
+    q = torch.randn((1, q_len, H, D), device=DEV).half()
+    k = torch.randn((1, Hkv, cap, D), device=DEV).half()
+    v = torch.randn((1, Hkv, cap, D), device=DEV).half()
+    out = torch.empty((1, q_len, H * D), dtype=torch.float16, device=DEV)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, cap), 4) // 4, dtype=torch.float32, device=DEV)
+    sc = 1.0 / np.sqrt(D)
+    fn = lambda: n.attn_fwd(q, q_len * H * D, H * D, k, v, Hkv * cap * D, cap * D, out, q_len * H * D, H * D,
+                            1, H, Hkv, D, q_len, past, sc, ws)
+    med, best = timeit(fn)
+    byts = 2 * Hkv * cap * D * 2 + 2 * H * q_len * D * 2
+    flops = 4 * H * D * q_len * (past + (q_len + 1) / 2)
+    print(f"attn {name}: H={H} q={q_len} past={past}  med {med*1e3:.1f} us (best {best*1e3:.1f})  "
+          f"{byts/med/1e6:.0f} GB/s  {flops/med/1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    print(torch.cuda.get_device_name(0))
+    bench_gather("persona-7b", PERSONA, 32, 32, 128, 4096)
+    bench_gather("game-7b", GAME, 32, 32, 128, 5000)
+    bench_gather("longbench-13b", [30, 8000, 20], 40, 40, 128, 9186)
+    bench_attn("persona cached", 32, 32, 128, 12, 1725)
+    bench_attn("game cached", 32, 32, 128, 14, 4390)
+    bench_attn("13b 8k cached", 40, 40, 128, 260, 8000)
+    bench_attn("decode", 32, 32, 128, 1, 1737)
+    bench_attn("encode 456", 32, 32, 128, 456, 0)
+    bench_attn("encode 815", 32, 32, 128, 815, 0)
+    bench_attn("nocache 1737", 32, 32, 128, 1737, 0)
+    bench_attn("nocache 4404", 32, 32, 128, 4404, 0)

@@ -1,0 +1,372 @@
+"""Generate the committed golden fixtures by running the REFERENCE implementation (imported from
+/root/reference via ``oracle/ref_shim.py``) in the build container.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*
+
+TEST INFRASTRUCTURE.  The reference never ships to the GPU box: only these fixtures (data: inputs and
+expected outputs) and this script are committed.  Inputs are reproducible without the reference:
+weights come from ``promptcache_amd.model.weights.make_weights_np(shape, seed, scale)`` (numpy PCG64),
+token ids from the deterministic stand-in tokenizer, PML text from files under ``tests/golden/pml/``
+(written by this script; the three synthetic schemas are authored here, not taken from the reference).
+
+Fixtures
+  pml_layout.json    integer layout of every parseable reference schema (examples/ and
+                     benchmark/schema/test/): schema length, encode paths, per-scaffold CRC32 of token /
+                     position ids, prompt assembly results (process() with and without cache)
+  pml_recover.json   libxml2 recovery behaviour on malformed snippets (pins pml_xml)
+  model_<case>.npz   tensors from the reference CacheEngine / GenerationEngine / LlamaForCausalLM on CPU:
+                     cached-prefill logits, no-cache logits, layer-0 attention output, sampled rows of the
+                     staged KV and of the stored module KV, greedy tokens, inv_freq
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "prompt-cache_amd"))
+
+from oracle import ref_shim  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = ref_shim.REFERENCE_ROOT
+
+
+def crc(xs) -> int:
+    return zlib.crc32(np.asarray(list(xs), dtype=np.int64).tobytes())
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic PML (authored for this repo) -- small enough that tensor fixtures stay tiny
+# ---------------------------------------------------------------------------------------------------
+
+SYN_UNION = """<schema name="trip">
+    <system>You are a careful travel planner. Answer briefly.</system>
+    <user>
+        Plan a trip with the following constraints.
+        <module name="length">
+            <union scaffold="weekend">
+                <module name="weekend">The trip lasts two days, Saturday and Sunday, with one night away.</module>
+                <module name="week">The trip lasts seven days and may include two different cities.</module>
+            </union>
+        </module>
+        <module name="budget">
+            The budget is <parameter name="amount" length="6" scaffold="unknown"/> dollars in total,
+            <union>
+                <module name="frugal">and every meal should be cheap street food.</module>
+                <module name="lavish">and at least one dinner should be a tasting menu
+                    <module name="wine">with paired wines</module>.
+                </module>
+            </union>
+        </module>
+        <module name="pets">A small dog travels with us.</module>
+    </user>
+</schema>
+"""
+SYN_UNION_PROMPT = """<prompt schema='trip'>
+    <length><week/></length>
+    <budget amount="1500"><lavish><wine/></lavish></budget>
+    <user>Where should we go in October?</user>
+</prompt>"""
+SYN_UNION_PROMPT2 = """<prompt schema='trip'>
+    <pets/>
+    <budget amount="90"><frugal/></budget>
+    <user>Suggest two places.</user>
+</prompt>"""
+
+SYN_FLAT = """<schema name="doc">
+    <system>Answer using the documents.</system>
+    <user>
+        <module name="a">Document A. The river Ouse rises in the hills and runs east for ninety miles before it meets the sea near a small harbour town.</module>
+        <module name="b">Document B. Copper prices were stable through the spring, then fell sharply once the new mine opened in the north.</module>
+        <module name="c">Document C. The committee meets on the first Monday of each month unless that day is a public holiday.</module>
+    </user>
+</schema>
+"""
+SYN_FLAT_PROMPT = """<prompt schema='doc'><a/><b/><c/><user>When does the committee meet?</user></prompt>"""
+
+PERSONA_PROMPT = """<prompt schema='persona'>
+    <age><young-adult/></age>
+    <residence><seaside/></residence>
+    <education><doctorate/></education>
+    <occupation><technology/></occupation>
+    <martial-status><married/></martial-status>
+    <personality><introverted/></personality>
+    <user>Introduce about yourself.</user>
+</prompt>"""   # README.md:60-82 of the reference
+
+GAME_PROMPT = """<prompt schema='code-generation-game'>
+    <unit.py/><map.py/><player.py/><game.py/><database.py/>
+    <user>Create a main entry for the game:</user>
+</prompt>"""    # demo.py:66-77 of the reference
+
+
+def build_ref_lm(pc, shape_name: str, seed: int, scale: float):
+    import importlib
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.tokenizer import StandInTokenizer
+    from promptcache_amd.model.weights import make_weights_np
+
+    shape = SHAPES[shape_name]
+    w16 = make_weights_np(shape, seed, scale)
+    model = ref_shim.make_reference_llama(shape.to_dict(), {k: v.astype(np.float32) for k, v in w16.items()})
+    rm = importlib.import_module("promptcache.model")
+
+    class RefLM(rm.LanguageModel):
+        def __init__(self):
+            tok = StandInTokenizer(shape.vocab_size)
+            super().__init__("ref", model, tok, [tok.eos_token_id], ["</s>"])
+            self.formatter = rm.FormatConversation(system=("<s> [INST] <<SYS>>\n", "<</SYS>>\n\n", "<s> [INST] "),
+                                                   user=("", "[/INST]"), assistant=("", "</s><s> [INST] "))
+
+        def get_formatter(self):
+            return self.formatter
+
+    return RefLM(), shape
+
+
+class TokOnlyLM:
+    """Tokenizer-only stand-in for layout goldens (no model needed to lay out a schema)."""
+
+    def __init__(self, vocab=32000):
+        from promptcache_amd.model.tokenizer import StandInTokenizer
+        self.tok = StandInTokenizer(vocab)
+        self.unk_token_id = 0
+        self.eos_token_id = 2
+
+    def encode(self, text):
+        return self.tok.encode(text)
+
+
+def layout_goldens(pc):
+    import importlib
+    rm = importlib.import_module("promptcache.model")
+    rs = importlib.import_module("promptcache.schema")
+    rp = importlib.import_module("promptcache.prompt")
+    rce = importlib.import_module("promptcache.cache_engine")
+    fmt = rm.FormatConversation(system=("<s> [INST] <<SYS>>\n", "<</SYS>>\n\n", "<s> [INST] "),
+                                user=("", "[/INST]"), assistant=("", "</s><s> [INST] "))
+    lm = TokOnlyLM()
+    files = [("examples/persona_generation.xml", None), ("examples/code_generation_game.xml", 800),
+             ("examples/code_generation_bookstore.xml", None), ("examples/parameterized_prompts.xml", None),
+             ("examples/personalization-education.xml", None), ("benchmark/schema/test/schema_mbti.xml", None),
+             ("benchmark/schema/test/schema_mbti_short.xml", None), ("benchmark/schema/test/schema_persona.xml", None),
+             ("benchmark/schema/test/schema_persona_long.xml", None), ("benchmark/schema/test/empty.xml", None),
+             ("syn:trip", None), ("syn:doc", None), ("syn:trip", 12)]
+    out = {}
+    for fn, max_tokens in files:
+        if fn.startswith("syn:"):
+            text = fmt({"syn:trip": SYN_UNION, "syn:doc": SYN_FLAT}[fn])
+        else:
+            text = rp.read_file(os.path.join(REF, fn), [fmt])
+        key = fn + (f"@{max_tokens}" if max_tokens else "")
+        try:
+            sc = rs.Schema(text, lm, max_tokens=max_tokens)
+        except Exception as e:  # schema the reference itself rejects
+            out[key] = {"error": type(e).__name__, "message": str(e)}
+            continue
+        # L1 path enumeration exactly as SchemaCache._process does it (cache_engine.py:188-210)
+        stack, paths = [], [rs.Path()]
+        if sc.contains_union():
+            stack.append((list(), True, sc))
+        while stack:
+            path, is_default_parent, u = stack.pop()
+            for e in u.children:
+                if type(e) == rs.Module and e.contains_union():
+                    stack.append((path + [u.name], is_default_parent, e))
+                elif type(e) == rs.UnionModule:
+                    for n in e.modules:
+                        is_default = e.scaffold_name == n.name and is_default_parent
+                        if n.contains_union():
+                            stack.append((path + [u.name], is_default, n))
+                        if not is_default:
+                            paths.append(rs.Path(path + [u.name, n.name]).next)
+        rec = {"name": sc.name, "length": len(sc), "paths": [], "max_tokens": max_tokens}
+        for p in paths:
+            sf = sc.get_scaffold(p)
+            tgt = sf.select(p).all_token_sequences()
+            rec["paths"].append({"path": str(p), "n": len(sf.token_ids()), "ids_crc": crc(sf.token_ids()),
+                                 "pos_crc": crc(sf.position_ids()),
+                                 "targets": [[t.offset, len(t)] for t in tgt]})
+        out[key] = rec
+    # prompt assembly through the reference CacheEngine.process (no model: no_cache schema caches)
+    prompts = {"examples/persona_generation.xml": PERSONA_PROMPT, "examples/code_generation_game.xml@800": GAME_PROMPT,
+               "syn:trip": SYN_UNION_PROMPT, "syn:trip#2": SYN_UNION_PROMPT2, "syn:doc": SYN_FLAT_PROMPT}
+
+    class NoModelLM(TokOnlyLM):
+        device = "cpu"
+
+        def get_cache_shape(self):
+            return 1, 1, 8
+
+    for key, ptxt in prompts.items():
+        skey = key.split("#")[0]
+        fn, _, mt = skey.partition("@")
+        max_tokens = int(mt) if mt else None
+        text = fmt({"syn:trip": SYN_UNION, "syn:doc": SYN_FLAT}[fn]) if fn.startswith("syn:") else \
+            rp.read_file(os.path.join(REF, fn), [fmt])
+        nlm = NoModelLM()
+        eng = rce.CacheEngine(64, nlm, target_device="cpu")
+        eng.add_schema(text, max_tokens=max_tokens, no_cache=True)
+        prompt = rp.Prompt(ptxt, [fmt])
+        ids, pos, _, _ = eng.process(prompt, no_cache=True)
+        # the cached branch needs cache_l1; replay its integer part only (used sequences, args, text)
+        used, arg_ids, arg_pos = [], [], []
+        sc = eng.get_schema(prompt.schema)
+        stack = [(prompt, sc)]
+        while stack:
+            ref, module = stack.pop()
+            used += [(m.offset, len(m)) for m in module.token_sequences()]
+            for arg in ref.args:
+                prm = [p for p in module.parameters() if p.name == arg.name][0]
+                a = nlm.encode(arg.value)
+                arg_ids += a
+                arg_pos += prm.position_ids()[:len(a)]
+            for m in ref.modules:
+                stack.append((m, module.select(m.name)))
+        if len(prompt.text) > 0:
+            t = nlm.encode(prompt.text)
+            arg_ids += t
+            arg_pos += list(range(len(sc), len(sc) + len(t)))
+        out.setdefault("prompts", {})[key] = {
+            "prompt": ptxt, "text": prompt.text, "nocache_n": len(ids), "nocache_ids_crc": crc(ids),
+            "nocache_pos_crc": crc(pos), "used": used, "new_ids": arg_ids, "new_pos": arg_pos}
+    return out
+
+
+def recover_goldens():
+    import xml.etree.ElementTree as ET
+    snippets = ["<a>x < y</a>", "<a>x <= y</a>", "<a>1 <2 3</a>", "<a>p & q</a>", "<a>p &foo; q</a>", "<a>x <b>y</a>",
+                "<a>a < b > c</a>", "<a>x<</a>", "<a>t</b></a>", "<a><b>t</a>", "<a>x <- y</a>",
+                "<a>&lt;s&gt; [INST] &lt;&lt;SYS&gt;&gt;\n x &amp; y &quot;q&quot; &apos;z&apos; &#65;&#x42;</a>",
+                "<s n='1'><m name=\"k\">if a <= b and c < d:\n    pass</m> tail <u/> t2</s>",
+                # after the first error libxml2 2.9 drops predefined entities but keeps character references
+                "<a>x < y &lt;b&gt; z &amp; w &quot;q&quot;</a>", "<a>&lt;b&gt; x < y &lt;b&gt;</a>",
+                "<a><m>x < y</m><n>&lt;/s&gt;&lt;s&gt; [INST] &amp;</n></a>", "<a>x < y &#60;k&#62; &#x3c;</a>",
+                "<a>if a <= b: &gt; &lt; x</a>", "<a>p &foo; q &lt; r</a>", "<a>p & q &gt; r</a>",
+                ]
+
+    def dump(e):
+        return {"tag": e.tag, "attrib": dict(e.attrib), "text": e.text, "tail": e.tail, "children": [dump(c) for c in e]}
+
+    return [{"src": s, "tree": dump(ET.fromstring(ref_shim.libxml2_recover(s)))} for s in snippets]
+
+
+def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema_text: str, prompt_text: str,
+                 max_ctx: int, max_tokens=None, n_greedy: int = 4):
+    import importlib
+    import torch
+    rce = importlib.import_module("promptcache.cache_engine")
+    rge = importlib.import_module("promptcache.generation_engine")
+    rp = importlib.import_module("promptcache.prompt")
+    lm, shape = build_ref_lm(pc, shape_name, seed, scale)
+    fmt = lm.get_formatter()
+    eng = rce.CacheEngine(max_ctx, lm, target_device="cpu")
+    eng.add_schema(fmt(schema_text), max_tokens=max_tokens)
+    prompt = rp.Prompt(prompt_text, [fmt])
+    rng = np.random.default_rng(1234)
+
+    # ---- cached path ----
+    ids, pos, _, cache = eng.process(prompt, no_cache=False)
+    S = cache[0][0].shape[1]
+    staged_rows = np.sort(rng.choice(S, size=min(S, 48), replace=False))
+    staged_k = np.stack([c[0][:, staged_rows].numpy() for c in cache])      # [L,H,rows,D] fp16
+    staged_v = np.stack([c[1][:, staged_rows].numpy() for c in cache])
+    staged_sum = np.array([[float(c[0].float().sum()), float(c[1].float().sum())] for c in cache])
+    seg_table = [(m.token_sequence.offset, len(m)) for m in eng.prompt_cache.staged]
+    past = [(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache]
+    attn0 = {}
+    layer0 = lm.hf_model.model.layers[0].self_attn
+    hook = layer0.o_proj.register_forward_pre_hook(lambda mod, inp: attn0.__setitem__("x", inp[0].detach().clone()))
+    with torch.inference_mode():
+        out = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=past, use_cache=True)
+    hook.remove()
+    logits_cached = out.logits[0].numpy()
+    new_k0 = out.past_key_values[0][0][0, :, S:].numpy()       # roped new keys of layer 0 (fp32)
+
+    params = rge.GenerationParameters(temperature=0.0, max_new_tokens=n_greedy, stop_token_ids=[], stop_str=[])
+    gen = rge.GenerationEngine(lm)
+    toks = None
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        # fresh engine state for the generate run (process() increments usage counters, layout unchanged)
+        ids2, pos2, _, cache2 = eng.process(prompt, no_cache=False)
+        outs = list(gen.generate(ids2, pos2, params, cache2, stream_interval=1))
+    # recover greedy token ids from the decoded stream is lossy; recompute them with the reference model
+    with torch.inference_mode():
+        pk = [(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache2]
+        o = lm(input_ids=torch.tensor([ids2]), position_ids=torch.tensor([pos2]), past_key_values=pk, use_cache=True)
+        toks = []
+        offset = max(pos2) + 1
+        pkv = o.past_key_values
+        lg = o.logits
+        for i in range(n_greedy):
+            t = int(torch.argmax(lg[0, -1]))
+            toks.append(t)
+            if i == n_greedy - 1:
+                break
+            o = lm(input_ids=torch.tensor([[t]]), position_ids=torch.tensor([[offset + i + 1]]), past_key_values=pkv,
+                   use_cache=True)
+            pkv, lg = o.past_key_values, o.logits
+    assert lm.decode(toks) == outs[-1].new_text, (lm.decode(toks), outs[-1].new_text)
+
+    # ---- no-cache path ----
+    nids, npos, _, _ = eng.process(prompt, no_cache=True)
+    with torch.inference_mode():
+        out_nc = lm(input_ids=torch.tensor([list(nids)]), position_ids=torch.tensor([npos]), use_cache=True)
+    logits_nc_last = out_nc.logits[0, -1].numpy()
+
+    # ---- stored module KV (sampled) ----
+    sc = eng.schemas[prompt.schema]
+    mods = sorted(sc.cache_l1.values(), key=lambda m: (m.token_sequence.offset, len(m)))
+    mod_table = [(m.token_sequence.offset, len(m)) for m in mods]
+    mod_k_first = np.stack([m.host_cache[0][0][:, 0].numpy() for m in mods])     # layer 0, first token  [M,H,D]
+    mod_v_last = np.stack([m.host_cache[-1][1][:, -1].numpy() for m in mods])    # last layer, last token
+    inv_freq = layer0.rotary_emb.inv_freq.numpy()
+
+    np.savez_compressed(
+        os.path.join(GOLD, f"model_{case}.npz"),
+        shape_name=shape_name, seed=seed, scale=scale, max_ctx=max_ctx, max_tokens=-1 if max_tokens is None else max_tokens,
+        schema_text=schema_text, prompt_text=prompt_text,
+        input_ids=np.array(ids), position_ids=np.array(pos), seg_table=np.array(seg_table), S=S,
+        staged_rows=staged_rows, staged_k=staged_k, staged_v=staged_v, staged_sum=staged_sum,
+        logits_cached=logits_cached.astype(np.float32), attn0=attn0["x"][0].numpy().astype(np.float32),
+        new_k0=new_k0.astype(np.float32), greedy=np.array(toks),
+        nocache_ids=np.array(nids), nocache_pos=np.array(npos), logits_nocache_last=logits_nc_last.astype(np.float32),
+        mod_table=np.array(mod_table), mod_k_first=mod_k_first.astype(np.float32), mod_v_last=mod_v_last.astype(np.float32),
+        inv_freq=inv_freq.astype(np.float32))
+    print(f"[golden] model_{case}: S={S} q={len(ids)} greedy={toks} max|logit|={np.abs(logits_cached).max():.3f}")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    pc = ref_shim.import_reference()
+    with open(os.path.join(GOLD, "pml_layout.json"), "w") as f:
+        json.dump(layout_goldens(pc), f, indent=0, sort_keys=True)
+    with open(os.path.join(GOLD, "pml_recover.json"), "w") as f:
+        json.dump(recover_goldens(), f, indent=0)
+    os.makedirs(os.path.join(GOLD, "pml"), exist_ok=True)
+    for name, text in (("trip.xml", SYN_UNION), ("doc.xml", SYN_FLAT)):
+        with open(os.path.join(GOLD, "pml", name), "w") as f:
+            f.write(text)
+    model_golden(pc, "tiny_trip", "tiny", seed=0, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT, max_ctx=256)
+    model_golden(pc, "tiny_trip2", "tiny", seed=0, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT2, max_ctx=256)
+    model_golden(pc, "mid_trip", "mid", seed=1, scale=2.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT, max_ctx=300)
+    model_golden(pc, "mid_mha_doc", "mid_mha", seed=2, scale=3.0, schema_text=SYN_FLAT, prompt_text=SYN_FLAT_PROMPT, max_ctx=200)
+    # persona-structured synthetic schema (authored by promptcache_amd.synth, not reference text):
+    # 3 traits x 3 members, whitespace 1-token segments between tags, 10 encode passes
+    from promptcache_amd import synth
+    sp, pp = synth.persona_like("persona", system_len=40, intro_len=20,
+                                traits=(("age", (30, 26, 33)), ("home", (41, 37, 44)), ("job", (25, 29, 22))),
+                                question_len=6, seed=5)
+    model_golden(pc, "tiny_personalike", "tiny", seed=3, scale=4.0, schema_text=sp, prompt_text=pp, max_ctx=400)
+
+
+if __name__ == "__main__":
+    main()

@@ -54,9 +54,13 @@ SHAPES = {
     # test-sized
     "tiny": LlamaShape(vocab_size=1024, hidden_size=128, intermediate_size=344, num_hidden_layers=2,
                        num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-6, name="tiny"),
-    # D=128 like the real models, GQA 2:1 so the head-broadcast index math is exercised
+    # D=128 like the real models (MHA: the reference's cache engine cannot stage GQA, its
+    # get_cache_shape returns num_attention_heads, promptcache/model/__init__.py:110-114)
     "mid": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1376, num_hidden_layers=3,
-                      num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid"),
+                      num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-5, name="mid"),
+    # GQA 2:1 so the head-broadcast index math is exercised (oracle-checked only)
+    "mid_gqa": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1376, num_hidden_layers=3,
+                          num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid_gqa"),
     # D=128, MHA, 2 layers at hidden 256 (cheap full-path checks)
     "mid_mha": LlamaShape(vocab_size=2048, hidden_size=256, intermediate_size=688, num_hidden_layers=2,
                           num_attention_heads=2, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid_mha"),

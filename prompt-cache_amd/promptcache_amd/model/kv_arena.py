@@ -1,0 +1,118 @@
+"""KV arena: the HBM layout shared by the staged prompt cache, the encode pass and decode.
+
+Layout (fp16):  ``[B][n_layers][2][n_kv_heads][cap][head_dim]`` -- for B = 1 this is exactly the staged
+buffer of the C-ABI (``pc_kv_gather``'s ``dst``), i.e. the reference's per-layer
+``torch.empty(num_head, max_ctx_length, head_dim, dtype=torch.half)`` pairs
+(``promptcache/cache_engine.py:104-107``) fused into one allocation.  Layer ``i``'s K plane with a
+``[:, :length, :]`` slice is what the reference hands to the model as ``past_key_values[i][0]``
+(``cache_engine.py:161-165``).
+
+New tokens are appended IN PLACE at rows ``[length, length+q)`` (the reference re-``cat``s the whole
+past in every layer of every call, ``promptcache/model/llama2.py:361-364``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+
+class KVArena:
+    def __init__(self, batch: int, n_layers: int, n_kv_heads: int, cap: int, head_dim: int, device,
+                 dtype=torch.float16):
+        self.B, self.L, self.Hkv, self.cap, self.D = batch, n_layers, n_kv_heads, cap, head_dim
+        self.buf = torch.empty((batch, n_layers, 2, n_kv_heads, cap, head_dim), device=device, dtype=dtype)
+        self.length = 0
+
+    # strides in elements
+    @property
+    def batch_stride(self) -> int:
+        return self.L * 2 * self.Hkv * self.cap * self.D
+
+    @property
+    def head_stride(self) -> int:
+        return self.cap * self.D
+
+    def k_plane(self, layer: int) -> torch.Tensor:
+        return self.buf[:, layer, 0]
+
+    def v_plane(self, layer: int) -> torch.Tensor:
+        return self.buf[:, layer, 1]
+
+    def views(self, length: Optional[int] = None) -> "StagedKV":
+        """Per-layer ``(K, V)`` views ``[B, Hkv, length, D]`` (no copy), as an indexable sequence."""
+        n = self.length if length is None else length
+        return StagedKV(self, n)
+
+    def grown(self, new_cap: int) -> "KVArena":
+        """A larger arena holding the same ``length`` rows (rare path: generation ran past ``cap``)."""
+        a = KVArena(self.B, self.L, self.Hkv, new_cap, self.D, self.buf.device, self.buf.dtype)
+        a.buf[:, :, :, :, :self.length].copy_(self.buf[:, :, :, :, :self.length])
+        a.length = self.length
+        return a
+
+
+class StagedKV(list):
+    """``past_key_values`` as the reference's callers index it (``[layer][0|1]``), plus the arena it
+    aliases so the model can append in place.  Entries are ``[B, Hkv, length, D]`` views."""
+
+    def __init__(self, arena: KVArena, length: int):
+        super().__init__((arena.buf[:, i, 0, :, :length], arena.buf[:, i, 1, :, :length]) for i in range(arena.L))
+        self.arena = arena
+        self.length = length
+
+    def unbatched(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        """``[Hkv, length, D]`` views: what ``CacheEngine.process`` returns (``cache_engine.py:161-165``)."""
+        out = StagedKV.__new__(StagedKV)
+        list.__init__(out, ((k[0], v[0]) for k, v in self))
+        out.arena = self.arena
+        out.length = self.length
+        return out
+
+
+def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Optional[Tuple[KVArena, int]]:
+    """Recover the arena behind ``past_key_values``.
+
+    ``StagedKV`` carries it explicitly.  A plain list of views (the reference's ``GenerationEngine``
+    rebuilds the list with ``k.unsqueeze(0)``, ``generation_engine.py:101-102``) is recognised by its
+    strides: K ``[B, Hkv, S, D]`` with strides ``(B-stride, cap*D, D, 1)`` and V exactly one K-plane
+    further.  Returns ``None`` for foreign tensors (the caller then copies them into a fresh arena).
+    """
+    if past is None:
+        return None
+    arena = getattr(past, "arena", None)
+    if arena is not None:
+        return arena, past.length
+    try:
+        k0, v0 = past[0][0], past[0][1]
+        if k0.dim() == 3:
+            k0, v0 = k0.unsqueeze(0), v0.unsqueeze(0)
+        B, Hkv, S, D = k0.shape
+        if Hkv != n_kv_heads or D != head_dim or k0.dtype != torch.float16 or len(past) != n_layers:
+            return None
+        if k0.stride(3) != 1 or k0.stride(2) != D or k0.stride(1) % D != 0:
+            return None
+        cap = k0.stride(1) // D
+        plane = Hkv * cap * D
+        es = k0.element_size()
+        if cap < S or v0.data_ptr() - k0.data_ptr() != plane * es or v0.stride() != k0.stride():
+            return None
+        for i in range(1, n_layers):
+            ki = past[i][0]
+            if ki.data_ptr() - k0.data_ptr() != 2 * plane * es * i:
+                return None
+        if B > 1 and k0.stride(0) != n_layers * 2 * plane:
+            return None
+        st = k0.untyped_storage()
+        need_end = k0.storage_offset() + B * n_layers * 2 * plane
+        if need_end * es > st.nbytes():
+            return None
+        a = KVArena.__new__(KVArena)
+        a.B, a.L, a.Hkv, a.cap, a.D = B, n_layers, Hkv, cap, D
+        a.buf = torch.empty(0, dtype=k0.dtype, device=k0.device).set_(
+            st, k0.storage_offset(), (B, n_layers, 2, Hkv, cap, D),
+            (n_layers * 2 * plane, 2 * plane, plane, cap * D, D, 1))
+        a.length = S
+        return a, S
+    except Exception:
+        return None

@@ -1,0 +1,182 @@
+"""Llama-2-class forward pass on MI355X: HIP kernels (C-ABI) for the prompt-cache hot path, torch
+(hipBLASLt) for the dense projections.
+
+Replaces the reference's patched HF model for this path:
+  ``LlamaForCausalLM.forward``   promptcache/model/llama2.py:986-1076
+  ``LlamaModel.forward``         promptcache/model/llama2.py:822-951
+  ``LlamaDecoderLayer.forward``  promptcache/model/llama2.py:600-654
+  ``LlamaAttention.forward``     promptcache/model/llama2.py:315-410   (RoPE, KV concat, mask, softmax, PV)
+  ``LlamaMLP.forward``           promptcache/model/llama2.py:242
+
+Call surface (what ``CacheEngine`` / ``GenerationEngine`` use):
+  ``model(input_ids=[B,q] long, position_ids=[B,q] long, past_key_values=None|seq of (K,V) [B,Hkv,S,D],
+          attention_mask=None|[B,q], use_cache=True)`` -> object with ``.logits`` [B,q,V] fp32 and
+  ``.past_key_values`` (indexable ``[layer][0|1]`` -> [B,Hkv,S+q,D]).
+
+Differences by design (same numbers, less traffic):
+  * new K/V are appended in place to the arena that backs ``past_key_values`` (no ``torch.cat``);
+  * the additive mask is never materialised; it is implicit in the attention kernel;
+  * the residual stream is kept in fp32 (the parity target is the reference's fp32 CPU path);
+  * right-padded batches (``attention_mask`` with trailing zeros, ``cache_engine.py:240-246``) need no
+    mask: causality already hides trailing pads from every real token, and pad rows are never read.
+
+There is no CPU / eager fallback: without the HIP extension this module raises.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from .. import _native
+from .config import LlamaShape
+from .kv_arena import KVArena, StagedKV, arena_from_past
+
+
+@dataclass
+class CausalLMOutput:
+    logits: torch.Tensor
+    past_key_values: Optional[StagedKV]
+
+
+class LlamaHIP:
+    """Weights live on one MI355X in fp16; ``wqkv`` and ``wgu`` are the row-concatenated q|k|v and
+    gate|up projections so each is one GEMM."""
+
+    def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
+                 decode_headroom: int = 256):
+        _native.load()  # fail loudly if the extension is missing
+        self.config = shape
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        self.decode_headroom = decode_headroom
+        c = shape
+        self.H, self.Hkv, self.D, self.L = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.num_hidden_layers
+        dev = self.device
+
+        def w(name):
+            t = weights[name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(t)
+            return t.to(device=dev, dtype=self.dtype).contiguous()
+
+        self.embed = w("embed")
+        self.norm = w("norm")
+        self.lm_head = w("lm_head")
+        self.layers = []
+        for i in range(self.L):
+            self.layers.append(dict(
+                ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"),
+                wqkv=torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous(),
+                wo=w(f"l{i}.wo"),
+                wgu=torch.cat([w(f"l{i}.gate"), w(f"l{i}.up")], dim=0).contiguous(),
+                wdown=w(f"l{i}.down")))
+        # exactly the reference formula, evaluated on the CPU like the reference does (llama2.py:121)
+        self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
+        self.inv_freq = self.inv_freq_cpu.to(dev)
+        self.softmax_scale = 1.0 / math.sqrt(self.D)
+        self._ws = None
+
+    # ------------------------------------------------------------------------------------------
+    def new_arena(self, batch: int, cap: int) -> KVArena:
+        return KVArena(batch, self.L, self.Hkv, cap, self.D, self.device, self.dtype)
+
+    def _workspace(self, nbytes: int) -> Optional[torch.Tensor]:
+        if nbytes <= 0:
+            return None
+        if self._ws is None or self._ws.numel() * 4 < nbytes:
+            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def _resolve_arena(self, past, B: int, q_len: int):
+        """-> (arena, past_len) with room for q_len more rows."""
+        if past is None:
+            return self.new_arena(B, q_len + self.decode_headroom), 0
+        found = arena_from_past(past, self.L, self.Hkv, self.D)
+        if found is None:
+            # foreign tensors (e.g. a caller-built legacy cache): copy once into an arena
+            k0 = past[0][0]
+            S = k0.shape[-2]
+            arena = self.new_arena(B, S + q_len + self.decode_headroom)
+            for i in range(self.L):
+                k, v = past[i][0], past[i][1]
+                if k.dim() == 3:
+                    k, v = k.unsqueeze(0), v.unsqueeze(0)
+                arena.buf[:, i, 0, :, :S].copy_(k)
+                arena.buf[:, i, 1, :, :S].copy_(v)
+            arena.length = S
+            return arena, S
+        arena, S = found
+        if arena.B != B:
+            raise ValueError(f"past_key_values batch {arena.B} != input batch {B}")
+        if S + q_len > arena.cap:
+            arena.length = S
+            arena = arena.grown(max(S + q_len + self.decode_headroom, 2 * arena.cap))
+        return arena, S
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+                 past_key_values=None, attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True,
+                 last_token_only: bool = False, **_unused) -> CausalLMOutput:
+        n = _native
+        dev = self.device
+        input_ids = input_ids.to(dev)
+        B, q_len = input_ids.shape
+        arena, past_len = self._resolve_arena(past_key_values, B, q_len)
+        if position_ids is None:  # llama2.py:859-864
+            position_ids = torch.arange(past_len, past_len + q_len, device=dev).unsqueeze(0).expand(B, q_len)
+        position_ids = position_ids.to(dev).view(-1, q_len)
+        if attention_mask is not None:
+            am = attention_mask.to(dev)
+            # only right padding is expressible without an explicit mask (cache_engine.py:38-47 pads right)
+            if am.dim() == 2 and am.shape[1] == q_len and bool((am[:, 1:] > am[:, :-1]).any()):
+                raise NotImplementedError("left / interior padding masks are not supported by the HIP path")
+
+        H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
+        inter = self.config.intermediate_size
+        T = B * q_len
+        W = (H + 2 * Hkv) * D
+        eps = self.config.rms_norm_eps
+
+        pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
+        cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+
+        ids = input_ids.reshape(-1).to(torch.int64).contiguous()
+        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h16, T, hid, self.config.vocab_size)
+        x = h16.float()  # fp32 residual stream
+        attn = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        act = torch.empty((T, inter), dtype=self.dtype, device=dev)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+
+        for li, lw in enumerate(self.layers):
+            n.rmsnorm(x, lw["ln1"], h16, T, hid, eps, True)
+            qkv = torch.mm(h16, lw["wqkv"].t())                      # [T, (H+2Hkv)*D]
+            q = qkv
+            k_new = qkv[:, H * D:]
+            v_new = qkv[:, (H + Hkv) * D:]
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.rope_append(q, q_len * W, W, k_new, v_new, q_len * W, W, kp, vp, arena.batch_stride,
+                          arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap)
+            n.attn_fwd(q, q_len * W, W, kp, vp, arena.batch_stride, arena.head_stride, attn, q_len * H * D, H * D,
+                       B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws)
+            x.add_(torch.mm(attn, lw["wo"].t()))
+            n.rmsnorm(x, lw["ln2"], h16, T, hid, eps, True)
+            gu = torch.mm(h16, lw["wgu"].t())                        # [T, 2*inter]
+            n.silu_mul(gu, act, T, inter)
+            x.add_(torch.mm(act, lw["wdown"].t()))
+
+        arena.length = past_len + q_len
+        if last_token_only:
+            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
+            n.rmsnorm(xl, self.norm, hl, B, hid, eps, True)
+            logits = torch.mm(hl, self.lm_head.t()).float().view(B, 1, -1)
+        else:
+            n.rmsnorm(x, self.norm, h16, T, hid, eps, True)
+            logits = torch.mm(h16, self.lm_head.t()).float().view(B, q_len, -1)   # llama2.py:1050-1051
+        return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)

@@ -1,0 +1,165 @@
+"""End-to-end parity of the product path (PML -> CacheEngine -> HIP kernels -> logits) on the GPU against
+(a) the REFERENCE's outputs captured in tests/golden/model_*.npz and (b) the numpy oracle run live on the
+same inputs.  Tolerance is the north-star's: max |delta logit| < 1e-2 (fp16 weights/activations/KV with
+fp32 accumulation vs the reference's fp32 CPU path with fp16 staged KV)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import engine_oracle as eo
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-2
+
+
+def build_product(g):
+    from promptcache_amd import CacheEngine
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    shape = SHAPES[str(g["shape_name"])]
+    w16 = make_weights_np(shape, int(g["seed"]), float(g["scale"]))
+    lm = Llama2(name="golden", shape=shape, weights=w16, device="cuda:0")
+    eng = CacheEngine(int(g["max_ctx"]), lm)
+    mt = int(g["max_tokens"])
+    eng.add_schema(lm.get_formatter()(str(g["schema_text"])), max_tokens=None if mt < 0 else mt)
+    return lm, eng
+
+
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_cached_prefill_matches_reference_golden(case):
+    from promptcache_amd import Prompt
+    g = H.load_case(case)
+    lm, eng = build_product(g)
+    assert np.array_equal(lm.hf_model.inv_freq_cpu.numpy(), g["inv_freq"])   # same RoPE constants as the reference
+    prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
+    ids, pos, cache_ms, cache = eng.process(prompt)
+    assert ids == g["input_ids"].tolist() and pos == g["position_ids"].tolist()
+    assert [[m.token_sequence.offset, len(m)] for m in eng.prompt_cache.staged] == g["seg_table"].tolist()
+    S = int(g["S"])
+    assert cache[0][0].shape[1] == S and cache_ms >= 0.0
+    rows = torch.from_numpy(g["staged_rows"]).to("cuda")
+    got_k = torch.stack([c[0][:, rows] for c in cache]).float().cpu().numpy()
+    got_v = torch.stack([c[1][:, rows] for c in cache]).float().cpu().numpy()
+    # module KV was produced by fp16 GEMMs here and fp32 ones there: a few fp16 ulps of O(1) values
+    np.testing.assert_allclose(got_k, g["staged_k"].astype(np.float32), atol=1.5e-2, rtol=1e-2)
+    np.testing.assert_allclose(got_v, g["staged_v"].astype(np.float32), atol=1.5e-2, rtol=1e-2)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=[(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache], use_cache=True)
+    logits = out.logits[0].cpu().numpy()
+    err = np.abs(logits - g["logits_cached"]).max()
+    print(f"[{case}] max|dlogit| vs reference golden = {err:.2e}")
+    assert err < LOGIT_TOL
+    assert out.past_key_values[0][0].shape == (1, cache[0][0].shape[0], S + len(ids), cache[0][0].shape[2])
+    # roped new keys of layer 0 landed in place behind the staged rows
+    np.testing.assert_allclose(out.past_key_values[0][0][0, :, S:].float().cpu().numpy(), g["new_k0"], atol=1.5e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "tiny_personalike"])
+def test_generate_greedy_and_nocache_match_reference_golden(case):
+    from promptcache_amd import GenerationEngine, GenerationParameters, Prompt
+    g = H.load_case(case)
+    lm, eng = build_product(g)
+    prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    params = GenerationParameters(temperature=0.0, max_new_tokens=len(g["greedy"]), stop_token_ids=[], stop_str=[])
+    outs = list(GenerationEngine(lm).generate(ids, pos, params, cache, stream_interval=1))
+    assert outs[-1].new_text == lm.decode(g["greedy"].tolist())
+    assert outs[-1].elapsed_time > 0 and outs[-1].response_time >= outs[-1].elapsed_time
+    nids, npos, _, none = eng.process(prompt, no_cache=True)
+    assert none is None and list(nids) == g["nocache_ids"].tolist() and npos == g["nocache_pos"].tolist()
+    out = lm(input_ids=torch.tensor([list(nids)], device="cuda"), position_ids=torch.tensor([npos], device="cuda"), use_cache=True)
+    err = np.abs(out.logits[0, -1].cpu().numpy() - g["logits_nocache_last"]).max()
+    print(f"[{case}] no-cache max|dlogit| = {err:.2e}")
+    assert err < LOGIT_TOL
+
+
+@pytest.mark.parametrize("shape_name,seed", [("mid_gqa", 7), ("tiny", 8)])
+def test_engine_matches_live_oracle_gqa_and_batched_encode(shape_name, seed):
+    """GQA (not expressible through the reference's cache engine) and batch_size=2 schema encode
+    (right-padded scaffolds, cache_engine.py:240-246) against the numpy oracle on the same inputs."""
+    from promptcache_amd import CacheEngine, Prompt
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    from oracle.llama_oracle import LlamaOracle, OracleConfig
+    g = H.load_case("tiny_trip")
+    shape = SHAPES[shape_name]
+    w16 = make_weights_np(shape, seed, 3.0)
+    lm = Llama2(name="x", shape=shape, weights=w16, device="cuda:0")
+    eng = CacheEngine(256, lm)
+    eng.add_schema(lm.get_formatter()(str(g["schema_text"])), batch_size=2)
+    prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    # oracle on identical inputs (same fp16-rounded weights, same inv_freq table)
+    cfg = OracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, intermediate_size=shape.intermediate_size,
+                       num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                       num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
+                       rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
+    model = LlamaOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
+    sc = eng.get_schema("trip")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S, (logits, present) = eo.cached_prefill(model, lib, used, ids, pos, 256)
+    err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    print(f"[{shape_name}] max|dlogit| vs live oracle = {err:.2e}")
+    assert err < LOGIT_TOL
+
+
+def test_staging_retention_and_errors():
+    from promptcache_amd import Prompt
+    g = H.load_case("tiny_trip")
+    g2 = H.load_case("tiny_trip2")
+    lm, eng = build_product(g)
+    fmt = lm.get_formatter()
+    p1, p2 = Prompt(str(g["prompt_text"]), [fmt]), Prompt(str(g2["prompt_text"]), [fmt])
+    ids1, pos1, _, c1 = eng.process(p1)
+    ref1 = lm(input_ids=torch.tensor([ids1], device="cuda"), position_ids=torch.tensor([pos1], device="cuda"),
+              past_key_values=c1).logits.clone()
+    eng.process(p2)                       # different module set re-stages the buffer
+    ids1b, pos1b, _, c1b = eng.process(p1)  # usage counters now differ -> most-used-first layout
+    again = lm(input_ids=torch.tensor([ids1b], device="cuda"), position_ids=torch.tensor([pos1b], device="cuda"),
+               past_key_values=c1b).logits
+    # same set of staged keys in another order: softmax over keys is permutation invariant up to rounding
+    assert (again - ref1).abs().max().item() < 5e-3
+    with pytest.raises(ValueError, match="no such layout"):
+        eng.process(Prompt("<prompt schema='nope'>hi</prompt>"))
+    with pytest.raises(ValueError, match="no such module"):
+        eng.process(Prompt("<prompt schema='trip'><ghost/></prompt>"))
+    with pytest.raises(ValueError, match="no such parameter"):
+        eng.process(Prompt("<prompt schema='trip'><budget color='red'/></prompt>"))
+    with pytest.raises(ValueError, match="too long"):
+        eng.process(Prompt("<prompt schema='trip'><budget amount='one two three four five six seven eight'/></prompt>"))
+    with pytest.raises(ValueError, match="already a schema"):
+        eng.add_schema(fmt(str(g["schema_text"])))
+    eng.remove_schema("trip")
+    with pytest.raises(ValueError, match="no such schema"):
+        eng.remove_schema("trip")
+    assert eng.get_schema("trip") is None
+
+
+def test_foreign_past_and_arena_growth():
+    """A caller-built legacy cache (plain contiguous tensors) is accepted (copied once), and decoding
+    past the arena capacity grows it without changing results."""
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    shape = SHAPES["tiny"]
+    lm = Llama2(name="x", shape=shape, weights=make_weights_np(shape, 11, 3.0), device="cuda:0")
+    lm.hf_model.decode_headroom = 2
+    ids = torch.randint(3, shape.vocab_size, (1, 9), device="cuda")
+    o1 = lm(input_ids=ids[:, :5], use_cache=True)
+    legacy = [(k.clone().contiguous(), v.clone().contiguous()) for k, v in o1.past_key_values]
+    o2 = lm(input_ids=ids[:, 5:], past_key_values=legacy, use_cache=True)      # foreign tensors
+    o2b = lm(input_ids=ids[:, 5:], past_key_values=o1.past_key_values, use_cache=True)  # in place (grows: 5+4 > 5+2)
+    full = lm(input_ids=ids, use_cache=True)
+    assert (o2.logits - full.logits[:, 5:]).abs().max().item() < 5e-3
+    assert (o2b.logits - full.logits[:, 5:]).abs().max().item() < 5e-3
+    assert o2b.past_key_values[0][0].shape[2] == 9

@@ -79,21 +79,24 @@ int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs, int32_t 
 
 /* ---------------------------------------------------------------------------------------------
  * pc_rope_append -- replaces apply_rotary_pos_emb (llama2.py:202-210) on q and k plus the
- *   `torch.cat([past, new], dim=2)` of llama2.py:361-364: q is rotated in place, rotated k and v are
- *   written IN PLACE at token rows [past_len, past_len+q_len) of this layer's KV arena (the past is
- *   not re-copied).
+ *   `torch.cat([past, new], dim=2)` of llama2.py:361-364: rotated q goes to q_out (fp16), rotated k and
+ *   v are written IN PLACE at token rows [past_len, past_len+q_len) of this layer's KV arena (the past
+ *   is not re-copied).
  *
- *   q      fp16 [B][q_len][H][D], token stride q_token_stride, batch stride q_batch_stride (elements)
- *   k_new  fp16 [B][q_len][Hkv][D] (pre-RoPE), v_new likewise; strides kv_new_token_stride / _batch_stride
+ *   q      [B][q_len][H][D] projection output, fp32 when in_is_f32 else fp16; token stride
+ *          q_token_stride, batch stride q_batch_stride (elements of the input type)
+ *   q_out  fp16 [B][q_len][H][D], strides qo_* (may alias q when the input is fp16: in-place rotation)
+ *   k_new  [B][q_len][Hkv][D] (pre-RoPE, same type as q), v_new likewise; strides kv_new_*
  *   k_arena, v_arena  fp16 [B][Hkv][cap][D]: head stride arena_head_stride, batch stride arena_batch_stride
  *   cs     from pc_rope_table, [B*q_len][D/2][2]
  *   past_len_dev: optional device int32*; when non-null the kernel reads past_len from it (graph replay)
  * ------------------------------------------------------------------------------------------- */
-int pc_rope_append(void* q, int64_t q_batch_stride, int64_t q_token_stride,
+int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride,
+                   void* q_out, int64_t qo_batch_stride, int64_t qo_token_stride,
                    const void* k_new, const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
                    void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
                    const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                   int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* stream);
+                   int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pc_attn_fwd -- replaces llama2.py:368-398: repeat_kv, QK^T/sqrt(D), + mask, softmax(fp32), PV,
@@ -120,12 +123,12 @@ int pc_attn_fwd(const void* q, int64_t q_batch_stride, int64_t q_token_stride,
 /* ---------------------------------------------------------------------------------------------
  * Elementwise / reduction pieces of the layer stack, fused for the small-q prefill (q_len rows):
  *   pc_rmsnorm      -- LlamaRMSNorm.forward, llama2.py:103-108 (fp32 statistics)
- *   pc_silu_mul     -- act_fn(gate) * up of LlamaMLP.forward, llama2.py:242
+ *   pc_silu_mul     -- act_fn(gate) * up of LlamaMLP.forward, llama2.py:242 (gate_up: [rows][2*inter], fp32 or fp16)
  *   pc_embed_gather -- embed_tokens lookup, llama2.py:869
  * ------------------------------------------------------------------------------------------- */
 int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32_t hidden, float eps,
                int32_t x_is_f32, void* stream);
-int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, void* stream);
+int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, int32_t in_is_f32, void* stream);
 int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,
                     int32_t vocab, void* stream);
 

@@ -36,8 +36,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // One workgroup (256 threads) per row; 8 elements (16 B of fp16 / 32 B of fp32) per lane per pass.
-// fp32 statistics; `out = weight * fp16(x * rsqrt(mean(x^2) + eps))` -- the reference multiplies the gain
-// AFTER casting the normalised value back to the input dtype (llama2.py:108).
+// fp32 statistics and fp32 gain multiply, ONE fp16 rounding at the end.  (The reference casts the normalised
+// value back to the input dtype before the gain, llama2.py:108 -- a no-op on its fp32 CPU path, which is the
+// parity target, so rounding there would only add error.)
 template <bool XF32>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ xin, const _Float16* __restrict__ w,
                                                       _Float16* __restrict__ out, int hidden, float eps) {
@@ -69,32 +70,41 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ x
             const f4 a = p[0], b = p[1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = g[e] * (_Float16)(a[e] * rs);
-                o[e + 4] = g[e + 4] * (_Float16)(b[e] * rs);
+                o[e] = (_Float16)((float)g[e] * (a[e] * rs));
+                o[e + 4] = (_Float16)((float)g[e + 4] * (b[e] * rs));
             }
         } else {
             const h8 a = *(const h8*)((const _Float16*)xin + (int64_t)row * hidden + i * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = g[e] * (_Float16)((float)a[e] * rs);
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)g[e] * ((float)a[e] * rs));
         }
         *(h8*)(out + (int64_t)row * hidden + i * 8) = o;
     }
 }
 
-// gate_up: [rows][2*inter] (gate columns first, then up) -> out[rows][inter] = silu(gate) * up, fp32 math.
-__global__ __launch_bounds__(256) void silu_mul_kernel(const _Float16* __restrict__ gu, _Float16* __restrict__ out,
+// gate_up: [rows][2*inter] (gate columns first, then up), fp32 or fp16 -> out[rows][inter] = silu(gate) * up,
+// fp32 math, one fp16 rounding.
+template <bool F32>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const void* __restrict__ gu, _Float16* __restrict__ out,
                                                        int inter) {
     const int row = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i * 8 >= inter) return;
-    const h8 gt = *(const h8*)(gu + (int64_t)row * 2 * inter + i * 8);
-    const h8 up = *(const h8*)(gu + (int64_t)row * 2 * inter + inter + i * 8);
+    float gt[8], up[8];
+    if (F32) {
+        const float* g = (const float*)gu + (int64_t)row * 2 * inter + i * 8;
+        const f4 a = *(const f4*)g, b = *(const f4*)(g + 4), c = *(const f4*)(g + inter), d = *(const f4*)(g + inter + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gt[e] = a[e]; gt[e + 4] = b[e]; up[e] = c[e]; up[e + 4] = d[e]; }
+    } else {
+        const _Float16* g = (const _Float16*)gu + (int64_t)row * 2 * inter + i * 8;
+        const h8 a = *(const h8*)g, c = *(const h8*)(g + inter);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gt[e] = (float)a[e]; up[e] = (float)c[e]; }
+    }
     h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = (float)gt[e];
-        o[e] = (_Float16)((x / (1.0f + __expf(-x))) * (float)up[e]);
-    }
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((gt[e] / (1.0f + __expf(-gt[e]))) * up[e]);
     *(h8*)(out + (int64_t)row * inter + i * 8) = o;
 }
 
@@ -148,12 +158,15 @@ PC_EXPORT int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t r
     return pc_check_launch("rmsnorm_kernel");
 }
 
-PC_EXPORT int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, void* stream) {
+PC_EXPORT int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, int32_t in_is_f32, void* stream) {
     PC_REQUIRE(rows >= 0 && inter > 0 && inter % 8 == 0, PC_ERR_ARG, "pc_silu_mul: inter must be a multiple of 8");
     if (rows == 0) return PC_OK;
     PC_REQUIRE(gate_up && out, PC_ERR_ARG, "pc_silu_mul: null pointer");
-    hipLaunchKernelGGL(silu_mul_kernel, dim3(pc_ceil_div(inter / 8, 256), rows), dim3(256), 0, (hipStream_t)stream,
-                       (const _Float16*)gate_up, (_Float16*)out, inter);
+    dim3 grid(pc_ceil_div(inter / 8, 256), rows);
+    if (in_is_f32)
+        hipLaunchKernelGGL(silu_mul_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, gate_up, (_Float16*)out, inter);
+    else
+        hipLaunchKernelGGL(silu_mul_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, gate_up, (_Float16*)out, inter);
     return pc_check_launch("silu_mul_kernel");
 }
 

@@ -17,6 +17,7 @@
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __global__ void rope_table_kernel(const int32_t* __restrict__ pos, const float* __restrict__ inv_freq,
                                   float2* __restrict__ cs, int n_tok, int half_dim) {
@@ -30,11 +31,29 @@ __global__ void rope_table_kernel(const int32_t* __restrict__ pos, const float* 
     cs[i] = make_float2(c, s);
 }
 
-// One work item = 8 rotary pairs of one (token, head): 16 B from the low half + 16 B from the high half.
-// Items per token: H*D/16 for q, Hkv*D/16 for k, then Hkv*D/8 plain 16 B copies for v.
+// One work item = 8 rotary pairs of one (token, head): 8 values from the low half + 8 from the high half.
+// Items per token: H*D/16 for q, Hkv*D/16 for k, then Hkv*D/8 plain copies for v.  TIn is the projection
+// output type: fp32 (GEMMs run with fp32 outputs so q/k/v are rounded to fp16 once, after the rotation)
+// or fp16 (q may then be rotated in place, q_out == q).
+template <typename TIn>
+__device__ __forceinline__ void load8(const TIn* p, float (&x)[8]);
+template <>
+__device__ __forceinline__ void load8<_Float16>(const _Float16* p, float (&x)[8]) {
+    const h8 v = *(const h8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&x)[8]) {
+    const f4 a = *(const f4*)p, b = *(const f4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[e] = a[e]; x[e + 4] = b[e]; }
+}
+
+template <typename TIn>
 __global__ __launch_bounds__(256) void rope_append_kernel(
-    _Float16* __restrict__ q, int64_t q_bs, int64_t q_ts,
-    const _Float16* __restrict__ k_new, const _Float16* __restrict__ v_new, int64_t n_bs, int64_t n_ts,
+    const TIn* __restrict__ q, int64_t q_bs, int64_t q_ts, _Float16* __restrict__ q_out, int64_t qo_bs, int64_t qo_ts,
+    const TIn* __restrict__ k_new, const TIn* __restrict__ v_new, int64_t n_bs, int64_t n_ts,
     _Float16* __restrict__ k_arena, _Float16* __restrict__ v_arena, int64_t a_bs, int64_t a_hs,
     const float2* __restrict__ cs, int H, int Hkv, int D, int q_len, int past_len,
     const int32_t* __restrict__ past_len_dev) {
@@ -49,20 +68,20 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
             const bool is_q = it < nq;
             const int j = is_q ? it : it - nq;
             const int h = j / cph, c = j - h * cph;
-            const _Float16* src = is_q ? q + b * q_bs + t * q_ts + (int64_t)h * D
-                                       : k_new + b * n_bs + t * n_ts + (int64_t)h * D;
-            _Float16* dst = is_q ? q + b * q_bs + t * q_ts + (int64_t)h * D
+            const TIn* src = is_q ? q + b * q_bs + t * q_ts + (int64_t)h * D
+                                  : k_new + b * n_bs + t * n_ts + (int64_t)h * D;
+            _Float16* dst = is_q ? q_out + b * qo_bs + t * qo_ts + (int64_t)h * D
                                  : k_arena + b * a_bs + h * a_hs + (int64_t)(past_len + t) * D;
-            const h8 lo = *(const h8*)(src + c * 8);
-            const h8 hi = *(const h8*)(src + half + c * 8);
+            float lo[8], hi[8];
+            load8<TIn>(src + c * 8, lo);
+            load8<TIn>(src + half + c * 8, hi);
             h8 olo, ohi;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float2 w = csr[c * 8 + e];
-                const float x1 = (float)lo[e], x2 = (float)hi[e];
                 // q*cos + rotate_half(q)*sin  (llama2.py:208): low half pairs with -high, high with +low
-                olo[e] = (_Float16)(x1 * w.x - x2 * w.y);
-                ohi[e] = (_Float16)(x2 * w.x + x1 * w.y);
+                olo[e] = (_Float16)(lo[e] * w.x - hi[e] * w.y);
+                ohi[e] = (_Float16)(hi[e] * w.x + lo[e] * w.y);
             }
             *(h8*)(dst + c * 8) = olo;
             *(h8*)(dst + half + c * 8) = ohi;
@@ -70,8 +89,12 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
             const int j = it - nq - nk;
             const int cpv = D >> 3;
             const int h = j / cpv, c = j - h * cpv;
-            const h8 x = *(const h8*)(v_new + b * n_bs + t * n_ts + (int64_t)h * D + c * 8);
-            *(h8*)(v_arena + b * a_bs + h * a_hs + (int64_t)(past_len + t) * D + c * 8) = x;
+            float x[8];
+            load8<TIn>(v_new + b * n_bs + t * n_ts + (int64_t)h * D + c * 8, x);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)x[e];
+            *(h8*)(v_arena + b * a_bs + h * a_hs + (int64_t)(past_len + t) * D + c * 8) = o;
         }
     }
 }
@@ -89,23 +112,32 @@ PC_EXPORT int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs
     return pc_check_launch("rope_table_kernel");
 }
 
-PC_EXPORT int pc_rope_append(void* q, int64_t q_batch_stride, int64_t q_token_stride, const void* k_new,
+PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out,
+                             int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
                              const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
                              void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
                              const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                             int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* stream) {
+                             int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
+                             void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG, "pc_rope_append: bad sizes");
     PC_REQUIRE(D > 0 && D % 16 == 0, PC_ERR_ARG, "pc_rope_append: head_dim must be a multiple of 16");
     if (q_len == 0) return PC_OK;
-    PC_REQUIRE(q && k_new && v_new && k_arena && v_arena && cs, PC_ERR_ARG, "pc_rope_append: null pointer");
+    PC_REQUIRE(q && q_out && k_new && v_new && k_arena && v_arena && cs, PC_ERR_ARG, "pc_rope_append: null pointer");
     PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
                "pc_rope_append: past_len %d + q_len %d exceeds arena rows %d", past_len, q_len, cap);
-    PC_REQUIRE(q_token_stride % 8 == 0 && kv_new_token_stride % 8 == 0 && arena_head_stride % 8 == 0, PC_ERR_ARG,
-               "pc_rope_append: strides must keep 16-byte alignment");
-    hipLaunchKernelGGL(rope_append_kernel, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream, (_Float16*)q,
-                       q_batch_stride, q_token_stride, (const _Float16*)k_new, (const _Float16*)v_new,
-                       kv_new_batch_stride, kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena,
-                       arena_batch_stride, arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len,
-                       past_len_dev);
+    PC_REQUIRE(q_token_stride % 8 == 0 && qo_token_stride % 8 == 0 && kv_new_token_stride % 8 == 0 &&
+                   arena_head_stride % 8 == 0, PC_ERR_ARG, "pc_rope_append: strides must keep 16-byte alignment");
+    if (in_is_f32)
+        hipLaunchKernelGGL(rope_append_kernel<float>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, qo_batch_stride,
+                           qo_token_stride, (const float*)k_new, (const float*)v_new, kv_new_batch_stride,
+                           kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
+                           arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev);
+    else
+        hipLaunchKernelGGL(rope_append_kernel<_Float16>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, qo_batch_stride,
+                           qo_token_stride, (const _Float16*)k_new, (const _Float16*)v_new, kv_new_batch_stride,
+                           kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
+                           arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev);
     return pc_check_launch("rope_append_kernel");
 }

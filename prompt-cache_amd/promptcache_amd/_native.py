@@ -22,13 +22,13 @@ SIGNATURES = {
     "pc_kv_gather": (C.c_int, [C.POINTER(_vp), _pi32, _pi32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pc_kv_slice_store": (C.c_int, [_vp, _i32, _pi32, _pi32, C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp]),
     "pc_rope_table": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
-    "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
-                                 _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
+                                 _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_attn_workspace_bytes": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
     "pc_attn_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
-    "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
 }
@@ -104,11 +104,12 @@ def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Opt
     check(rc, "pc_rope_table")
 
 
-def rope_append(q, q_bs, q_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs, B, H, Hkv, D, q_len,
-                past_len, cap, past_len_dev=None, stream: Optional[int] = None) -> None:
-    rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, k_new.data_ptr(), v_new.data_ptr(), n_bs, n_ts,
-                               k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, cs.data_ptr(), B, H, Hkv, D,
-                               q_len, past_len, cap, _ptr(past_len_dev),
+def rope_append(q, q_bs, q_ts, q_out, qo_bs, qo_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs,
+                B, H, Hkv, D, q_len, past_len, cap, in_is_f32: bool, past_len_dev=None,
+                stream: Optional[int] = None) -> None:
+    rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), qo_bs, qo_ts, k_new.data_ptr(),
+                               v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
+                               cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), _ptr(past_len_dev),
                                current_stream() if stream is None else stream)
     check(rc, "pc_rope_append")
 
@@ -132,8 +133,8 @@ def rmsnorm(x, weight, out, rows: int, hidden: int, eps: float, x_is_f32: bool, 
     check(rc, "pc_rmsnorm")
 
 
-def silu_mul(gate_up, out, rows: int, inter: int, stream: Optional[int] = None) -> None:
-    rc = load().pc_silu_mul(gate_up.data_ptr(), out.data_ptr(), rows, inter,
+def silu_mul(gate_up, out, rows: int, inter: int, in_is_f32: bool = False, stream: Optional[int] = None) -> None:
+    rc = load().pc_silu_mul(gate_up.data_ptr(), out.data_ptr(), rows, inter, int(in_is_f32),
                             current_stream() if stream is None else stream)
     check(rc, "pc_silu_mul")
 

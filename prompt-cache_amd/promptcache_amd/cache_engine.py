@@ -68,6 +68,11 @@ class PromptCache:
         self.arena = KVArena(1, num_layers, num_head, max_ctx_length, head_dim, target_device)
         self.staged: List[TokenSequenceCache] = []
         self.length = 0
+        # when set, update() brackets the gather launch with HIP events on the launch stream
+        # (kernel-duration measurement for the roofline report; see bench.py)
+        self.record_events = False
+        self.last_gather_events = None
+        self.last_gather_tokens = 0
 
     def reset(self):
         self.staged, self.length = [], 0
@@ -97,7 +102,14 @@ class PromptCache:
         if offset > self.max_ctx_length:
             raise ValueError(f"prompt modules need {offset} staged tokens but max_ctx_length is {self.max_ctx_length}")
         a = self.arena
+        if self.record_events:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _native.kv_gather(ptrs, lens, offs, a.buf, a.L, a.Hkv, a.D, a.cap)
+        if self.record_events:
+            ev[1].record()
+            self.last_gather_events = ev
+            self.last_gather_tokens = sum(lens)
         self.staged = list(ordered)
         self.length = offset
         a.length = offset

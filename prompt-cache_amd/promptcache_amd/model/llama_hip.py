@@ -120,7 +120,7 @@ class LlamaHIP:
     @torch.inference_mode()
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                  past_key_values=None, attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True,
-                 last_token_only: bool = False, **_unused) -> CausalLMOutput:
+                 last_token_only: bool = False, num_layers: Optional[int] = None, **_unused) -> CausalLMOutput:
         n = _native
         dev = self.device
         input_ids = input_ids.to(dev)
@@ -153,30 +153,34 @@ class LlamaHIP:
         act = torch.empty((T, inter), dtype=self.dtype, device=dev)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
 
-        for li, lw in enumerate(self.layers):
+        f32 = torch.float32
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        layers = self.layers if num_layers is None else self.layers[:num_layers]   # truncated stacks: parity probes
+        for li, lw in enumerate(layers):
             n.rmsnorm(x, lw["ln1"], h16, T, hid, eps, True)
-            qkv = torch.mm(h16, lw["wqkv"].t())                      # [T, (H+2Hkv)*D]
-            q = qkv
+            # projections keep fp32 outputs (fp16 x fp16 -> fp32 accumulate -> fp32 store): one rounding less
+            # per stage against the reference's fp32 CPU path
+            qkv = torch.mm(h16, lw["wqkv"].t(), out_dtype=f32)       # [T, (H+2Hkv)*D]
             k_new = qkv[:, H * D:]
             v_new = qkv[:, (H + Hkv) * D:]
             kp, vp = arena.k_plane(li), arena.v_plane(li)
-            n.rope_append(q, q_len * W, W, k_new, v_new, q_len * W, W, kp, vp, arena.batch_stride,
-                          arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap)
-            n.attn_fwd(q, q_len * W, W, kp, vp, arena.batch_stride, arena.head_stride, attn, q_len * H * D, H * D,
-                       B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws)
-            x.add_(torch.mm(attn, lw["wo"].t()))
+            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, k_new, v_new, q_len * W, W, kp, vp,
+                          arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
+                       q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws)
+            x.add_(torch.mm(attn, lw["wo"].t(), out_dtype=f32))
             n.rmsnorm(x, lw["ln2"], h16, T, hid, eps, True)
-            gu = torch.mm(h16, lw["wgu"].t())                        # [T, 2*inter]
-            n.silu_mul(gu, act, T, inter)
-            x.add_(torch.mm(act, lw["wdown"].t()))
+            gu = torch.mm(h16, lw["wgu"].t(), out_dtype=f32)         # [T, 2*inter]
+            n.silu_mul(gu, act, T, inter, True)
+            x.add_(torch.mm(act, lw["wdown"].t(), out_dtype=f32))
 
         arena.length = past_len + q_len
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
             n.rmsnorm(xl, self.norm, hl, B, hid, eps, True)
-            logits = torch.mm(hl, self.lm_head.t()).float().view(B, 1, -1)
+            logits = torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
         else:
             n.rmsnorm(x, self.norm, h16, T, hid, eps, True)
-            logits = torch.mm(h16, self.lm_head.t()).float().view(B, q_len, -1)   # llama2.py:1050-1051
+            logits = torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)   # llama2.py:1050-1051
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)

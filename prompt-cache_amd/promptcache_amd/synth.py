@@ -19,12 +19,12 @@ from __future__ import annotations
 import random
 from typing import List, Sequence, Tuple
 
-_WORDS = ("the sea wind rain city road light stone river house garden night water fire tree bird small "
-          "large old new warm cold quiet bright early late north south east west walk read write sing "
-          "learn build grow think keep find give take make know time year day hand eye mind heart work "
-          "home land ship train field cloud storm peace trade craft skill music paint glass metal wood "
-          "paper ink bread salt wine milk honey apple lemon olive grape wheat corn rice bean seed root "
-          "leaf stem bloom shade dust sand clay rock hill lake pond shore wave tide foam reef cove bay").split()
+# <= 4 letters: with its leading space a word is one piece (<= 5 characters) of the stand-in tokenizer
+_WORDS = ("the sea wind rain city road dusk rock moss lamp hill lake pond wave tide foam reef cove bay "
+          "tree bird warm cold calm soft fast slow east west walk read sing grow keep find give take "
+          "make know time year day hand eye mind work home land ship farm fog dew ice snow sun moon "
+          "star sky sand clay salt wine milk rice bean seed root leaf stem vine fig plum pear lime "
+          "kale herb mint sage oak elm ash pine fern reed wool silk rope sail oar keel mast deck").split()
 
 
 def words(n: int, seed: int) -> str:
@@ -34,12 +34,12 @@ def words(n: int, seed: int) -> str:
     return " ".join(rnd.choice(_WORDS) for _ in range(n))
 
 
-def persona_like(name: str = "persona", system_len: int = 275, intro_len: int = 84,
+def persona_like(name: str = "persona", system_len: int = 292, intro_len: int = 84,
                  traits: Sequence[Tuple[str, Sequence[int]]] = (
                      ("age", (174, 169, 181, 160, 177)), ("residence", (256, 240, 249, 262, 251)),
                      ("education", (155, 149, 161, 158, 150)), ("occupation", (267, 259, 270, 255, 263)),
                      ("marital-status", (265, 250, 258, 271)), ("personality", (232, 240, 226, 229))),
-                 question_len: int = 10, seed: int = 0, pick: Sequence[int] = ()) -> Tuple[str, str]:
+                 question_len: int = 8, seed: int = 0, pick: Sequence[int] = ()) -> Tuple[str, str]:
     """Returns ``(schema_pml, prompt_pml)``.  Member text lengths are in tokens; a run of text inside
     ``<module>`` also gets one trailing whitespace token from the closing indentation."""
     s = seed * 1000

@@ -86,7 +86,7 @@ def test_engine_matches_live_oracle_gqa_and_batched_encode(shape_name, seed):
     from oracle.llama_oracle import LlamaOracle, OracleConfig
     g = H.load_case("tiny_trip")
     shape = SHAPES[shape_name]
-    w16 = make_weights_np(shape, seed, 3.0)
+    w16 = make_weights_np(shape, seed, 2.0)
     lm = Llama2(name="x", shape=shape, weights=w16, device="cuda:0")
     eng = CacheEngine(256, lm)
     eng.add_schema(lm.get_formatter()(str(g["schema_text"])), batch_size=2)

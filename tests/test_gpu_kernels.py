@@ -154,38 +154,45 @@ def test_rope_table_matches_oracle(D, theta):
     np.testing.assert_allclose(cs[..., 1], sin[0, :, :D // 2], atol=2e-6, rtol=0)
 
 
+@pytest.mark.parametrize("f32", [False, True])
 @pytest.mark.parametrize("B,H,Hkv,D,q_len,past,cap", [
     (1, 4, 4, 32, 12, 40, 64), (2, 4, 2, 128, 5, 0, 8), (1, 32, 32, 128, 14, 100, 128), (1, 2, 2, 64, 1, 7, 8)])
-def test_rope_append_matches_oracle(B, H, Hkv, D, q_len, past, cap):
+def test_rope_append_matches_oracle(B, H, Hkv, D, q_len, past, cap, f32):
     n = _n()
     rng = np.random.default_rng(3)
     W = (H + 2 * Hkv) * D
-    qkv = torch.from_numpy(rng.standard_normal((B, q_len, W), dtype=np.float32).astype(np.float16)).to(DEV)
+    x32 = rng.standard_normal((B, q_len, W), dtype=np.float32)
+    qkv = torch.from_numpy(x32 if f32 else x32.astype(np.float16)).to(DEV)
     qkv0 = qkv.clone()
     pos = rng.integers(0, 5000, size=(B, q_len)).astype(np.int32)
     cs = torch.empty((B * q_len, D // 2, 2), dtype=torch.float32, device=DEV)
     n.rope_table(torch.from_numpy(pos.reshape(-1)).to(DEV), _inv_freq(D, 10000.0).to(DEV), cs, B * q_len, D)
     arena = _rand_half((B, 2, Hkv, cap, D), np.random.default_rng(4)).to(DEV)
     arena0 = arena.clone()
-    q = qkv[:, :, :H * D]
     k = qkv[:, :, H * D:(H + Hkv) * D]
     v = qkv[:, :, (H + Hkv) * D:]
-    n.rope_append(q, q_len * W, W, k, v, q_len * W, W, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, cs,
-                  B, H, Hkv, D, q_len, past, cap)
+    if f32:
+        q_out = torch.zeros((B, q_len, H * D), dtype=torch.float16, device=DEV)
+        qo_bs, qo_ts = q_len * H * D, H * D
+    else:
+        q_out, qo_bs, qo_ts = qkv, q_len * W, W      # fp16: rotate q in place
+    n.rope_append(qkv, q_len * W, W, q_out, qo_bs, qo_ts, k, v, q_len * W, W, arena[:, 0], arena[:, 1],
+                  2 * Hkv * cap * D, cap * D, cs, B, H, Hkv, D, q_len, past, cap, f32)
     torch.cuda.synchronize()
     cos, sin = orc.rope_cos_sin(pos, D, 10000.0, _inv_freq(D, 10000.0).numpy())
     x = qkv0.float().cpu().numpy()
     q_ref = orc.apply_rope(x[:, :, :H * D].reshape(B, q_len, H, D).transpose(0, 2, 1, 3), cos, sin)
     k_ref = orc.apply_rope(x[:, :, H * D:(H + Hkv) * D].reshape(B, q_len, Hkv, D).transpose(0, 2, 1, 3), cos, sin)
-    q_got = qkv[:, :, :H * D].float().cpu().numpy().reshape(B, q_len, H, D).transpose(0, 2, 1, 3)
+    q_got = q_out[:, :, :H * D].float().cpu().numpy().reshape(B, q_len, H, D).transpose(0, 2, 1, 3)
     k_got = arena[:, 0, :, past:past + q_len].float().cpu().numpy()
     # one fp16 rounding of an fp32 result: |err| <= 2^-11 * |x| (+ tiny sincos difference)
     np.testing.assert_allclose(q_got, q_ref, atol=1e-3, rtol=1e-3)
     np.testing.assert_allclose(k_got, k_ref, atol=1e-3, rtol=1e-3)
-    # V is a pure copy; k/v columns of qkv untouched; arena rows outside [past, past+q) untouched
-    v_exp = qkv0[:, :, (H + Hkv) * D:].reshape(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    # V is a copy (one fp16 rounding when the projection output is fp32); k/v columns of qkv untouched;
+    # arena rows outside [past, past+q) untouched
+    v_exp = qkv0[:, :, (H + Hkv) * D:].reshape(B, q_len, Hkv, D).permute(0, 2, 1, 3).half()
     assert torch.equal(arena[:, 1, :, past:past + q_len].contiguous().view(torch.int16), v_exp.contiguous().view(torch.int16))
-    assert torch.equal(qkv[:, :, H * D:].view(torch.int16), qkv0[:, :, H * D:].view(torch.int16))
+    assert torch.equal(qkv[:, :, H * D:], qkv0[:, :, H * D:])
     mask = torch.ones(cap, dtype=torch.bool)
     mask[past:past + q_len] = False
     mask = mask.to(DEV)
@@ -198,7 +205,7 @@ def test_rope_append_bounds():
     cs = torch.zeros((4, 16, 2), dtype=torch.float32, device=DEV)
     arena = torch.zeros((1, 2, 1, 8, 32), dtype=torch.float16, device=DEV)
     with pytest.raises(RuntimeError, match="exceeds arena rows"):
-        n.rope_append(qkv, 0, 96, qkv, qkv, 0, 96, arena[:, 0], arena[:, 1], 0, 256, cs, 1, 1, 1, 32, 4, 5, 8)
+        n.rope_append(qkv, 0, 96, qkv, 0, 96, qkv, qkv, 0, 96, arena[:, 0], arena[:, 1], 0, 256, cs, 1, 1, 1, 32, 4, 5, 8, False)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -351,12 +358,14 @@ def test_silu_mul_and_embed():
     n = _n()
     rng = np.random.default_rng(10)
     rows, inter = 5, 11008
-    gu = torch.from_numpy(rng.standard_normal((rows, 2 * inter), dtype=np.float32).astype(np.float16)).to(DEV)
-    out = torch.empty((rows, inter), dtype=torch.float16, device=DEV)
-    n.silu_mul(gu, out, rows, inter)
-    g = gu.float().cpu().numpy()
-    ref = orc.silu(g[:, :inter]) * g[:, inter:]
-    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3, rtol=2e-3)
+    g32 = rng.standard_normal((rows, 2 * inter), dtype=np.float32)
+    for f32 in (False, True):
+        gu = torch.from_numpy(g32 if f32 else g32.astype(np.float16)).to(DEV)
+        out = torch.empty((rows, inter), dtype=torch.float16, device=DEV)
+        n.silu_mul(gu, out, rows, inter, f32)
+        g = gu.float().cpu().numpy()
+        ref = orc.silu(g[:, :inter]) * g[:, inter:]
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3, rtol=2e-3)
     table = torch.from_numpy(rng.standard_normal((100, 128), dtype=np.float32).astype(np.float16)).to(DEV)
     ids = torch.tensor([0, 99, 5, 5, 42], dtype=torch.int64, device=DEV)
     e = torch.empty((5, 128), dtype=torch.float16, device=DEV)

@@ -86,13 +86,15 @@ int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs, int32_t 
  *   q      [B][q_len][H][D] projection output, fp32 when in_is_f32 else fp16; token stride
  *          q_token_stride, batch stride q_batch_stride (elements of the input type)
  *   q_out  fp16 [B][q_len][H][D], strides qo_* (may alias q when the input is fp16: in-place rotation)
+ *   q_out_lo  optional fp16 plane, same strides: fp16(q_rot - fp16(q_rot)), the low-order half of the
+ *          split-precision q that pc_attn_fwd consumes in its small-q (HBM-bound) instantiation
  *   k_new  [B][q_len][Hkv][D] (pre-RoPE, same type as q), v_new likewise; strides kv_new_*
  *   k_arena, v_arena  fp16 [B][Hkv][cap][D]: head stride arena_head_stride, batch stride arena_batch_stride
  *   cs     from pc_rope_table, [B*q_len][D/2][2]
  *   past_len_dev: optional device int32*; when non-null the kernel reads past_len from it (graph replay)
  * ------------------------------------------------------------------------------------------- */
 int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride,
-                   void* q_out, int64_t qo_batch_stride, int64_t qo_token_stride,
+                   void* q_out, void* q_out_lo, int64_t qo_batch_stride, int64_t qo_token_stride,
                    const void* k_new, const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
                    void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
                    const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
@@ -105,20 +107,22 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *   accumulation, MFMA fp16 x fp16 -> fp32 for both contractions, flash-style (scores are never
  *   materialised), split over the KV axis when (heads x q-blocks) cannot fill the chip.
  *
- *   q    fp16 [B][q_len][H][D]  RoPE applied;  k, v fp16 arena planes [B][Hkv][cap][D] holding
+ *   q    fp16 [B][q_len][H][D]  RoPE applied (q_lo: optional low-order plane, same layout, may be NULL);  k, v fp16 arena planes [B][Hkv][cap][D] holding
  *        past_len + q_len valid rows;  out fp16 [B][q_len][H*D] (token stride out_token_stride).
  *   workspace: >= pc_attn_workspace_bytes(...) bytes of device memory (split-KV partials).
  *   past_len_dev: optional device int32* (graph replay; then `past_len` is the upper bound used
  *        for sizing the launch).
+ *   out_frag_hi/_lo: optional (both or neither; B*q_len <= 64): instead of `out`, write the result as
+ *        split-precision fragment planes [ceil(B*q_len/16)][H*D/32][64][8] consumed by pc_gemm_skinny (o_proj).
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
 
-int pc_attn_fwd(const void* q, int64_t q_batch_stride, int64_t q_token_stride,
+int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
                 const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride,
                 void* out, int64_t out_batch_stride, int64_t out_token_stride,
                 int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
                 float softmax_scale, void* workspace, int64_t workspace_bytes,
-                const int32_t* past_len_dev, void* stream);
+                const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Elementwise / reduction pieces of the layer stack, fused for the small-q prefill (q_len rows):
@@ -131,6 +135,28 @@ int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32
 int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, int32_t in_is_f32, void* stream);
 int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,
                     int32_t vocab, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight-streaming projections for the small-q regime (M = B*q_len <= 64), csrc/pc_gemm.hip.
+ *
+ * Fragment-major layouts (register image of mfma_f32_16x16x32_f16 operands, fp16):
+ *   weights      Wf[N/16][K/32][64][8]   lane l = 16*g + n  holds W[16*tile + n][32*ks + 8*g .. +8]
+ *                (W is the nn.Linear [N][K] matrix; build once at load: view(N/16,16,K/32,4,8).permute(0,2,3,1,4))
+ *   activations  Xf[M/16 rounded up][K/32][64][8]   lane l = 16*g + m  holds X[16*mt + m][32*ks + 8*g .. +8]
+ *                two planes: hi = fp16(x), lo = fp16(x - hi)  (lo may be NULL: single-precision pass)
+ *
+ * pc_gemm_skinny -- replaces the nn.Linear calls of llama2.py:345-347 (q|k|v fused), :405 (+ residual add
+ *   :638), :242 (gate/up + SiLU*up; down + residual add :644) and :1050 (lm_head) when M <= 64:
+ *     epilogue 0  y[m][n]  = sum_k X[m][k] W[n][k]          fp32 [M][ldy]
+ *     epilogue 1  y[m][n] += ...                            fp32 residual stream, in place
+ *     epilogue 2  W = [gate ; up] (N = 2*inter): of[m][j] = silu(gate_j) * up_j written as fragment planes
+ *                 [M/16][inter/32][64][8] (hi, lo) for the down projection
+ * pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes.
+ * ------------------------------------------------------------------------------------------- */
+int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
+                   int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
+int pc_rmsnorm_frag(const float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
+                    float eps, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

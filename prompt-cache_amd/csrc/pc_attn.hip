@@ -47,13 +47,20 @@ constexpr float kNegBig = -1.0e30f;  // finite "-inf" for the running max
 
 struct AttnParams {
     const _Float16* q; int64_t q_bs, q_ts;
+    const _Float16* q_lo;   // optional low-order plane of q (same strides), consumed when HP
     const _Float16* k; const _Float16* v; int64_t kv_bs, kv_hs;
     _Float16* out; int64_t o_bs, o_ts;
+    _Float16* of_hi; _Float16* of_lo;   // optional: fragment-major split-precision output planes (pc_gemm.hip)
     float* part_o; float* part_ml;
     const int32_t* past_len_dev;
     int32_t H, Hkv, q_len, past_len, nsplit;
     float scale_log2;
 };
+
+// position of element (row m, feature k) in a fragment-major plane with KS k-steps (see pc_gemm.hip)
+__device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
+    return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
+}
 
 __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     // ds_read_b64_tr_b16: within a 16-lane group, lane i receives sub-element (i%4) of the 8 bytes
@@ -62,7 +69,11 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     return __builtin_bit_cast(h4, r);
 }
 
-template <int D>
+// HP ("high precision", used when q_len <= 64 where the kernel is HBM-bound and MFMA time is free): Q and P
+// enter the MFMAs as split-precision pairs (hi = fp16(x), lo = fp16(x - hi)), i.e. two MFMAs per fragment.
+// Against the reference's fp32 CPU path this removes the two largest rounding terms of the kernel (fp16 Q:
+// 2.5e-3, fp16 P: 1.7e-3 max |delta logit| on a 7b-shaped layer); K/V stay fp16 as staged.
+template <int D, bool HP>
 __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = D / 32;   // MFMA k-steps across the head dim (QK^T)
     constexpr int DB = D / 16;   // 16-wide head-dim blocks of O^T
@@ -97,13 +108,17 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     const int wave_vis_end = past_len + wave_rows_end;
     const int row_vis_end = (qi < q_len) ? past_len + qi + 1 : 0;  // keys [0, row_vis_end) are visible
 
-    h8 qf[KS];
+    h8 qf[KS], qfl[HP ? KS : 1];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         qf[ks] = z;
-        if (wave_active && qi < q_len)
-            qf[ks] = *(const h8*)(p.q + b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 32 + g * 8);
+        if (HP) qfl[ks] = z;
+        if (wave_active && qi < q_len) {
+            const int64_t off = b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 32 + g * 8;
+            qf[ks] = *(const h8*)(p.q + off);
+            if (HP && p.q_lo) qfl[ks] = *(const h8*)(p.q_lo + off);
+        }
     }
 
     f4 o[DB];
@@ -114,22 +129,26 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
     const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
 
-    for (int key0 = ks0; key0 < kend; key0 += kTK) {
-        // ---- cooperative, coalesced tile load (zero-fill rows at/after kend: a garbage V row would
-        //      turn 0 * NaN into NaN in the PV MFMA) ----
-        u32x4 kr[LPT], vr[LPT];
+    // Register-staged, software-pipelined tiles: the global loads of tile i+1 are issued right after tile i
+    // has been written to LDS and stay in flight while tile i is consumed (HBM latency hides under the MFMAs).
+    u32x4 kr[LPT], vr[LPT];
+    auto issue_loads = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int c = tid + i * kThreads;
             const int row = c / CPR, col = c - row * CPR;
             const int key = key0 + row;
             u32x4 z = {0u, 0u, 0u, 0u};
-            kr[i] = z; vr[i] = z;
+            kr[i] = z; vr[i] = z;   // zero-fill rows at/after kend: a garbage V row would turn 0 * NaN into NaN
             if (key < kend) {
                 kr[i] = *(const u32x4*)(kbase + (int64_t)key * D + col * 8);
                 vr[i] = *(const u32x4*)(vbase + (int64_t)key * D + col * 8);
             }
         }
+    };
+    if (ks0 < kend) issue_loads(ks0);
+
+    for (int key0 = ks0; key0 < kend; key0 += kTK) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int c = tid + i * kThreads;
@@ -138,6 +157,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             *(u32x4*)(Vl + row * D + (col << 3)) = vr[i];
         }
         __syncthreads();
+        if (key0 + kTK < kend) issue_loads(key0 + kTK);
 
         if (wave_active && key0 < wave_vis_end) {
             // ---- S^T = K . Q^T : four 16-key blocks ----
@@ -152,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
                     const int chunk = ks * 4 + g;
                     const h8 a = *(const h8*)(Kl + row * D + ((chunk ^ (row & (CPR - 1))) << 3));
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], acc, 0, 0, 0);
+                    if (HP) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qfl[ks], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -166,14 +187,16 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             const float m_new = fmaxf(m_run, mx);       // stays finite (m_run starts at -1e30)
             const float alpha = exp2f(m_run - m_new);
             float rs = 0.f;
-            h8 pb[2];
+            h8 pb[2], pbl[HP ? 2 : 1];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = exp2f(sv[kb][r] - m_new);   // exp2(-inf) = 0 for masked keys
                     rs += e;
-                    pb[kb >> 1][(kb & 1) * 4 + r] = (_Float16)e;
+                    const _Float16 eh = (_Float16)e;
+                    pb[kb >> 1][(kb & 1) * 4 + r] = eh;
+                    if (HP) pbl[kb >> 1][(kb & 1) * 4 + r] = (_Float16)(e - (float)eh);
                 }
             }
             rs += __shfl_xor(rs, 16);
@@ -194,6 +217,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
                     const h4 hi = lds_tr_read(vp + 16 * D);   // keys 32t + 16 + 4g + {0..3}
                     const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
+                    if (HP) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
                 }
             }
         }
@@ -203,6 +227,24 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     if (!(wave_active && qi < q_len)) return;
     if (p.nsplit == 1) {
         const float inv = 1.0f / l_run;
+        if (p.of_hi) {
+            // o_proj consumes split-precision fragment planes: row = token index over B*q_len, k = h*D + d
+            const int row = b * q_len + qi, KSo = p.H * D / 32;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = o[db][r] * inv;
+                    hi[r] = (_Float16)v;
+                    lo[r] = (_Float16)(v - (float)hi[r]);
+                }
+                const int64_t off = frag_off(row, h * D + db * 16 + g * 4, KSo);
+                *(h4*)(p.of_hi + off) = hi;
+                *(h4*)(p.of_lo + off) = lo;
+            }
+            return;
+        }
         _Float16* op = p.out + b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + g * 4;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
@@ -222,7 +264,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
 // Merge split-KV partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i.
 template <int D>
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                    _Float16* __restrict__ out, int64_t o_bs, int64_t o_ts, int H, int q_len,
+                                    _Float16* __restrict__ out, int64_t o_bs, int64_t o_ts,
+                                    _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo, int H, int q_len,
                                     int nsplit) {
     const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
     const int64_t base = ((int64_t)b * H + h) * nsplit;
@@ -235,14 +278,24 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
         den += w * part_ml[slot * 2 + 1];
         num += w * part_o[slot * D + d];
     }
-    out[b * o_bs + (int64_t)qi * o_ts + (int64_t)h * D + d] = (_Float16)(num / den);
+    const float v = num / den;
+    if (of_hi) {
+        const int64_t off = frag_off(b * q_len + qi, h * D + d, H * D / 32);
+        const _Float16 hi = (_Float16)v;
+        of_hi[off] = hi;
+        of_lo[off] = (_Float16)(v - (float)hi);
+    } else {
+        out[b * o_bs + (int64_t)qi * o_ts + (int64_t)h * D + d] = (_Float16)v;
+    }
 }
 
 int choose_nsplit(int B, int H, int q_len, int kv_len) {
     static const int forced = [] { const char* e = getenv("PC_ATTN_NSPLIT"); return e ? atoi(e) : 0; }();
     const int nqblk = pc_ceil_div(q_len, kQB);
     const int base = B * H * nqblk;
-    int ns = forced > 0 ? forced : 1024 / (base > 0 ? base : 1);  // aim at ~4 workgroups per CU
+    // ~1.25 workgroups per CU: fewer, longer KV streams per workgroup beat many short ones (measured on the
+    // persona shape: 10 splits x 32 heads = 18.7 us vs 13 splits 20.3 us vs 4 splits 23.8 us per layer)
+    int ns = forced > 0 ? forced : (320 + base / 2) / (base > 0 ? base : 1);
     const int max_by_len = kv_len / (2 * kTK);                   // keep >= 2 tiles per split
     if (ns > max_by_len) ns = max_by_len;
     if (ns > kMaxSplit) ns = kMaxSplit;
@@ -253,12 +306,13 @@ int choose_nsplit(int B, int H, int q_len, int kv_len) {
 template <int D>
 int launch_attn(const AttnParams& p, int B, hipStream_t stream) {
     dim3 grid(pc_ceil_div(p.q_len, kQB), p.H, B * p.nsplit);
-    hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(kThreads), 0, stream, p);
+    if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     int rc = pc_check_launch("attn_fwd_kernel");
     if (rc != PC_OK) return rc;
     if (p.nsplit > 1) {
         hipLaunchKernelGGL(attn_combine_kernel<D>, dim3(p.q_len, p.H, B), dim3(D), 0, stream, p.part_o, p.part_ml,
-                           p.out, p.o_bs, p.o_ts, p.H, p.q_len, p.nsplit);
+                           p.out, p.o_bs, p.o_ts, p.of_hi, p.of_lo, p.H, p.q_len, p.nsplit);
         rc = pc_check_launch("attn_combine_kernel");
     }
     return rc;
@@ -273,22 +327,28 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
 
-PC_EXPORT int pc_attn_fwd(const void* q, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
                           const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
                           int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
                           int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
-                          int64_t workspace_bytes, const int32_t* past_len_dev, void* stream) {
+                          int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
+                          void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
     if (q_len == 0) return PC_OK;
-    PC_REQUIRE(q && k && v && out, PC_ERR_ARG, "pc_attn_fwd: null pointer");
+    PC_REQUIRE(q && k && v && (out || (out_frag_hi && out_frag_lo)), PC_ERR_ARG, "pc_attn_fwd: null pointer");
+    PC_REQUIRE((out_frag_hi == nullptr) == (out_frag_lo == nullptr), PC_ERR_ARG, "pc_attn_fwd: need both fragment planes");
+    PC_REQUIRE(!out_frag_hi || (B * q_len <= 64 && (H * D) % 32 == 0), PC_ERR_ARG,
+               "pc_attn_fwd: fragment-plane output is for the skinny regime (B*q_len <= 64)");
     PC_REQUIRE(q_token_stride % 8 == 0 && kv_head_stride % 8 == 0 && out_token_stride % 4 == 0, PC_ERR_ARG,
                "pc_attn_fwd: strides must keep 16-byte (q, kv) / 8-byte (out) alignment");
     AttnParams p;
     p.q = (const _Float16*)q; p.q_bs = q_batch_stride; p.q_ts = q_token_stride;
+    p.q_lo = (const _Float16*)q_lo;
     p.k = (const _Float16*)k; p.v = (const _Float16*)v; p.kv_bs = kv_batch_stride; p.kv_hs = kv_head_stride;
     p.out = (_Float16*)out; p.o_bs = out_batch_stride; p.o_ts = out_token_stride;
+    p.of_hi = (_Float16*)out_frag_hi; p.of_lo = (_Float16*)out_frag_lo;
     p.past_len_dev = past_len_dev;
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;

@@ -1,0 +1,338 @@
+// Weight-streaming projections for the small-q prefill / decode regime (M = B*q_len <= 64 rows).
+//
+// Replaces  q_proj/k_proj/v_proj   promptcache/model/llama2.py:345-347   (one fused [q|k|v] GEMM)
+//           o_proj + residual       promptcache/model/llama2.py:405, :638
+//           gate/up + SiLU*up       promptcache/model/llama2.py:242       (act_fn(gate(x)) * up(x))
+//           down_proj + residual    promptcache/model/llama2.py:242, :644
+//           lm_head                 promptcache/model/llama2.py:1050
+//           LlamaRMSNorm (producer) promptcache/model/llama2.py:103-108   (pc_rmsnorm_frag)
+//
+// Regime.  With q ~ 10..50 new tokens the projections are pure weight streaming: 2*P bytes (13.5 GB for
+// 7b) once per forward, ~1 FLOP/B per row -- HBM-bound, far below the MFMA roof.  The design goal is
+// therefore one perfectly sequential HBM stream per wave and nothing else on the critical path.
+//
+// Layouts (all "fragment-major", i.e. the exact register image of mfma_f32_16x16x32_f16 operands):
+//   weights  Wf[N/16][K/32][64 lanes][8 halfs]: lane l = 16*g + n holds W[16*tile + n][32*ks + 8*g .. +8].
+//            Built ONCE at model load from the nn.Linear [N][K] matrix; a wave-instruction then reads 1 KiB
+//            contiguous and consecutive k-steps are consecutive KiBs (the row-major layout would give 16 rows x
+//            64 B per instruction).
+//   activations  Xf[plane][M/16][K/32][64][8]: lane l = 16*g + m holds X[16*mt + m][32*ks + 8*g .. +8];
+//            written directly in this form by the producers (pc_rmsnorm_frag, the attention epilogue, the
+//            SiLU epilogue below).  Two planes, hi = fp16(x) and lo = fp16(x - hi): the MFMA is issued twice
+//            per weight fragment, which is free under the HBM roof and keeps ~22 bits of the activations
+//            (the parity target is the reference's fp32 CPU path; weights are exact in fp16 by construction).
+//
+// Kernel.  D[n][m] = sum_k W[n][k] X[m][k] with A = weight fragment, B = activation fragment, so a lane owns
+// token m = lane&15 and 4 consecutive output features (C/D map: col = lane&15, row = 4*(lane>>4)+reg).
+// Workgroup = 8 waves that split K eight ways over the same T output tiles (every projection then yields
+// >= ~256 workgroups even for N = 4096); partial tiles are reduced through LDS in fixed wave order
+// (deterministic, no atomics), then the epilogue runs on the reduced tile:
+//   EPI_STORE  y[m][n]  = v                     (fp32 row-major: qkv for RoPE, logits)
+//   EPI_ADD    y[m][n] += v                     (fp32 residual stream, o_proj / down_proj)
+//   EPI_SILU   Of[m][j] = silu(gate_j) * up_j   (gate tile i and up tile inter/16 + i reduced in the same
+//                                                workgroup; written as hi/lo fragment planes for down_proj)
+// Algorithmic bytes per launch: N*K*2 (weights once) [+ M*K*4 activations from L2 per workgroup].
+#include <hip/hip_fp16.h>
+
+#include "pc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2 };
+
+struct GemmParams {
+    const _Float16* wf;      // [ntiles][KS][64][8]
+    const _Float16* xf_hi;   // [MT][KS][64][8]
+    const _Float16* xf_lo;   // same, may be null (single pass)
+    float* y; int64_t ldy;   // EPI_STORE / EPI_ADD
+    _Float16* of_hi; _Float16* of_lo; int32_t KSo;  // EPI_SILU: output planes [MT][KSo][64][8]
+    int32_t M, ntiles, KS, npairs;
+};
+
+__device__ __forceinline__ h8 ldg_h8(const _Float16* p) { return *(const h8*)p; }
+__device__ __forceinline__ h8 ldg_h8_nt(const _Float16* p) {
+    return __builtin_bit_cast(h8, __builtin_nontemporal_load((const u32x4*)p));
+}
+
+// position of element (row m, feature k) in a fragment-major plane with KS k-steps
+__device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
+    return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
+}
+
+// One k-block of U k-steps: issue every load (U * (TT + 2*MT) KiB per wave in flight), then the MFMAs.
+// The activation loads are predicated per lane on "row m exists" (one exec-masked region per block): pad
+// rows cost no L2 traffic -- at M = 12 that is 25 % of the activation bytes, at M = 1 (decode) 94 % -- and
+// their stale register contents only reach output columns that are never stored.
+template <int MT, int TT, bool TWO, int U>
+__device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], const _Float16* xh_base,
+                                        const _Float16* xl_base, int KS, int ks, const bool (&row_ok)[MT],
+                                        f4 (&acc)[MT][TT]) {
+    h8 w[U][TT], xh[U][MT], xl[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + u) * 512);   // 1 KiB / wave, streamed once
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xh[u][a] = z;
+            if (TWO) xl[u][a] = z;
+        }
+        if (row_ok[a]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t off = ((int64_t)a * KS + ks + u) * 512;
+                xh[u][a] = ldg_h8(xh_base + off);                                                // L2-resident
+                if (TWO) xl[u][a] = ldg_h8(xl_base + off);
+            }
+        }
+    }
+    // keep the whole block's loads in flight: hipcc otherwise sinks each load next to its MFMA and waits
+    // vmcnt(0) per k-step (measured in the ISA), which turns a streaming kernel into a latency chain
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], xh[u][a], acc[a][t], 0, 0, 0);
+                if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], xl[u][a], acc[a][t], 0, 0, 0);
+            }
+}
+
+template <int MT, int T, int EPI, bool TWO, int U>
+__global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams p) {
+    constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
+    __shared__ __attribute__((aligned(16))) float red[kWaves][MT * TT][64][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar loop control
+    const int KS = p.KS;
+    const int ksw = (KS + kWaves - 1) / kWaves;
+    const int ks0 = wave * ksw;
+    const int ks1 = (ks0 + ksw < KS) ? ks0 + ksw : KS;
+
+    // tiles of this workgroup (clamped: a clamped duplicate tile recomputes a valid tile and is not stored)
+    int tile[TT];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = blockIdx.x * T + t;
+        if (EPI == EPI_SILU) {
+            const int ic = i < p.npairs ? i : p.npairs - 1;
+            tile[t] = ic;                 // gate rows
+            tile[T + t] = p.npairs + ic;  // up rows
+        } else {
+            tile[t] = i < p.ntiles ? i : p.ntiles - 1;
+        }
+    }
+
+    f4 acc[MT][TT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[a][t] = z; }
+
+    const _Float16* wbase[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) wbase[t] = p.wf + ((int64_t)tile[t] * KS * 64 + lane) * 8;
+    const _Float16* xh_base = p.xf_hi + lane * 8;
+    const _Float16* xl_base = TWO ? p.xf_lo + lane * 8 : nullptr;
+
+    bool row_ok[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < p.M;
+    int ks = ks0;
+    for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U>(wbase, xh_base, xl_base, KS, ks, row_ok, acc);
+    for (; ks < ks1; ++ks) k_block<MT, TT, TWO, 1>(wbase, xh_base, xl_base, KS, ks, row_ok, acc);
+
+    // ---- split-K reduction through LDS, fixed order ----
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) *(f4*)red[wave][a * TT + t][lane] = acc[a][t];
+    __syncthreads();
+
+    // MT*TT <= 8 items (enforced at launch), one per wave; a/t are recomputed arithmetically (no runtime
+    // indexing of register arrays).
+    constexpr int TE = (EPI == EPI_SILU) ? T : TT;   // epilogue items per M-tile
+    constexpr int NOUT = MT * TE;
+    static_assert(MT * TT <= kWaves, "one reduced tile per wave");
+    if (wave < NOUT) {
+        const int a = wave / TE;
+        const int t = wave - a * TE;
+        f4 v = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const f4 x = *(const f4*)red[w][a * TT + t][lane];
+            v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+            if (EPI == EPI_SILU) {
+                const f4 y = *(const f4*)red[w][a * TT + T + t][lane];
+                u[0] += y[0]; u[1] += y[1]; u[2] += y[2]; u[3] += y[3];
+            }
+        }
+        const int row = a * 16 + m;
+        const int unit = blockIdx.x * T + t;                       // tile (or gate/up pair) index
+        const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
+        if (unit < nunits && row < p.M) {
+            if (EPI == EPI_SILU) {
+                const int j0 = unit * 16 + g * 4;   // intermediate feature index of v[0]
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = (v[r] / (1.0f + __expf(-v[r]))) * u[r];
+                    hi[r] = (_Float16)s;
+                    lo[r] = (_Float16)(s - (float)hi[r]);
+                }
+                const int64_t off = frag_off(row, j0, p.KSo);
+                *(h4*)(p.of_hi + off) = hi;
+                *(h4*)(p.of_lo + off) = lo;
+            } else {
+                float* yp = p.y + (int64_t)row * p.ldy + unit * 16 + g * 4;
+                if (EPI == EPI_ADD) {
+                    const f4 old = *(const f4*)yp;
+                    v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+                }
+                *(f4*)yp = v;
+            }
+        }
+    }
+}
+
+// RMSNorm producing split-precision fragment planes: one workgroup per row.
+__global__ __launch_bounds__(256) void rmsnorm_frag_kernel(const float* __restrict__ x, const _Float16* __restrict__ w,
+                                                           _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo,
+                                                           int hidden, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int nv = hidden >> 3;
+    const float* xr = x + (int64_t)row * hidden;
+    float ss = 0.f;
+    for (int i = tid; i < nv; i += 256) {
+        const f4 a = *(const f4*)(xr + i * 8), b = *(const f4*)(xr + i * 8 + 4);
+        ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
+    const int KS = hidden >> 5;
+    for (int i = tid; i < nv; i += 256) {
+        const f4 a = *(const f4*)(xr + i * 8), b = *(const f4*)(xr + i * 8 + 4);
+        const h8 gw = *(const h8*)(w + i * 8);
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)gw[e] * ((e < 4 ? a[e] : b[e - 4]) * rs);
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+        const int64_t off = frag_off(row, i * 8, KS);
+        *(h8*)(of_hi + off) = hi;
+        *(h8*)(of_lo + off) = lo;
+    }
+}
+
+// U = k-steps per load block.  A wave keeps U*TT KiB of weights (+ U*MT*{1,2} KiB of L2-resident activations)
+// in flight; with one or two workgroups per CU the chip needs >= ~8 KiB of weight bytes per wave outstanding
+// to cover HBM latency at full bandwidth (measured: U*TT = 4 KiB left o_proj at 3.4 TB/s).
+template <int MT, int T, int EPI>
+int launch_one(const GemmParams& p, int units, hipStream_t s) {
+    constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
+    constexpr int UD = (MT * TT >= 8) ? 2 : (MT * TT >= 3 ? 4 : 8);     // default depth
+    static const int forced = [] { const char* e = getenv("PC_GEMM_U"); return e ? atoi(e) : 0; }();
+    const dim3 grid(pc_ceil_div(units, T)), block(kThreads);
+    const bool two = p.xf_lo != nullptr;
+#define PC_GO(UV)                                                                                     \
+    do {                                                                                              \
+        if (two) hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UV>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UV>), grid, block, 0, s, p);    \
+    } while (0)
+    if constexpr (MT * TT <= 2) {
+        if (forced == 16) { PC_GO(16); return pc_check_launch("gemm_skinny_kernel"); }
+    }
+    if constexpr (MT * TT <= 4) {
+        if (forced == 8) { PC_GO(8); return pc_check_launch("gemm_skinny_kernel"); }
+        if (forced == 4) { PC_GO(4); return pc_check_launch("gemm_skinny_kernel"); }
+    }
+    if (forced == 2) { PC_GO(2); return pc_check_launch("gemm_skinny_kernel"); }
+    PC_GO(UD);
+#undef PC_GO
+    return pc_check_launch("gemm_skinny_kernel");
+}
+
+// T is limited by MT * TT <= 8 reduced tiles per workgroup (TT = 2T for the SiLU epilogue).
+template <int MT, int EPI>
+int launch_T(const GemmParams& p, int T, int units, hipStream_t s) {
+    constexpr int kMaxT = 8 / MT / (EPI == EPI_SILU ? 2 : 1);
+    if (T > kMaxT) T = kMaxT;
+    if constexpr (kMaxT >= 8) { if (T >= 8) return launch_one<MT, 8, EPI>(p, units, s); }
+    if constexpr (kMaxT >= 4) { if (T >= 4) return launch_one<MT, 4, EPI>(p, units, s); }
+    if constexpr (kMaxT >= 3) { if (T == 3) return launch_one<MT, 3, EPI>(p, units, s); }
+    if constexpr (kMaxT >= 2) { if (T >= 2) return launch_one<MT, 2, EPI>(p, units, s); }
+    return launch_one<MT, 1, EPI>(p, units, s);
+}
+
+template <int EPI>
+int launch_MT(const GemmParams& p, int T, int units, hipStream_t s) {
+    const int mt = pc_ceil_div(p.M, 16);
+    if (mt <= 1) return launch_T<1, EPI>(p, T, units, s);
+    if (mt == 2) return launch_T<2, EPI>(p, T, units, s);
+    return launch_T<4, EPI>(p, T, units, s);
+}
+
+// tiles (or gate/up pairs) per workgroup: fill ~256 CUs with one round of workgroups where possible
+int choose_T(int units) {
+    static const int forced = [] { const char* e = getenv("PC_GEMM_T"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    // smallest T in {1,2,3,4,8} whose grid fits one round of 256 CUs (a partial second round idles most of
+    // the chip: 344 workgroups ran at 4.4 TB/s where 230 run the same bytes in one round)
+    const int cand[5] = {1, 2, 3, 4, 8};
+    for (int i = 0; i < 5; ++i)
+        if (pc_ceil_div(units, cand[i]) <= 256) return cand[i];
+    return 8;
+}
+
+}  // namespace
+
+PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
+                             int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream) {
+    PC_REQUIRE(M > 0 && M <= 64, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..64 (use a dense GEMM above)", M);
+    PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
+    PC_REQUIRE(wf && xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
+    GemmParams p;
+    p.wf = (const _Float16*)wf; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
+    p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
+    p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (epilogue == EPI_SILU) {
+        PC_REQUIRE(N % 64 == 0, PC_ERR_ARG, "pc_gemm_skinny: SiLU epilogue needs N = 2*inter with inter%%32==0");
+        PC_REQUIRE(of_hi && of_lo, PC_ERR_ARG, "pc_gemm_skinny: SiLU epilogue needs output planes");
+        p.npairs = N / 32;          // inter / 16
+        p.KSo = (N / 2) / 32;       // k-steps of the consumer (down_proj, K = inter)
+        return launch_MT<EPI_SILU>(p, choose_T(p.npairs), p.npairs, s);
+    }
+    PC_REQUIRE(y && ldy >= N && ldy % 4 == 0, PC_ERR_ARG, "pc_gemm_skinny: bad output");
+    if (epilogue == EPI_ADD) return launch_MT<EPI_ADD>(p, choose_T(p.ntiles), p.ntiles, s);
+    PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_skinny: unknown epilogue %d", epilogue);
+    return launch_MT<EPI_STORE>(p, choose_T(p.ntiles), p.ntiles, s);
+}
+
+PC_EXPORT int pc_rmsnorm_frag(const float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,
+                              int32_t hidden, float eps, void* stream) {
+    PC_REQUIRE(rows > 0 && rows <= 64 && hidden > 0 && hidden % 32 == 0, PC_ERR_ARG, "pc_rmsnorm_frag: bad sizes");
+    PC_REQUIRE(x && weight && xf_hi && xf_lo, PC_ERR_ARG, "pc_rmsnorm_frag: null pointer");
+    hipLaunchKernelGGL(rmsnorm_frag_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
+                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps);
+    return pc_check_launch("rmsnorm_frag_kernel");
+}

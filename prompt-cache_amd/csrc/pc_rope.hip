@@ -52,7 +52,8 @@ __device__ __forceinline__ void load8<float>(const float* p, float (&x)[8]) {
 
 template <typename TIn>
 __global__ __launch_bounds__(256) void rope_append_kernel(
-    const TIn* __restrict__ q, int64_t q_bs, int64_t q_ts, _Float16* __restrict__ q_out, int64_t qo_bs, int64_t qo_ts,
+    const TIn* __restrict__ q, int64_t q_bs, int64_t q_ts, _Float16* __restrict__ q_out, _Float16* __restrict__ q_out_lo,
+    int64_t qo_bs, int64_t qo_ts,
     const TIn* __restrict__ k_new, const TIn* __restrict__ v_new, int64_t n_bs, int64_t n_ts,
     _Float16* __restrict__ k_arena, _Float16* __restrict__ v_arena, int64_t a_bs, int64_t a_hs,
     const float2* __restrict__ cs, int H, int Hkv, int D, int q_len, int past_len,
@@ -75,16 +76,24 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
             float lo[8], hi[8];
             load8<TIn>(src + c * 8, lo);
             load8<TIn>(src + half + c * 8, hi);
-            h8 olo, ohi;
+            h8 olo, ohi, rlo, rhi;   // r*: low-order residuals (second plane of the split-precision q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float2 w = csr[c * 8 + e];
                 // q*cos + rotate_half(q)*sin  (llama2.py:208): low half pairs with -high, high with +low
-                olo[e] = (_Float16)(lo[e] * w.x - hi[e] * w.y);
-                ohi[e] = (_Float16)(hi[e] * w.x + lo[e] * w.y);
+                const float a = lo[e] * w.x - hi[e] * w.y, b2 = hi[e] * w.x + lo[e] * w.y;
+                olo[e] = (_Float16)a;
+                ohi[e] = (_Float16)b2;
+                rlo[e] = (_Float16)(a - (float)olo[e]);
+                rhi[e] = (_Float16)(b2 - (float)ohi[e]);
             }
             *(h8*)(dst + c * 8) = olo;
             *(h8*)(dst + half + c * 8) = ohi;
+            if (is_q && q_out_lo) {
+                _Float16* dl = q_out_lo + b * qo_bs + t * qo_ts + (int64_t)h * D;
+                *(h8*)(dl + c * 8) = rlo;
+                *(h8*)(dl + half + c * 8) = rhi;
+            }
         } else {
             const int j = it - nq - nk;
             const int cpv = D >> 3;
@@ -112,7 +121,7 @@ PC_EXPORT int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs
     return pc_check_launch("rope_table_kernel");
 }
 
-PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out,
+PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
                              int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
                              const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
                              void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
@@ -129,13 +138,13 @@ PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_to
                    arena_head_stride % 8 == 0, PC_ERR_ARG, "pc_rope_append: strides must keep 16-byte alignment");
     if (in_is_f32)
         hipLaunchKernelGGL(rope_append_kernel<float>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, qo_batch_stride,
+                           (const float*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, (_Float16*)q_out_lo, qo_batch_stride,
                            qo_token_stride, (const float*)k_new, (const float*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
                            arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev);
     else
         hipLaunchKernelGGL(rope_append_kernel<_Float16>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
-                           (const _Float16*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, qo_batch_stride,
+                           (const _Float16*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, (_Float16*)q_out_lo, qo_batch_stride,
                            qo_token_stride, (const _Float16*)k_new, (const _Float16*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
                            arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev);

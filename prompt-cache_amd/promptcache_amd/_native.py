@@ -22,11 +22,13 @@ SIGNATURES = {
     "pc_kv_gather": (C.c_int, [C.POINTER(_vp), _pi32, _pi32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pc_kv_slice_store": (C.c_int, [_vp, _i32, _pi32, _pi32, C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp]),
     "pc_rope_table": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
-    "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
+    "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                  _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_attn_workspace_bytes": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
-    "pc_attn_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
-                              _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp]),
+    "pc_attn_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+                              _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -105,9 +107,9 @@ def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Opt
 
 
 def rope_append(q, q_bs, q_ts, q_out, qo_bs, qo_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs,
-                B, H, Hkv, D, q_len, past_len, cap, in_is_f32: bool, past_len_dev=None,
+                B, H, Hkv, D, q_len, past_len, cap, in_is_f32: bool, past_len_dev=None, q_out_lo=None,
                 stream: Optional[int] = None) -> None:
-    rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), qo_bs, qo_ts, k_new.data_ptr(),
+    rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
                                v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
                                cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), _ptr(past_len_dev),
                                current_stream() if stream is None else stream)
@@ -119,12 +121,57 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
-             workspace=None, past_len_dev=None, stream: Optional[int] = None) -> None:
+             workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None) -> None:
+    """``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
-    rc = load().pc_attn_fwd(q.data_ptr(), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, out.data_ptr(),
+    fh, fl = (None, None) if out_frag is None else out_frag
+    rc = load().pc_attn_fwd(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, _ptr(out),
                             o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, _ptr(workspace), ws_bytes,
-                            _ptr(past_len_dev), current_stream() if stream is None else stream)
+                            _ptr(past_len_dev), _ptr(fh), _ptr(fl), current_stream() if stream is None else stream)
     check(rc, "pc_attn_fwd")
+
+
+EPI_STORE, EPI_ADD, EPI_SILU = 0, 1, 2
+
+
+def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0, of_hi=None, of_lo=None,
+                stream: Optional[int] = None) -> None:
+    rc = load().pc_gemm_skinny(wf.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue, _ptr(y), ldy,
+                               _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_skinny")
+
+
+def rmsnorm_frag(x_f32, weight, xf_hi, xf_lo, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
+    rc = load().pc_rmsnorm_frag(x_f32.data_ptr(), weight.data_ptr(), xf_hi.data_ptr(), xf_lo.data_ptr(), rows, hidden, eps,
+                                current_stream() if stream is None else stream)
+    check(rc, "pc_rmsnorm_frag")
+
+
+def to_weight_frags(w):
+    """nn.Linear weight [N, K] (fp16) -> fragment-major Wf[N/16][K/32][64][8] (see include/promptcache_hip.h)."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0, (N, K)
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def to_act_frags(x):
+    """[M, K] float tensor -> (hi, lo) fp16 fragment planes [ceil(M/16)][K/32][64][8] (test/utility helper; the
+    hot path produces these planes directly in the kernels)."""
+    import torch
+    M, K = x.shape
+    mt = (M + 15) // 16
+    xp = torch.zeros((mt * 16, K), dtype=torch.float32, device=x.device)
+    xp[:M] = x.float()
+    hi = xp.half()
+    lo = (xp - hi.float()).half()
+    f = lambda t: t.view(mt, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+    return f(hi), f(lo)
+
+
+def from_act_frags(f, M: int):
+    """Inverse of the plane layout: [mt][K/32][64][8] -> [M, K] (test helper)."""
+    mt, ks = f.shape[0], f.shape[1]
+    return f.view(mt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(mt * 16, ks * 32)[:M]
 
 
 def rmsnorm(x, weight, out, rows: int, hidden: int, eps: float, x_is_f32: bool, stream: Optional[int] = None) -> None:

@@ -45,8 +45,10 @@ class LlamaHIP:
     """Weights live on one MI355X in fp16; ``wqkv`` and ``wgu`` are the row-concatenated q|k|v and
     gate|up projections so each is one GEMM."""
 
+    SKINNY_MAX_ROWS = 64   # B*q_len at or below this runs the weight-streaming kernels (pc_gemm.hip)
+
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
-                 decode_headroom: int = 256):
+                 decode_headroom: int = 256, skinny: bool = True):
         _native.load()  # fail loudly if the extension is missing
         self.config = shape
         self.device = torch.device(device)
@@ -65,19 +67,32 @@ class LlamaHIP:
         self.embed = w("embed")
         self.norm = w("norm")
         self.lm_head = w("lm_head")
+        # Two resident images of every projection (288 GB of HBM: 2 x 13.5 GB for 7b is cheap):
+        # row-major [N][K] for the dense (large q: encode / no-cache) GEMMs, and the MFMA-fragment-major
+        # image the weight-streaming kernels read as one sequential stream per wave (small q: cached
+        # prefill, decode).  Shapes that do not tile (N%16, K%32) simply keep the dense path.
+        self.skinny = bool(skinny) and c.hidden_size % 32 == 0 and c.intermediate_size % 32 == 0 and \
+            c.vocab_size % 16 == 0 and (self.H * self.D) % 32 == 0
+        fr = _native.to_weight_frags if self.skinny else (lambda t: None)
+        self.lm_head_f = fr(self.lm_head)
         self.layers = []
         for i in range(self.L):
-            self.layers.append(dict(
-                ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"),
-                wqkv=torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous(),
-                wo=w(f"l{i}.wo"),
-                wgu=torch.cat([w(f"l{i}.gate"), w(f"l{i}.up")], dim=0).contiguous(),
-                wdown=w(f"l{i}.down")))
+            wqkv = torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous()
+            wgu = torch.cat([w(f"l{i}.gate"), w(f"l{i}.up")], dim=0).contiguous()
+            wo, wdown = w(f"l{i}.wo"), w(f"l{i}.down")
+            self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown,
+                                    wqkv_f=fr(wqkv), wo_f=fr(wo), wgu_f=fr(wgu), wdown_f=fr(wdown)))
         # exactly the reference formula, evaluated on the CPU like the reference does (llama2.py:121)
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
         self.softmax_scale = 1.0 / math.sqrt(self.D)
         self._ws = None
+        # hipGraph cache for the small-q (prefill over staged KV / decode) forward: one captured graph per
+        # (B, q_len, arena, split count); past_len, token ids and positions are read from device buffers so
+        # every decode step and every same-shaped prompt replays the same graph.
+        self.use_graphs = True
+        self._graphs = {}
+        self.max_graphs = 64
 
     # ------------------------------------------------------------------------------------------
     def new_arena(self, batch: int, cap: int) -> KVArena:
@@ -142,10 +157,17 @@ class LlamaHIP:
         eps = self.config.rms_norm_eps
 
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
+        ids = input_ids.reshape(-1).to(torch.int64).contiguous()
+        if self.skinny and T <= self.SKINNY_MAX_ROWS:
+            if self.use_graphs:
+                logits = self._graphed_skinny(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
+            else:
+                logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
+            arena.length = past_len + q_len
+            return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
+
         cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
         n.rope_table(pos32, self.inv_freq, cs, T, D)
-
-        ids = input_ids.reshape(-1).to(torch.int64).contiguous()
         h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
         n.embed_gather(self.embed, ids, h16, T, hid, self.config.vocab_size)
         x = h16.float()  # fp32 residual stream
@@ -184,3 +206,92 @@ class LlamaHIP:
             n.rmsnorm(x, self.norm, h16, T, hid, eps, True)
             logits = torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)   # llama2.py:1050-1051
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
+
+    # ------------------------------------------------------------------------------------------
+    def _graphed_skinny(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Replay (capturing on first use) the hipGraph of the small-q forward for this shape."""
+        n = _native
+        nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
+        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            T = B * q_len
+            st_ids = torch.zeros(T, dtype=torch.int64, device=self.device)
+            st_pos = torch.zeros(T, dtype=torch.int32, device=self.device)
+            st_past = torch.zeros(1, dtype=torch.int32, device=self.device)
+            st_ids.copy_(ids); st_pos.copy_(pos32); st_past.fill_(past_len)
+            # one eager pass first (loads code objects / sizes the allocator), then capture
+            self._forward_skinny(st_ids, st_pos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward_skinny(st_ids, st_pos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
+            ent = (g, st_ids, st_pos, st_past, out)
+            self._graphs[key] = ent
+        g, st_ids, st_pos, st_past, out = ent
+        st_ids.copy_(ids)
+        st_pos.copy_(pos32)
+        st_past.fill_(past_len)
+        g.replay()
+        return out.clone()
+
+    def _forward_skinny(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Layer stack for T = B*q_len <= 64 rows: every projection is a weight-streaming pc_gemm_skinny
+        launch over fragment-major weights with split-precision (hi/lo fp16) activations; residual adds and
+        SiLU*up are fused into GEMM epilogues; RMSNorm and attention emit the fragment planes directly.
+        ``past_dev`` (device int32[1]) makes the pass graph-capturable: the kernels read past_len from it."""
+        n = _native
+        dev = self.device
+        c = self.config
+        H, Hkv, D, hid, inter = self.H, self.Hkv, self.D, c.hidden_size, c.intermediate_size
+        T = B * q_len
+        W = (H + 2 * Hkv) * D
+        eps = c.rms_norm_eps
+        mt = (T + 15) // 16
+        cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
+        x = h16.float()  # fp32 residual stream
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)       # low-order plane of the split-precision q
+        ws_bytes = n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len)
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
+
+        def planes(k):
+            return (torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev),
+                    torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev))
+
+        xh, xl = planes(hid)
+        ah, al = planes(H * D)
+        ch, cl = planes(inter)
+        qkv = torch.empty((T, W), dtype=torch.float32, device=dev)
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps)
+            n.gemm_skinny(lw["wqkv_f"], xh, xl, T, W, hid, n.EPI_STORE, y=qkv, ldy=W)
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:],
+                          q_len * W, W, kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len,
+                          past_len, arena.cap, True, past_len_dev=past_dev, q_out_lo=q16l)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                       B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                       q_lo=q16l)
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)           # x += attn @ Wo^T
+            n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps)
+            n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)  # silu(g)*u
+            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)        # x += act @ Wd^T
+        V = c.vocab_size
+        if last_token_only:
+            xlast = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            lh, ll = planes(hid)
+            n.rmsnorm_frag(xlast, self.norm, lh, ll, B, hid, eps)
+            logits = torch.empty((B, V), dtype=torch.float32, device=dev)
+            n.gemm_skinny(self.lm_head_f, lh, ll, B, V, hid, n.EPI_STORE, y=logits, ldy=V)
+            return logits.view(B, 1, V)
+        n.rmsnorm_frag(x, self.norm, xh, xl, T, hid, eps)
+        logits = torch.empty((T, V), dtype=torch.float32, device=dev)
+        n.gemm_skinny(self.lm_head_f, xh, xl, T, V, hid, n.EPI_STORE, y=logits, ldy=V)          # llama2.py:1050-1051
+        return logits.view(B, q_len, V)

@@ -147,16 +147,22 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
  *
  * pc_gemm_skinny -- replaces the nn.Linear calls of llama2.py:345-347 (q|k|v fused), :405 (+ residual add
  *   :638), :242 (gate/up + SiLU*up; down + residual add :644) and :1050 (lm_head) when M <= 64:
- *     epilogue 0  y[m][n]  = sum_k X[m][k] W[n][k]          fp32 [M][ldy]
+ *     epilogue 0  y[m][n]  = sum_k X[m][k] W[n][k]          fp32 [M][ldy]; with kslices > 1 the K axis is also
+ *                 split across workgroups and slice s writes its partial sums to y + s*M*ldy (slabs
+ *                 [kslices][M][ldy]) -- used for the N = hidden projections (o_proj, down_proj), whose few
+ *                 output tiles would otherwise make every workgroup re-read the whole activation matrix;
+ *                 pc_rmsnorm_frag adds the slabs to the residual stream in fixed order (deterministic)
  *     epilogue 1  y[m][n] += ...                            fp32 residual stream, in place
  *     epilogue 2  W = [gate ; up] (N = 2*inter): of[m][j] = silu(gate_j) * up_j written as fragment planes
  *                 [M/16][inter/32][64][8] (hi, lo) for the down projection
- * pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes.
+ * pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes;
+ *   optional prologue x += slabs[0] + ... + slabs[nslabs-1] (each [rows][hidden], the residual adds of
+ *   llama2.py:638 / :644 fed by a K-sliced pc_gemm_skinny), written back to x in place.
  * ------------------------------------------------------------------------------------------- */
 int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
-                   int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
-int pc_rmsnorm_frag(const float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
-                    float eps, void* stream);
+                   int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices, void* stream);
+int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
+                    float eps, const float* slabs, int32_t nslabs, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

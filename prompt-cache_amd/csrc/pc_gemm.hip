@@ -54,6 +54,7 @@ struct GemmParams {
     float* y; int64_t ldy;   // EPI_STORE / EPI_ADD
     _Float16* of_hi; _Float16* of_lo; int32_t KSo;  // EPI_SILU: output planes [MT][KSo][64][8]
     int32_t M, ntiles, KS, npairs;
+    int32_t kslices; int64_t slab_stride;   // EPI_STORE only: grid.y K-slices, slice s writes y + s*slab_stride
 };
 
 __device__ __forceinline__ h8 ldg_h8(const _Float16* p) { return *(const h8*)p; }
@@ -70,15 +71,21 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
 // The activation loads are predicated per lane on "row m exists" (one exec-masked region per block): pad
 // rows cost no L2 traffic -- at M = 12 that is 25 % of the activation bytes, at M = 1 (decode) 94 % -- and
 // their stale register contents only reach output columns that are never stored.
-template <int MT, int TT, bool TWO, int U>
+// TAIL: the last, partial block of a wave's K range (nvalid < U k-steps): the missing steps re-read the last
+// valid one and their weight fragments are zeroed, so the tail keeps the same load depth as a full block
+// instead of degenerating into nvalid serial load->wait->MFMA round trips.
+template <int MT, int TT, bool TWO, int U, bool TAIL>
 __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], const _Float16* xh_base,
-                                        const _Float16* xl_base, int KS, int ks, const bool (&row_ok)[MT],
+                                        const _Float16* xl_base, int KS, int ks, int nvalid, const bool (&row_ok)[MT],
                                         f4 (&acc)[MT][TT]) {
     h8 w[U][TT], xh[U][MT], xl[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int t = 0; t < TT; ++t) w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + u) * 512);   // 1 KiB / wave, streamed once
+        for (int t = 0; t < TT; ++t) {
+            const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+            w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + uu) * 512);   // 1 KiB / wave, streamed once
+        }
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -90,7 +97,8 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
         if (row_ok[a]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t off = ((int64_t)a * KS + ks + u) * 512;
+                const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+                const int64_t off = ((int64_t)a * KS + ks + uu) * 512;
                 xh[u][a] = ldg_h8(xh_base + off);                                                // L2-resident
                 if (TWO) xl[u][a] = ldg_h8(xl_base + off);
             }
@@ -99,6 +107,15 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
     // keep the whole block's loads in flight: hipcc otherwise sinks each load next to its MFMA and waits
     // vmcnt(0) per k-step (measured in the ISA), which turns a streaming kernel into a latency chain
     __builtin_amdgcn_sched_barrier(0);
+    if (TAIL) {
+#pragma unroll
+        for (int u = 1; u < U; ++u)
+            if (u >= nvalid) {
+                h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < TT; ++t) w[u][t] = z;
+            }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -118,9 +135,14 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar loop control
     const int KS = p.KS;
-    const int ksw = (KS + kWaves - 1) / kWaves;
-    const int ks0 = wave * ksw;
-    const int ks1 = (ks0 + ksw < KS) ? ks0 + ksw : KS;
+    // K range of this workgroup (grid.y slices K across workgroups; partial sums then go to per-slice slabs
+    // that the consumer -- pc_rmsnorm_frag -- adds up in fixed order), then eight ways across the waves
+    const int ksq = (KS + p.kslices - 1) / p.kslices;
+    const int kq0 = blockIdx.y * ksq;
+    const int kq1 = (kq0 + ksq < KS) ? kq0 + ksq : KS;
+    const int ksw = (kq1 - kq0 + kWaves - 1) / kWaves;
+    const int ks0 = kq0 + wave * ksw;
+    const int ks1 = (ks0 + ksw < kq1) ? ks0 + ksw : kq1;
 
     // tiles of this workgroup (clamped: a clamped duplicate tile recomputes a valid tile and is not stored)
     int tile[TT];
@@ -152,8 +174,8 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 #pragma unroll
     for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < p.M;
     int ks = ks0;
-    for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U>(wbase, xh_base, xl_base, KS, ks, row_ok, acc);
-    for (; ks < ks1; ++ks) k_block<MT, TT, TWO, 1>(wbase, xh_base, xl_base, KS, ks, row_ok, acc);
+    for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
+    if (ks < ks1) k_block<MT, TT, TWO, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
 
     // ---- split-K reduction through LDS, fixed order ----
 #pragma unroll
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
                 *(h4*)(p.of_hi + off) = hi;
                 *(h4*)(p.of_lo + off) = lo;
             } else {
-                float* yp = p.y + (int64_t)row * p.ldy + unit * 16 + g * 4;
+                float* yp = p.y + (int64_t)blockIdx.y * p.slab_stride + (int64_t)row * p.ldy + unit * 16 + g * 4;
                 if (EPI == EPI_ADD) {
                     const f4 old = *(const f4*)yp;
                     v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
@@ -209,22 +231,36 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 }
 
 // RMSNorm producing split-precision fragment planes: one workgroup per row.
-__global__ __launch_bounds__(256) void rmsnorm_frag_kernel(const float* __restrict__ x, const _Float16* __restrict__ w,
+// Optional prologue: x[row] += slab[0][row] + slab[1][row] + ... (fixed order), the K-sliced partial sums a
+// preceding pc_gemm_skinny left behind -- the residual add of llama2.py:638 / :644 happens here, in place.
+__global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x, const _Float16* __restrict__ w,
                                                            _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo,
-                                                           int hidden, float eps) {
+                                                           int hidden, float eps, const float* __restrict__ slabs,
+                                                           int nslabs, int64_t slab_stride) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = hidden >> 3;
-    const float* xr = x + (int64_t)row * hidden;
+    float* xr = x + (int64_t)row * hidden;
     float ss = 0.f;
     for (int i = tid; i < nv; i += 256) {
-        const f4 a = *(const f4*)(xr + i * 8), b = *(const f4*)(xr + i * 8 + 4);
+        f4 a = *(const f4*)(xr + i * 8), b = *(const f4*)(xr + i * 8 + 4);
+        if (nslabs > 0) {
+            for (int s = 0; s < nslabs; ++s) {
+                const float* sp = slabs + s * slab_stride + (int64_t)row * hidden + i * 8;
+                const f4 c = *(const f4*)sp, d = *(const f4*)(sp + 4);
+                a[0] += c[0]; a[1] += c[1]; a[2] += c[2]; a[3] += c[3];
+                b[0] += d[0]; b[1] += d[1]; b[2] += d[2]; b[3] += d[3];
+            }
+            *(f4*)(xr + i * 8) = a;
+            *(f4*)(xr + i * 8 + 4) = b;
+        }
         ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
+    // (each thread re-reads only elements it wrote itself above: same i -> same thread)
     const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
     const int KS = hidden >> 5;
     for (int i = tid; i < nv; i += 256) {
@@ -251,7 +287,7 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
     constexpr int UD = (MT * TT >= 8) ? 2 : (MT * TT >= 3 ? 4 : 8);     // default depth
     static const int forced = [] { const char* e = getenv("PC_GEMM_U"); return e ? atoi(e) : 0; }();
-    const dim3 grid(pc_ceil_div(units, T)), block(kThreads);
+    const dim3 grid(pc_ceil_div(units, T), p.kslices), block(kThreads);
     const bool two = p.xf_lo != nullptr;
 #define PC_GO(UV)                                                                                     \
     do {                                                                                              \
@@ -306,7 +342,8 @@ int choose_T(int units) {
 }  // namespace
 
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
-                             int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream) {
+                             int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
+                             void* stream) {
     PC_REQUIRE(M > 0 && M <= 64, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..64 (use a dense GEMM above)", M);
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
@@ -314,6 +351,9 @@ PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_l
     p.wf = (const _Float16*)wf; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
     p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
+    PC_REQUIRE(kslices >= 1 && kslices <= 16 && (kslices == 1 || epilogue == EPI_STORE), PC_ERR_ARG,
+               "pc_gemm_skinny: K-slicing (kslices=%d) is available for the plain-store epilogue only", kslices);
+    p.kslices = kslices; p.slab_stride = (int64_t)M * ldy;
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == EPI_SILU) {
         PC_REQUIRE(N % 64 == 0, PC_ERR_ARG, "pc_gemm_skinny: SiLU epilogue needs N = 2*inter with inter%%32==0");
@@ -325,14 +365,15 @@ PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_l
     PC_REQUIRE(y && ldy >= N && ldy % 4 == 0, PC_ERR_ARG, "pc_gemm_skinny: bad output");
     if (epilogue == EPI_ADD) return launch_MT<EPI_ADD>(p, choose_T(p.ntiles), p.ntiles, s);
     PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_skinny: unknown epilogue %d", epilogue);
-    return launch_MT<EPI_STORE>(p, choose_T(p.ntiles), p.ntiles, s);
+    return launch_MT<EPI_STORE>(p, choose_T(p.ntiles * kslices) , p.ntiles, s);
 }
 
-PC_EXPORT int pc_rmsnorm_frag(const float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,
-                              int32_t hidden, float eps, void* stream) {
+PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,
+                              int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream) {
     PC_REQUIRE(rows > 0 && rows <= 64 && hidden > 0 && hidden % 32 == 0, PC_ERR_ARG, "pc_rmsnorm_frag: bad sizes");
-    PC_REQUIRE(x && weight && xf_hi && xf_lo, PC_ERR_ARG, "pc_rmsnorm_frag: null pointer");
+    PC_REQUIRE(x && weight && xf_hi && xf_lo && nslabs >= 0 && (nslabs == 0 || slabs), PC_ERR_ARG,
+               "pc_rmsnorm_frag: null pointer");
     hipLaunchKernelGGL(rmsnorm_frag_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
-                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps);
+                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps, slabs, nslabs, (int64_t)rows * hidden);
     return pc_check_launch("rmsnorm_frag_kernel");
 }

@@ -27,8 +27,8 @@ SIGNATURES = {
     "pc_attn_workspace_bytes": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
     "pc_attn_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -135,14 +135,18 @@ EPI_STORE, EPI_ADD, EPI_SILU = 0, 1, 2
 
 
 def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0, of_hi=None, of_lo=None,
-                stream: Optional[int] = None) -> None:
+                kslices: int = 1, stream: Optional[int] = None) -> None:
+    """``kslices > 1`` (plain-store epilogue): ``y`` is ``[kslices][M][ldy]`` slabs of partial sums."""
     rc = load().pc_gemm_skinny(wf.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue, _ptr(y), ldy,
-                               _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
+                               _ptr(of_hi), _ptr(of_lo), kslices, current_stream() if stream is None else stream)
     check(rc, "pc_gemm_skinny")
 
 
-def rmsnorm_frag(x_f32, weight, xf_hi, xf_lo, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
+def rmsnorm_frag(x_f32, weight, xf_hi, xf_lo, rows: int, hidden: int, eps: float, slabs=None, nslabs: int = 0,
+                 stream: Optional[int] = None) -> None:
+    """``slabs`` ([nslabs][rows][hidden] fp32): added to ``x_f32`` in place (fixed order) before the norm."""
     rc = load().pc_rmsnorm_frag(x_f32.data_ptr(), weight.data_ptr(), xf_hi.data_ptr(), xf_lo.data_ptr(), rows, hidden, eps,
+                                _ptr(slabs), nslabs if slabs is not None else 0,
                                 current_stream() if stream is None else stream)
     check(rc, "pc_rmsnorm_frag")
 

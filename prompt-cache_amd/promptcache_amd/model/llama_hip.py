@@ -90,6 +90,7 @@ class LlamaHIP:
         # hipGraph cache for the small-q (prefill over staged KV / decode) forward: one captured graph per
         # (B, q_len, arena, split count); past_len, token ids and positions are read from device buffers so
         # every decode step and every same-shaped prompt replays the same graph.
+        self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
         self.use_graphs = True
         self._graphs = {}
         self.max_graphs = 64
@@ -268,9 +269,14 @@ class LlamaHIP:
         ah, al = planes(H * D)
         ch, cl = planes(inter)
         qkv = torch.empty((T, W), dtype=torch.float32, device=dev)
+        # The two N = hidden projections (o_proj, down_proj) split K over KQ workgroup slices and leave KQ slabs of
+        # partial sums; the next RMSNorm launch folds them into the residual stream (x += sum of slabs).
+        KQ = self.kslices
+        slabs = torch.empty((KQ, T, hid), dtype=torch.float32, device=dev)
+        pending = 0                                   # slabs waiting to be added to x
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
-            n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps)
+            n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps, slabs, pending)
             n.gemm_skinny(lw["wqkv_f"], xh, xl, T, W, hid, n.EPI_STORE, y=qkv, ldy=W)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:],
@@ -279,19 +285,22 @@ class LlamaHIP:
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l)
-            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)           # x += attn @ Wo^T
-            n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps)
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ)   # attn @ Wo^T
+            n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm
             n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)  # silu(g)*u
-            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)        # x += act @ Wd^T
+            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ)  # act @ Wd^T
+            pending = KQ
         V = c.vocab_size
         if last_token_only:
+            if pending:
+                x.add_(slabs.sum(dim=0))
             xlast = x.view(B, q_len, hid)[:, -1, :].contiguous()
             lh, ll = planes(hid)
             n.rmsnorm_frag(xlast, self.norm, lh, ll, B, hid, eps)
             logits = torch.empty((B, V), dtype=torch.float32, device=dev)
             n.gemm_skinny(self.lm_head_f, lh, ll, B, V, hid, n.EPI_STORE, y=logits, ldy=V)
             return logits.view(B, 1, V)
-        n.rmsnorm_frag(x, self.norm, xh, xl, T, hid, eps)
+        n.rmsnorm_frag(x, self.norm, xh, xl, T, hid, eps, slabs, pending)
         logits = torch.empty((T, V), dtype=torch.float32, device=dev)
         n.gemm_skinny(self.lm_head_f, xh, xl, T, V, hid, n.EPI_STORE, y=logits, ldy=V)          # llama2.py:1050-1051
         return logits.view(B, q_len, V)

@@ -424,19 +424,40 @@ def test_gemm_skinny_silu_epilogue(M, inter, K):
     assert (got - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("nslabs", [0, 4])
 @pytest.mark.parametrize("rows,hidden", [(12, 4096), (1, 128), (33, 5120)])
-def test_rmsnorm_frag_matches_oracle(rows, hidden):
+def test_rmsnorm_frag_matches_oracle(rows, hidden, nslabs):
     n = _n()
     rng = np.random.default_rng(13)
     x = rng.standard_normal((rows, hidden), dtype=np.float32) * 3
+    sl = rng.standard_normal((max(nslabs, 1), rows, hidden), dtype=np.float32)
     w = (1 + 0.1 * rng.standard_normal(hidden, dtype=np.float32)).astype(np.float16)
     mt = (rows + 15) // 16
     hi = torch.zeros((mt, hidden // 32, 64, 8), dtype=torch.float16, device=DEV)
     lo = torch.zeros_like(hi)
-    n.rmsnorm_frag(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), hi, lo, rows, hidden, 1e-5)
+    xd = torch.from_numpy(x).to(DEV)
+    n.rmsnorm_frag(xd, torch.from_numpy(w).to(DEV), hi, lo, rows, hidden, 1e-5, torch.from_numpy(sl).to(DEV), nslabs)
+    xe = x.copy()
+    for s_ in range(nslabs):
+        xe = xe + sl[s_]                       # fixed order, fp32
+    np.testing.assert_array_equal(xd.cpu().numpy(), xe)          # residual updated in place, bit-exact
     got = (n.from_act_frags(hi, rows).float() + n.from_act_frags(lo, rows).float()).cpu().numpy()
-    ref = orc.rmsnorm(x, w.astype(np.float32), 1e-5)
+    ref = orc.rmsnorm(xe, w.astype(np.float32), 1e-5)
     np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K,kq", [(12, 4096, 4096, 4), (12, 4096, 11008, 4), (3, 64, 96, 2), (20, 512, 1376, 3)])
+def test_gemm_skinny_k_slices(M, N, K, kq):
+    """K-sliced launch: the slabs add up to the full product."""
+    n = _n()
+    rng = np.random.default_rng(15)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    slabs = torch.full((kq, M, N), 3.0, dtype=torch.float32, device=DEV)
+    n.gemm_skinny(n.to_weight_frags(w), hi, lo, M, N, K, n.EPI_STORE, y=slabs, ldy=N, kslices=kq)
+    ref = (x.double() @ w.double().t()).float()
+    assert (slabs.sum(0) - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
 
 
 @pytest.mark.parametrize("B,H,Hkv,D,q_len,past", [(1, 32, 32, 128, 12, 1725), (1, 4, 4, 32, 17, 3), (2, 4, 2, 128, 12, 300),

@@ -63,13 +63,13 @@ def bench_attn(name, H, Hkv, D, q_len, past):
           f"{byts/med/1e6:.0f} GB/s  {flops/med/1e9:.1f} TFLOP/s")
 
 
-def bench_gemm(name, M, N, K, epi):
+def bench_gemm(name, M, N, K, epi, kq=1):
     ncopy = max(2, int(700e6 / (N * K * 2)) + 1)          # rotate through > 256 MB (Infinity Cache) of weights
     ws = [n.to_weight_frags(torch.randn(N, K, device=DEV).half() * 0.05) for _ in range(ncopy)]
     x = torch.randn(M, K, device=DEV)
     hi, lo = n.to_act_frags(x)
     mt = (M + 15) // 16
-    y = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    y = torch.zeros((kq, M, N), dtype=torch.float32, device=DEV)
     oh = torch.empty((mt, max(N // 64, 1), 64, 8), dtype=torch.float16, device=DEV)
     ol = torch.empty_like(oh)
     i = [0]
@@ -79,9 +79,9 @@ def bench_gemm(name, M, N, K, epi):
         if epi == 2:
             n.gemm_skinny(ws[i[0]], hi, lo, M, N, K, 2, of_hi=oh, of_lo=ol)
         else:
-            n.gemm_skinny(ws[i[0]], hi, lo, M, N, K, epi, y=y, ldy=N)
+            n.gemm_skinny(ws[i[0]], hi, lo, M, N, K, epi, y=y, ldy=N, kslices=kq)
     med, best = timeit(fn, iters=40)
-    print(f"gemm {name}: M={M} N={N} K={K} epi={epi}  med {med*1e3:.1f} us (best {best*1e3:.1f})  weights {N*K*2/med/1e6:.0f} GB/s")
+    print(f"gemm {name}: M={M} N={N} K={K} epi={epi} kq={kq}  med {med*1e3:.1f} us (best {best*1e3:.1f})  weights {N*K*2/med/1e6:.0f} GB/s")
 
 
 if __name__ == "__main__":
@@ -89,6 +89,9 @@ if __name__ == "__main__":
         M = 12
         bench_gemm("qkv", M, 12288, 4096, 0)
         bench_gemm("o", M, 4096, 4096, 1)
+        for kq in (2, 4, 8):
+            bench_gemm("o", M, 4096, 4096, 0, kq)
+            bench_gemm("down", M, 4096, 11008, 0, kq)
         bench_gemm("gate_up", M, 22016, 4096, 2)
         bench_gemm("down", M, 4096, 11008, 1)
         bench_gemm("lm_head", M, 32000, 4096, 0)

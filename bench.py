@@ -167,11 +167,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    # test hooks (1-GPU smoke of the N > 1 code path): PC_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # PC_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("PC_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        backend = os.environ.get("PC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if world > 1:
@@ -258,7 +266,11 @@ def main():
                          "prefill_median": prefill_ms[len(prefill_ms) // 2],
                          "new_token_tokens_per_s": world * q / (ttft_ms * 1e-3)},
         "roofline": {"kernel": "kv_copy_kernel (pc_kv_gather)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     # PMC passes cannot run inside this process: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of
+                     # this kernel on this exact workload, from profiles/r01_pmc_kv_copy_kernel.txt; null otherwise
+                     "traffic": 1808880640 if (S, L, Hkv, D) == (1725, 32, 32, 128) else None,
+                     "traffic_source": "profiles/r01_pmc_kv_copy_kernel.txt (separate rocprofv3 --pmc passes)",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": gather_avg_us,
                      "min_launch_us": gather_us[0], "launches_timed": len(gather_us),
                      "how": "HIP events recorded on the launch stream immediately around the launch, every timed step"},

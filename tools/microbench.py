@@ -85,6 +85,15 @@ def bench_gemm(name, M, N, K, epi, kq=1):
 
 
 if __name__ == "__main__":
+    if "--gather-only" in sys.argv:      # PMC passes: a handful of launches of the persona gather, nothing else
+        segs = [torch.randn((32, 2, 32, ln, 128), device=DEV).half() for ln in PERSONA]
+        dst = torch.empty((32, 2, 32, 4096, 128), dtype=torch.float16, device=DEV)
+        offs = np.concatenate([[0], np.cumsum(PERSONA)[:-1]]).astype(int).tolist()
+        for _ in range(5):
+            n.kv_gather([s_.data_ptr() for s_ in segs], PERSONA, offs, dst, 32, 32, 128, 4096)
+        torch.cuda.synchronize()
+        print("gather-only done: algorithmic bytes per launch", 2 * sum(PERSONA) * 32 * 2 * 32 * 128 * 2)
+        sys.exit(0)
     if "--gemm" in sys.argv:
         M = 12
         bench_gemm("qkv", M, 12288, 4096, 0)

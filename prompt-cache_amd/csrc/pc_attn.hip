@@ -262,6 +262,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
 }
 
 // Merge split-KV partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i.
+// One workgroup per (query row, head), one thread per head dim.  (A variant with one workgroup per head and
+// float4 items measured 8.0 us vs 6.3 us per launch inside the captured forward: more parallel, shorter chains win.)
 template <int D>
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                     _Float16* __restrict__ out, int64_t o_bs, int64_t o_ts,

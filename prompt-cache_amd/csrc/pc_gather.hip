@@ -99,6 +99,8 @@ __global__ __launch_bounds__(kThreads) void kv_copy_kernel(const CopyArgs a) {
 }
 
 int launch_batches(SegDesc* descs, int nseg, int planes, hipStream_t stream) {
+    // Non-temporal loads/stores (PC_GATHER_NT=1) look +2..5 % in an isolated loop but measured 373 us vs 355 us per
+    // launch inside the real TTFT step (the attention that follows re-reads the staged rows): default off.
     static const bool nt = [] { const char* e = getenv("PC_GATHER_NT"); return e && e[0] == '1'; }();
     for (int base = 0; base < nseg; base += kMaxSeg) {
         CopyArgs a;

@@ -161,6 +161,18 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
  * ------------------------------------------------------------------------------------------- */
 int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
                    int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices, void* stream);
+/* pc_gemm_qkv_rope -- the fused q|k|v projection of the small-q path: llama2.py:345-347 (projections),
+ *   :357-359 (RoPE at the supplied position ids) and :361-364 (KV concat) in ONE weight-streaming launch.
+ *   wf_perm: fragment image of the row-PERMUTED [q;k;v] weight: inside every head, tile j (16 rows) holds
+ *            features 8j..8j+7 followed by their rotary partners D/2+8j..D/2+8j+7
+ *            (perm[h*D + 16j + r] = h*D + 8j + r for r < 8, h*D + D/2 + 8j + r - 8 otherwise).
+ *   outputs: rotated q as split-precision planes q_hi/q_lo [B*q_len][H*D] (token stride q_token_stride);
+ *            rotated k and v written in place at rows [past_len, past_len+q_len) of the arena planes. */
+int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, int32_t M, int32_t K,
+                     const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
+                     int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
+                     int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
+                     void* stream);
 int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
                     float eps, const float* slabs, int32_t nslabs, void* stream);
 

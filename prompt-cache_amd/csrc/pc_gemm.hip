@@ -31,8 +31,15 @@
 //   EPI_ADD    y[m][n] += v                     (fp32 residual stream, o_proj / down_proj)
 //   EPI_SILU   Of[m][j] = silu(gate_j) * up_j   (gate tile i and up tile inter/16 + i reduced in the same
 //                                                workgroup; written as hi/lo fragment planes for down_proj)
+//   EPI_ROPE   fused q|k|v projection epilogue: RoPE at the supplied position ids on q and k
+//              (apply_rotary_pos_emb, llama2.py:202-210), rotated q -> split-precision fp16 planes for the
+//              attention kernel, rotated k and v -> appended IN PLACE to the layer's KV arena (the torch.cat
+//              of llama2.py:361-364).  The weight rows are permuted at load so that a 16-row tile holds 8
+//              rotary pairs (rows 0-7: features 8j..8j+7, rows 8-15: the partners D/2 + 8j..): the partner of a
+//              lane's value sits in lane ^ 32, one shuffle, no extra pass and no fp32 q|k|v round trip.
 // Algorithmic bytes per launch: N*K*2 (weights once) [+ M*K*4 activations from L2 per workgroup].
 #include <hip/hip_fp16.h>
+#include <string.h>
 
 #include "pc_common.h"
 
@@ -45,7 +52,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2 };
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2, EPI_ROPE = 3 };
+
+struct RopeEpi {          // EPI_ROPE outputs
+    const float2* cs;     // [B*q_len][D/2] (cos, sin) from pc_rope_table
+    _Float16* q_hi; _Float16* q_lo; int64_t q_ts;        // [B*q_len][H*D] planes, token stride q_ts
+    _Float16* k_arena; _Float16* v_arena; int64_t a_bs, a_hs;
+    const int32_t* past_len_dev;
+    int32_t H, Hkv, D, q_len, past_len;
+};
 
 struct GemmParams {
     const _Float16* wf;      // [ntiles][KS][64][8]
@@ -55,6 +70,7 @@ struct GemmParams {
     _Float16* of_hi; _Float16* of_lo; int32_t KSo;  // EPI_SILU: output planes [MT][KSo][64][8]
     int32_t M, ntiles, KS, npairs;
     int32_t kslices; int64_t slab_stride;   // EPI_STORE only: grid.y K-slices, slice s writes y + s*slab_stride
+    RopeEpi rope;
 };
 
 __device__ __forceinline__ h8 ldg_h8(const _Float16* p) { return *(const h8*)p; }
@@ -218,6 +234,8 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
                 const int64_t off = frag_off(row, j0, p.KSo);
                 *(h4*)(p.of_hi + off) = hi;
                 *(h4*)(p.of_lo + off) = lo;
+            } else if (EPI == EPI_ROPE) {
+                // handled below (needs the cross-lane exchange from every lane, valid or not)
             } else {
                 float* yp = p.y + (int64_t)blockIdx.y * p.slab_stride + (int64_t)row * p.ldy + unit * 16 + g * 4;
                 if (EPI == EPI_ADD) {
@@ -225,6 +243,44 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
                     v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
                 }
                 *(f4*)yp = v;
+            }
+        }
+        if (EPI == EPI_ROPE) {
+            const RopeEpi& e = p.rope;
+            // partner half of every value lives in lane ^ 32 (rows 8..15 of the permuted tile)
+            f4 pv;
+            pv[0] = __shfl_xor(v[0], 32); pv[1] = __shfl_xor(v[1], 32); pv[2] = __shfl_xor(v[2], 32); pv[3] = __shfl_xor(v[3], 32);
+            if (unit < nunits && row < p.M) {
+                const int tpd = e.D >> 4;                       // tiles per head
+                const int hh = unit / tpd, j = unit - hh * tpd;
+                const bool is_hi = g >= 2;
+                const int i0 = 8 * j + 4 * (g & 1);            // rotary frequency index of v[0]
+                const int d0 = i0 + (is_hi ? (e.D >> 1) : 0);  // feature index inside the head
+                const int bb = row / e.q_len, tt = row - bb * e.q_len;
+                if (hh < e.H + e.Hkv) {
+                    const float2* cs = e.cs + (int64_t)row * (e.D >> 1) + i0;
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 w = cs[r];
+                        // q*cos + rotate_half(q)*sin (llama2.py:208): low half pairs with -high, high with +low
+                        const float o = is_hi ? (v[r] * w.x + pv[r] * w.y) : (v[r] * w.x - pv[r] * w.y);
+                        hi[r] = (_Float16)o;
+                        lo[r] = (_Float16)(o - (float)hi[r]);
+                    }
+                    if (hh < e.H) {
+                        const int64_t off = (int64_t)row * e.q_ts + (int64_t)hh * e.D + d0;
+                        *(h4*)(e.q_hi + off) = hi;
+                        *(h4*)(e.q_lo + off) = lo;
+                    } else {
+                        const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
+                        *(h4*)(e.k_arena + bb * e.a_bs + (int64_t)(hh - e.H) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hi;
+                    }
+                } else {
+                    const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
+                    h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *(h4*)(e.v_arena + bb * e.a_bs + (int64_t)(hh - e.H - e.Hkv) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hv;
+                }
             }
         }
     }
@@ -348,6 +404,7 @@ PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_l
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
     GemmParams p;
+    memset(&p, 0, sizeof(p));
     p.wf = (const _Float16*)wf; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
     p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
@@ -366,6 +423,30 @@ PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_l
     if (epilogue == EPI_ADD) return launch_MT<EPI_ADD>(p, choose_T(p.ntiles), p.ntiles, s);
     PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_skinny: unknown epilogue %d", epilogue);
     return launch_MT<EPI_STORE>(p, choose_T(p.ntiles * kslices) , p.ntiles, s);
+}
+
+PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, int32_t M, int32_t K,
+                               const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena,
+                               void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
+                               int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
+                               const int32_t* past_len_dev, void* stream) {
+    const int N = (H + 2 * Hkv) * D;
+    PC_REQUIRE(M > 0 && M <= 64 && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 64", M);
+    PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
+    PC_REQUIRE(wf_perm && xf_hi && cs && q_hi && q_lo && k_arena && v_arena, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
+    PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
+               "pc_gemm_qkv_rope: past_len %d + q_len %d exceeds arena rows %d", past_len, q_len, cap);
+    PC_REQUIRE(q_token_stride % 4 == 0 && arena_head_stride % 4 == 0, PC_ERR_ARG, "pc_gemm_qkv_rope: strides must keep 8-byte alignment");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.wf = (const _Float16*)wf_perm; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
+    p.y = nullptr; p.ldy = 0; p.of_hi = nullptr; p.of_lo = nullptr; p.KSo = 0;
+    p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.kslices = 1; p.slab_stride = 0;
+    p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
+    p.rope.k_arena = (_Float16*)k_arena; p.rope.v_arena = (_Float16*)v_arena; p.rope.a_bs = arena_batch_stride;
+    p.rope.a_hs = arena_head_stride; p.rope.past_len_dev = past_len_dev;
+    p.rope.H = H; p.rope.Hkv = Hkv; p.rope.D = D; p.rope.q_len = q_len; p.rope.past_len = past_len;
+    return launch_MT<EPI_ROPE>(p, choose_T(p.ntiles), p.ntiles, (hipStream_t)stream);
 }
 
 PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,

@@ -28,6 +28,8 @@ SIGNATURES = {
     "pc_attn_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
+                                   _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -140,6 +142,25 @@ def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None,
     rc = load().pc_gemm_skinny(wf.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue, _ptr(y), ldy,
                                _ptr(of_hi), _ptr(of_lo), kslices, current_stream() if stream is None else stream)
     check(rc, "pc_gemm_skinny")
+
+
+def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,
+                  past_len, cap, past_len_dev=None, stream: Optional[int] = None) -> None:
+    rc = load().pc_gemm_qkv_rope(wf_perm.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, K, cs.data_ptr(), q_hi.data_ptr(),
+                                 q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D,
+                                 q_len, past_len, cap, _ptr(past_len_dev), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_qkv_rope")
+
+
+def qkv_rope_row_perm(n_heads_total: int, D: int):
+    """Row permutation of the fused [q;k;v] weight for pc_gemm_qkv_rope: tile j of a head = features
+    8j..8j+7 then D/2+8j..D/2+8j+7."""
+    import torch
+    idx = []
+    for h in range(n_heads_total):
+        for j in range(D // 16):
+            idx += [h * D + 8 * j + r for r in range(8)] + [h * D + D // 2 + 8 * j + r for r in range(8)]
+    return torch.tensor(idx, dtype=torch.long)
 
 
 def rmsnorm_frag(x_f32, weight, xf_hi, xf_lo, rows: int, hidden: int, eps: float, slabs=None, nslabs: int = 0,

@@ -80,8 +80,14 @@ class LlamaHIP:
             wqkv = torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous()
             wgu = torch.cat([w(f"l{i}.gate"), w(f"l{i}.up")], dim=0).contiguous()
             wo, wdown = w(f"l{i}.wo"), w(f"l{i}.down")
+            if self.skinny:
+                if i == 0:
+                    self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2 * self.Hkv, self.D).to(dev)
+                wqkv_f = fr(wqkv[self._qkv_perm].contiguous())     # rotary pairs share a 16-row tile (pc_gemm_qkv_rope)
+            else:
+                wqkv_f = None
             self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown,
-                                    wqkv_f=fr(wqkv), wo_f=fr(wo), wgu_f=fr(wgu), wdown_f=fr(wdown)))
+                                    wqkv_f=wqkv_f, wo_f=fr(wo), wgu_f=fr(wgu), wdown_f=fr(wdown)))
         # exactly the reference formula, evaluated on the CPU like the reference does (llama2.py:121)
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
@@ -268,7 +274,6 @@ class LlamaHIP:
         xh, xl = planes(hid)
         ah, al = planes(H * D)
         ch, cl = planes(inter)
-        qkv = torch.empty((T, W), dtype=torch.float32, device=dev)
         # The two N = hidden projections (o_proj, down_proj) split K over KQ workgroup slices and leave KQ slabs of
         # partial sums; the next RMSNorm launch folds them into the residual stream (x += sum of slabs).
         KQ = self.kslices
@@ -277,11 +282,10 @@ class LlamaHIP:
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps, slabs, pending)
-            n.gemm_skinny(lw["wqkv_f"], xh, xl, T, W, hid, n.EPI_STORE, y=qkv, ldy=W)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
-            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:],
-                          q_len * W, W, kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len,
-                          past_len, arena.cap, True, past_len_dev=past_dev, q_out_lo=q16l)
+            # q|k|v projection + RoPE + in-place KV append in one weight-streaming launch
+            n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                            arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l)

@@ -481,3 +481,48 @@ def test_attn_fragment_plane_output(B, H, Hkv, D, q_len, past):
     got = (n.from_act_frags(fh, T).float() + n.from_act_frags(fl, T).float()).cpu().numpy().reshape(B, q_len, H * D)
     ref = _ref_attn(q, k, v, past)
     np.testing.assert_allclose(got, ref, atol=3e-3, rtol=1e-2)   # fp16 P inside the kernel; fp32-ish output
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 7, 512), (1, 4, 4, 32, 17, 0, 128),
+                                                       (1, 2, 2, 64, 1, 30, 256)])
+def test_gemm_qkv_rope_fused_equals_unfused(B, H, Hkv, D, q_len, past, hid):
+    """Fused projection + RoPE + KV-append epilogue == plain-store GEMM followed by pc_rope_append: same dot
+    products (only the weight rows are permuted inside the tiles), same rotation up to how the compiler contracts
+    a*c -/+ b*s into FMAs, so the fp16 results agree to one ulp and almost always exactly."""
+    n = _n()
+    rng = np.random.default_rng(16)
+    T = B * q_len
+    W = (H + 2 * Hkv) * D
+    cap = past + q_len + 2
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((T, hid), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    pos = rng.integers(0, 3000, size=T).astype(np.int32)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(torch.from_numpy(pos).to(DEV), _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    # unfused reference path
+    qkv = torch.empty((T, W), dtype=torch.float32, device=DEV)
+    n.gemm_skinny(n.to_weight_frags(w), hi, lo, T, W, hid, n.EPI_STORE, y=qkv, ldy=W)
+    arena_a = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    qa = torch.zeros((T, H * D), dtype=torch.float16, device=DEV)
+    qal = torch.zeros_like(qa)
+    n.rope_append(qkv, q_len * W, W, qa, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
+                  arena_a[:, 0], arena_a[:, 1], 2 * Hkv * cap * D, cap * D, cs, B, H, Hkv, D, q_len, past, cap, True, q_out_lo=qal)
+    # fused path
+    perm = n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)
+    arena_b = torch.zeros_like(arena_a)
+    qb = torch.zeros_like(qa)
+    qbl = torch.zeros_like(qa)
+    n.gemm_qkv_rope(n.to_weight_frags(w[perm].contiguous()), hi, lo, T, hid, cs, qb, qbl, H * D, arena_b[:, 0], arena_b[:, 1],
+                    2 * Hkv * cap * D, cap * D, B, H, Hkv, D, q_len, past, cap)
+    torch.cuda.synchronize()
+    def close(a, b):
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= 2e-3 * max(1.0, float(a.float().abs().max())), float(d.max())     # <= 1 fp16 ulp
+        assert float((a != b).float().mean()) < 0.02
+    close(qa, qb)
+    close(arena_a, arena_b)
+    assert torch.equal(arena_a[:, 1], arena_b[:, 1])                       # V is a pure fp32 -> fp16 conversion
+    rec_a, rec_b = qa.float() + qal.float(), qb.float() + qbl.float()      # split-precision q: ~fp32 agreement
+    assert float((rec_a - rec_b).abs().max()) < 1e-5 * max(1.0, float(rec_a.abs().max()))
+    assert float(arena_b[:, :, :, past:past + q_len].abs().sum()) > 0 and float(arena_b[:, :, :, :past].abs().sum()) == 0

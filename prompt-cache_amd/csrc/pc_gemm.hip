@@ -289,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 // RMSNorm producing split-precision fragment planes: one workgroup per row.
 // Optional prologue: x[row] += slab[0][row] + slab[1][row] + ... (fixed order), the K-sliced partial sums a
 // preceding pc_gemm_skinny left behind -- the residual add of llama2.py:638 / :644 happens here, in place.
+template <int G>   // G = 8-element groups per thread: the whole row stays in registers between the two passes
 __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x, const _Float16* __restrict__ w,
                                                            _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo,
                                                            int hidden, float eps, const float* __restrict__ slabs,
@@ -297,47 +298,69 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = hidden >> 3;
     float* xr = x + (int64_t)row * hidden;
+    f4 va[G], vb[G];
     float ss = 0.f;
-    for (int i = tid; i < nv; i += 256) {
-        f4 a = *(const f4*)(xr + i * 8), b = *(const f4*)(xr + i * 8 + 4);
-        if (nslabs > 0) {
-            for (int s = 0; s < nslabs; ++s) {
-                const float* sp = slabs + s * slab_stride + (int64_t)row * hidden + i * 8;
-                const f4 c = *(const f4*)sp, d = *(const f4*)(sp + 4);
-                a[0] += c[0]; a[1] += c[1]; a[2] += c[2]; a[3] += c[3];
-                b[0] += d[0]; b[1] += d[1]; b[2] += d[2]; b[3] += d[3];
-            }
-            *(f4*)(xr + i * 8) = a;
-            *(f4*)(xr + i * 8 + 4) = b;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int i = tid + k * 256;
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        va[k] = z; vb[k] = z;
+        if (i < nv) {
+            va[k] = *(const f4*)(xr + i * 8);
+            vb[k] = *(const f4*)(xr + i * 8 + 4);
         }
-        ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
     }
+    if (nslabs > 0) {
+        for (int s = 0; s < nslabs; ++s) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int i = tid + k * 256;
+                if (i < nv) {
+                    const float* sp = slabs + s * slab_stride + (int64_t)row * hidden + i * 8;
+                    const f4 c = *(const f4*)sp, d = *(const f4*)(sp + 4);
+                    va[k][0] += c[0]; va[k][1] += c[1]; va[k][2] += c[2]; va[k][3] += c[3];
+                    vb[k][0] += d[0]; vb[k][1] += d[1]; vb[k][2] += d[2]; vb[k][3] += d[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int i = tid + k * 256;
+            if (i < nv) {
+                *(f4*)(xr + i * 8) = va[k];
+                *(f4*)(xr + i * 8 + 4) = vb[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+        ss += va[k][0] * va[k][0] + va[k][1] * va[k][1] + va[k][2] * va[k][2] + va[k][3] * va[k][3] +
+              vb[k][0] * vb[k][0] + vb[k][1] * vb[k][1] + vb[k][2] * vb[k][2] + vb[k][3] * vb[k][3];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    // (each thread re-reads only elements it wrote itself above: same i -> same thread)
     const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
     const int KS = hidden >> 5;
-    for (int i = tid; i < nv; i += 256) {
-        const f4 a = *(const f4*)(xr + i * 8), b = *(const f4*)(xr + i * 8 + 4);
-        const h8 gw = *(const h8*)(w + i * 8);
-        h8 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = (float)gw[e] * ((e < 4 ? a[e] : b[e - 4]) * rs);
-            hi[e] = (_Float16)v;
-            lo[e] = (_Float16)(v - (float)hi[e]);
+    for (int k = 0; k < G; ++k) {
+        const int i = tid + k * 256;
+        if (i < nv) {
+            const h8 gw = *(const h8*)(w + i * 8);
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (float)gw[e] * ((e < 4 ? va[k][e] : vb[k][e - 4]) * rs);
+                hi[e] = (_Float16)v;
+                lo[e] = (_Float16)(v - (float)hi[e]);
+            }
+            const int64_t off = frag_off(row, i * 8, KS);
+            *(h8*)(of_hi + off) = hi;
+            *(h8*)(of_lo + off) = lo;
         }
-        const int64_t off = frag_off(row, i * 8, KS);
-        *(h8*)(of_hi + off) = hi;
-        *(h8*)(of_lo + off) = lo;
     }
 }
 
-// U = k-steps per load block.  A wave keeps U*TT KiB of weights (+ U*MT*{1,2} KiB of L2-resident activations)
-// in flight; with one or two workgroups per CU the chip needs >= ~8 KiB of weight bytes per wave outstanding
-// to cover HBM latency at full bandwidth (measured: U*TT = 4 KiB left o_proj at 3.4 TB/s).
 template <int MT, int T, int EPI>
 int launch_one(const GemmParams& p, int units, hipStream_t s) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
@@ -454,7 +477,12 @@ PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* x
     PC_REQUIRE(rows > 0 && rows <= 64 && hidden > 0 && hidden % 32 == 0, PC_ERR_ARG, "pc_rmsnorm_frag: bad sizes");
     PC_REQUIRE(x && weight && xf_hi && xf_lo && nslabs >= 0 && (nslabs == 0 || slabs), PC_ERR_ARG,
                "pc_rmsnorm_frag: null pointer");
-    hipLaunchKernelGGL(rmsnorm_frag_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
-                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps, slabs, nslabs, (int64_t)rows * hidden);
+    PC_REQUIRE(hidden <= 16384, PC_ERR_ARG, "pc_rmsnorm_frag: hidden %d > 16384", hidden);
+    const int groups = pc_ceil_div(hidden / 8, 256);
+#define PC_RMS(GV)                                                                                                   \
+    hipLaunchKernelGGL(rmsnorm_frag_kernel<GV>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight, \
+                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps, slabs, nslabs, (int64_t)rows * hidden)
+    if (groups <= 1) PC_RMS(1); else if (groups <= 2) PC_RMS(2); else if (groups <= 4) PC_RMS(4); else PC_RMS(8);
+#undef PC_RMS
     return pc_check_launch("rmsnorm_frag_kernel");
 }

@@ -166,9 +166,9 @@ class SchemaCache:
         mine = shards[rank]
 
         encoded_tokens = 0
-        local_segments: List[Tuple[TokenSequence, torch.Tensor]] = []
-        for b0 in range(0, len(mine), batch_size):
-            group = [jobs[i] for i in mine[b0:b0 + batch_size]]
+        per_job: Dict[int, List[Tuple[TokenSequence, torch.Tensor]]] = {}
+        for idxs in self._pack(mine, [len(j["token_ids"]) for j in jobs], batch_size):
+            group = [jobs[i] for i in idxs]
             ids_pad, mask = pad_batch([j["token_ids"] for j in group], lm.eos_token_id)
             pos_pad, _ = pad_batch([j["position_ids"] for j in group], 0)
             out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
@@ -185,8 +185,10 @@ class SchemaCache:
                 lens = [len(tc) for tc in owned]
                 stores = [torch.empty((L, 2, Hkv, n, D), dtype=torch.float16, device=dev) for n in lens]
                 _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
-                local_segments += list(zip(owned, stores))
+                per_job[idxs[row]] = list(zip(owned, stores))
             del out, arena
+        # ascending job order == the global segment order restricted to this rank (what the all-gather plan assumes)
+        local_segments: List[Tuple[TokenSequence, torch.Tensor]] = [p for i in sorted(per_job) for p in per_job[i]]
 
         if world > 1:
             # one exchange step: every GPU ends with the whole module library
@@ -203,6 +205,28 @@ class SchemaCache:
         self.encode_stats = dict(passes=len(mine), total_passes=len(jobs), encoded_tokens=encoded_tokens,
                                  cached_tokens=sum(len(c) for c in self.cache_l1.values()))
         gc.collect()
+
+    # tokens (padding included) one encode forward may carry when scaffolds are packed into a batch
+    encode_token_budget = 8192
+
+    def _pack(self, mine: List[int], lengths: List[int], batch_size: int) -> List[List[int]]:
+        """Group this rank's scaffold passes into right-padded batches.  ``batch_size`` is the reference's knob
+        (``cache_engine.py:232``: consecutive passes, in order); with the default of 1 the engine packs on its own:
+        longest first, as many passes per forward as fit ``encode_token_budget`` rows -- dense GEMMs at M ~ 600
+        rows run at ~75 % of their M ~ 5000 rate on MI355X, and padded rows never influence real ones."""
+        if batch_size > 1:
+            return [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
+        order = sorted(mine, key=lambda i: (-lengths[i], i))
+        groups, cur = [], []
+        for i in order:
+            width = lengths[cur[0]] if cur else lengths[i]
+            if cur and ((len(cur) + 1) * width > self.encode_token_budget or len(cur) >= 16):
+                groups.append(cur)
+                cur = []
+            cur.append(i)
+        if cur:
+            groups.append(cur)
+        return groups
 
     def get_cache_l1(self, seq: TokenSequence) -> Optional[TokenSequenceCache]:
         return self.cache_l1.get(id(seq))

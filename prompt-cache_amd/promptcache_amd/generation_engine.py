@@ -1,21 +1,23 @@
 """Generation engine: one prefill over the staged KV (TTFT), then token-by-token decode.
 
-Mirrors ``promptcache/generation_engine.py`` of the reference -- ``GenerationParameters`` (:21-42),
-``is_partial_stop`` (:45-50), ``Output`` (:53-58), ``GenerationEngine.generate`` (:67-209) -- including
-its observable quirks: the first decoded token is placed at position ``max(position_ids) + 2``
-(``position_offset + i`` with ``i`` starting at 1, :82/:132), and ``Output`` is built as
-``Output(text, new_text, inference_time, response_time)`` (:201), so the field named
-``elapsed_time`` carries the prefill latency (TTFT) and ``response_time`` the running total.
+Public surface of ``promptcache/generation_engine.py`` in the reference -- ``GenerationParameters`` (:21-42),
+``is_partial_stop`` (:45-50), ``Output`` (:53-58), ``GenerationEngine.generate`` (:67-209) -- kept, including
+its observable quirks:
 
-What changes underneath: the model appends K/V in place to the arena behind ``cache`` (no ``torch.cat``
-of the whole past per layer per step, ``llama2.py:361-364``) and only the last row goes through
-``lm_head`` during decode.
+* the first decoded token is placed at position ``max(position_ids) + 2``: the reference adds the loop index,
+  which starts at 1 for the first decode step, to ``max(position_ids) + 1`` (:82, :132);
+* ``Output`` is constructed positionally as ``Output(text, new_text, inference_time, response_time)`` (:201), so
+  the field called ``response_time`` carries the running total and ``elapsed_time`` the prefill latency (TTFT).
+
+Underneath, every forward is the HIP path: K/V of new tokens are appended in place to the arena behind ``cache``
+(no per-layer ``torch.cat`` of the whole past, ``llama2.py:361-364``) and each decode step replays one captured
+hipGraph (``model/llama_hip.py``).
 """
 from __future__ import annotations
 
 import gc
 from dataclasses import dataclass, field
-from typing import Generator, List, Optional
+from typing import Generator, List, Optional, Tuple
 
 import torch
 
@@ -34,28 +36,29 @@ class GenerationParameters:
     stop_str: List[str] = field(default_factory=list)
     echo: bool = True
 
+    @property
+    def greedy(self) -> bool:
+        return self.temperature < 1e-5 or self.top_p < 1e-8
+
     def get_logits_processor(self):
-        from transformers.generation.logits_process import (
-            LogitsProcessorList, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
-            TopPLogitsWarper)
-        p = LogitsProcessorList()
+        """Same processor chain, same order and thresholds as the reference (:32-42)."""
+        from transformers.generation import logits_process as lp
+        chain = lp.LogitsProcessorList()
         if self.temperature >= 1e-5 and self.temperature != 1.0:
-            p.append(TemperatureLogitsWarper(self.temperature))
+            chain.append(lp.TemperatureLogitsWarper(self.temperature))
         if self.repetition_penalty > 1.0:
-            p.append(RepetitionPenaltyLogitsProcessor(self.repetition_penalty))
+            chain.append(lp.RepetitionPenaltyLogitsProcessor(self.repetition_penalty))
         if 1e-8 <= self.top_p < 1.0:
-            p.append(TopPLogitsWarper(self.top_p))
+            chain.append(lp.TopPLogitsWarper(self.top_p))
         if self.top_k > 0:
-            p.append(TopKLogitsWarper(self.top_k))
-        return p
+            chain.append(lp.TopKLogitsWarper(self.top_k))
+        return chain
 
 
 def is_partial_stop(output: str, stop_str: str) -> bool:
-    """Whether the tail of ``output`` could still grow into ``stop_str`` (reference :45-50)."""
-    for i in range(0, min(len(output), len(stop_str))):
-        if stop_str.startswith(output[-i:]):
-            return True
-    return False
+    """True while the tail of ``output`` may still grow into ``stop_str`` (reference :45-50; note that
+    ``output[-0:]`` is the whole string, so the first probe compares against everything generated so far)."""
+    return any(stop_str.startswith(output[-i:]) for i in range(0, min(len(output), len(stop_str))))
 
 
 @dataclass
@@ -66,86 +69,92 @@ class Output:
     elapsed_time: float = 0.0
 
 
+class _Timer:
+    """HIP-event stopwatch around one ``lm()`` call (the reference's measuring recipe, :104-115)."""
+
+    def __enter__(self):
+        self.t0 = torch.cuda.Event(enable_timing=True)
+        self.t1 = torch.cuda.Event(enable_timing=True)
+        self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.t1.record()
+        torch.cuda.synchronize()
+        self.ms = self.t0.elapsed_time(self.t1)
+        return False
+
+
 class GenerationEngine:
     def __init__(self, lm: LanguageModel, verbose: bool = False):
         self.lm = lm
         self.verbose = verbose
 
+    # -- pieces of the loop ---------------------------------------------------------------------
+    def _forward(self, ids: List[int], positions: List[int], past) -> Tuple[torch.Tensor, object, float]:
+        dev = self.lm.device
+        ids_t = torch.tensor([ids], device=dev, dtype=torch.long)
+        pos_t = torch.tensor([positions], device=dev, dtype=torch.long)
+        with _Timer() as t:
+            out = self.lm(input_ids=ids_t, position_ids=pos_t, past_key_values=past, use_cache=True)
+        return out.logits, out.past_key_values, t.ms
+
+    @staticmethod
+    def _pick(last_logits: torch.Tensor, greedy: bool) -> int:
+        if greedy:
+            return int(torch.argmax(last_logits))
+        return int(torch.multinomial(torch.softmax(last_logits, dim=-1), num_samples=1))
+
+    def _render(self, output_ids: List[int], new_ids: List[int], stop_strs: List[str]) -> Tuple[str, str, bool, bool]:
+        """-> (text, new_text, hit_stop_string, partially_matched)."""
+        text, new_text = self.lm.decode(output_ids), self.lm.decode(new_ids)
+        for stop in stop_strs:
+            cut = new_text.rfind(stop, 0)
+            if cut != -1:
+                return text, new_text[:cut], True, False
+            if is_partial_stop(text, stop):
+                return text, new_text, False, True
+        return text, new_text, False, False
+
+    # -- the generator ----------------------------------------------------------------------------
     @torch.inference_mode()
     def generate(self, token_ids: List[int], position_ids: List[int], params: GenerationParameters,
                  cache=None, stream_interval: int = 2, use_full_position_ids: bool = False
                  ) -> Generator[Output, None, None]:
-        lm = self.lm
-        device = lm.device
         processors = params.get_logits_processor()
-        greedy = params.temperature < 1e-5 or params.top_p < 1e-8
-        output_ids = list(token_ids)
-        new_output_ids: List[int] = []
-        position_offset = max(position_ids) + 1
         prompt_positions = list(position_ids)
+        first_free = max(prompt_positions) + 1
+        output_ids, new_ids = list(token_ids), []
+        total_ms = ttft_ms = 0.0
         past = None
-        inference_time = 0.0
-        response_time = 0.0
-        new_token_id = 0
 
-        for i in range(params.max_new_tokens):
-            start = torch.cuda.Event(enable_timing=True)
-            end = torch.cuda.Event(enable_timing=True)
-            if past is None:
-                ids_t = torch.tensor([list(token_ids)], device=device, dtype=torch.long)
-                pos_t = torch.tensor([prompt_positions], device=device, dtype=torch.long)
+        for step in range(params.max_new_tokens):
+            if step == 0:
                 if cache is not None and not isinstance(cache, StagedKV):
-                    # plain list of [Hkv,S,D] views: add the batch dim like the reference (:101-102)
+                    # a plain list of [Hkv, S, D] views: add the batch dim like the reference does (:101-102)
                     cache = [(k.unsqueeze(0), v.unsqueeze(0)) if k.dim() == 3 else (k, v) for k, v in cache]
-                start.record()
-                out = lm(input_ids=ids_t, position_ids=pos_t, past_key_values=cache, use_cache=True)
-                end.record()
-                torch.cuda.synchronize()
-                inference_time += start.elapsed_time(end)
-                response_time = inference_time            # TTFT as the reference reports it (:114-118)
+                logits, past, ms = self._forward(list(token_ids), prompt_positions, cache)
+                ttft_ms = ms
                 if self.verbose:
-                    print(f"Prefill latency: {inference_time:.2f} ms")
+                    print(f"Prefill latency: {ms:.2f} ms")
             else:
-                ids_t = torch.tensor([[new_token_id]], device=device, dtype=torch.long)
-                if use_full_position_ids:
-                    pos_t = torch.tensor([prompt_positions + list(range(position_offset, position_offset + i))],
-                                         device=device, dtype=torch.long)
-                else:
-                    pos_t = torch.tensor([[position_offset + i]], device=device, dtype=torch.long)
-                start.record()
-                out = lm(input_ids=ids_t, position_ids=pos_t, past_key_values=past, use_cache=True)
-                end.record()
-                torch.cuda.synchronize()
-                inference_time += start.elapsed_time(end)
-            logits = out.logits
-            past = out.past_key_values
+                positions = (prompt_positions + list(range(first_free, first_free + step))) if use_full_position_ids \
+                    else [first_free + step]
+                logits, past, ms = self._forward([new_ids[-1]], positions, past)
+            total_ms += ms
 
-            history = torch.as_tensor([output_ids], device=device) if params.repetition_penalty > 1.0 else None
-            last = processors(history, logits[:, -1, :])[0]
-            if greedy:
-                new_token_id = int(torch.argmax(last))
-            else:
-                new_token_id = int(torch.multinomial(torch.softmax(last, dim=-1), num_samples=1))
-            output_ids.append(new_token_id)
-            new_output_ids.append(new_token_id)
+            history = torch.as_tensor([output_ids], device=self.lm.device) if params.repetition_penalty > 1.0 else None
+            token = self._pick(processors(history, logits[:, -1, :])[0], params.greedy)
+            output_ids.append(token)
+            new_ids.append(token)
 
-            stopped = new_token_id in params.stop_token_ids
-            if i % stream_interval == 0 or i == params.max_new_tokens - 1 or stopped:
-                text = lm.decode(output_ids)
-                new_text = lm.decode(new_output_ids)
-                partial = False
-                for stop in params.stop_str:
-                    pos = new_text.rfind(stop, 0)
-                    if pos != -1:
-                        new_text = new_text[:pos]
-                        stopped = True
-                        break
-                    partial = is_partial_stop(text, stop)
-                    if partial:
-                        break
+            done = token in params.stop_token_ids
+            if step % stream_interval == 0 or step == params.max_new_tokens - 1 or done:
+                text, new_text, hit, partial = self._render(output_ids, new_ids, params.stop_str)
+                done = done or hit
                 if not partial:
-                    yield Output(text, new_text, inference_time, response_time)
-            if stopped:
+                    yield Output(text, new_text, total_ms, ttft_ms)
+            if done:
                 break
 
         del past

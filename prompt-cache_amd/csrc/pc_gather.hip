@@ -12,19 +12,17 @@
 // per-side plane stride.  The kernel is HBM-bound: algorithmic bytes = 2 * S * planes * D * 2
 // (read once + write once).
 //
-// Work decomposition: tile = <=16 KiB of one segment-plane (64 tokens at D=128); a workgroup owns one
-// tile index for PP consecutive planes.  Lanes move 16 B each (global_load/store_dwordx4, 1 KiB per
-// wave-instruction, fully coalesced); 8 loads are issued before the first store so each lane keeps
-// 128 B in flight.  Short segments (the 1-token whitespace runs between PML tags: 17 of the 25
+// Work decomposition: tile = <=32 KiB of one segment-plane (128 tokens at D=128); a workgroup owns one
+// tile index for 2 consecutive planes.  Lanes move 16 B each (global_load/store_dwordx4, 1 KiB per
+// wave-instruction, fully coalesced); 16 loads are issued before the first store so each lane keeps
+// 256 B in flight.  Short segments (the 1-token whitespace runs between PML tags: 17 of the 25
 // segments of the persona prompt) fold several planes into one pass so no lane idles.
 #include "pc_common.h"
 
 namespace {
 
 constexpr int kMaxSeg = 40;          // descriptors per launch (kernarg-resident, 40 B each)
-constexpr int kTileBytes = 16384;    // per plane per workgroup
-constexpr int kPlanesPerWG = 8;
-constexpr int kUnroll = 8;
+// tile size / planes per workgroup / loads in flight: see launch_batches (env-overridable for sweeps)
 constexpr int kThreads = 256;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -42,10 +40,13 @@ struct CopyArgs {
     SegDesc seg[kMaxSeg];
     int32_t nseg;
     int32_t planes;
+    int32_t tile_bytes;      // per plane per workgroup (multiple of 16)
+    int32_t planes_per_wg;
 };
 
-template <bool NT>
+template <bool NT, int kUnroll>
 __global__ __launch_bounds__(kThreads) void kv_copy_kernel(const CopyArgs a) {
+    const int kTileBytes = a.tile_bytes, kPlanesPerWG = a.planes_per_wg;
     const int tile = blockIdx.x;
     // Wave-uniform scan of the (<=40 entry) kernarg table: scalar loads, no divergence.
     int s = 0;
@@ -102,6 +103,13 @@ int launch_batches(SegDesc* descs, int nseg, int planes, hipStream_t stream) {
     // Non-temporal loads/stores (PC_GATHER_NT=1) look +2..5 % in an isolated loop but measured 373 us vs 355 us per
     // launch inside the real TTFT step (the attention that follows re-reads the staged rows): default off.
     static const bool nt = [] { const char* e = getenv("PC_GATHER_NT"); return e && e[0] == '1'; }();
+    // Tiling swept inside the real TTFT step on MI355X (tools/gather_sweep.py; persona prompt, 1.81 GB per launch):
+    //   16 KiB x 8 planes, 8 loads in flight  : 361 us (5.0 TB/s)      8 KiB x 8, 8 : 336 us (5.4 TB/s)
+    //   64 KiB x 2 planes, 16 loads in flight : 327 us (5.5 TB/s)     32 KiB x 2, 16 : 318 us (5.7 TB/s)  <- default
+    // i.e. long contiguous runs per workgroup (32 KiB per plane) and 256 B per lane outstanding.
+    static const int tile_bytes = [] { const char* e = getenv("PC_GATHER_TILE"); return e ? atoi(e) : 32768; }();
+    static const int ppw = [] { const char* e = getenv("PC_GATHER_PPW"); return e ? atoi(e) : 2; }();
+    static const int unroll = [] { const char* e = getenv("PC_GATHER_UNROLL"); return e ? atoi(e) : 16; }();
     for (int base = 0; base < nseg; base += kMaxSeg) {
         CopyArgs a;
         const int n = (nseg - base < kMaxSeg) ? nseg - base : kMaxSeg;
@@ -109,14 +117,18 @@ int launch_batches(SegDesc* descs, int nseg, int planes, hipStream_t stream) {
         for (int i = 0; i < n; ++i) {
             a.seg[i] = descs[base + i];
             a.seg[i].tile_start = tiles;
-            tiles += (a.seg[i].bytes_per_plane + kTileBytes - 1) / kTileBytes;
+            tiles += (a.seg[i].bytes_per_plane + tile_bytes - 1) / tile_bytes;
         }
         a.nseg = n;
         a.planes = planes;
+        a.tile_bytes = tile_bytes;
+        a.planes_per_wg = ppw;
         if (tiles == 0) continue;
-        dim3 grid(tiles, pc_ceil_div(planes, kPlanesPerWG));
-        if (nt) hipLaunchKernelGGL(kv_copy_kernel<true>, grid, dim3(kThreads), 0, stream, a);
-        else    hipLaunchKernelGGL(kv_copy_kernel<false>, grid, dim3(kThreads), 0, stream, a);
+        dim3 grid(tiles, pc_ceil_div(planes, ppw));
+        if (nt) hipLaunchKernelGGL((kv_copy_kernel<true, 8>), grid, dim3(kThreads), 0, stream, a);
+        else if (unroll == 8) hipLaunchKernelGGL((kv_copy_kernel<false, 8>), grid, dim3(kThreads), 0, stream, a);
+        else if (unroll == 4) hipLaunchKernelGGL((kv_copy_kernel<false, 4>), grid, dim3(kThreads), 0, stream, a);
+        else    hipLaunchKernelGGL((kv_copy_kernel<false, 16>), grid, dim3(kThreads), 0, stream, a);
         int rc = pc_check_launch("kv_copy_kernel");
         if (rc != PC_OK) return rc;
     }

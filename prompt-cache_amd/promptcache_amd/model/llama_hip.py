@@ -163,13 +163,17 @@ class LlamaHIP:
         W = (H + 2 * Hkv) * D
         eps = self.config.rms_norm_eps
 
+        if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
+            # the graph's static int64 / int32 input buffers are filled straight from the caller's tensors
+            # (copy_ converts), so no separate dtype-conversion launches sit in front of the replay
+            logits = self._graphed_skinny(input_ids.reshape(-1), position_ids.reshape(-1), arena, B, q_len, past_len,
+                                          last_token_only, num_layers)
+            arena.length = past_len + q_len
+            return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
         if self.skinny and T <= self.SKINNY_MAX_ROWS:
-            if self.use_graphs:
-                logits = self._graphed_skinny(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
-            else:
-                logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
+            logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
             arena.length = past_len + q_len
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 

@@ -54,6 +54,7 @@ struct AttnParams {
     float* part_o; float* part_ml;
     const int32_t* past_len_dev;
     int32_t H, Hkv, q_len, past_len, nsplit;
+    int32_t xcd_remap, nqblk, nbatch;
     float scale_log2;
 };
 
@@ -85,8 +86,22 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     __shared__ __attribute__((aligned(16))) _Float16 Vl[kTK * D];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int qblk = blockIdx.x, h = blockIdx.y;
-    const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
+    int qblk, h, b, split;
+    if (p.xcd_remap) {
+        // 1-D grid, XCD-aware (q >> 64, no KV split): the dispatcher places block i on XCD i % 8, and every
+        // q-block of a head streams the same K/V.  Heads are dealt to XCDs (h % 8) and an XCD walks the q-blocks
+        // of one head after another, heaviest (last) q-block first, so a head's K/V (2.25 MB at S = 4.4k) is
+        // served from that XCD's 4 MiB L2 instead of crossing the fabric once per q-block.
+        const int nqb = p.nqblk, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int per_xcd = (p.H * p.nbatch + 7) >> 3;          // (batch, head) pairs per XCD
+        const int pair = (slot / nqb) * 8 + xcd;                // pair index = b * H + h
+        if (slot / nqb >= per_xcd || pair >= p.H * p.nbatch) return;
+        qblk = nqb - 1 - (slot % nqb);
+        b = pair / p.H; h = pair - b * p.H; split = 0;
+    } else {
+        qblk = blockIdx.x; h = blockIdx.y;
+        b = blockIdx.z / p.nsplit; split = blockIdx.z - b * p.nsplit;
+    }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
     const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
@@ -306,8 +321,14 @@ int choose_nsplit(int B, int H, int q_len, int kv_len) {
 }
 
 template <int D>
-int launch_attn(const AttnParams& p, int B, hipStream_t stream) {
-    dim3 grid(pc_ceil_div(p.q_len, kQB), p.H, B * p.nsplit);
+int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
+    AttnParams p = p0;
+    static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
+    p.nqblk = pc_ceil_div(p.q_len, kQB);
+    p.nbatch = B;
+    p.xcd_remap = (p.nsplit == 1 && p.nqblk >= 4 && !no_remap) ? 1 : 0;
+    dim3 grid(p.nqblk, p.H, B * p.nsplit);
+    if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
     if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     int rc = pc_check_launch("attn_fwd_kernel");

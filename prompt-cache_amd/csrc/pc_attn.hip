@@ -169,7 +169,10 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             const int c = tid + i * kThreads;
             const int row = c / CPR, col = c - row * CPR;
             *(u32x4*)(Kl + row * D + ((col ^ (row & (CPR - 1))) << 3)) = kr[i];
-            *(u32x4*)(Vl + row * D + (col << 3)) = vr[i];
+            // V rows are rotated by 32 B per row (mod the row): the 8 rows a 32-lane half of ds_read_b64_tr_b16
+            // touches then sit in 8 different 32-B windows of the 256-B bank row instead of the same one (the
+            // unrotated tile measured SQ_LDS_BANK_CONFLICT = 68 % of SQ_LDS_IDX_ACTIVE: an 8-way conflict)
+            *(u32x4*)(Vl + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
         }
         __syncthreads();
         if (key0 + kTK < kend) issue_loads(key0 + kTK);
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             for (int db = 0; db < DB; ++db) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const _Float16* vp = Vl + (t * 32 + g * 4 + (n >> 2)) * D + db * 16 + (n & 3) * 4;
+                    const int vrow = t * 32 + g * 4 + (n >> 2);          // (vrow + 16) & 7 == vrow & 7: same rotation
+                    const _Float16* vp = Vl + vrow * D + ((db * 16 + (n & 3) * 4 + 16 * (vrow & 7)) & (D - 1));
                     const h4 lo = lds_tr_read(vp);            // keys 32t + 4g + {0..3}
                     const h4 hi = lds_tr_read(vp + 16 * D);   // keys 32t + 16 + 4g + {0..3}
                     const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};

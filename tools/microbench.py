@@ -94,6 +94,11 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         print("gather-only done: algorithmic bytes per launch", 2 * sum(PERSONA) * 32 * 2 * 32 * 128 * 2)
         sys.exit(0)
+    if "--attn-only" in sys.argv:        # PMC passes: a few launches of the large-q (MFMA-bound) attention shapes
+        for _ in range(2):
+            bench_attn("nocache 4404", 32, 32, 128, 4404, 0)
+            bench_attn("nocache 1737", 32, 32, 128, 1737, 0)
+        sys.exit(0)
     if "--gemm" in sys.argv:
         M = 12
         bench_gemm("qkv", M, 12288, 4096, 0)

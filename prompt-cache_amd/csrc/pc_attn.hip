@@ -63,6 +63,10 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
     return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
 }
 
+// v_exp_f32 directly: arguments here are <= 0 (or -inf), so the denormal-range scaling that exp2f() wraps
+// around the instruction (v_cmp + v_cndmask + v_ldexp per call) buys nothing.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     // ds_read_b64_tr_b16: within a 16-lane group, lane i receives sub-element (i%4) of the 8 bytes
     // addressed by lanes {i/4, 4+i/4, 8+i/4, 12+i/4} (verified by pc_probe_layouts on hardware).
@@ -203,14 +207,14 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);       // stays finite (m_run starts at -1e30)
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = fast_exp2(m_run - m_new);
             float rs = 0.f;
             h8 pb[2], pbl[HP ? 2 : 1];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(sv[kb][r] - m_new);   // exp2(-inf) = 0 for masked keys
+                    const float e = fast_exp2(sv[kb][r] - m_new);   // exp2(-inf) = 0 for masked keys
                     rs += e;
                     const _Float16 eh = (_Float16)e;
                     pb[kb >> 1][(kb & 1) * 4 + r] = eh;
@@ -220,11 +224,16 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             rs += __shfl_xor(rs, 16);
             rs += __shfl_xor(rs, 32);
             l_run = l_run * alpha + rs;
-            m_run = m_new;
+            // Rescale O only when some row's running max actually moved (alpha == 1 otherwise: identical result).
+            // The accumulators live in AGPRs; an unconditional multiply costs an accvgpr read + write per register
+            // per tile (176 moves in the ISA), and after the first few tiles the max rarely changes.
+            if (__any(m_new > m_run)) {
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+                for (int db = 0; db < DB; ++db) {
+                    o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+                }
             }
+            m_run = m_new;
             // ---- O^T += V^T . P^T : two 32-key steps x DB head-dim blocks ----
 #pragma unroll
             for (int db = 0; db < DB; ++db) {

@@ -74,6 +74,9 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     return __builtin_bit_cast(h4, r);
 }
 
+// (Tried and dropped: 32 query rows per wave -- two 16-row sub-tiles sharing every K / V^T fragment read.  It halves
+// LDS reads per flop but needs 256 VGPRs (1 wave per SIMD) and halves the workgroup count: 322 us vs 323 us at
+// q = S = 4.4k, 30 us vs 16 us at q = 456.)
 // HP ("high precision", used when q_len <= 64 where the kernel is HBM-bound and MFMA time is free): Q and P
 // enter the MFMAs as split-precision pairs (hi = fp16(x), lo = fp16(x - hi)), i.e. two MFMAs per fragment.
 // Against the reference's fp32 CPU path this removes the two largest rounding terms of the kernel (fp16 Q:

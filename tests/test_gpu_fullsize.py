@@ -89,7 +89,7 @@ def test_config4_13b_shape_8k_context_dense_path():
 def test_prefill_plus_decode_equals_longer_prefill_7b_shape():
     lm = _lm("llama2-7b", layers=2, seed=3)
     m = lm.hf_model
-    ids = torch.randint(3, 32000, (1, 40), device="cuda")
+    ids = torch.randint(3, 32000, (1, 40), generator=torch.Generator().manual_seed(6)).cuda()
     pos = torch.arange(100, 140, device="cuda").unsqueeze(0)
     full = m(input_ids=ids, position_ids=pos, use_cache=True)
     part = m(input_ids=ids[:, :37], position_ids=pos[:, :37], use_cache=True)
@@ -109,7 +109,7 @@ def test_mid_q_range_uses_two_row_tiles():
     """17..64 new tokens: skinny projections with 2-4 row tiles against the dense path (q > 64 code)."""
     lm = _lm("llama2-7b", layers=2, seed=4)
     m = lm.hf_model
-    ids = torch.randint(3, 32000, (1, 60), device="cuda")
+    ids = torch.randint(3, 32000, (1, 60), generator=torch.Generator().manual_seed(5)).cuda()
     a = m(input_ids=ids, use_cache=False)
     m.skinny = False
     b = m(input_ids=ids, use_cache=False)

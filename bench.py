@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=4096)        # config/llm_config_llama2_7b.json of the reference
     ap.add_argument("--cpu-layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-context", action="store_true", help="skip the extra (untimed) no-cache / decode / GEMM-roofline runs")
     args = ap.parse_args()
 
     import torch
@@ -277,14 +278,14 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      # PMC passes cannot run inside this process: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of
                      # this kernel on this exact workload, from profiles/r01_pmc_kv_copy_kernel.txt; null otherwise
-                     "traffic": 1808880640 if (S, L, Hkv, D) == (1725, 32, 32, 128) else None,
+                     "traffic": 1808914637 if (S, L, Hkv, D) == (1725, 32, 32, 128) else None,
                      "traffic_source": "profiles/r01_pmc_kv_copy_kernel.txt (separate rocprofv3 --pmc passes)",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": gather_avg_us,
                      "min_launch_us": gather_us[0], "launches_timed": len(gather_us),
                      "how": "HIP events recorded on the launch stream immediately around the launch, every timed step"},
         "encode": encode,
     }
-    if rank == 0:
+    if rank == 0 and not args.no_context:
         result["roofline_gemm"] = gemm_roofline(lm, q)
         # context (outside the timed region): the same prompt WITHOUT the prompt cache (cache_engine.py:476-493:
         # every token re-encoded, positions range(N)) and the hipGraph-captured decode rate after the prefill

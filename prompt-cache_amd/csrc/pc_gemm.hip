@@ -146,7 +146,10 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
 template <int MT, int T, int EPI, bool TWO, int U>
 __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams p) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
-    __shared__ __attribute__((aligned(16))) float red[kWaves][MT * TT][64][4];
+    constexpr int TPI = (EPI == EPI_SILU) ? 2 : 1;                 // tiles per output item
+    constexpr int kRT = (MT * TT < 8) ? MT * TT : 8;               // tiles per wave in the reduction buffer (<= 64 KiB)
+    constexpr int IPR = kRT / TPI;                                 // items per reduction round
+    __shared__ __attribute__((aligned(16))) float red[kWaves][kRT][64][4];
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar loop control
@@ -194,27 +197,37 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     if (ks < ks1) k_block<MT, TT, TWO, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
 
     // ---- split-K reduction through LDS, fixed order ----
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int t = 0; t < TT; ++t) *(f4*)red[wave][a * TT + t][lane] = acc[a][t];
-    __syncthreads();
-
-    // MT*TT <= 8 items (enforced at launch), one per wave; a/t are recomputed arithmetically (no runtime
-    // indexing of register arrays).
+    // An output item is one reduced tile (a gate/up pair of tiles for the SiLU epilogue).  Up to kRT tiles per
+    // wave fit the LDS buffer, so the items go through it in rounds of IPR, one item per wave per round; the
+    // unrolled round/slot indices keep every acc[][] access compile-time (no runtime-indexed register arrays).
     constexpr int TE = (EPI == EPI_SILU) ? T : TT;   // epilogue items per M-tile
     constexpr int NOUT = MT * TE;
-    static_assert(MT * TT <= kWaves, "one reduced tile per wave");
-    if (wave < NOUT) {
-        const int a = wave / TE;
-        const int t = wave - a * TE;
+    constexpr int ROUNDS = (NOUT + IPR - 1) / IPR;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+    if (r > 0) __syncthreads();                      // the previous round's readers are done with the buffer
+#pragma unroll
+    for (int i = 0; i < IPR; ++i) {
+        const int item = r * IPR + i;
+        if (item < NOUT) {
+            const int a = item / TE, t = item - a * TE;
+            *(f4*)red[wave][i * TPI][lane] = acc[a][t];
+            if (EPI == EPI_SILU) *(f4*)red[wave][i * TPI + 1][lane] = acc[a][T + t];
+        }
+    }
+    __syncthreads();
+
+    const int item = r * IPR + wave;
+    if (wave < IPR && item < NOUT) {
+        const int a = item / TE;
+        const int t = item - a * TE;
         f4 v = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
-            const f4 x = *(const f4*)red[w][a * TT + t][lane];
+            const f4 x = *(const f4*)red[w][wave * TPI][lane];
             v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
             if (EPI == EPI_SILU) {
-                const f4 y = *(const f4*)red[w][a * TT + T + t][lane];
+                const f4 y = *(const f4*)red[w][wave * TPI + 1][lane];
                 u[0] += y[0]; u[1] += y[1]; u[2] += y[2]; u[3] += y[3];
             }
         }
@@ -284,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
             }
         }
     }
+    }   // rounds
 }
 
 // RMSNorm producing split-precision fragment planes: one workgroup per row.
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
 template <int MT, int T, int EPI>
 int launch_one(const GemmParams& p, int units, hipStream_t s) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
-    constexpr int UD = (MT * TT >= 8) ? 2 : (MT * TT >= 3 ? 4 : 8);     // default depth
+    constexpr int UD = (MT * TT >= 16) ? 1 : (MT * TT >= 8) ? 2 : (MT * TT >= 3 ? 4 : 8);     // default depth
     static const int forced = [] { const char* e = getenv("PC_GEMM_U"); return e ? atoi(e) : 0; }();
     const dim3 grid(pc_ceil_div(units, T), p.kslices), block(kThreads);
     const bool two = p.xf_lo != nullptr;
@@ -386,10 +400,12 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
     return pc_check_launch("gemm_skinny_kernel");
 }
 
-// T is limited by MT * TT <= 8 reduced tiles per workgroup (TT = 2T for the SiLU epilogue).
+// Weight tiles per workgroup (TT = 2T for the SiLU epilogue) are limited by registers: MT * TT accumulators of 4
+// VGPRs each next to the in-flight operands.  Wide workgroups matter most for MT > 1: every workgroup reads all of
+// the activation planes, so that traffic is (#workgroups x planes) and at MT = 4 it exceeds the weights'.
 template <int MT, int EPI>
 int launch_T(const GemmParams& p, int T, int units, hipStream_t s) {
-    constexpr int kMaxT = 8 / MT / (EPI == EPI_SILU ? 2 : 1);
+    constexpr int kMaxT = (MT == 4 ? 6 : 8) / (EPI == EPI_SILU ? 2 : 1);
     if (T > kMaxT) T = kMaxT;
     if constexpr (kMaxT >= 8) { if (T >= 8) return launch_one<MT, 8, EPI>(p, units, s); }
     if constexpr (kMaxT >= 4) { if (T >= 4) return launch_one<MT, 4, EPI>(p, units, s); }

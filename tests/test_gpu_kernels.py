@@ -379,7 +379,9 @@ def test_silu_mul_and_embed():
 # ---------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("M,N,K", [(12, 12288, 4096), (1, 4096, 4096), (16, 4096, 11008), (17, 256, 128), (33, 1024, 512),
-                                   (64, 4096, 4096), (12, 32000, 4096), (5, 48, 32), (14, 15360, 5120)])
+                                   (64, 4096, 4096), (12, 32000, 4096), (5, 48, 32), (14, 15360, 5120),
+                                   # wide workgroups: more tiles than one reduction round holds (MT*T > 8)
+                                   (64, 12288, 4096), (24, 32000, 4096), (48, 16384, 512)])
 @pytest.mark.parametrize("two_pass", [True, False])
 def test_gemm_skinny_store_and_add(M, N, K, two_pass):
     n = _n()
@@ -406,7 +408,8 @@ def test_gemm_skinny_store_and_add(M, N, K, two_pass):
     assert torch.equal(y, y3)
 
 
-@pytest.mark.parametrize("M,inter,K", [(12, 11008, 4096), (3, 64, 32), (20, 1376, 512), (50, 13824, 5120)])
+@pytest.mark.parametrize("M,inter,K", [(12, 11008, 4096), (3, 64, 32), (20, 1376, 512), (50, 13824, 5120),
+                                       (64, 11008, 4096), (24, 13824, 5120), (31, 11008, 4096)])
 def test_gemm_skinny_silu_epilogue(M, inter, K):
     n = _n()
     rng = np.random.default_rng(12)
@@ -446,7 +449,8 @@ def test_rmsnorm_frag_matches_oracle(rows, hidden, nslabs):
     np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-5)
 
 
-@pytest.mark.parametrize("M,N,K,kq", [(12, 4096, 4096, 4), (12, 4096, 11008, 4), (3, 64, 96, 2), (20, 512, 1376, 3)])
+@pytest.mark.parametrize("M,N,K,kq", [(12, 4096, 4096, 4), (12, 4096, 11008, 4), (3, 64, 96, 2), (20, 512, 1376, 3),
+                                      (40, 4096, 4096, 4), (64, 4096, 11008, 4), (30, 5120, 13824, 4)])
 def test_gemm_skinny_k_slices(M, N, K, kq):
     """K-sliced launch: the slabs add up to the full product."""
     n = _n()
@@ -484,7 +488,8 @@ def test_attn_fragment_plane_output(B, H, Hkv, D, q_len, past):
 
 
 @pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 7, 512), (1, 4, 4, 32, 17, 0, 128),
-                                                       (1, 2, 2, 64, 1, 30, 256)])
+                                                       (1, 2, 2, 64, 1, 30, 256), (1, 32, 32, 128, 40, 100, 4096),
+                                                       (2, 32, 32, 128, 12, 9, 4096), (1, 40, 40, 128, 64, 0, 5120)])
 def test_gemm_qkv_rope_fused_equals_unfused(B, H, Hkv, D, q_len, past, hid):
     """Fused projection + RoPE + KV-append epilogue == plain-store GEMM followed by pc_rope_append: same dot
     products (only the weight rows are permuted inside the tiles), same rotation up to how the compiler contracts

@@ -99,6 +99,12 @@ if __name__ == "__main__":
             bench_attn("nocache 4404", 32, 32, 128, 4404, 0)
             bench_attn("nocache 1737", 32, 32, 128, 1737, 0)
         sys.exit(0)
+    if "--gemm-msweep" in sys.argv:      # how the weight-streaming rate holds up as the row tiles (MT = ceil(M/16)) grow
+        for M in (12, 16, 24, 32, 48, 64):
+            bench_gemm("qkv", M, 12288, 4096, 0)
+            bench_gemm("gate_up", M, 22016, 4096, 2)
+            bench_gemm("down", M, 4096, 11008, 0, 4)
+        sys.exit(0)
     if "--gemm" in sys.argv:
         M = 12
         bench_gemm("qkv", M, 12288, 4096, 0)

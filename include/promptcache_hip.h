@@ -112,7 +112,7 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *   workspace: >= pc_attn_workspace_bytes(...) bytes of device memory (split-KV partials).
  *   past_len_dev: optional device int32* (graph replay; then `past_len` is the upper bound used
  *        for sizing the launch).
- *   out_frag_hi/_lo: optional (both or neither; B*q_len <= 64): instead of `out`, write the result as
+ *   out_frag_hi/_lo: optional (both or neither; B*q_len <= 512): instead of `out`, write the result as
  *        split-precision fragment planes [ceil(B*q_len/16)][H*D/32][64][8] consumed by pc_gemm_skinny (o_proj).
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
@@ -137,7 +137,10 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
                     int32_t vocab, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Weight-streaming projections for the small-q regime (M = B*q_len <= 64), csrc/pc_gemm.hip.
+ * Weight-streaming projections for the small-q regime (M = B*q_len <= 512), csrc/pc_gemm.hip.
+ *   M <= 64:  eight waves split K over the same output tiles; split-precision (hi + lo) activations.
+ *   M <= 512: the waves split the rows, weight tiles are staged through LDS by dedicated waves; the hi
+ *             activation plane only (xf_lo is ignored), i.e. fp16 activations as in the dense path.
  *
  * Fragment-major layouts (register image of mfma_f32_16x16x32_f16 operands, fp16):
  *   weights      Wf[N/16][K/32][64][8]   lane l = 16*g + n  holds W[16*tile + n][32*ks + 8*g .. +8]
@@ -146,7 +149,7 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
  *                two planes: hi = fp16(x), lo = fp16(x - hi)  (lo may be NULL: single-precision pass)
  *
  * pc_gemm_skinny -- replaces the nn.Linear calls of llama2.py:345-347 (q|k|v fused), :405 (+ residual add
- *   :638), :242 (gate/up + SiLU*up; down + residual add :644) and :1050 (lm_head) when M <= 64:
+ *   :638), :242 (gate/up + SiLU*up; down + residual add :644) and :1050 (lm_head) when M <= 512:
  *     epilogue 0  y[m][n]  = sum_k X[m][k] W[n][k]          fp32 [M][ldy]; with kslices > 1 the K axis is also
  *                 split across workgroups and slice s writes its partial sums to y + s*M*ldy (slabs
  *                 [kslices][M][ldy]) -- used for the N = hidden projections (o_proj, down_proj), whose few

@@ -378,8 +378,8 @@ PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_strid
     if (q_len == 0) return PC_OK;
     PC_REQUIRE(q && k && v && (out || (out_frag_hi && out_frag_lo)), PC_ERR_ARG, "pc_attn_fwd: null pointer");
     PC_REQUIRE((out_frag_hi == nullptr) == (out_frag_lo == nullptr), PC_ERR_ARG, "pc_attn_fwd: need both fragment planes");
-    PC_REQUIRE(!out_frag_hi || (B * q_len <= 64 && (H * D) % 32 == 0), PC_ERR_ARG,
-               "pc_attn_fwd: fragment-plane output is for the skinny regime (B*q_len <= 64)");
+    PC_REQUIRE(!out_frag_hi || (B * q_len <= 512 && (H * D) % 32 == 0), PC_ERR_ARG,
+               "pc_attn_fwd: fragment-plane output is for the weight-streaming regime (B*q_len <= 512)");
     PC_REQUIRE(q_token_stride % 8 == 0 && kv_head_stride % 8 == 0 && out_token_stride % 4 == 0, PC_ERR_ARG,
                "pc_attn_fwd: strides must keep 16-byte (q, kv) / 8-byte (out) alignment");
     AttnParams p;

@@ -143,6 +143,76 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
             }
 }
 
+// Epilogue of one reduced 16 x 16 tile.  v (and u = the "up" tile for EPI_SILU) follow the MFMA C/D map: this lane
+// holds output row `row` (token) and features unit*16 + 4*g .. +3.  Must be called by all 64 lanes of a wave
+// (EPI_ROPE exchanges rotary partners across lanes).
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, int row, int unit, int g, int slice) {
+    const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
+    if (unit < nunits && row < p.M) {
+        if (EPI == EPI_SILU) {
+            const int j0 = unit * 16 + g * 4;   // intermediate feature index of v[0]
+            h4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = (v[r] / (1.0f + __expf(-v[r]))) * u[r];
+                hi[r] = (_Float16)s;
+                lo[r] = (_Float16)(s - (float)hi[r]);
+            }
+            const int64_t off = frag_off(row, j0, p.KSo);
+            *(h4*)(p.of_hi + off) = hi;
+            *(h4*)(p.of_lo + off) = lo;
+        } else if (EPI == EPI_ROPE) {
+            // handled below (needs the cross-lane exchange from every lane, valid or not)
+        } else {
+            float* yp = p.y + (int64_t)slice * p.slab_stride + (int64_t)row * p.ldy + unit * 16 + g * 4;
+            if (EPI == EPI_ADD) {
+                const f4 old = *(const f4*)yp;
+                v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+            }
+            *(f4*)yp = v;
+        }
+    }
+    if (EPI == EPI_ROPE) {
+        const RopeEpi& e = p.rope;
+        // partner half of every value lives in lane ^ 32 (rows 8..15 of the permuted tile)
+        f4 pv;
+        pv[0] = __shfl_xor(v[0], 32); pv[1] = __shfl_xor(v[1], 32); pv[2] = __shfl_xor(v[2], 32); pv[3] = __shfl_xor(v[3], 32);
+        if (unit < nunits && row < p.M) {
+            const int tpd = e.D >> 4;                       // tiles per head
+            const int hh = unit / tpd, j = unit - hh * tpd;
+            const bool is_hi = g >= 2;
+            const int i0 = 8 * j + 4 * (g & 1);            // rotary frequency index of v[0]
+            const int d0 = i0 + (is_hi ? (e.D >> 1) : 0);  // feature index inside the head
+            const int bb = row / e.q_len, tt = row - bb * e.q_len;
+            if (hh < e.H + e.Hkv) {
+                const float2* cs = e.cs + (int64_t)row * (e.D >> 1) + i0;
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float2 w = cs[r];
+                    // q*cos + rotate_half(q)*sin (llama2.py:208): low half pairs with -high, high with +low
+                    const float o = is_hi ? (v[r] * w.x + pv[r] * w.y) : (v[r] * w.x - pv[r] * w.y);
+                    hi[r] = (_Float16)o;
+                    lo[r] = (_Float16)(o - (float)hi[r]);
+                }
+                if (hh < e.H) {
+                    const int64_t off = (int64_t)row * e.q_ts + (int64_t)hh * e.D + d0;
+                    *(h4*)(e.q_hi + off) = hi;
+                    *(h4*)(e.q_lo + off) = lo;
+                } else {
+                    const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
+                    *(h4*)(e.k_arena + bb * e.a_bs + (int64_t)(hh - e.H) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hi;
+                }
+            } else {
+                const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
+                h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *(h4*)(e.v_arena + bb * e.a_bs + (int64_t)(hh - e.H - e.Hkv) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hv;
+            }
+        }
+    }
+}
+
 template <int MT, int T, int EPI, bool TWO, int U>
 __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams p) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
@@ -231,71 +301,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
                 u[0] += y[0]; u[1] += y[1]; u[2] += y[2]; u[3] += y[3];
             }
         }
-        const int row = a * 16 + m;
-        const int unit = blockIdx.x * T + t;                       // tile (or gate/up pair) index
-        const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
-        if (unit < nunits && row < p.M) {
-            if (EPI == EPI_SILU) {
-                const int j0 = unit * 16 + g * 4;   // intermediate feature index of v[0]
-                h4 hi, lo;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = (v[r] / (1.0f + __expf(-v[r]))) * u[r];
-                    hi[r] = (_Float16)s;
-                    lo[r] = (_Float16)(s - (float)hi[r]);
-                }
-                const int64_t off = frag_off(row, j0, p.KSo);
-                *(h4*)(p.of_hi + off) = hi;
-                *(h4*)(p.of_lo + off) = lo;
-            } else if (EPI == EPI_ROPE) {
-                // handled below (needs the cross-lane exchange from every lane, valid or not)
-            } else {
-                float* yp = p.y + (int64_t)blockIdx.y * p.slab_stride + (int64_t)row * p.ldy + unit * 16 + g * 4;
-                if (EPI == EPI_ADD) {
-                    const f4 old = *(const f4*)yp;
-                    v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
-                }
-                *(f4*)yp = v;
-            }
-        }
-        if (EPI == EPI_ROPE) {
-            const RopeEpi& e = p.rope;
-            // partner half of every value lives in lane ^ 32 (rows 8..15 of the permuted tile)
-            f4 pv;
-            pv[0] = __shfl_xor(v[0], 32); pv[1] = __shfl_xor(v[1], 32); pv[2] = __shfl_xor(v[2], 32); pv[3] = __shfl_xor(v[3], 32);
-            if (unit < nunits && row < p.M) {
-                const int tpd = e.D >> 4;                       // tiles per head
-                const int hh = unit / tpd, j = unit - hh * tpd;
-                const bool is_hi = g >= 2;
-                const int i0 = 8 * j + 4 * (g & 1);            // rotary frequency index of v[0]
-                const int d0 = i0 + (is_hi ? (e.D >> 1) : 0);  // feature index inside the head
-                const int bb = row / e.q_len, tt = row - bb * e.q_len;
-                if (hh < e.H + e.Hkv) {
-                    const float2* cs = e.cs + (int64_t)row * (e.D >> 1) + i0;
-                    h4 hi, lo;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float2 w = cs[r];
-                        // q*cos + rotate_half(q)*sin (llama2.py:208): low half pairs with -high, high with +low
-                        const float o = is_hi ? (v[r] * w.x + pv[r] * w.y) : (v[r] * w.x - pv[r] * w.y);
-                        hi[r] = (_Float16)o;
-                        lo[r] = (_Float16)(o - (float)hi[r]);
-                    }
-                    if (hh < e.H) {
-                        const int64_t off = (int64_t)row * e.q_ts + (int64_t)hh * e.D + d0;
-                        *(h4*)(e.q_hi + off) = hi;
-                        *(h4*)(e.q_lo + off) = lo;
-                    } else {
-                        const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
-                        *(h4*)(e.k_arena + bb * e.a_bs + (int64_t)(hh - e.H) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hi;
-                    }
-                } else {
-                    const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
-                    h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    *(h4*)(e.v_arena + bb * e.a_bs + (int64_t)(hh - e.H - e.Hkv) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hv;
-                }
-            }
-        }
+        tile_epilogue<EPI>(p, v, u, a * 16 + m, (int)blockIdx.x * T + t, g, (int)blockIdx.y);
     }
     }   // rounds
 }
@@ -414,9 +420,215 @@ int launch_T(const GemmParams& p, int T, int units, hipStream_t s) {
     return launch_one<MT, 1, EPI>(p, units, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 65..512 rows ("mid M": long questions in front of a staged cache).  Still weight streaming -- the weights are
+// read once -- but a workgroup can no longer afford to split K across its waves: every workgroup would re-read
+// all the activation planes and hold MT*TT accumulators per wave.  Here the waves split the ROWS instead:
+//   * compute wave w (w < ceil(M/64)) owns rows [64w, 64w+64) x all TT weight tiles of the workgroup
+//     (4 x TT accumulators), reads its own activation fragments straight from L2 (prefetched one k-step ahead)
+//     and the weight fragments from LDS;
+//   * kStageWaves extra waves do nothing but stream the workgroup's weight tiles HBM -> registers -> LDS, three
+//     stages (24-32 KiB each) deep.  Their load queues hold only weight loads, the compute waves' queues only
+//     activation loads: a wave's loads complete in order, so one wave issuing both would make every L2-hit
+//     activation load wait behind ~2 us HBM weight loads.
+// One raw s_barrier per stage (LDS-only wait: `__syncthreads()` would drain the prefetch queues).
+// Activations: the hi plane only (fp16 activations x fp16 weights -> fp32, the precision of the dense path).
+constexpr int kStageWaves = 4;
+constexpr int kRowsMaxM = 512;
+
+// stage visited at position st of a workgroup's rotated walk over nst stages (positions >= nst: clamp, then rotate)
+__device__ __forceinline__ int rot_stage(int st, int rot, int nst) {
+    st = st < nst ? st : nst - 1;
+    const int se = st + rot;
+    return se < nst ? se : se - nst;
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int TT, int EPI, int MTW>
+__global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const GemmParams p) {
+    constexpr int T = (EPI == EPI_SILU) ? TT / 2 : TT;   // output units (tiles, or gate/up pairs) per workgroup
+    constexpr int KC = (TT <= 4) ? 8 : 4;                // k-steps per stage
+    constexpr int F = TT * KC;                           // 1-KiB fragments per stage
+    constexpr int FPW = F / kStageWaves;
+    constexpr int PD = (MTW == 2) ? 3 : 1, NX = PD + 1;  // activation prefetch distance (k-steps) / register sets
+    static_assert(F % kStageWaves == 0 && KC % NX == 0, "stage must split evenly over the staging waves");
+    __shared__ __attribute__((aligned(16))) _Float16 wbuf[2][F][64][8];
+
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RW = (p.M + 16 * MTW - 1) / (16 * MTW);
+    const int KS = p.KS;
+    const int ksq = (KS + p.kslices - 1) / p.kslices;
+    const int kq0 = blockIdx.y * ksq;
+    const int kq1 = (kq0 + ksq < KS) ? kq0 + ksq : KS;
+    const int nst = (kq1 - kq0 + KC - 1) / KC;
+    const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
+    // (Rotating the K walk per workgroup, so that workgroups do not read the same activation fragments from L2 in
+    // lockstep, measured no gain: L2 channel conflicts are not what bounds this kernel.)
+    constexpr int rot = 0;
+
+    if (wave >= RW) {
+        // ---------------- staging wave ----------------
+        const int sidx = wave - RW;
+        const _Float16* src[FPW];
+        int kst[FPW];
+#pragma unroll
+        for (int i = 0; i < FPW; ++i) {
+            const int f = sidx + kStageWaves * i;        // fragment of the stage: k-step-major, tile-minor
+            const int kk = f / TT, tt = f - kk * TT;
+            int unit = blockIdx.x * T + (EPI == EPI_SILU ? (tt < T ? tt : tt - T) : tt);
+            if (unit >= nunits) unit = nunits - 1;       // clamped duplicates are computed and never stored
+            const int tile = (EPI == EPI_SILU && tt >= T) ? p.npairs + unit : unit;
+            kst[i] = kk;
+            src[i] = p.wf + (((int64_t)tile * KS + kq0 + kk) * 64 + lane) * 8;
+        }
+        h8 r0[FPW], r1[FPW], r2[FPW];
+        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        // loads of stage st into a register set; k-steps past the end of the K range re-read the last valid
+        // one (never out of bounds) and are zeroed when they are written to LDS
+#define PC_STAGE_LOAD(R, ST)                                                                  \
+        {                                                                                     \
+            const int se = rot_stage((ST), rot, nst);                                         \
+            _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
+                const int kabs = kq0 + se * KC + kst[i];                                      \
+                const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);                           \
+                R[i] = ldg_h8_nt(src[i] + ((int64_t)se * KC - back) * 512);                   \
+            }                                                                                 \
+        }
+#define PC_STAGE_WRITE(R, ST)                                                                 \
+        {                                                                                     \
+            const int se = rot_stage((ST), rot, nst);                                         \
+            _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
+                const bool ok = kq0 + se * KC + kst[i] < kq1;                                 \
+                *(h8*)wbuf[(ST) & 1][sidx + kStageWaves * i][lane] = ok ? R[i] : zero;        \
+            }                                                                                 \
+        }
+        // Loads are issued unconditionally (stages past the end re-read the last valid k-step): a load under a
+        // branch makes hipcc's vmcnt bookkeeping assume the not-taken path and wait for the NEWEST loads
+        // before each LDS write, which would drain the three-stage prefetch every stage.
+        PC_STAGE_LOAD(r0, 0)
+        PC_STAGE_LOAD(r1, 1)
+        for (int st = 0; st < nst; st += 3) {
+            PC_STAGE_LOAD(r2, st + 2)
+            PC_STAGE_WRITE(r0, st)
+            lds_barrier();
+            PC_STAGE_LOAD(r0, st + 3)
+            if (st + 1 < nst) {
+                PC_STAGE_WRITE(r1, st + 1)
+                lds_barrier();
+            }
+            PC_STAGE_LOAD(r1, st + 4)
+            if (st + 2 < nst) {
+                PC_STAGE_WRITE(r2, st + 2)
+                lds_barrier();
+            }
+        }
+#undef PC_STAGE_LOAD
+#undef PC_STAGE_WRITE
+        return;
+    }
+
+    // ---------------- compute wave ----------------
+    f4 acc[MTW][TT];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[a][t] = z; }
+    // Activation loads are unconditional as well (same vmcnt reason): row tiles past the end of the planes are
+    // clamped to the last one, pad rows inside it are read as they are -- output column m depends on
+    // activation row m only, and rows >= M are never stored.
+    const _Float16* xa[MTW];
+    const int mt_last = ((p.M + 15) >> 4) - 1;
+#pragma unroll
+    for (int a = 0; a < MTW; ++a) {
+        int mt = MTW * wave + a;
+        mt = mt < mt_last ? mt : mt_last;
+        xa[a] = p.xf_hi + (((int64_t)mt * KS + kq0) * 64 + lane) * 8;
+    }
+    const int klast = kq1 - 1 - kq0;                     // last valid k-step, relative to kq0
+    // k-step (relative to kq0) processed at sequence position i; positions past the end repeat the last one
+    auto kseq = [&](int i) {
+        int sq = i / KC;
+        const int j = i - sq * KC;
+        sq = sq < nst ? sq : nst - 1;
+        const int k = rot_stage(sq, rot, nst) * KC + j;
+        return k < klast ? k : klast;
+    };
+    h8 xs[NX][MTW];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        const int kn = kseq(d);
+#pragma unroll
+        for (int a = 0; a < MTW; ++a) xs[d][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+    }
+    for (int st = 0; st < nst; ++st) {
+        lds_barrier();                                   // stage st is in wbuf[st & 1]
+        const _Float16* wst = &wbuf[st & 1][0][lane][0];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            // prefetch the activation fragments PD k-steps ahead (clamped at the end of the K range)
+            const int kn = kseq(st * KC + j + PD);
+#pragma unroll
+            for (int a = 0; a < MTW; ++a) xs[(j + PD) % NX][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+            __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead of this k-step's MFMAs (see k_block)
+            h8 w[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) w[t] = *(const h8*)(wst + (j * TT + t) * 512);
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int a = 0; a < MTW; ++a)
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xs[j % NX][a], acc[a][t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f4 u = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_SILU) u = acc[a][T + t];
+            tile_epilogue<EPI>(p, acc[a][t], u, (MTW * wave + a) * 16 + m, (int)blockIdx.x * T + t, g, (int)blockIdx.y);
+        }
+}
+
+// Launch shape of the rows kernel.  Rows per compute wave: 32 while that needs <= 12 compute waves (M <= 384; more,
+// narrower waves hide the L2 latency of the activation loads and spread evenly over the four SIMDs), else 64.
+// Weight tiles per workgroup: the smallest of {3,4,6,8} ({2,3,4} gate/up pairs) that fits the grid into one round.
+template <int EPI>
+int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
+    static const int forced = [] { const char* e = getenv("PC_GEMM_ROWS_TT"); return e ? atoi(e) : 0; }();
+    const GemmParams& p = p_in;
+    const bool narrow = pc_ceil_div(p.M, 32) <= 12;
+    const int RW = narrow ? pc_ceil_div(p.M, 32) : pc_ceil_div(p.M, 64);
+    const dim3 block((RW + kStageWaves) * 64);
+#define PC_ROWS(TTV)                                                                                       \
+    do {                                                                                                   \
+        constexpr int TV = (EPI == EPI_SILU) ? (TTV) / 2 : (TTV);                                          \
+        const dim3 grid(pc_ceil_div(units, TV), p.kslices);                                                \
+        if (narrow) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 2>), grid, block, 0, s, p);             \
+        else if constexpr ((TTV) <= 6) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4>), grid, block, 0, s, p); \
+        return pc_check_launch("gemm_rows_kernel");                                                        \
+    } while (0)
+    const int work = units * p.kslices;
+    if constexpr (EPI == EPI_SILU) {
+        if (forced == 4 || (!forced && pc_ceil_div(work, 2) <= 256)) PC_ROWS(4);
+        if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(6);
+        PC_ROWS(8);
+    } else {
+        if (forced == 3 || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(3);
+        if (forced == 4 || (!forced && pc_ceil_div(work, 4) <= 256)) PC_ROWS(4);
+        if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 6) <= 256)) PC_ROWS(6);
+        PC_ROWS(8);
+    }
+#undef PC_ROWS
+}
+
 template <int EPI>
 int launch_MT(const GemmParams& p, int T, int units, hipStream_t s) {
     const int mt = pc_ceil_div(p.M, 16);
+    if (mt > 4) return launch_rows<EPI>(p, units, s);
     if (mt <= 1) return launch_T<1, EPI>(p, T, units, s);
     if (mt == 2) return launch_T<2, EPI>(p, T, units, s);
     return launch_T<4, EPI>(p, T, units, s);
@@ -439,7 +651,7 @@ int choose_T(int units) {
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
                              int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
                              void* stream) {
-    PC_REQUIRE(M > 0 && M <= 64, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..64 (use a dense GEMM above)", M);
+    PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
     GemmParams p;
@@ -470,7 +682,7 @@ PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const voi
                                int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                                const int32_t* past_len_dev, void* stream) {
     const int N = (H + 2 * Hkv) * D;
-    PC_REQUIRE(M > 0 && M <= 64 && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 64", M);
+    PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
     PC_REQUIRE(wf_perm && xf_hi && cs && q_hi && q_lo && k_arena && v_arena, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
     PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
@@ -490,7 +702,7 @@ PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const voi
 
 PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,
                               int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream) {
-    PC_REQUIRE(rows > 0 && rows <= 64 && hidden > 0 && hidden % 32 == 0, PC_ERR_ARG, "pc_rmsnorm_frag: bad sizes");
+    PC_REQUIRE(rows > 0 && rows <= kRowsMaxM && hidden > 0 && hidden % 32 == 0, PC_ERR_ARG, "pc_rmsnorm_frag: bad sizes");
     PC_REQUIRE(x && weight && xf_hi && xf_lo && nslabs >= 0 && (nslabs == 0 || slabs), PC_ERR_ARG,
                "pc_rmsnorm_frag: null pointer");
     PC_REQUIRE(hidden <= 16384, PC_ERR_ARG, "pc_rmsnorm_frag: hidden %d > 16384", hidden);

@@ -45,7 +45,8 @@ class LlamaHIP:
     """Weights live on one MI355X in fp16; ``wqkv`` and ``wgu`` are the row-concatenated q|k|v and
     gate|up projections so each is one GEMM."""
 
-    SKINNY_MAX_ROWS = 64   # B*q_len at or below this runs the weight-streaming kernels (pc_gemm.hip)
+    SKINNY_MAX_ROWS = 64   # B*q_len at or below this: split-precision weight-streaming kernels inside one hipGraph
+    MID_MAX_ROWS = 512     # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True):
@@ -172,7 +173,7 @@ class LlamaHIP:
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
-        if self.skinny and T <= self.SKINNY_MAX_ROWS:
+        if self.skinny and T <= self.MID_MAX_ROWS:
             logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
             arena.length = past_len + q_len
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)

@@ -163,3 +163,48 @@ def test_foreign_past_and_arena_growth():
     assert (o2.logits - full.logits[:, 5:]).abs().max().item() < 5e-3
     assert (o2b.logits - full.logits[:, 5:]).abs().max().item() < 5e-3
     assert o2b.past_key_values[0][0].shape[2] == 9
+
+
+@pytest.mark.parametrize("shape_name,q_words,seed", [("mid_gqa", 80, 3), ("mid", 250, 4), ("tiny", 400, 5)])
+def test_long_question_over_staged_cache_matches_live_oracle(shape_name, q_words, seed):
+    """65..512 new tokens behind a staged cache: the row-split weight-streaming projections (pc_gemm.hip) with fused
+    RoPE/append and SiLU epilogues, against the numpy oracle on the same inputs."""
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    from oracle.llama_oracle import LlamaOracle, OracleConfig
+    shape = SHAPES[shape_name]
+    w16 = make_weights_np(shape, seed, 2.0)
+    lm = Llama2(name="x", shape=shape, weights=w16, device="cuda:0")
+    schema_text, prompt_text = synth.flat_docs(f"lq{seed}", 10, (40, 25), q_words, seed=seed)
+    eng = CacheEngine(1024, lm)
+    eng.add_schema(lm.get_formatter()(schema_text))
+    prompt = Prompt(prompt_text, [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    assert 64 < len(ids) <= lm.hf_model.MID_MAX_ROWS
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    cfg = OracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, intermediate_size=shape.intermediate_size,
+                       num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                       num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
+                       rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
+    model = LlamaOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
+    sc = eng.get_schema(f"lq{seed}")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S, (logits, present) = eo.cached_prefill(model, lib, used, ids, pos, 1024)
+    err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    print(f"[{shape_name} q={len(ids)}] max|dlogit| vs live oracle = {err:.2e}")
+    assert err < LOGIT_TOL
+    # the same forward through the dense path (hipBLASLt projections) agrees as well
+    lm.hf_model.skinny = False
+    eng.prompt_cache.reset()
+    ids2, pos2, _, cache2 = eng.process(prompt)
+    out2 = lm(input_ids=torch.tensor([ids2], device="cuda"), position_ids=torch.tensor([pos2], device="cuda"),
+              past_key_values=cache2, use_cache=True)
+    assert (out2.logits - out.logits).abs().max().item() < LOGIT_TOL

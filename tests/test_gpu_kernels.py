@@ -531,3 +531,88 @@ def test_gemm_qkv_rope_fused_equals_unfused(B, H, Hkv, D, q_len, past, hid):
     rec_a, rec_b = qa.float() + qal.float(), qb.float() + qbl.float()      # split-precision q: ~fp32 agreement
     assert float((rec_a - rec_b).abs().max()) < 1e-5 * max(1.0, float(rec_a.abs().max()))
     assert float(arena_b[:, :, :, past:past + q_len].abs().sum()) > 0 and float(arena_b[:, :, :, :past].abs().sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# 65..512 rows: the row-split weight-streaming kernel (hi activation plane only)
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K,kq", [(65, 4096, 4096, 1), (100, 12288, 4096, 1), (259, 15360, 5120, 1), (512, 4096, 4096, 1),
+                                      (130, 48, 32, 1), (70, 64, 96, 2), (259, 5120, 13824, 4), (200, 4096, 11008, 4),
+                                      (96, 32000, 4096, 1)])
+def test_gemm_rows_store_add_slices(M, N, K, kq):
+    n = _n()
+    rng = np.random.default_rng(21)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    wf = n.to_weight_frags(w)
+    hi, lo = n.to_act_frags(x)
+    ref = (x.half().double() @ w.double().t()).float()          # the hi plane is fp16(x)
+    tol = 2e-4 * float(ref.abs().max()) + 1e-5
+    y = torch.full((kq, M, N), 7.0, dtype=torch.float32, device=DEV)
+    n.gemm_skinny(wf, hi, lo, M, N, K, n.EPI_STORE, y=y, ldy=N, kslices=kq)
+    assert (y.sum(dim=0) - ref).abs().max().item() < tol * kq
+    y3 = torch.empty_like(y)
+    n.gemm_skinny(wf, hi, lo, M, N, K, n.EPI_STORE, y=y3, ldy=N, kslices=kq)
+    assert torch.equal(y, y3)
+    if kq == 1:
+        y2 = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+        n.gemm_skinny(wf, hi, None, M, N, K, n.EPI_ADD, y=y2, ldy=N)
+        assert (y2 - 7.0 - ref).abs().max().item() < tol + 1e-5
+
+
+@pytest.mark.parametrize("M,inter,K", [(65, 11008, 4096), (259, 13824, 5120), (300, 64, 32), (128, 1376, 512), (512, 11008, 4096)])
+def test_gemm_rows_silu_epilogue(M, inter, K):
+    n = _n()
+    rng = np.random.default_rng(22)
+    w = torch.from_numpy((0.05 * rng.standard_normal((2 * inter, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    mt = (M + 15) // 16
+    oh = torch.zeros((mt, inter // 32, 64, 8), dtype=torch.float16, device=DEV)
+    ol = torch.zeros_like(oh)
+    n.gemm_skinny(n.to_weight_frags(w), hi, lo, M, 2 * inter, K, n.EPI_SILU, of_hi=oh, of_lo=ol)
+    gu = x.half().double() @ w.double().t()
+    g, u = gu[:, :inter], gu[:, inter:]
+    ref = (g / (1 + torch.exp(-g)) * u).float()
+    got = n.from_act_frags(oh, M).float() + n.from_act_frags(ol, M).float()
+    assert (got - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 100, 50, 4096), (1, 40, 40, 128, 259, 0, 5120),
+                                                       (2, 4, 2, 128, 40, 7, 512), (1, 4, 4, 32, 65, 3, 128)])
+def test_gemm_rows_qkv_rope(B, H, Hkv, D, q_len, past, hid):
+    """Row-split kernel with the fused RoPE / KV-append epilogue against the plain-store launch + pc_rope_append."""
+    n = _n()
+    rng = np.random.default_rng(23)
+    T = B * q_len
+    W = (H + 2 * Hkv) * D
+    cap = past + q_len + 2
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((T, hid), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    pos = rng.integers(0, 3000, size=T).astype(np.int32)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(torch.from_numpy(pos).to(DEV), _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    qkv = torch.empty((T, W), dtype=torch.float32, device=DEV)
+    n.gemm_skinny(n.to_weight_frags(w), hi, lo, T, W, hid, n.EPI_STORE, y=qkv, ldy=W)
+    arena_a = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    qa = torch.zeros((T, H * D), dtype=torch.float16, device=DEV)
+    qal = torch.zeros_like(qa)
+    n.rope_append(qkv, q_len * W, W, qa, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
+                  arena_a[:, 0], arena_a[:, 1], 2 * Hkv * cap * D, cap * D, cs, B, H, Hkv, D, q_len, past, cap, True, q_out_lo=qal)
+    perm = n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)
+    arena_b = torch.zeros_like(arena_a)
+    qb = torch.zeros_like(qa)
+    qbl = torch.zeros_like(qa)
+    n.gemm_qkv_rope(n.to_weight_frags(w[perm].contiguous()), hi, lo, T, hid, cs, qb, qbl, H * D, arena_b[:, 0], arena_b[:, 1],
+                    2 * Hkv * cap * D, cap * D, B, H, Hkv, D, q_len, past, cap)
+    torch.cuda.synchronize()
+    ref = x.half().double() @ w.double().t()
+    assert (qkv.double() - ref).abs().max().item() < 2e-4 * float(ref.abs().max())
+    for a, b in ((qa, qb), (arena_a, arena_b)):
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= 2e-3 * max(1.0, float(a.float().abs().max()))
+        assert float((a != b).float().mean()) < 0.02
+    assert torch.equal(arena_a[:, 1], arena_b[:, 1])
+    assert float(arena_b[:, :, :, past:past + q_len].abs().sum()) > 0 and float(arena_b[:, :, :, :past].abs().sum()) == 0

@@ -105,6 +105,18 @@ if __name__ == "__main__":
             bench_gemm("gate_up", M, 22016, 4096, 2)
             bench_gemm("down", M, 4096, 11008, 0, 4)
         sys.exit(0)
+    if "--gemm-rows" in sys.argv:        # 65..512 rows: the row-split kernel, 7b and 13b projection shapes
+        for M in (96, 128, 259, 512):
+            bench_gemm("qkv-7b", M, 12288, 4096, 0)
+            bench_gemm("gate_up-7b", M, 22016, 4096, 2)
+            bench_gemm("down-7b", M, 4096, 11008, 0, 4)
+            bench_gemm("o-7b", M, 4096, 4096, 0, 4)
+        for M in (259,):
+            bench_gemm("qkv-13b", M, 15360, 5120, 0)
+            bench_gemm("gate_up-13b", M, 27648, 5120, 2)
+            bench_gemm("down-13b", M, 5120, 13824, 0, 4)
+            bench_gemm("o-13b", M, 5120, 5120, 0, 4)
+        sys.exit(0)
     if "--gemm" in sys.argv:
         M = 12
         bench_gemm("qkv", M, 12288, 4096, 0)

@@ -74,6 +74,10 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     return __builtin_bit_cast(h4, r);
 }
 
+// (Tried and dropped for q_len <= 16: the four waves of a workgroup taking different key tiles -- four tiles in
+// flight per workgroup, one HBM round trip for a 4-tile range, partials merged through LDS.  In the captured forward
+// it ran 13.6 us + 5.0 us combine (7 splits) against 12.4 us + 6.2 us (10 splits) for this kernel: the launch is
+// bound by streaming 28.5 MB of K/V (~6 us) plus one latency and the serial tail, not by the number of round trips.)
 // (Tried and dropped: 32 query rows per wave -- two 16-row sub-tiles sharing every K / V^T fragment read.  It halves
 // LDS reads per flop but needs 256 VGPRs (1 wave per SIMD) and halves the workgroup count: 322 us vs 323 us at
 // q = S = 4.4k, 30 us vs 16 us at q = 456.)

@@ -178,6 +178,18 @@ int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, 
                      void* stream);
 int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
                     float eps, const float* slabs, int32_t nslabs, void* stream);
+/* Fused-RMSNorm variants for M <= 16 rows: the activation operand is the fp32 residual stream x [M][K] itself; the
+ *   launch computes y = W . (norm_weight * x) * rsqrt(mean(x^2) + eps) -- LlamaRMSNorm (llama2.py:103-108) folded
+ *   into the projection that consumes it (:345-347 for q|k|v, :242 for gate/up, :1050 after the final norm), so the
+ *   norm costs neither a launch nor a pass over x.  Epilogues 0 (store) and 2 (SiLU*up) for pc_gemm_skinny_norm;
+ *   pc_gemm_qkv_rope_norm is pc_gemm_qkv_rope with this source.  Needs |norm_weight * x| < 65504 (fp16 range). */
+int pc_gemm_skinny_norm(const void* wf, const float* x, const void* norm_weight, float eps, int32_t M, int32_t N,
+                        int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
+int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_weight, float eps, int32_t M, int32_t K,
+                          const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
+                          int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
+                          int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
+                          void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

@@ -70,6 +70,8 @@ struct GemmParams {
     _Float16* of_hi; _Float16* of_lo; int32_t KSo;  // EPI_SILU: output planes [MT][KSo][64][8]
     int32_t M, ntiles, KS, npairs;
     int32_t kslices; int64_t slab_stride;   // EPI_STORE only: grid.y K-slices, slice s writes y + s*slab_stride
+    // NORM activation source (M <= 16): the fp32 residual stream itself; RMSNorm is folded into the launch
+    const float* xn; const _Float16* gamma; float eps;
     RopeEpi rope;
 };
 
@@ -143,6 +145,59 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
             }
 }
 
+// NORM variant of k_block for M <= 16: the activation operand is produced on the fly from the fp32 residual stream
+// x[M][K] and the RMSNorm weight: the wave loads 8 floats of its row per k-step (the same bytes as the two fp16
+// planes), forms g*x as a split-precision pair and accumulates sum(x^2) of its K slice in `ss`.  The 1/rms factor
+// is a per-row scalar and the GEMM is linear in the activations, so it is applied to the reduced tile in the
+// epilogue -- LlamaRMSNorm (llama2.py:103-108) costs no launch and no pass over x of its own.  Needs |g*x| < 65504.
+template <int TT, int U, bool TAIL>
+__device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT], const float* xrow, const _Float16* gam,
+                                             int ks, int nvalid, bool row_ok, f4 (&acc)[1][TT], float& ss) {
+    h8 w[U][TT], gw[U];
+    f4 xa[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+            w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + uu) * 512);
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        xa[u][0] = z; xa[u][1] = z;
+        gw[u] = *(const h8*)(gam + (ks + uu) * 32);
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+            xa[u][0] = *(const f4*)(xrow + (ks + uu) * 32);
+            xa[u][1] = *(const f4*)(xrow + (ks + uu) * 32 + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (TAIL && u >= nvalid) continue;              // the re-read k-step contributes nothing
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = e < 4 ? xa[u][0][e] : xa[u][1][e - 4];
+            ss += xv * xv;
+            const float v = xv * (float)gw[u][e];
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], hi, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], lo, acc[0][t], 0, 0, 0);
+        }
+    }
+}
+
 // Epilogue of one reduced 16 x 16 tile.  v (and u = the "up" tile for EPI_SILU) follow the MFMA C/D map: this lane
 // holds output row `row` (token) and features unit*16 + 4*g .. +3.  Must be called by all 64 lanes of a wave
 // (EPI_ROPE exchanges rotary partners across lanes).
@@ -213,8 +268,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
     }
 }
 
-template <int MT, int T, int EPI, bool TWO, int U>
+template <int MT, int T, int EPI, bool TWO, int U, bool NORM = false>
 __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams p) {
+    static_assert(!NORM || (MT == 1 && TWO), "the fused-RMSNorm source is for one row tile");
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
     constexpr int TPI = (EPI == EPI_SILU) ? 2 : 1;                 // tiles per output item
     constexpr int kRT = (MT * TT < 8) ? MT * TT : 8;               // tiles per wave in the reduction buffer (<= 64 KiB)
@@ -263,8 +319,20 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 #pragma unroll
     for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < p.M;
     int ks = ks0;
-    for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
-    if (ks < ks1) k_block<MT, TT, TWO, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+    [[maybe_unused]] float ss = 0.f;
+    __shared__ float ssl[kWaves][16];
+    if constexpr (NORM) {
+        const float* xrow = p.xn + (int64_t)m * (KS * 32) + g * 8;
+        const _Float16* gam = p.gamma + g * 8;
+        for (; ks + U <= ks1; ks += U) k_block_norm<TT, U, false>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss);
+        if (ks < ks1) k_block_norm<TT, U, true>(wbase, xrow, gam, ks, ks1 - ks, row_ok[0], acc, ss);
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (g == 0) ssl[wave][m] = ss;                   // this wave's share of sum(x^2) of row m
+    } else {
+        for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
+        if (ks < ks1) k_block<MT, TT, TWO, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+    }
 
     // ---- split-K reduction through LDS, fixed order ----
     // An output item is one reduced tile (a gate/up pair of tiles for the SiLU epilogue).  Up to kRT tiles per
@@ -300,6 +368,14 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
                 const f4 y = *(const f4*)red[w][wave * TPI + 1][lane];
                 u[0] += y[0]; u[1] += y[1]; u[2] += y[2]; u[3] += y[3];
             }
+        }
+        if constexpr (NORM) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) tot += ssl[w][m];
+            const float rs = rsqrtf(tot / (float)(KS * 32) + p.eps);
+            v[0] *= rs; v[1] *= rs; v[2] *= rs; v[3] *= rs;
+            u[0] *= rs; u[1] *= rs; u[2] *= rs; u[3] *= rs;
         }
         tile_epilogue<EPI>(p, v, u, a * 16 + m, (int)blockIdx.x * T + t, g, (int)blockIdx.y);
     }
@@ -390,6 +466,12 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
     const bool two = p.xf_lo != nullptr;
 #define PC_GO(UV)                                                                                     \
     do {                                                                                              \
+        if constexpr (MT == 1 && EPI != EPI_ADD) {                                                    \
+            if (p.xn) {                                                                               \
+                hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UV, true>), grid, block, 0, s, p); \
+                break;                                                                                \
+            }                                                                                         \
+        }                                                                                             \
         if (two) hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UV>), grid, block, 0, s, p); \
         else hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UV>), grid, block, 0, s, p);    \
     } while (0)
@@ -648,14 +730,18 @@ int choose_T(int units) {
 
 }  // namespace
 
-PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
-                             int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
-                             void* stream) {
+namespace {
+int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma, float eps,
+                     int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
+                     int32_t kslices, void* stream) {
     PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
-    PC_REQUIRE(wf && xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
+    PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
+    PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && epilogue != EPI_ADD), PC_ERR_ARG,
+               "pc_gemm_skinny_norm: the fused-RMSNorm source needs M <= 16, no K-slicing, epilogue 0 or 2");
     GemmParams p;
     memset(&p, 0, sizeof(p));
+    p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
     p.wf = (const _Float16*)wf; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
     p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
@@ -676,21 +762,66 @@ PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_l
     return launch_MT<EPI_STORE>(p, choose_T(p.ntiles * kslices) , p.ntiles, s);
 }
 
+int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma,
+                       float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
+                       void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
+                       int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
+                       const int32_t* past_len_dev, void* stream);
+}  // namespace
+
+PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
+                             int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
+                             void* stream) {
+    PC_REQUIRE(xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
+    return gemm_skinny_impl(wf, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, kslices, stream);
+}
+
+PC_EXPORT int pc_gemm_skinny_norm(const void* wf, const float* x, const void* norm_weight, float eps, int32_t M, int32_t N,
+                                  int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
+                                  void* stream) {
+    PC_REQUIRE(x && norm_weight, PC_ERR_ARG, "pc_gemm_skinny_norm: null pointer");
+    return gemm_skinny_impl(wf, nullptr, nullptr, x, norm_weight, eps, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream);
+}
+
 PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, int32_t M, int32_t K,
                                const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena,
                                void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                                int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                                const int32_t* past_len_dev, void* stream) {
+    PC_REQUIRE(xf_hi, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
+    return gemm_qkv_rope_impl(wf_perm, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
+                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
+                              past_len_dev, stream);
+}
+
+PC_EXPORT int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_weight, float eps, int32_t M,
+                                    int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
+                                    void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                                    int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
+                                    int32_t cap, const int32_t* past_len_dev, void* stream) {
+    PC_REQUIRE(x && norm_weight && M <= 16, PC_ERR_ARG, "pc_gemm_qkv_rope_norm: needs x, the norm weight and M <= 16");
+    return gemm_qkv_rope_impl(wf_perm, nullptr, nullptr, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
+                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
+                              past_len_dev, stream);
+}
+
+namespace {
+int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma,
+                       float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
+                       void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
+                       int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
+                       const int32_t* past_len_dev, void* stream) {
     const int N = (H + 2 * Hkv) * D;
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
-    PC_REQUIRE(wf_perm && xf_hi && cs && q_hi && q_lo && k_arena && v_arena, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
+    PC_REQUIRE(wf_perm && (xf_hi || xn) && cs && q_hi && q_lo && k_arena && v_arena, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
     PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
                "pc_gemm_qkv_rope: past_len %d + q_len %d exceeds arena rows %d", past_len, q_len, cap);
     PC_REQUIRE(q_token_stride % 4 == 0 && arena_head_stride % 4 == 0, PC_ERR_ARG, "pc_gemm_qkv_rope: strides must keep 8-byte alignment");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.wf = (const _Float16*)wf_perm; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
+    p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
     p.y = nullptr; p.ldy = 0; p.of_hi = nullptr; p.of_lo = nullptr; p.KSo = 0;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.kslices = 1; p.slab_stride = 0;
     p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
@@ -699,6 +830,7 @@ PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const voi
     p.rope.H = H; p.rope.Hkv = Hkv; p.rope.D = D; p.rope.q_len = q_len; p.rope.past_len = past_len;
     return launch_MT<EPI_ROPE>(p, choose_T(p.ntiles), p.ntiles, (hipStream_t)stream);
 }
+}  // namespace
 
 PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,
                               int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream) {

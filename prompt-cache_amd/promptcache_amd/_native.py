@@ -31,6 +31,9 @@ SIGNATURES = {
     "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "pc_gemm_skinny_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "pc_gemm_qkv_rope_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
+                                        _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -150,6 +153,23 @@ def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_
                                  q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D,
                                  q_len, past_len, cap, _ptr(past_len_dev), current_stream() if stream is None else stream)
     check(rc, "pc_gemm_qkv_rope")
+
+
+def gemm_skinny_norm(wf, x_f32, norm_weight, eps: float, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,
+                     of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
+    """RMSNorm folded into the projection (M <= 16): y = W . (norm_weight * x) * rsqrt(mean(x^2) + eps)."""
+    rc = load().pc_gemm_skinny_norm(wf.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, N, K, epilogue, _ptr(y),
+                                    ldy, _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_skinny_norm")
+
+
+def gemm_qkv_rope_norm(wf_perm, x_f32, norm_weight, eps: float, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H,
+                       Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None) -> None:
+    rc = load().pc_gemm_qkv_rope_norm(wf_perm.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, K, cs.data_ptr(),
+                                      q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs,
+                                      a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
+                                      current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_qkv_rope_norm")
 
 
 def qkv_rope_row_perm(n_heads_total: int, D: int):

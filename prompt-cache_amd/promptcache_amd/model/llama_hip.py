@@ -25,6 +25,7 @@ There is no CPU / eager fallback: without the HIP extension this module raises.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -46,6 +47,7 @@ class LlamaHIP:
     gate|up projections so each is one GEMM."""
 
     SKINNY_MAX_ROWS = 64   # B*q_len at or below this: split-precision weight-streaming kernels inside one hipGraph
+    NORM_FUSED_MAX_ROWS = 16   # ... and at or below this the RMSNorms are folded into the projections
     MID_MAX_ROWS = 512     # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
@@ -98,6 +100,7 @@ class LlamaHIP:
         # (B, q_len, arena, split count); past_len, token ids and positions are read from device buffers so
         # every decode step and every same-shaped prompt replays the same graph.
         self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
+        self.fuse_norm = os.environ.get("PC_FUSE_NORM", "1") != "0"
         self.use_graphs = True
         self._graphs = {}
         self.max_graphs = 64
@@ -220,11 +223,39 @@ class LlamaHIP:
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
     # ------------------------------------------------------------------------------------------
+    def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
+                           last_token_only):
+        """T <= 16 rows: six launches per layer.  Both RMSNorms are folded into the projections that consume them
+        (pc_gemm_*_norm read the fp32 residual stream directly) and both residual adds into the o_proj / down_proj
+        epilogues, so x is the only activation that round-trips through memory in fp32."""
+        n = _native
+        c = self.config
+        H, Hkv, D, hid, inter = self.H, self.Hkv, self.D, c.hidden_size, c.intermediate_size
+        T, eps, V = B * q_len, c.rms_norm_eps, c.vocab_size
+        for li, lw in enumerate(layers):
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                                 arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                       B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                       q_lo=q16l)
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)                   # x += attn @ Wo^T
+            n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)
+            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)                # x += act @ Wd^T
+        if last_token_only:
+            xs = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            logits = torch.empty((B, V), dtype=torch.float32, device=self.device)
+            n.gemm_skinny_norm(self.lm_head_f, xs, self.norm, eps, B, V, hid, n.EPI_STORE, y=logits, ldy=V)
+            return logits.view(B, 1, V)
+        logits = torch.empty((T, V), dtype=torch.float32, device=self.device)
+        n.gemm_skinny_norm(self.lm_head_f, x, self.norm, eps, T, V, hid, n.EPI_STORE, y=logits, ldy=V)
+        return logits.view(B, q_len, V)
+
     def _graphed_skinny(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
         """Replay (capturing on first use) the hipGraph of the small-q forward for this shape."""
         n = _native
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
-        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers)
+        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm)
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= self.max_graphs:
@@ -285,6 +316,9 @@ class LlamaHIP:
         slabs = torch.empty((KQ, T, hid), dtype=torch.float32, device=dev)
         pending = 0                                   # slabs waiting to be added to x
         layers = self.layers if num_layers is None else self.layers[:num_layers]
+        if T <= self.NORM_FUSED_MAX_ROWS and self.fuse_norm:
+            return self._layers_norm_fused(x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
+                                           last_token_only)
         for li, lw in enumerate(layers):
             n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)

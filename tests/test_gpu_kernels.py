@@ -616,3 +616,91 @@ def test_gemm_rows_qkv_rope(B, H, Hkv, D, q_len, past, hid):
         assert float((a != b).float().mean()) < 0.02
     assert torch.equal(arena_a[:, 1], arena_b[:, 1])
     assert float(arena_b[:, :, :, past:past + q_len].abs().sum()) > 0 and float(arena_b[:, :, :, :past].abs().sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# RMSNorm folded into the projection (M <= 16)
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K", [(12, 12288, 4096), (1, 4096, 4096), (16, 32000, 4096), (5, 48, 32), (14, 15360, 5120), (3, 64, 96)])
+def test_gemm_skinny_norm_store(M, N, K):
+    n = _n()
+    rng = np.random.default_rng(31)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy((3.0 * rng.standard_normal((M, K), dtype=np.float32))).to(DEV)
+    gam = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(K, dtype=np.float32)).astype(np.float16)).to(DEV)
+    eps = 1e-5
+    y = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+    n.gemm_skinny_norm(n.to_weight_frags(w), x, gam, eps, M, N, K, n.EPI_STORE, y=y, ldy=N)
+    xd = x.double()
+    xn = xd * torch.rsqrt((xd * xd).mean(dim=1, keepdim=True) + eps) * gam.double()
+    ref = (xn @ w.double().t()).float()
+    assert (y - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
+    # and against the two-launch path (pc_rmsnorm_frag + pc_gemm_skinny): same math, fp32-level agreement
+    mt = (M + 15) // 16
+    hi = torch.zeros((mt, K // 32, 64, 8), dtype=torch.float16, device=DEV)
+    lo = torch.zeros_like(hi)
+    n.rmsnorm_frag(x.clone(), gam, hi, lo, M, K, eps)
+    y2 = torch.empty_like(y)
+    n.gemm_skinny(n.to_weight_frags(w), hi, lo, M, N, K, n.EPI_STORE, y=y2, ldy=N)
+    assert (y - y2).abs().max().item() < 1e-4 * float(ref.abs().max()) + 1e-5
+    y3 = torch.empty_like(y)
+    n.gemm_skinny_norm(n.to_weight_frags(w), x, gam, eps, M, N, K, n.EPI_STORE, y=y3, ldy=N)
+    assert torch.equal(y, y3)
+
+
+@pytest.mark.parametrize("M,inter,K", [(12, 11008, 4096), (3, 64, 32), (16, 13824, 5120), (1, 1376, 512)])
+def test_gemm_skinny_norm_silu(M, inter, K):
+    n = _n()
+    rng = np.random.default_rng(32)
+    w = torch.from_numpy((0.05 * rng.standard_normal((2 * inter, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy((2.0 * rng.standard_normal((M, K), dtype=np.float32))).to(DEV)
+    gam = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(K, dtype=np.float32)).astype(np.float16)).to(DEV)
+    eps = 1e-6
+    oh = torch.zeros((1, inter // 32, 64, 8), dtype=torch.float16, device=DEV)
+    ol = torch.zeros_like(oh)
+    n.gemm_skinny_norm(n.to_weight_frags(w), x, gam, eps, M, 2 * inter, K, n.EPI_SILU, of_hi=oh, of_lo=ol)
+    xd = x.double()
+    xn = xd * torch.rsqrt((xd * xd).mean(dim=1, keepdim=True) + eps) * gam.double()
+    gu = xn @ w.double().t()
+    g, u = gu[:, :inter], gu[:, inter:]
+    ref = (g / (1 + torch.exp(-g)) * u).float()
+    got = n.from_act_frags(oh, M).float() + n.from_act_frags(ol, M).float()
+    assert (got - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 7, 512), (1, 2, 2, 64, 1, 30, 256)])
+def test_gemm_qkv_rope_norm_equals_two_launches(B, H, Hkv, D, q_len, past, hid):
+    n = _n()
+    rng = np.random.default_rng(33)
+    T = B * q_len
+    W = (H + 2 * Hkv) * D
+    cap = past + q_len + 2
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy((2.0 * rng.standard_normal((T, hid), dtype=np.float32))).to(DEV)
+    gam = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(hid, dtype=np.float32)).astype(np.float16)).to(DEV)
+    eps = 1e-5
+    pos = rng.integers(0, 3000, size=T).astype(np.int32)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(torch.from_numpy(pos).to(DEV), _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    perm = n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)
+    wf = n.to_weight_frags(w[perm].contiguous())
+    mt = (T + 15) // 16
+    hi = torch.zeros((mt, hid // 32, 64, 8), dtype=torch.float16, device=DEV)
+    lo = torch.zeros_like(hi)
+    n.rmsnorm_frag(x.clone(), gam, hi, lo, T, hid, eps)
+    arena_a = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    qa = torch.zeros((T, H * D), dtype=torch.float16, device=DEV); qal = torch.zeros_like(qa)
+    n.gemm_qkv_rope(wf, hi, lo, T, hid, cs, qa, qal, H * D, arena_a[:, 0], arena_a[:, 1], 2 * Hkv * cap * D, cap * D,
+                    B, H, Hkv, D, q_len, past, cap)
+    arena_b = torch.zeros_like(arena_a)
+    qb = torch.zeros_like(qa); qbl = torch.zeros_like(qa)
+    n.gemm_qkv_rope_norm(wf, x, gam, eps, T, hid, cs, qb, qbl, H * D, arena_b[:, 0], arena_b[:, 1], 2 * Hkv * cap * D, cap * D,
+                         B, H, Hkv, D, q_len, past, cap)
+    torch.cuda.synchronize()
+    for a, b in ((qa, qb), (arena_a, arena_b)):
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= 2e-3 * max(1.0, float(a.float().abs().max()))      # <= 1 fp16 ulp
+        assert float((a != b).float().mean()) < 0.02
+    rec_a, rec_b = qa.float() + qal.float(), qb.float() + qbl.float()
+    assert float((rec_a - rec_b).abs().max()) < 2e-5 * max(1.0, float(rec_a.abs().max()))

@@ -519,13 +519,6 @@ int launch_T(const GemmParams& p, int T, int units, hipStream_t s) {
 constexpr int kStageWaves = 4;
 constexpr int kRowsMaxM = 512;
 
-// stage visited at position st of a workgroup's rotated walk over nst stages (positions >= nst: clamp, then rotate)
-__device__ __forceinline__ int rot_stage(int st, int rot, int nst) {
-    st = st < nst ? st : nst - 1;
-    const int se = st + rot;
-    return se < nst ? se : se - nst;
-}
-
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int TT, int EPI, int MTW>
@@ -549,10 +542,10 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
     const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
     // (Rotating the K walk per workgroup, so that workgroups do not read the same activation fragments from L2 in
     // lockstep, measured no gain: L2 channel conflicts are not what bounds this kernel.)
-    constexpr int rot = 0;
 
     if (wave >= RW) {
         // ---------------- staging wave ----------------
+        if (nst <= 0) return;                            // empty K slice (kslices > k-steps): nothing to stream
         const int sidx = wave - RW;
         const _Float16* src[FPW];
         int kst[FPW];
@@ -572,7 +565,7 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
         // one (never out of bounds) and are zeroed when they are written to LDS
 #define PC_STAGE_LOAD(R, ST)                                                                  \
         {                                                                                     \
-            const int se = rot_stage((ST), rot, nst);                                         \
+            const int se = (ST) < nst ? (ST) : nst - 1;   /* stages past the end: the last one */ \
             _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
                 const int kabs = kq0 + se * KC + kst[i];                                      \
                 const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);                           \
@@ -581,7 +574,7 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
         }
 #define PC_STAGE_WRITE(R, ST)                                                                 \
         {                                                                                     \
-            const int se = rot_stage((ST), rot, nst);                                         \
+            const int se = (ST);                                                              \
             _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
                 const bool ok = kq0 + se * KC + kst[i] < kq1;                                 \
                 *(h8*)wbuf[(ST) & 1][sidx + kStageWaves * i][lane] = ok ? R[i] : zero;        \
@@ -630,20 +623,16 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
         xa[a] = p.xf_hi + (((int64_t)mt * KS + kq0) * 64 + lane) * 8;
     }
     const int klast = kq1 - 1 - kq0;                     // last valid k-step, relative to kq0
-    // k-step (relative to kq0) processed at sequence position i; positions past the end repeat the last one
-    auto kseq = [&](int i) {
-        int sq = i / KC;
-        const int j = i - sq * KC;
-        sq = sq < nst ? sq : nst - 1;
-        const int k = rot_stage(sq, rot, nst) * KC + j;
-        return k < klast ? k : klast;
-    };
+    // k-step (relative to kq0) loaded for sequence position i; positions past the end repeat the last one
+    auto kseq = [&](int i) { return i < klast ? i : klast; };
     h8 xs[NX][MTW];
+    if (nst > 0) {                                       // (an empty K slice stores zeros below)
 #pragma unroll
-    for (int d = 0; d < PD; ++d) {
-        const int kn = kseq(d);
+        for (int d = 0; d < PD; ++d) {
+            const int kn = kseq(d);
 #pragma unroll
-        for (int a = 0; a < MTW; ++a) xs[d][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+            for (int a = 0; a < MTW; ++a) xs[d][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+        }
     }
     for (int st = 0; st < nst; ++st) {
         lds_barrier();                                   // stage st is in wbuf[st & 1]

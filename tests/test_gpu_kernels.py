@@ -539,7 +539,7 @@ def test_gemm_qkv_rope_fused_equals_unfused(B, H, Hkv, D, q_len, past, hid):
 
 @pytest.mark.parametrize("M,N,K,kq", [(65, 4096, 4096, 1), (100, 12288, 4096, 1), (259, 15360, 5120, 1), (512, 4096, 4096, 1),
                                       (130, 48, 32, 1), (70, 64, 96, 2), (259, 5120, 13824, 4), (200, 4096, 11008, 4),
-                                      (96, 32000, 4096, 1)])
+                                      (96, 32000, 4096, 1), (70, 32, 64, 4)])     # last: two of the four K slices are empty
 def test_gemm_rows_store_add_slices(M, N, K, kq):
     n = _n()
     rng = np.random.default_rng(21)

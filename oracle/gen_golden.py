@@ -130,6 +130,37 @@ def build_ref_lm(pc, shape_name: str, seed: int, scale: float):
     return RefLM(), shape
 
 
+def build_ref_falcon_lm(pc, shape_name: str, seed: int, scale: float):
+    """The reference ``Falcon`` adapter surface (promptcache/model/__init__.py:206-258: formatter, stop strings,
+    ``get_cache_shape`` = (L, 1, D)) around the reference ``FalconForCausalLM`` with seeded weights."""
+    import importlib
+    from promptcache_amd.model.config import FALCON_SHAPES
+    from promptcache_amd.model.tokenizer import StandInTokenizer
+    from promptcache_amd.model.weights import make_falcon_weights_np
+
+    shape = FALCON_SHAPES[shape_name]
+    w16 = make_falcon_weights_np(shape, seed, scale)
+    model = ref_shim.make_reference_falcon(shape.to_dict(), {k: v.astype(np.float32) for k, v in w16.items()})
+    rm = importlib.import_module("promptcache.model")
+    rprompt = importlib.import_module("promptcache.prompt")
+
+    class RefFalconLM(rm.LanguageModel):
+        def __init__(self):
+            tok = StandInTokenizer(shape.vocab_size)
+            super().__init__("ref-falcon", model, tok, list(range(12)), ["<|endoftext|>", "\nUser"])
+            conv = rm.FormatConversation(system=("", "\n\n", ""), user=("User: ", "\n\nAssistant:"), assistant=(" ", "\n\n"))
+            self.formatter = rprompt.PreprocessorList([lambda t: t.replace("\r\n", "\n").replace("\n\n", "\n"), conv])
+
+        def get_formatter(self):
+            return self.formatter
+
+        def get_cache_shape(self):
+            c = self.hf_model.config
+            return c.num_hidden_layers, 1, c.hidden_size // c.num_attention_heads
+
+    return RefFalconLM(), shape
+
+
 class TokOnlyLM:
     """Tokenizer-only stand-in for layout goldens (no model needed to lay out a schema)."""
 
@@ -258,13 +289,13 @@ def recover_goldens():
 
 
 def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema_text: str, prompt_text: str,
-                 max_ctx: int, max_tokens=None, n_greedy: int = 4):
+                 max_ctx: int, max_tokens=None, n_greedy: int = 4, family: str = "llama"):
     import importlib
     import torch
     rce = importlib.import_module("promptcache.cache_engine")
     rge = importlib.import_module("promptcache.generation_engine")
     rp = importlib.import_module("promptcache.prompt")
-    lm, shape = build_ref_lm(pc, shape_name, seed, scale)
+    lm, shape = (build_ref_falcon_lm if family == "falcon" else build_ref_lm)(pc, shape_name, seed, scale)
     fmt = lm.get_formatter()
     eng = rce.CacheEngine(max_ctx, lm, target_device="cpu")
     eng.add_schema(fmt(schema_text), max_tokens=max_tokens)
@@ -281,8 +312,13 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
     seg_table = [(m.token_sequence.offset, len(m)) for m in eng.prompt_cache.staged]
     past = [(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache]
     attn0 = {}
-    layer0 = lm.hf_model.model.layers[0].self_attn
-    hook = layer0.o_proj.register_forward_pre_hook(lambda mod, inp: attn0.__setitem__("x", inp[0].detach().clone()))
+    if family == "falcon":
+        layer0 = lm.hf_model.transformer.h[0].self_attention
+        o_proj, rotary = layer0.dense, layer0.maybe_rotary
+    else:
+        layer0 = lm.hf_model.model.layers[0].self_attn
+        o_proj, rotary = layer0.o_proj, layer0.rotary_emb
+    hook = o_proj.register_forward_pre_hook(lambda mod, inp: attn0.__setitem__("x", inp[0].detach().clone()))
     with torch.inference_mode():
         out = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=past, use_cache=True)
     hook.remove()
@@ -326,9 +362,11 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
     sc = eng.schemas[prompt.schema]
     mods = sorted(sc.cache_l1.values(), key=lambda m: (m.token_sequence.offset, len(m)))
     mod_table = [(m.token_sequence.offset, len(m)) for m in mods]
-    mod_k_first = np.stack([m.host_cache[0][0][:, 0].numpy() for m in mods])     # layer 0, first token  [M,H,D]
-    mod_v_last = np.stack([m.host_cache[-1][1][:, -1].numpy() for m in mods])    # last layer, last token
-    inv_freq = layer0.rotary_emb.inv_freq.numpy()
+    def heads_first(t):     # multi-query stores are [len, D]: cache_engine.py:286-287 squeezes the single head away
+        return t if t.dim() == 3 else t.unsqueeze(0)
+    mod_k_first = np.stack([heads_first(m.host_cache[0][0])[:, 0].numpy() for m in mods])     # layer 0, first token  [M,H,D]
+    mod_v_last = np.stack([heads_first(m.host_cache[-1][1])[:, -1].numpy() for m in mods])    # last layer, last token
+    inv_freq = rotary.inv_freq.numpy()
 
     np.savez_compressed(
         os.path.join(GOLD, f"model_{case}.npz"),
@@ -366,7 +404,19 @@ def main():
                                 traits=(("age", (30, 26, 33)), ("home", (41, 37, 44)), ("job", (25, 29, 22))),
                                 question_len=6, seed=5)
     model_golden(pc, "tiny_personalike", "tiny", seed=3, scale=4.0, schema_text=sp, prompt_text=pp, max_ctx=400)
+    falcon_goldens(pc)
+
+
+def falcon_goldens(pc):
+    """Falcon adapter fixtures (reference FalconForCausalLM, multi-query cache shape (L, 1, D))."""
+    model_golden(pc, "falcon_tiny_trip", "falcon-tiny", seed=5, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT,
+                 max_ctx=256, family="falcon")
+    model_golden(pc, "falcon_mid_doc", "falcon-mid", seed=6, scale=3.0, schema_text=SYN_FLAT, prompt_text=SYN_FLAT_PROMPT,
+                 max_ctx=200, family="falcon")
 
 
 if __name__ == "__main__":
+    if "--falcon-only" in sys.argv:      # add the Falcon fixtures without regenerating the others
+        falcon_goldens(ref_shim.import_reference())
+        sys.exit(0)
     main()

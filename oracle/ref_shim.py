@@ -158,3 +158,43 @@ def make_reference_llama(cfg_dict: dict, weights_fp32: dict):
     assert not missing and not unexpected, (missing, unexpected)
     model.eval()
     return model
+
+
+def make_reference_falcon(cfg_dict: dict, weights_fp32: dict):
+    """Instantiate the reference ``FalconForCausalLM`` (promptcache/model/falcon.py:1224) in the falcon-7b
+    architecture (multi_query, parallel_attn, rotary, no bias) and load the given weights.
+
+    Harness-side compatibility shims for transformers 5.x (the reference pins 4.34): ``rope_scaling`` /
+    ``rope_theta`` attributes on the config (falcon.py:333-339 reads them), a dict-typed ``_tied_weights_keys``, and
+    ``get_head_mask`` (removed from ``PreTrainedModel``; falcon.py:1108 only needs ``[None] * n_layers``)."""
+    import torch
+    import transformers
+
+    import_reference()
+    falcon = importlib.import_module("promptcache.model.falcon")
+    cfg = transformers.FalconConfig(
+        vocab_size=cfg_dict["vocab_size"], hidden_size=cfg_dict["hidden_size"],
+        num_hidden_layers=cfg_dict["num_hidden_layers"], num_attention_heads=cfg_dict["num_attention_heads"],
+        layer_norm_epsilon=cfg_dict["layer_norm_epsilon"], multi_query=True, parallel_attn=True, bias=False,
+        new_decoder_architecture=False, alibi=False, tie_word_embeddings=False, bos_token_id=1, eos_token_id=2)
+    cfg.rope_theta = cfg_dict["rope_theta"]
+    cfg.rope_scaling = None
+    cfg.use_cache = True
+    falcon.FalconForCausalLM._tied_weights_keys = {}
+    if not hasattr(falcon.FalconModel, "get_head_mask"):
+        falcon.FalconModel.get_head_mask = lambda self, head_mask, n, **_k: [None] * n
+    model = falcon.FalconForCausalLM(cfg)
+    sd = {"transformer.word_embeddings.weight": weights_fp32["embed"], "transformer.ln_f.weight": weights_fp32["lnf_w"],
+          "transformer.ln_f.bias": weights_fp32["lnf_b"], "lm_head.weight": weights_fp32["lm_head"]}
+    names = {"ln_w": "input_layernorm.weight", "ln_b": "input_layernorm.bias",
+             "wqkv": "self_attention.query_key_value.weight", "wo": "self_attention.dense.weight",
+             "w1": "mlp.dense_h_to_4h.weight", "w2": "mlp.dense_4h_to_h.weight"}
+    for i in range(cfg_dict["num_hidden_layers"]):
+        for s_, hf in names.items():
+            sd[f"transformer.h.{i}.{hf}"] = weights_fp32[f"l{i}.{s_}"]
+    sd = {k: torch.from_numpy(v.astype("float32")) for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "rotary" not in m and "inv_freq" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    model.eval()
+    return model

@@ -122,6 +122,14 @@ def _llama_formatter() -> FormatConversation:
                               user=("", "[/INST]"), assistant=("", "</s><s> [INST] "))
 
 
+def _falcon_formatter() -> PreprocessorList:
+    """Reference :212-235: newline normalisation, then the chat strings."""
+    def rep(prompt: str) -> str:
+        return prompt.replace("\r\n", "\n").replace("\n\n", "\n")
+    conv = FormatConversation(system=("", "\n\n", ""), user=("User: ", "\n\nAssistant:"), assistant=(" ", "\n\n"))
+    return PreprocessorList([rep, conv])
+
+
 class _LlamaFamily(LanguageModel):
     """Shared constructor: a local HF checkpoint directory when one exists, else (explicitly requested)
     seeded random weights at the named shape with the deterministic stand-in tokenizer -- the build and

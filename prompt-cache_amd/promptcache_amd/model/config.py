@@ -50,6 +50,61 @@ class LlamaShape:
             name=os.path.basename(os.path.normpath(path)))
 
 
+@dataclass
+class FalconShape:
+    """Falcon-7b-class decoder (``promptcache/model/falcon.py``: multi-query attention with ONE shared K/V head,
+    parallel attention + MLP behind a single LayerNorm, GELU MLP of width 4*hidden, rotary positions, no biases in
+    the linears).  The reference reads these from HF ``config.json`` via ``FalconConfig``; its cache shape is
+    ``(L, 1, head_dim)`` (``promptcache/model/__init__.py:256-258``)."""
+    vocab_size: int = 65024
+    hidden_size: int = 4544
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 71
+    layer_norm_epsilon: float = 1e-5
+    rope_theta: float = 10000.0
+    initializer_range: float = 0.02
+    tie_word_embeddings: bool = False
+    name: str = "falcon"
+
+    num_key_value_heads = 1            # multi_query
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def intermediate_size(self) -> int:
+        return 4 * self.hidden_size
+
+    @property
+    def kv_bytes_per_token(self) -> int:
+        return 2 * self.num_hidden_layers * self.head_dim * 2
+
+    def to_dict(self):
+        return asdict(self)
+
+    @classmethod
+    def from_hf_dir(cls, path: str) -> "FalconShape":
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        if c.get("new_decoder_architecture") or not c.get("multi_query", True) or not c.get("parallel_attn", True) \
+                or c.get("alibi") or c.get("bias"):
+            raise ValueError("only the falcon-7b architecture (multi_query, parallel_attn, rotary, no bias) is supported")
+        return cls(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+                   num_hidden_layers=c.get("num_hidden_layers", c.get("n_layer")),
+                   num_attention_heads=c.get("num_attention_heads", c.get("n_head")),
+                   layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-5), rope_theta=c.get("rope_theta", 10000.0),
+                   tie_word_embeddings=c.get("tie_word_embeddings", True),
+                   name=os.path.basename(os.path.normpath(path)))
+
+
+FALCON_SHAPES = {
+    "falcon-tiny": FalconShape(vocab_size=1024, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, name="falcon-tiny"),
+    # head_dim 64 like falcon-7b, an odd head count like its 71
+    "falcon-mid": FalconShape(vocab_size=2048, hidden_size=448, num_hidden_layers=2, num_attention_heads=7, name="falcon-mid"),
+    "falcon-7b": FalconShape(name="falcon-7b"),
+}
+
 SHAPES = {
     # test-sized
     "tiny": LlamaShape(vocab_size=1024, hidden_size=128, intermediate_size=344, num_hidden_layers=2,

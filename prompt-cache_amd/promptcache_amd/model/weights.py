@@ -54,6 +54,42 @@ def make_weights_np(cfg: LlamaShape, seed: int = 0, scale: float = 1.0) -> Dict[
     return out
 
 
+def falcon_weight_shapes(cfg) -> Dict[str, tuple]:
+    """Key names for the Falcon adapter: ``embed``, ``l{i}.ln_w|ln_b|wqkv|wo|w1|w2``, ``lnf_w``, ``lnf_b``, ``lm_head``;
+    ``wqkv`` is the fused ``query_key_value`` matrix ``[(H + 2) * D, hidden]`` = H query heads, then the shared key
+    head, then the shared value head (``falcon.py:393-396``)."""
+    hid, D, H = cfg.hidden_size, cfg.head_dim, cfg.num_attention_heads
+    shapes = {"embed": (cfg.vocab_size, hid)}
+    for i in range(cfg.num_hidden_layers):
+        shapes[f"l{i}.ln_w"] = (hid,)
+        shapes[f"l{i}.ln_b"] = (hid,)
+        shapes[f"l{i}.wqkv"] = ((H + 2) * D, hid)
+        shapes[f"l{i}.wo"] = (hid, hid)
+        shapes[f"l{i}.w1"] = (4 * hid, hid)
+        shapes[f"l{i}.w2"] = (hid, 4 * hid)
+    shapes["lnf_w"] = (hid,)
+    shapes["lnf_b"] = (hid,)
+    shapes["lm_head"] = (cfg.vocab_size, hid)
+    return shapes
+
+
+def make_falcon_weights_np(cfg, seed: int = 0, scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """fp16 numpy weights for a FalconShape: LayerNorm gains 1 + 0.1 N(0,1), LayerNorm biases 0.1 N(0,1)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in falcon_weight_shapes(cfg).items():
+        if name.endswith("_b"):
+            w = 0.1 * rng.standard_normal(shp, dtype=np.float32)
+        elif len(shp) == 1:
+            w = 1.0 + 0.1 * rng.standard_normal(shp, dtype=np.float32)
+        else:
+            w = (cfg.initializer_range * scale) * rng.standard_normal(shp, dtype=np.float32)
+        out[name] = w.astype(np.float16)
+    if cfg.tie_word_embeddings:
+        out["lm_head"] = out["embed"]
+    return out
+
+
 _HF_MAP = {
     "ln1": "input_layernorm.weight", "wq": "self_attn.q_proj.weight", "wk": "self_attn.k_proj.weight",
     "wv": "self_attn.v_proj.weight", "wo": "self_attn.o_proj.weight",

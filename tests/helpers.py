@@ -6,6 +6,16 @@ import numpy as np
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["tiny_trip", "tiny_trip2", "mid_trip", "mid_mha_doc", "tiny_personalike"]
+FALCON_CASES = ["falcon_tiny_trip", "falcon_mid_doc"]     # reference Falcon adapter: multi-query cache (L, 1, D)
+
+
+def is_falcon(g) -> bool:
+    return str(g["shape_name"]).startswith("falcon")
+
+
+def shape_for_case(g):
+    from promptcache_amd.model.config import FALCON_SHAPES, SHAPES
+    return (FALCON_SHAPES if is_falcon(g) else SHAPES)[str(g["shape_name"])]
 
 
 def load_case(name):
@@ -31,6 +41,11 @@ def llama_formatter():
     return _llama_formatter()
 
 
+def formatter_for_case(g):
+    from promptcache_amd.model import _falcon_formatter
+    return _falcon_formatter() if is_falcon(g) else llama_formatter()
+
+
 def assemble(schema, prompt, lm):
     """Integer part of CacheEngine.process: (used TokenSequence objects, new ids, new positions)."""
     used, ids, pos = [], [], []
@@ -54,11 +69,10 @@ def assemble(schema, prompt, lm):
 
 def layout_for_case(g):
     """Schema, encode jobs (reference path order), prompt assembly for a model golden."""
-    from promptcache_amd.model.config import SHAPES
     from promptcache_amd.pml import Prompt, Schema
-    shape = SHAPES[str(g["shape_name"])]
+    shape = shape_for_case(g)
     lm = TokOnlyLM(shape.vocab_size)
-    fmt = llama_formatter()
+    fmt = formatter_for_case(g)
     mt = int(g["max_tokens"])
     schema = Schema(fmt(str(g["schema_text"])), lm, max_tokens=None if mt < 0 else mt)
     jobs = []
@@ -73,7 +87,14 @@ def layout_for_case(g):
 
 def oracle_for_case(g, shape):
     from oracle.llama_oracle import LlamaOracle, OracleConfig
-    from promptcache_amd.model.weights import make_weights_np
+    from promptcache_amd.model.weights import make_falcon_weights_np, make_weights_np
+    if is_falcon(g):
+        from oracle.falcon_oracle import FalconOracle, FalconOracleConfig
+        w16 = make_falcon_weights_np(shape, int(g["seed"]), float(g["scale"]))
+        cfg = FalconOracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size,
+                                 num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                                 layer_norm_epsilon=shape.layer_norm_epsilon, rope_theta=shape.rope_theta, inv_freq=g["inv_freq"])
+        return FalconOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()}), w16
     w16 = make_weights_np(shape, int(g["seed"]), float(g["scale"]))
     cfg = OracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size,
                        intermediate_size=shape.intermediate_size, num_hidden_layers=shape.num_hidden_layers,

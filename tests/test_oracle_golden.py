@@ -7,7 +7,7 @@ from oracle import engine_oracle as eo
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("case", H.MODEL_CASES)
+@pytest.mark.parametrize("case", H.MODEL_CASES + H.FALCON_CASES)
 def test_oracle_reproduces_reference_outputs(case):
     g = H.load_case(case)
     shape, schema, jobs, prompt, used, ids, pos = H.layout_for_case(g)
@@ -41,7 +41,7 @@ def test_oracle_reproduces_reference_outputs(case):
     assert toks == g["greedy"].tolist()
 
 
-@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc"])
+@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "falcon_mid_doc"])
 def test_oracle_nocache_path(case):
     from promptcache_amd.pml import Prompt
     g = H.load_case(case)

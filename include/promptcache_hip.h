@@ -191,6 +191,21 @@ int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_
                           int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
                           void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Falcon adapter (promptcache/model/falcon.py; multi-query, parallel attention + MLP): the ops the Llama path does
+ * not have.  Everything else (pc_kv_gather with Hkv = 1, pc_rope_*, pc_attn_fwd with H/Hkv = H, pc_gemm_*) is shared.
+ *   pc_layernorm       torch.nn.LayerNorm (falcon.py:757, :1020) of fp32 x [rows][hidden] -> fp16
+ *   pc_layernorm_frag  the same, written as split-precision fragment planes, with the slab-folding prologue of
+ *                      pc_rmsnorm_frag (x += slabs[0] + ... first: the o_proj and dense_4h_to_h partial sums)
+ *   pc_gelu            nn.GELU() (falcon.py:726, erf form) fp32 -> fp16, n elements (n % 8 == 0)
+ *   pc_gemm_skinny epilogue 4: of[m][j] = gelu(y[m][j]) as fragment planes [M/16][N/32][64][8] (dense_h_to_4h)
+ * ------------------------------------------------------------------------------------------- */
+int pc_layernorm(const float* x, const void* weight, const void* bias, void* out, int32_t rows, int32_t hidden,
+                 float eps, void* stream);
+int pc_layernorm_frag(float* x, const void* weight, const void* bias, void* xf_hi, void* xf_lo, int32_t rows,
+                      int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream);
+int pc_gelu(const float* x, void* out, int64_t n, void* stream);
+
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);

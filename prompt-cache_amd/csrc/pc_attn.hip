@@ -270,9 +270,9 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
                 h4 hi, lo;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = o[db][r] * inv;
-                    hi[r] = (_Float16)v;
-                    lo[r] = (_Float16)(v - (float)hi[r]);
+                    _Float16 vh, vl;
+                    pc_split(o[db][r] * inv, vh, vl);
+                    hi[r] = vh; lo[r] = vl;
                 }
                 const int64_t off = frag_off(row, h * D + db * 16 + g * 4, KSo);
                 *(h4*)(p.of_hi + off) = hi;
@@ -318,9 +318,10 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
     const float v = num / den;
     if (of_hi) {
         const int64_t off = frag_off(b * q_len + qi, h * D + d, H * D / 32);
-        const _Float16 hi = (_Float16)v;
+        _Float16 hi, lo;
+        pc_split(v, hi, lo);
         of_hi[off] = hi;
-        of_lo[off] = (_Float16)(v - (float)hi);
+        of_lo[off] = lo;
     } else {
         out[b * o_bs + (int64_t)qi * o_ts + (int64_t)h * D + d] = (_Float16)v;
     }

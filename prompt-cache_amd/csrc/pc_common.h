@@ -30,3 +30,15 @@ static inline int pc_check_launch(const char* what) {
 }
 
 static inline int pc_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// fp32 -> split-precision fp16 pair (hi = fp16(s), lo = fp16(s - hi)).  The value is pinned in a register first:
+// under -ffp-contract=fast hipcc may fuse the multiply that produced s into the conversion (v_fma_mix*_f16) for one
+// of the two uses and not the other, and the pair then describes two different roundings of the product (observed in
+// the GELU epilogue: hi one fp16 ulp off with lo of the wrong sign, at values within an fp32 ulp of an fp16 tie).
+__device__ __forceinline__ void pc_split(float s, _Float16& hi, _Float16& lo) {
+    asm volatile("" : "+v"(s));
+    hi = (_Float16)s;
+    lo = (_Float16)(s - (float)hi);
+}
+#endif

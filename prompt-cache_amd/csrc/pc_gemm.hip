@@ -52,7 +52,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2, EPI_ROPE = 3 };
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2, EPI_ROPE = 3, EPI_GELU = 4 };
 
 struct RopeEpi {          // EPI_ROPE outputs
     const float2* cs;     // [B*q_len][D/2] (cos, sin) from pc_rope_table
@@ -187,8 +187,9 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
             const float xv = e < 4 ? xa[u][0][e] : xa[u][1][e - 4];
             ss += xv * xv;
             const float v = xv * (float)gw[u][e];
-            hi[e] = (_Float16)v;
-            lo[e] = (_Float16)(v - (float)hi[e]);
+            _Float16 vh, vl;
+            pc_split(v, vh, vl);
+            hi[e] = vh; lo[e] = vl;
         }
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -211,10 +212,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s = (v[r] / (1.0f + __expf(-v[r]))) * u[r];
-                hi[r] = (_Float16)s;
-                lo[r] = (_Float16)(s - (float)hi[r]);
+                _Float16 sh, sl;
+                pc_split(s, sh, sl);
+                hi[r] = sh; lo[r] = sl;
             }
             const int64_t off = frag_off(row, j0, p.KSo);
+            *(h4*)(p.of_hi + off) = hi;
+            *(h4*)(p.of_lo + off) = lo;
+        } else if (EPI == EPI_GELU) {
+            // nn.GELU() (falcon.py:726, exact erf form) of the reduced tile, as split-precision planes for dense_4h_to_h
+            h4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                _Float16 sh, sl;
+                pc_split(s, sh, sl);
+                hi[r] = sh; lo[r] = sl;
+            }
+            const int64_t off = frag_off(row, unit * 16 + g * 4, p.KSo);
             *(h4*)(p.of_hi + off) = hi;
             *(h4*)(p.of_lo + off) = lo;
         } else if (EPI == EPI_ROPE) {
@@ -248,8 +263,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
                     const float2 w = cs[r];
                     // q*cos + rotate_half(q)*sin (llama2.py:208): low half pairs with -high, high with +low
                     const float o = is_hi ? (v[r] * w.x + pv[r] * w.y) : (v[r] * w.x - pv[r] * w.y);
-                    hi[r] = (_Float16)o;
-                    lo[r] = (_Float16)(o - (float)hi[r]);
+                    _Float16 oh, ol;
+                    pc_split(o, oh, ol);
+                    hi[r] = oh; lo[r] = ol;
                 }
                 if (hh < e.H) {
                     const int64_t off = (int64_t)row * e.q_ts + (int64_t)hh * e.D + d0;
@@ -385,12 +401,16 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 // RMSNorm producing split-precision fragment planes: one workgroup per row.
 // Optional prologue: x[row] += slab[0][row] + slab[1][row] + ... (fixed order), the K-sliced partial sums a
 // preceding pc_gemm_skinny left behind -- the residual add of llama2.py:638 / :644 happens here, in place.
-template <int G>   // G = 8-element groups per thread: the whole row stays in registers between the two passes
+// LN = true: torch.nn.LayerNorm instead (Falcon, falcon.py:757): mean removed (two passes over the register-resident
+// row, no cancellation), bias `b` added after the gain.
+template <int G, bool LN = false>   // G = 8-element groups per thread: the whole row stays in registers between the passes
 __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x, const _Float16* __restrict__ w,
                                                            _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo,
                                                            int hidden, float eps, const float* __restrict__ slabs,
-                                                           int nslabs, int64_t slab_stride) {
+                                                           int nslabs, int64_t slab_stride,
+                                                           const _Float16* __restrict__ b = nullptr) {
     __shared__ float red[4];
+    __shared__ float redm[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = hidden >> 3;
     float* xr = x + (int64_t)row * hidden;
@@ -428,6 +448,25 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
             }
         }
     }
+    float mu = 0.f;
+    if (LN) {
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < G; ++k)       // lanes past the end of the row hold zeros
+            sm += va[k][0] + va[k][1] + va[k][2] + va[k][3] + vb[k][0] + vb[k][1] + vb[k][2] + vb[k][3];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        if ((tid & 63) == 0) redm[tid >> 6] = sm;
+        __syncthreads();
+        mu = (redm[0] + redm[1] + redm[2] + redm[3]) / (float)hidden;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            if (tid + k * 256 < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[k][e] -= mu; vb[k][e] -= mu; }
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < G; ++k)
         ss += va[k][0] * va[k][0] + va[k][1] * va[k][1] + va[k][2] * va[k][2] + va[k][3] * va[k][3] +
@@ -443,12 +482,16 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
         const int i = tid + k * 256;
         if (i < nv) {
             const h8 gw = *(const h8*)(w + i * 8);
+            h8 bw = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (LN) bw = *(const h8*)(b + i * 8);
             h8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = (float)gw[e] * ((e < 4 ? va[k][e] : vb[k][e - 4]) * rs);
-                hi[e] = (_Float16)v;
-                lo[e] = (_Float16)(v - (float)hi[e]);
+                float v = (float)gw[e] * ((e < 4 ? va[k][e] : vb[k][e - 4]) * rs);
+                if (LN) v += (float)bw[e];
+                _Float16 vh, vl;
+                pc_split(v, vh, vl);
+                hi[e] = vh; lo[e] = vl;
             }
             const int64_t off = frag_off(row, i * 8, KS);
             *(h8*)(of_hi + off) = hi;
@@ -726,7 +769,7 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
     PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
-    PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && epilogue != EPI_ADD), PC_ERR_ARG,
+    PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && (epilogue == EPI_STORE || epilogue == EPI_SILU)), PC_ERR_ARG,
                "pc_gemm_skinny_norm: the fused-RMSNorm source needs M <= 16, no K-slicing, epilogue 0 or 2");
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -744,6 +787,11 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
         p.npairs = N / 32;          // inter / 16
         p.KSo = (N / 2) / 32;       // k-steps of the consumer (down_proj, K = inter)
         return launch_MT<EPI_SILU>(p, choose_T(p.npairs), p.npairs, s);
+    }
+    if (epilogue == EPI_GELU) {
+        PC_REQUIRE(N % 32 == 0 && of_hi && of_lo, PC_ERR_ARG, "pc_gemm_skinny: GELU epilogue needs N%%32==0 and output planes");
+        p.KSo = N / 32;             // k-steps of the consumer (dense_4h_to_h, K = N)
+        return launch_MT<EPI_GELU>(p, choose_T(p.ntiles), p.ntiles, s);
     }
     PC_REQUIRE(y && ldy >= N && ldy % 4 == 0, PC_ERR_ARG, "pc_gemm_skinny: bad output");
     if (epilogue == EPI_ADD) return launch_MT<EPI_ADD>(p, choose_T(p.ntiles), p.ntiles, s);
@@ -830,8 +878,25 @@ PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* x
     const int groups = pc_ceil_div(hidden / 8, 256);
 #define PC_RMS(GV)                                                                                                   \
     hipLaunchKernelGGL(rmsnorm_frag_kernel<GV>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight, \
-                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps, slabs, nslabs, (int64_t)rows * hidden)
+                       (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps, slabs, nslabs, (int64_t)rows * hidden,       \
+                       (const _Float16*)nullptr)
     if (groups <= 1) PC_RMS(1); else if (groups <= 2) PC_RMS(2); else if (groups <= 4) PC_RMS(4); else PC_RMS(8);
 #undef PC_RMS
     return pc_check_launch("rmsnorm_frag_kernel");
+}
+
+PC_EXPORT int pc_layernorm_frag(float* x, const void* weight, const void* bias, void* xf_hi, void* xf_lo, int32_t rows,
+                                int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream) {
+    PC_REQUIRE(rows > 0 && rows <= kRowsMaxM && hidden > 0 && hidden % 32 == 0 && hidden <= 16384, PC_ERR_ARG,
+               "pc_layernorm_frag: bad sizes");
+    PC_REQUIRE(x && weight && bias && xf_hi && xf_lo && nslabs >= 0 && (nslabs == 0 || slabs), PC_ERR_ARG,
+               "pc_layernorm_frag: null pointer");
+    const int groups = pc_ceil_div(hidden / 8, 256);
+#define PC_LN(GV)                                                                                                    \
+    hipLaunchKernelGGL((rmsnorm_frag_kernel<GV, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream, x,            \
+                       (const _Float16*)weight, (_Float16*)xf_hi, (_Float16*)xf_lo, hidden, eps, slabs, nslabs,      \
+                       (int64_t)rows * hidden, (const _Float16*)bias)
+    if (groups <= 1) PC_LN(1); else if (groups <= 2) PC_LN(2); else if (groups <= 4) PC_LN(4); else PC_LN(8);
+#undef PC_LN
+    return pc_check_launch("layernorm_frag_kernel");
 }

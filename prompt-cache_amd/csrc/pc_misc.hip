@@ -108,6 +108,61 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const void* __restrict__ 
     *(h8*)(out + (int64_t)row * inter + i * 8) = o;
 }
 
+// torch.nn.LayerNorm over the last dim (falcon.py:757, :1020): fp32 statistics (two passes: mean, then the centred
+// sum of squares -- no E[x^2] - mean^2 cancellation), affine in fp32, one fp16 rounding.  x fp32 [rows][hidden].
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const _Float16* __restrict__ w,
+                                                        const _Float16* __restrict__ b, _Float16* __restrict__ out,
+                                                        int hidden, float eps) {
+    __shared__ float red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int nv = hidden >> 3;
+    const float* xr = x + (int64_t)row * hidden;
+    float sm = 0.f;
+    for (int i = tid; i < nv; i += 256) {
+        const f4 a = *(const f4*)(xr + i * 8), c = *(const f4*)(xr + i * 8 + 4);
+        sm += a[0] + a[1] + a[2] + a[3] + c[0] + c[1] + c[2] + c[3];
+    }
+    sm = wave_sum(sm);
+    if ((tid & 63) == 0) red[0][tid >> 6] = sm;
+    __syncthreads();
+    const float mu = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)hidden;
+    float ss = 0.f;
+    for (int i = tid; i < nv; i += 256) {
+        const f4 a = *(const f4*)(xr + i * 8), c = *(const f4*)(xr + i * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ss += (a[e] - mu) * (a[e] - mu) + (c[e] - mu) * (c[e] - mu); }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[1][tid >> 6] = ss;
+    __syncthreads();
+    const float rs = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)hidden + eps);
+    for (int i = tid; i < nv; i += 256) {
+        const f4 a = *(const f4*)(xr + i * 8), c = *(const f4*)(xr + i * 8 + 4);
+        const h8 g = *(const h8*)(w + i * 8), bb = *(const h8*)(b + i * 8);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (_Float16)((a[e] - mu) * rs * (float)g[e] + (float)bb[e]);
+            o[e + 4] = (_Float16)((c[e] - mu) * rs * (float)g[e + 4] + (float)bb[e + 4]);
+        }
+        *(h8*)(out + (int64_t)row * hidden + i * 8) = o;
+    }
+}
+
+// nn.GELU() (falcon.py:726), the exact erf form: fp32 in -> fp16 out
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const f4 a = *(const f4*)(x + i * 8), c = *(const f4*)(x + i * 8 + 4);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (_Float16)(0.5f * a[e] * (1.0f + erff(a[e] * 0.70710678118654752f)));
+        o[e + 4] = (_Float16)(0.5f * c[e] * (1.0f + erff(c[e] * 0.70710678118654752f)));
+    }
+    *(h8*)(out + i * 8) = o;
+}
+
 __global__ __launch_bounds__(256) void embed_gather_kernel(const _Float16* __restrict__ table,
                                                            const int64_t* __restrict__ ids, _Float16* __restrict__ out,
                                                            int hidden, int vocab) {
@@ -168,6 +223,25 @@ PC_EXPORT int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t 
     else
         hipLaunchKernelGGL(silu_mul_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, gate_up, (_Float16*)out, inter);
     return pc_check_launch("silu_mul_kernel");
+}
+
+PC_EXPORT int pc_layernorm(const float* x, const void* weight, const void* bias, void* out, int32_t rows, int32_t hidden,
+                           float eps, void* stream) {
+    PC_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0, PC_ERR_ARG, "pc_layernorm: hidden must be a multiple of 8");
+    if (rows == 0) return PC_OK;
+    PC_REQUIRE(x && weight && bias && out, PC_ERR_ARG, "pc_layernorm: null pointer");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
+                       (const _Float16*)bias, (_Float16*)out, hidden, eps);
+    return pc_check_launch("layernorm_kernel");
+}
+
+PC_EXPORT int pc_gelu(const float* x, void* out, int64_t n, void* stream) {
+    PC_REQUIRE(n >= 0 && n % 8 == 0, PC_ERR_ARG, "pc_gelu: element count must be a multiple of 8");
+    if (n == 0) return PC_OK;
+    PC_REQUIRE(x && out, PC_ERR_ARG, "pc_gelu: null pointer");
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out, n8);
+    return pc_check_launch("gelu_kernel");
 }
 
 PC_EXPORT int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,

@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
                 const float2 w = csr[c * 8 + e];
                 // q*cos + rotate_half(q)*sin  (llama2.py:208): low half pairs with -high, high with +low
                 const float a = lo[e] * w.x - hi[e] * w.y, b2 = hi[e] * w.x + lo[e] * w.y;
-                olo[e] = (_Float16)a;
-                ohi[e] = (_Float16)b2;
-                rlo[e] = (_Float16)(a - (float)olo[e]);
-                rhi[e] = (_Float16)(b2 - (float)ohi[e]);
+                _Float16 t0, t1, t2, t3;
+                pc_split(a, t0, t1);
+                pc_split(b2, t2, t3);
+                olo[e] = t0; rlo[e] = t1;
+                ohi[e] = t2; rhi[e] = t3;
             }
             *(h8*)(dst + c * 8) = olo;
             *(h8*)(dst + half + c * 8) = ohi;

@@ -35,6 +35,9 @@ SIGNATURES = {
     "pc_gemm_qkv_rope_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
                                         _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
+    "pc_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "pc_layernorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "pc_gelu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
@@ -136,7 +139,7 @@ def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q
     check(rc, "pc_attn_fwd")
 
 
-EPI_STORE, EPI_ADD, EPI_SILU = 0, 1, 2
+EPI_STORE, EPI_ADD, EPI_SILU, EPI_GELU = 0, 1, 2, 4
 
 
 def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0, of_hi=None, of_lo=None,
@@ -153,6 +156,24 @@ def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_
                                  q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D,
                                  q_len, past_len, cap, _ptr(past_len_dev), current_stream() if stream is None else stream)
     check(rc, "pc_gemm_qkv_rope")
+
+
+def layernorm(x_f32, weight, bias, out, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
+    rc = load().pc_layernorm(x_f32.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, hidden, eps,
+                             current_stream() if stream is None else stream)
+    check(rc, "pc_layernorm")
+
+
+def layernorm_frag(x_f32, weight, bias, xf_hi, xf_lo, rows: int, hidden: int, eps: float, slabs=None, nslabs: int = 0,
+                   stream: Optional[int] = None) -> None:
+    rc = load().pc_layernorm_frag(x_f32.data_ptr(), weight.data_ptr(), bias.data_ptr(), xf_hi.data_ptr(), xf_lo.data_ptr(),
+                                  rows, hidden, eps, _ptr(slabs), nslabs, current_stream() if stream is None else stream)
+    check(rc, "pc_layernorm_frag")
+
+
+def gelu(x_f32, out, n: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_gelu(x_f32.data_ptr(), out.data_ptr(), n, current_stream() if stream is None else stream)
+    check(rc, "pc_gelu")
 
 
 def gemm_skinny_norm(wf, x_f32, norm_weight, eps: float, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,

@@ -5,8 +5,8 @@ Mirrors ``promptcache/model/__init__.py`` of the reference: ``FormatConversation
 ``GenerationEngine`` only ever talk to this surface, so an adapter whose ``hf_model`` is the native
 ``LlamaHIP`` forward makes the whole path run on the HIP kernels.
 
-Falcon / MPT adapters (reference :206-288) are outside the Llama-2-class scope of this build
-(SURVEY.md section 8f-4).
+``Falcon`` (reference :206-258) runs the same kernels through ``falcon_hip.FalconHIP`` (multi-query cache shape
+``(L, 1, D)``).  The MPT adapter (reference :261-288, ALiBi) is outside this build.
 """
 from __future__ import annotations
 
@@ -18,7 +18,7 @@ from typing import Callable, List, Optional, Tuple
 import torch
 
 from ..pml import Preprocessor, PreprocessorList, escape_xml  # noqa: F401  (re-exported like the reference)
-from .config import SHAPES, LlamaShape
+from .config import FALCON_SHAPES, SHAPES, FalconShape, LlamaShape
 from .tokenizer import StandInTokenizer
 
 # HF hub ids the reference's drivers use (demo.py:27, eval.py:36, config/*.json) -> shape presets
@@ -178,3 +178,48 @@ class Llama2(_LlamaFamily):
 
 class CodeLlama(_LlamaFamily):
     _default_name = "codellama/CodeLlama-13b-Instruct-hf"
+
+
+class Falcon(LanguageModel):
+    """Reference ``Falcon`` adapter (:206-258): newline-normalising formatter + chat strings, stop tokens 0..11,
+    stop strings ``<|endoftext|>`` / ``\\nUser``, and the multi-query cache shape ``(L, 1, head_dim)``."""
+
+    _default_name = "tiiuae/falcon-7b-instruct"
+
+    def __init__(self, name: Optional[str] = None, device: str = "cuda:0", shape: Optional[FalconShape] = None,
+                 weights=None, tokenizer=None, random_init: bool = False, seed: int = 0, **_hf_kwargs):
+        from .falcon_hip import FalconHIP
+        from . import weights as W
+
+        name = name or self._default_name
+        if weights is not None:
+            assert shape is not None, "pass shape= together with weights="
+        elif os.path.isdir(name):
+            shape = shape or FalconShape.from_hf_dir(name)
+            weights = W.load_falcon_safetensors(name, shape)
+            if tokenizer is None:
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(name)
+        else:
+            key = {"tiiuae/falcon-7b-instruct": "falcon-7b", "tiiuae/falcon-7b": "falcon-7b"}.get(name, name)
+            if shape is None:
+                if key not in FALCON_SHAPES:
+                    raise ValueError(f"unknown model {name!r}: pass a checkpoint directory or one of {sorted(FALCON_SHAPES)}")
+                shape = FALCON_SHAPES[key]
+            if not random_init:
+                raise FileNotFoundError(
+                    f"no checkpoint directory {name!r} (there is no network here); pass random_init=True to use "
+                    f"seeded N(0, {shape.initializer_range}) weights at the {shape.name} shape")
+            weights = W.random_falcon_weights_device(shape, device, torch.float16, seed)
+        if tokenizer is None:
+            tokenizer = StandInTokenizer(shape.vocab_size)
+        model = FalconHIP(shape, weights, device=device)
+        self.formatter = _falcon_formatter()
+        super().__init__(name, model, tokenizer, list(range(12)), ["<|endoftext|>", "\nUser"])
+
+    def get_formatter(self) -> Callable[[str], str]:
+        return self.formatter
+
+    def get_cache_shape(self) -> Tuple[int, int, int]:
+        c = self.hf_model.config
+        return c.num_hidden_layers, 1, c.head_dim

@@ -1,0 +1,174 @@
+"""Falcon-7b-class forward pass on MI355X (the reference's ``Falcon`` adapter: ``promptcache/model/falcon.py`` with
+``multi_query``, ``parallel_attn``, rotary positions, no linear biases).
+
+What differs from the Llama stack (``llama_hip.py``), per ``FalconDecoderLayer.forward`` (falcon.py:761-816):
+
+* ONE LayerNorm per layer feeds both the attention and the MLP (``parallel_attn``, :797-798), and the layer output is
+  ``x + attn + mlp`` (:810-813);
+* multi-query attention: the fused ``query_key_value`` projection yields H query heads and a single K and V head
+  (:393-396), so the module KV the cache engine stores / gathers is ``[L][2][1][len][D]`` -- 1/H of the Llama volume
+  per token (``Falcon.get_cache_shape``, ``promptcache/model/__init__.py:256-258``);
+* the MLP is ``dense_4h_to_h(gelu(dense_h_to_4h(x)))`` (:730-733).
+
+Arena management, the hipGraph cache and the dispatch by row count are inherited; the kernels are the same ones
+(``pc_kv_gather`` with Hkv = 1, ``pc_gemm_qkv_rope`` with H + 2 heads, ``pc_attn_fwd`` with a group size of H) plus
+``pc_layernorm`` / ``pc_layernorm_frag`` / ``pc_gelu`` and the GELU GEMM epilogue.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .. import _native
+from .config import FalconShape
+from .llama_hip import LlamaHIP
+
+
+class FalconHIP(LlamaHIP):
+    def __init__(self, shape: FalconShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
+                 skinny: bool = True):
+        _native.load()  # fail loudly if the extension is missing
+        self.config = shape
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        self.decode_headroom = decode_headroom
+        c = shape
+        self.H, self.Hkv, self.D, self.L = c.num_attention_heads, 1, c.head_dim, c.num_hidden_layers
+        dev = self.device
+
+        def w(name):
+            t = weights[name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(t)
+            return t.to(device=dev, dtype=self.dtype).contiguous()
+
+        self.embed = w("embed")
+        self.lnf_w, self.lnf_b = w("lnf_w"), w("lnf_b")
+        self.lm_head = self.embed if c.tie_word_embeddings and "lm_head" not in weights else w("lm_head")
+        hid = c.hidden_size
+        self.skinny = bool(skinny) and hid % 32 == 0 and c.vocab_size % 16 == 0 and ((self.H + 2) * self.D) % 16 == 0
+        fr = _native.to_weight_frags if self.skinny else (lambda t: None)
+        self.lm_head_f = fr(self.lm_head)
+        self.layers = []
+        for i in range(self.L):
+            wqkv, wo, w1, w2 = w(f"l{i}.wqkv"), w(f"l{i}.wo"), w(f"l{i}.w1"), w(f"l{i}.w2")
+            if self.skinny:
+                if i == 0:
+                    self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2, self.D).to(dev)
+                wqkv_f = fr(wqkv[self._qkv_perm].contiguous())
+            else:
+                wqkv_f = None
+            self.layers.append(dict(ln_w=w(f"l{i}.ln_w"), ln_b=w(f"l{i}.ln_b"), wqkv=wqkv, wo=wo, w1=w1, w2=w2,
+                                    wqkv_f=wqkv_f, wo_f=fr(wo), w1_f=fr(w1), w2_f=fr(w2)))
+        # falcon.py:99: the same formula as the Llama table, evaluated on the CPU in fp32
+        self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
+        self.inv_freq = self.inv_freq_cpu.to(dev)
+        self.softmax_scale = 1.0 / math.sqrt(self.D)        # inv_norm_factor, falcon.py:316
+        self._ws = None
+        self.kslices = 4
+        self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
+        self.use_graphs = True
+        self._graphs = {}
+        self.max_graphs = 64
+
+    # ------------------------------------------------------------------------------------------
+    def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        n = _native
+        dev = self.device
+        c = self.config
+        H, D, hid = self.H, self.D, c.hidden_size
+        T = B * q_len
+        W = (H + 2) * D
+        eps = c.layer_norm_epsilon
+        f32 = torch.float32
+        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
+        x = h16.float()  # fp32 residual stream
+        attn = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        act = torch.empty((T, 4 * hid), dtype=self.dtype, device=dev)
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            n.layernorm(x, lw["ln_w"], lw["ln_b"], h16, T, hid, eps)                              # falcon.py:779
+            qkv = torch.mm(h16, lw["wqkv"].t(), out_dtype=f32)                                    # [T, (H+2)*D]
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
+                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
+                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws)
+            h4 = torch.mm(h16, lw["w1"].t(), out_dtype=f32)                                       # same LayerNorm output (:798)
+            n.gelu(h4, act, T * 4 * hid)
+            x.add_(torch.mm(attn, lw["wo"].t(), out_dtype=f32))
+            x.add_(torch.mm(act, lw["w2"].t(), out_dtype=f32))
+        if last_token_only:
+            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
+            n.layernorm(xl, self.lnf_w, self.lnf_b, hl, B, hid, eps)
+            return torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
+        n.layernorm(x, self.lnf_w, self.lnf_b, h16, T, hid, eps)
+        return torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)
+
+    def _forward_skinny(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
+        """T <= 512 rows: weight-streaming projections (pc_gemm.hip).  The o_proj and dense_4h_to_h launches both leave
+        K-sliced slabs of partial sums; the next layer's LayerNorm launch folds all of them into the residual stream."""
+        n = _native
+        dev = self.device
+        c = self.config
+        H, D, hid = self.H, self.D, c.hidden_size
+        inter = 4 * hid
+        T = B * q_len
+        eps = c.layer_norm_epsilon
+        mt = (T + 15) // 16
+        f32 = torch.float32
+        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
+        x = h16.float()
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        ws_bytes = n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len)
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=f32, device=dev)
+
+        def planes(k):
+            return (torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev),
+                    torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev))
+
+        xh, xl = planes(hid)
+        ah, al = planes(H * D)
+        ch, cl = planes(inter)
+        KQ = self.kslices
+        slabs = torch.empty((2 * KQ, T, hid), dtype=f32, device=dev)      # [0:KQ] attention branch, [KQ:] MLP branch
+        pending = 0
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            n.layernorm_frag(x, lw["ln_w"], lw["ln_b"], xh, xl, T, hid, eps, slabs, pending)
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                            arena.head_stride, B, H, 1, D, q_len, past_len, arena.cap, past_dev)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                       B, H, 1, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                       q_lo=q16l)
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs[:KQ], ldy=hid, kslices=KQ)
+            n.gemm_skinny(lw["w1_f"], xh, xl, T, inter, hid, n.EPI_GELU, of_hi=ch, of_lo=cl)
+            n.gemm_skinny(lw["w2_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs[KQ:], ldy=hid, kslices=KQ)
+            pending = 2 * KQ
+        V = c.vocab_size
+        if last_token_only:
+            if pending:
+                x.add_(slabs.sum(dim=0))
+            xlast = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            lh, ll = planes(hid)
+            n.layernorm_frag(xlast, self.lnf_w, self.lnf_b, lh, ll, B, hid, eps)
+            logits = torch.empty((B, V), dtype=f32, device=dev)
+            n.gemm_skinny(self.lm_head_f, lh, ll, B, V, hid, n.EPI_STORE, y=logits, ldy=V)
+            return logits.view(B, 1, V)
+        n.layernorm_frag(x, self.lnf_w, self.lnf_b, xh, xl, T, hid, eps, slabs, pending)
+        logits = torch.empty((T, V), dtype=f32, device=dev)
+        n.gemm_skinny(self.lm_head_f, xh, xl, T, V, hid, n.EPI_STORE, y=logits, ldy=V)
+        return logits.view(B, q_len, V)

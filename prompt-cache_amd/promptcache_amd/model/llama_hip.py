@@ -161,12 +161,7 @@ class LlamaHIP:
             if am.dim() == 2 and am.shape[1] == q_len and bool((am[:, 1:] > am[:, :-1]).any()):
                 raise NotImplementedError("left / interior padding masks are not supported by the HIP path")
 
-        H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
-        inter = self.config.intermediate_size
         T = B * q_len
-        W = (H + 2 * Hkv) * D
-        eps = self.config.rms_norm_eps
-
         if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
             # the graph's static int64 / int32 input buffers are filled straight from the caller's tensors
             # (copy_ converts), so no separate dtype-conversion launches sit in front of the replay
@@ -181,6 +176,21 @@ class LlamaHIP:
             arena.length = past_len + q_len
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
+        logits = self._forward_dense(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
+        arena.length = past_len + q_len
+        return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
+
+    # ------------------------------------------------------------------------------------------
+    def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Layer stack for many rows (schema encode, no-cache prefill): hipBLASLt projections with fp32 outputs, HIP
+        kernels for everything between them."""
+        n = _native
+        dev = self.device
+        H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
+        inter = self.config.intermediate_size
+        T = B * q_len
+        W = (H + 2 * Hkv) * D
+        eps = self.config.rms_norm_eps
         cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
         n.rope_table(pos32, self.inv_freq, cs, T, D)
         h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
@@ -211,7 +221,6 @@ class LlamaHIP:
             n.silu_mul(gu, act, T, inter, True)
             x.add_(torch.mm(act, lw["wdown"].t(), out_dtype=f32))
 
-        arena.length = past_len + q_len
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
@@ -220,7 +229,7 @@ class LlamaHIP:
         else:
             n.rmsnorm(x, self.norm, h16, T, hid, eps, True)
             logits = torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)   # llama2.py:1050-1051
-        return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
+        return logits
 
     # ------------------------------------------------------------------------------------------
     def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,

@@ -134,3 +134,48 @@ def random_weights_device(cfg: LlamaShape, device, dtype, seed: int = 0):
         out[name] = w.to(dtype)
         del w
     return out
+
+
+def random_falcon_weights_device(cfg, device, dtype, seed: int = 0):
+    """Seeded weights for a FalconShape generated on ``device`` (true-shape runs: falcon-7b = 14.4 GB fp16)."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    for name, shp in falcon_weight_shapes(cfg).items():
+        if name.endswith("_b"):
+            w = 0.1 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        elif len(shp) == 1:
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        else:
+            w = torch.empty(shp, device=device, dtype=torch.float32).normal_(0.0, cfg.initializer_range, generator=g)
+        out[name] = w.to(dtype)
+        del w
+    if cfg.tie_word_embeddings:
+        out["lm_head"] = out["embed"]
+    return out
+
+
+def load_falcon_safetensors(path: str, cfg):
+    """Read an HF falcon-7b-class checkpoint directory (``*.safetensors``) into the key layout of
+    ``falcon_weight_shapes`` (HF names: ``transformer.h.{i}.self_attention.query_key_value`` etc.)."""
+    from safetensors import safe_open
+
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    raw = {}
+    for fn in files:
+        with safe_open(fn, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                raw[k] = f.get_tensor(k)
+    out = {"embed": raw["transformer.word_embeddings.weight"], "lnf_w": raw["transformer.ln_f.weight"],
+           "lnf_b": raw["transformer.ln_f.bias"]}
+    out["lm_head"] = raw.get("lm_head.weight", out["embed"])
+    names = {"ln_w": "input_layernorm.weight", "ln_b": "input_layernorm.bias", "wqkv": "self_attention.query_key_value.weight",
+             "wo": "self_attention.dense.weight", "w1": "mlp.dense_h_to_4h.weight", "w2": "mlp.dense_4h_to_h.weight"}
+    for i in range(cfg.num_hidden_layers):
+        for k, hf in names.items():
+            out[f"l{i}.{k}"] = raw[f"transformer.h.{i}.{hf}"]
+    return out

@@ -15,19 +15,22 @@ LOGIT_TOL = 1e-2
 
 def build_product(g):
     from promptcache_amd import CacheEngine
-    from promptcache_amd.model import Llama2
-    from promptcache_amd.model.config import SHAPES
-    from promptcache_amd.model.weights import make_weights_np
-    shape = SHAPES[str(g["shape_name"])]
-    w16 = make_weights_np(shape, int(g["seed"]), float(g["scale"]))
-    lm = Llama2(name="golden", shape=shape, weights=w16, device="cuda:0")
+    from promptcache_amd.model import Falcon, Llama2
+    from promptcache_amd.model.weights import make_falcon_weights_np, make_weights_np
+    shape = H.shape_for_case(g)
+    if H.is_falcon(g):
+        lm = Falcon(name="golden", shape=shape, weights=make_falcon_weights_np(shape, int(g["seed"]), float(g["scale"])),
+                    device="cuda:0")
+    else:
+        lm = Llama2(name="golden", shape=shape, weights=make_weights_np(shape, int(g["seed"]), float(g["scale"])),
+                    device="cuda:0")
     eng = CacheEngine(int(g["max_ctx"]), lm)
     mt = int(g["max_tokens"])
     eng.add_schema(lm.get_formatter()(str(g["schema_text"])), max_tokens=None if mt < 0 else mt)
     return lm, eng
 
 
-@pytest.mark.parametrize("case", H.MODEL_CASES)
+@pytest.mark.parametrize("case", H.MODEL_CASES + H.FALCON_CASES)
 def test_cached_prefill_matches_reference_golden(case):
     from promptcache_amd import Prompt
     g = H.load_case(case)
@@ -56,7 +59,7 @@ def test_cached_prefill_matches_reference_golden(case):
     np.testing.assert_allclose(out.past_key_values[0][0][0, :, S:].float().cpu().numpy(), g["new_k0"], atol=1.5e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "tiny_personalike"])
+@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "tiny_personalike", "falcon_tiny_trip", "falcon_mid_doc"])
 def test_generate_greedy_and_nocache_match_reference_golden(case):
     from promptcache_amd import GenerationEngine, GenerationParameters, Prompt
     g = H.load_case(case)

@@ -704,3 +704,66 @@ def test_gemm_qkv_rope_norm_equals_two_launches(B, H, Hkv, D, q_len, past, hid):
         assert float((a != b).float().mean()) < 0.02
     rec_a, rec_b = qa.float() + qal.float(), qb.float() + qbl.float()
     assert float((rec_a - rec_b).abs().max()) < 2e-5 * max(1.0, float(rec_a.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Falcon ops: LayerNorm (dense and fragment planes with slab folding), GELU (dense and GEMM epilogue)
+# ---------------------------------------------------------------------------------------------------
+
+def _ln_ref(x, w, b, eps):
+    xd = x.double()
+    mu = xd.mean(dim=1, keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=1, keepdim=True)
+    return (xd - mu) * torch.rsqrt(var + eps) * w.double() + b.double()
+
+
+@pytest.mark.parametrize("rows,hidden", [(12, 4544), (1, 128), (70, 448), (33, 5120)])
+@pytest.mark.parametrize("nslabs", [0, 8])
+def test_layernorm_dense_and_frag(rows, hidden, nslabs):
+    n = _n()
+    rng = np.random.default_rng(41)
+    x = torch.from_numpy((2.0 * rng.standard_normal((rows, hidden), dtype=np.float32) + 0.7)).to(DEV)
+    w = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(hidden, dtype=np.float32)).astype(np.float16)).to(DEV)
+    b = torch.from_numpy((0.3 * rng.standard_normal(hidden, dtype=np.float32)).astype(np.float16)).to(DEV)
+    eps = 1e-5
+    slabs = torch.from_numpy(rng.standard_normal((max(nslabs, 1), rows, hidden), dtype=np.float32)).to(DEV)
+    xsum = x + (slabs[:nslabs].sum(dim=0) if nslabs else 0)
+    ref = _ln_ref(xsum, w.float(), b.float(), eps).float()
+    mt = (rows + 15) // 16
+    hi = torch.zeros((mt, hidden // 32, 64, 8), dtype=torch.float16, device=DEV)
+    lo = torch.zeros_like(hi)
+    xw = x.clone()
+    n.layernorm_frag(xw, w, b, hi, lo, rows, hidden, eps, slabs if nslabs else None, nslabs)
+    got = n.from_act_frags(hi, rows).float() + n.from_act_frags(lo, rows).float()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, float(ref.abs().max()))
+    if nslabs:
+        assert (xw - xsum).abs().max().item() < 1e-5 * max(1.0, float(xsum.abs().max()))    # folded in place
+    out = torch.empty((rows, hidden), dtype=torch.float16, device=DEV)
+    n.layernorm(xsum.contiguous(), w, b, out, rows, hidden, eps)
+    assert (out.float() - ref).abs().max().item() < 2e-3 * max(1.0, float(ref.abs().max()))     # one fp16 rounding
+
+
+def test_gelu_dense():
+    n = _n()
+    x = torch.linspace(-8, 8, 4096 * 8, device=DEV).view(8, -1).contiguous()
+    out = torch.empty_like(x, dtype=torch.float16)
+    n.gelu(x, out, x.numel())
+    ref = torch.nn.functional.gelu(x.double()).float()
+    assert (out.float() - ref).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(12, 18176, 4544), (3, 64, 32), (40, 1792, 448), (100, 18176, 4544), (259, 512, 128)])
+def test_gemm_gelu_epilogue(M, N, K):
+    n = _n()
+    rng = np.random.default_rng(42)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    mt = (M + 15) // 16
+    oh = torch.zeros((mt, N // 32, 64, 8), dtype=torch.float16, device=DEV)
+    ol = torch.zeros_like(oh)
+    n.gemm_skinny(n.to_weight_frags(w), hi, lo, M, N, K, n.EPI_GELU, of_hi=oh, of_lo=ol)
+    xin = x if M <= 64 else x.half().float()            # the row-split kernel reads the hi plane only
+    ref = torch.nn.functional.gelu(xin.double() @ w.double().t()).float()
+    got = n.from_act_frags(oh, M).float() + n.from_act_frags(ol, M).float()
+    assert (got - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5

@@ -114,3 +114,46 @@ def test_mid_q_range_uses_two_row_tiles():
     m.skinny = False
     b = m(input_ids=ids, use_cache=False)
     assert (a.logits - b.logits).abs().max().item() < TOL
+
+
+def test_falcon_7b_shape_multi_query_cached_equals_nocache_and_oracle():
+    """falcon-7b layer shape (hidden 4544, 71 query heads sharing ONE K/V head, head_dim 64), 2 layers, small vocab:
+    cached == no-cache over a union-free schema, the staged multi-query KV is the module stores verbatim, and the
+    cached logits match the numpy oracle on identical weights."""
+    from oracle import engine_oracle as eo
+    from oracle.falcon_oracle import FalconOracle, FalconOracleConfig
+    from promptcache_amd import synth
+    from promptcache_amd.model import Falcon
+    from promptcache_amd.model.config import FalconShape
+    from promptcache_amd.model.weights import make_falcon_weights_np
+    shape = FalconShape(vocab_size=4096, hidden_size=4544, num_hidden_layers=2, num_attention_heads=71, name="falcon-7b-2l")
+    w16 = make_falcon_weights_np(shape, 9, 1.0)
+    lm = Falcon(name="falcon-7b-2l", shape=shape, weights=w16, device="cuda:0")
+    assert lm.get_cache_shape() == (2, 1, 64)
+    sp, pp = synth.flat_docs("fdocs", 20, (150, 90, 200), 10, seed=3)
+    S, q, err, kv_err = _cached_vs_nocache(lm, sp, pp, max_ctx=1024)
+    print(f"[falcon-7b shape] S={S} q={q} max|dlogit| cached vs no-cache = {err:.2e}, staged-vs-recomputed K = {kv_err:.2e}")
+    assert err < TOL and kv_err < 5e-3
+    # oracle on the same inputs
+    from promptcache_amd import CacheEngine, Prompt
+    fmt = lm.get_formatter()
+    eng = CacheEngine(1024, lm)
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+    ids, pos, _, cache = eng.process(prompt)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    cfg = FalconOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
+                             shape.layer_norm_epsilon, shape.rope_theta, lm.hf_model.inv_freq_cpu.numpy())
+    model = FalconOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
+    sc = eng.get_schema("fdocs")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S2, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 1024)
+    oerr = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    print(f"[falcon-7b shape] max|dlogit| vs numpy oracle = {oerr:.2e}")
+    assert S2 == S and oerr < TOL

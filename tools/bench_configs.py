@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "prompt-cache_amd"))
 from promptcache_amd import CacheEngine, Prompt, synth  # noqa: E402
-from promptcache_amd.model import Llama2  # noqa: E402
+from promptcache_amd.model import Falcon, Llama2  # noqa: E402
 
 
 def ttft(lm, eng, prompt, no_cache, reps=5):
@@ -43,6 +43,10 @@ def run(cfg):
         rng = np.random.default_rng(0)
         cases = [(f"squad-like entry {i}", synth.flat_docs(f"squad{i}", 20, (int(rng.integers(100, 400)),), int(rng.integers(10, 30)), seed=i + 1), 1024)
                  for i in range(4)]
+    elif cfg == 5:       # not a BASELINE config: the Falcon adapter (multi-query KV: 8 KiB per token instead of 512 KiB)
+        lm = Falcon("falcon-7b", random_init=True)
+        cases = [("falcon-7b, persona-structured schema", synth.persona_like(), 4096),
+                 ("falcon-7b, game-like schema", synth.flat_docs("game", 30, (306, 76, 800, 800, 800, 800, 800), 12), 5000)]
     else:
         lm = Llama2("llama2-13b", random_init=True)
         cases = [("longbench-like 8k context", synth.flat_docs("longbench", 10, (8000,), 255), 9186)]

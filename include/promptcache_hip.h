@@ -197,7 +197,8 @@ int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_
  *   pc_layernorm       torch.nn.LayerNorm (falcon.py:757, :1020) of fp32 x [rows][hidden] -> fp16
  *   pc_layernorm_frag  the same, written as split-precision fragment planes, with the slab-folding prologue of
  *                      pc_rmsnorm_frag (x += slabs[0] + ... first: the o_proj and dense_4h_to_h partial sums)
- *   pc_gelu            nn.GELU() (falcon.py:726, erf form) fp32 -> fp16, n elements (n % 8 == 0)
+ *                      (bias may be NULL in both: MPT's LayerNorm carries no bias, mpt.py:207, :215)
+ *   pc_gelu            nn.GELU() (falcon.py:726, mpt.py:187: erf form) fp32 -> fp16, n elements (n % 8 == 0)
  *   pc_gemm_skinny epilogue 4: of[m][j] = gelu(y[m][j]) as fragment planes [M/16][N/32][64][8] (dense_h_to_4h)
  * ------------------------------------------------------------------------------------------- */
 int pc_layernorm(const float* x, const void* weight, const void* bias, void* out, int32_t rows, int32_t hidden,
@@ -205,6 +206,19 @@ int pc_layernorm(const float* x, const void* weight, const void* bias, void* out
 int pc_layernorm_frag(float* x, const void* weight, const void* bias, void* xf_hi, void* xf_lo, int32_t rows,
                       int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream);
 int pc_gelu(const float* x, void* out, int64_t n, void* stream);
+
+/* pc_attn_fwd_alibi -- pc_attn_fwd plus the additive ALiBi term of the reference's MPT attention
+ *   (promptcache/model/mpt.py:90-110 slopes, :160-175 bias gathered at the POSITION IDS of the keys):
+ *     score[q][key] = q.k * softmax_scale + slope[h] * position_id[key]      (the reference's extra -slope*(max_pos)
+ *   is constant along a softmax row and drops out).  key_pos: fp32 [B][key_pos_batch_stride] position id of every
+ *   cached and new key, padded with anything finite up to a multiple of 64 entries past past_len + q_len, rows
+ *   16-byte aligned;  slopes_log2: fp32 [H] = slope[h] * log2(e). */
+int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+                      const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out, int64_t out_batch_stride,
+                      int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                      int32_t past_len, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                      const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo, const float* key_pos,
+                      int64_t key_pos_batch_stride, const float* slopes_log2, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

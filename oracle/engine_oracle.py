@@ -44,5 +44,19 @@ def cached_prefill(model: LlamaOracle, lib, used: Sequence, input_ids: List[int]
     return staged, S, out
 
 
-def generate_greedy(model: LlamaOracle, logits, present, position_ids: List[int], steps: int) -> List[int]:
-    return greedy_decode(model, logits, present, max(position_ids) + 1, steps)
+def generate_greedy(model: LlamaOracle, logits, present, position_ids: List[int], steps: int,
+                    use_full_position_ids: bool = False) -> List[int]:
+    """``use_full_position_ids`` (MPT, generation_engine.py:127-129): every step passes the prompt's full position list
+    plus ``range(offset, offset + loop_index)`` -- the first decoded token sits at ``offset``, not ``offset + 1``."""
+    if not use_full_position_ids:
+        return greedy_decode(model, logits, present, max(position_ids) + 1, steps)
+    offset = max(position_ids) + 1
+    out: List[int] = []
+    for i in range(steps):
+        tok = int(np.argmax(logits[0, -1]))
+        out.append(tok)
+        if i == steps - 1:
+            break
+        pos = list(position_ids) + list(range(offset, offset + i + 1))
+        logits, present = model.forward(np.array([[tok]]), np.array([pos]), past=present)
+    return out

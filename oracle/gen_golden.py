@@ -161,6 +161,38 @@ def build_ref_falcon_lm(pc, shape_name: str, seed: int, scale: float):
     return RefFalconLM(), shape
 
 
+def build_ref_mpt_lm(pc, shape_name: str, seed: int, scale: float):
+    """The reference ``Mpt`` adapter surface (promptcache/model/__init__.py:261-288: chat strings,
+    ``use_full_position_ids = True``, cache shape (L, H, D)) around the reference ``MptForCausalLM``."""
+    import importlib
+    from promptcache_amd.model.config import MPT_SHAPES
+    from promptcache_amd.model.tokenizer import StandInTokenizer
+    from promptcache_amd.model.weights import make_mpt_weights_np
+
+    shape = MPT_SHAPES[shape_name]
+    w16 = make_mpt_weights_np(shape, seed, scale)
+    model = ref_shim.make_reference_mpt(shape.to_dict(), {k: v.astype(np.float32) for k, v in w16.items()})
+    rm = importlib.import_module("promptcache.model")
+
+    class RefMptLM(rm.LanguageModel):
+        def __init__(self):
+            tok = StandInTokenizer(shape.vocab_size)
+            super().__init__("ref-mpt", model, tok, [50278, 0], [])
+            self.formatter = rm.FormatConversation(system=("<|im_start|>system\n", "<|im_end|>\n", ""),
+                                                   user=("<|im_start|>user\n", "<|im_end|>\n<|im_start|>assistant\n"),
+                                                   assistant=("", "<|im_end|>\n"))
+            self.use_full_position_ids = True
+
+        def get_formatter(self):
+            return self.formatter
+
+        def get_cache_shape(self):
+            c = self.hf_model.config
+            return c.n_layers, c.n_heads, c.d_model // c.n_heads
+
+    return RefMptLM(), shape
+
+
 class TokOnlyLM:
     """Tokenizer-only stand-in for layout goldens (no model needed to lay out a schema)."""
 
@@ -295,7 +327,8 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
     rce = importlib.import_module("promptcache.cache_engine")
     rge = importlib.import_module("promptcache.generation_engine")
     rp = importlib.import_module("promptcache.prompt")
-    lm, shape = (build_ref_falcon_lm if family == "falcon" else build_ref_lm)(pc, shape_name, seed, scale)
+    lm, shape = {"falcon": build_ref_falcon_lm, "mpt": build_ref_mpt_lm, "llama": build_ref_lm}[family](pc, shape_name, seed, scale)
+    full = bool(getattr(lm, "use_full_position_ids", False))     # MPT: position ids of every key (cache_engine.py:517-519)
     fmt = lm.get_formatter()
     eng = rce.CacheEngine(max_ctx, lm, target_device="cpu")
     eng.add_schema(fmt(schema_text), max_tokens=max_tokens)
@@ -303,7 +336,7 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
     rng = np.random.default_rng(1234)
 
     # ---- cached path ----
-    ids, pos, _, cache = eng.process(prompt, no_cache=False)
+    ids, pos, _, cache = eng.process(prompt, no_cache=False, return_full_position_ids=full)
     S = cache[0][0].shape[1]
     staged_rows = np.sort(rng.choice(S, size=min(S, 48), replace=False))
     staged_k = np.stack([c[0][:, staged_rows].numpy() for c in cache])      # [L,H,rows,D] fp16
@@ -315,6 +348,9 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
     if family == "falcon":
         layer0 = lm.hf_model.transformer.h[0].self_attention
         o_proj, rotary = layer0.dense, layer0.maybe_rotary
+    elif family == "mpt":
+        layer0 = lm.hf_model.transformer.blocks[0].attn
+        o_proj, rotary = layer0.out_proj, None
     else:
         layer0 = lm.hf_model.model.layers[0].self_attn
         o_proj, rotary = layer0.o_proj, layer0.rotary_emb
@@ -332,8 +368,8 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         # fresh engine state for the generate run (process() increments usage counters, layout unchanged)
-        ids2, pos2, _, cache2 = eng.process(prompt, no_cache=False)
-        outs = list(gen.generate(ids2, pos2, params, cache2, stream_interval=1))
+        ids2, pos2, _, cache2 = eng.process(prompt, no_cache=False, return_full_position_ids=full)
+        outs = list(gen.generate(ids2, pos2, params, cache2, stream_interval=1, use_full_position_ids=full))
     # recover greedy token ids from the decoded stream is lossy; recompute them with the reference model
     with torch.inference_mode():
         pk = [(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache2]
@@ -347,7 +383,9 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
             toks.append(t)
             if i == n_greedy - 1:
                 break
-            o = lm(input_ids=torch.tensor([[t]]), position_ids=torch.tensor([[offset + i + 1]]), past_key_values=pkv,
+            # generation_engine.py:127-132: full mode appends range(offset, offset + loop_index), else offset + loop_index
+            step_pos = (pos2 + list(range(offset, offset + i + 1))) if full else [offset + i + 1]
+            o = lm(input_ids=torch.tensor([[t]]), position_ids=torch.tensor([step_pos]), past_key_values=pkv,
                    use_cache=True)
             pkv, lg = o.past_key_values, o.logits
     assert lm.decode(toks) == outs[-1].new_text, (lm.decode(toks), outs[-1].new_text)
@@ -366,7 +404,7 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
         return t if t.dim() == 3 else t.unsqueeze(0)
     mod_k_first = np.stack([heads_first(m.host_cache[0][0])[:, 0].numpy() for m in mods])     # layer 0, first token  [M,H,D]
     mod_v_last = np.stack([heads_first(m.host_cache[-1][1])[:, -1].numpy() for m in mods])    # last layer, last token
-    inv_freq = rotary.inv_freq.numpy()
+    inv_freq = rotary.inv_freq.numpy() if rotary is not None else np.zeros(1, np.float32)
 
     np.savez_compressed(
         os.path.join(GOLD, f"model_{case}.npz"),
@@ -378,7 +416,7 @@ def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema
         new_k0=new_k0.astype(np.float32), greedy=np.array(toks),
         nocache_ids=np.array(nids), nocache_pos=np.array(npos), logits_nocache_last=logits_nc_last.astype(np.float32),
         mod_table=np.array(mod_table), mod_k_first=mod_k_first.astype(np.float32), mod_v_last=mod_v_last.astype(np.float32),
-        inv_freq=inv_freq.astype(np.float32))
+        inv_freq=inv_freq.astype(np.float32), full_position_ids=int(full))
     print(f"[golden] model_{case}: S={S} q={len(ids)} greedy={toks} max|logit|={np.abs(logits_cached).max():.3f}")
 
 
@@ -405,6 +443,7 @@ def main():
                                 question_len=6, seed=5)
     model_golden(pc, "tiny_personalike", "tiny", seed=3, scale=4.0, schema_text=sp, prompt_text=pp, max_ctx=400)
     falcon_goldens(pc)
+    mpt_goldens(pc)
 
 
 def falcon_goldens(pc):
@@ -415,7 +454,18 @@ def falcon_goldens(pc):
                  max_ctx=200, family="falcon")
 
 
+def mpt_goldens(pc):
+    """MPT adapter fixtures (reference MptForCausalLM: ALiBi bias gathered at the keys' position ids)."""
+    model_golden(pc, "mpt_tiny_trip", "mpt-tiny", seed=7, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT,
+                 max_ctx=256, family="mpt")
+    model_golden(pc, "mpt_mid_doc", "mpt-mid", seed=8, scale=3.0, schema_text=SYN_FLAT, prompt_text=SYN_FLAT_PROMPT,
+                 max_ctx=200, family="mpt")
+
+
 if __name__ == "__main__":
+    if "--mpt-only" in sys.argv:
+        mpt_goldens(ref_shim.import_reference())
+        sys.exit(0)
     if "--falcon-only" in sys.argv:      # add the Falcon fixtures without regenerating the others
         falcon_goldens(ref_shim.import_reference())
         sys.exit(0)

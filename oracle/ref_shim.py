@@ -198,3 +198,33 @@ def make_reference_falcon(cfg_dict: dict, weights_fp32: dict):
     assert not missing and not unexpected, (missing, unexpected)
     model.eval()
     return model
+
+
+def make_reference_mpt(cfg_dict: dict, weights_fp32: dict):
+    """Instantiate the reference ``MptForCausalLM`` (promptcache/model/mpt.py:594) and load the given weights.
+    Harness-side shim for transformers 5.x: dict-typed ``_tied_weights_keys``."""
+    import torch
+    import transformers
+
+    import_reference()
+    mpt = importlib.import_module("promptcache.model.mpt")
+    cfg = transformers.MptConfig(d_model=cfg_dict["hidden_size"], n_heads=cfg_dict["num_attention_heads"],
+                                 n_layers=cfg_dict["num_hidden_layers"], vocab_size=cfg_dict["vocab_size"],
+                                 max_seq_len=8192, layer_norm_epsilon=cfg_dict["layer_norm_epsilon"], no_bias=True,
+                                 tie_word_embeddings=False)
+    cfg.attn_config.alibi_bias_max = cfg_dict["alibi_bias_max"]
+    cfg.use_cache = True
+    mpt.MptForCausalLM._tied_weights_keys = {}
+    model = mpt.MptForCausalLM(cfg)
+    sd = {"transformer.wte.weight": weights_fp32["embed"], "transformer.norm_f.weight": weights_fp32["lnf"],
+          "lm_head.weight": weights_fp32["lm_head"]}
+    names = {"ln1": "norm_1.weight", "wqkv": "attn.Wqkv.weight", "wo": "attn.out_proj.weight", "ln2": "norm_2.weight",
+             "w1": "ffn.up_proj.weight", "w2": "ffn.down_proj.weight"}
+    for i in range(cfg_dict["num_hidden_layers"]):
+        for s_, hf in names.items():
+            sd[f"transformer.blocks.{i}.{hf}"] = weights_fp32[f"l{i}.{s_}"]
+    sd = {k: torch.from_numpy(v.astype("float32")) for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    model.eval()
+    return model

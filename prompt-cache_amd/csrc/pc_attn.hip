@@ -53,6 +53,9 @@ struct AttnParams {
     _Float16* of_hi; _Float16* of_lo;   // optional: fragment-major split-precision output planes (pc_gemm.hip)
     float* part_o; float* part_ml;
     const int32_t* past_len_dev;
+    // ALiBi (MPT, promptcache/model/mpt.py:90-110, :160-175): score += slope[h] * key_pos[b][key]; both pre-scaled to
+    // the log2 domain by the host (slope * log2 e), key_pos = the POSITION ID of each cached / new key
+    const float* key_pos; int64_t kp_bs; const float* slopes;
     int32_t H, Hkv, q_len, past_len, nsplit;
     int32_t xcd_remap, nqblk, nbatch;
     float scale_log2;
@@ -85,7 +88,7 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
 // enter the MFMAs as split-precision pairs (hi = fp16(x), lo = fp16(x - hi)), i.e. two MFMAs per fragment.
 // Against the reference's fp32 CPU path this removes the two largest rounding terms of the kernel (fp16 Q:
 // 2.5e-3, fp16 P: 1.7e-3 max |delta logit| on a 7b-shaped layer); K/V stay fp16 as staged.
-template <int D, bool HP>
+template <int D, bool HP, bool ALIBI = false>
 __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = D / 32;   // MFMA k-steps across the head dim (QK^T)
     constexpr int DB = D / 16;   // 16-wide head-dim blocks of O^T
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
 
     const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
     const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+    [[maybe_unused]] const float slope = ALIBI ? p.slopes[h] : 0.f;
+    [[maybe_unused]] const float* kpos = ALIBI ? p.key_pos + b * p.kp_bs : nullptr;
 
     // Register-staged, software-pipelined tiles: the global loads of tile i+1 are issued right after tile i
     // has been written to LDS and stay in flight while tile i is consumed (HBM latency hides under the MFMAs).
@@ -203,10 +208,17 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], acc, 0, 0, 0);
                     if (HP) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qfl[ks], acc, 0, 0, 0);
                 }
+                f4 kb4 = {0.f, 0.f, 0.f, 0.f};
+                if (ALIBI) {        // positions of this lane's 4 keys (rows past kend are masked below; the buffer
+                                    // is padded to a multiple of the tile, see pc_attn_fwd_alibi)
+                    kb4 = *(const f4*)(kpos + key0 + kb * 16 + g * 4);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = key0 + kb * 16 + g * 4 + r;
-                    const float s = (key < row_vis_end && key < kend) ? acc[r] * p.scale_log2 : -INFINITY;
+                    float sc = acc[r] * p.scale_log2;
+                    if (ALIBI) sc += slope * kb4[r];
+                    const float s = (key < row_vis_end && key < kend) ? sc : -INFINITY;
                     sv[kb][r] = s;
                     mx = fmaxf(mx, s);
                 }
@@ -350,7 +362,10 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     p.xcd_remap = (p.nsplit == 1 && p.nqblk >= 4 && !no_remap) ? 1 : 0;
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
     if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
-    if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
+    if (p.key_pos) {
+        if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(kThreads), 0, stream, p);
+    } else if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     int rc = pc_check_launch("attn_fwd_kernel");
     if (rc != PC_OK) return rc;
@@ -371,12 +386,13 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
 
-PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
-                          const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
-                          int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
-                          int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
-                          int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
-                          void* stream) {
+namespace {
+int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+                  const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
+                  int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
+                  int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
+                  int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
+                  const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -394,6 +410,7 @@ PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_strid
     p.out = (_Float16*)out; p.o_bs = out_batch_stride; p.o_ts = out_token_stride;
     p.of_hi = (_Float16*)out_frag_hi; p.of_lo = (_Float16*)out_frag_lo;
     p.past_len_dev = past_len_dev;
+    p.key_pos = key_pos; p.kp_bs = key_pos_batch_stride; p.slopes = slopes;
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
@@ -411,4 +428,31 @@ PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_strid
         case 64: return launch_attn<64>(p, B, (hipStream_t)stream);
         default: return launch_attn<128>(p, B, (hipStream_t)stream);
     }
+}
+}  // namespace
+
+PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+                          const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
+                          int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
+                          int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
+                          int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
+                          void* stream) {
+    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
+                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
+                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, nullptr, 0, nullptr, stream);
+}
+
+PC_EXPORT int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
+                                const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
+                                int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
+                                int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
+                                int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi,
+                                void* out_frag_lo, const float* key_pos, int64_t key_pos_batch_stride,
+                                const float* slopes_log2, void* stream) {
+    PC_REQUIRE(key_pos && slopes_log2 && key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0, PC_ERR_ARG,
+               "pc_attn_fwd_alibi: key_pos / slopes missing or key_pos rows not 16-byte aligned");
+    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
+                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
+                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
+                         slopes_log2, stream);
 }

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
         if (i < nv) {
             const h8 gw = *(const h8*)(w + i * 8);
             h8 bw = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (LN) bw = *(const h8*)(b + i * 8);
+            if (LN && b) bw = *(const h8*)(b + i * 8);
             h8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -889,8 +889,8 @@ PC_EXPORT int pc_layernorm_frag(float* x, const void* weight, const void* bias, 
                                 int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream) {
     PC_REQUIRE(rows > 0 && rows <= kRowsMaxM && hidden > 0 && hidden % 32 == 0 && hidden <= 16384, PC_ERR_ARG,
                "pc_layernorm_frag: bad sizes");
-    PC_REQUIRE(x && weight && bias && xf_hi && xf_lo && nslabs >= 0 && (nslabs == 0 || slabs), PC_ERR_ARG,
-               "pc_layernorm_frag: null pointer");
+    PC_REQUIRE(x && weight && xf_hi && xf_lo && nslabs >= 0 && (nslabs == 0 || slabs), PC_ERR_ARG,
+               "pc_layernorm_frag: null pointer");   /* bias may be NULL */
     const int groups = pc_ceil_div(hidden / 8, 256);
 #define PC_LN(GV)                                                                                                    \
     hipLaunchKernelGGL((rmsnorm_frag_kernel<GV, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream, x,            \

@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rs = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)hidden + eps);
     for (int i = tid; i < nv; i += 256) {
         const f4 a = *(const f4*)(xr + i * 8), c = *(const f4*)(xr + i * 8 + 4);
-        const h8 g = *(const h8*)(w + i * 8), bb = *(const h8*)(b + i * 8);
+        const h8 g = *(const h8*)(w + i * 8);
+        h8 bb = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (b) bb = *(const h8*)(b + i * 8);       // MPT's LayerNorm has no bias (mpt.py:207, :215)
         h8 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -229,7 +231,7 @@ PC_EXPORT int pc_layernorm(const float* x, const void* weight, const void* bias,
                            float eps, void* stream) {
     PC_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0, PC_ERR_ARG, "pc_layernorm: hidden must be a multiple of 8");
     if (rows == 0) return PC_OK;
-    PC_REQUIRE(x && weight && bias && out, PC_ERR_ARG, "pc_layernorm: null pointer");
+    PC_REQUIRE(x && weight && out, PC_ERR_ARG, "pc_layernorm: null pointer");   /* bias may be NULL */
     hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
                        (const _Float16*)bias, (_Float16*)out, hidden, eps);
     return pc_check_launch("layernorm_kernel");

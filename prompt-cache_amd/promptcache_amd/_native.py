@@ -27,6 +27,8 @@ SIGNATURES = {
     "pc_attn_workspace_bytes": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
     "pc_attn_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pc_attn_fwd_alibi": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+                                    _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -129,10 +131,20 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
-             workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None) -> None:
-    """``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``."""
+             workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
+             alibi=None) -> None:
+    """``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
+    ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi)."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
+    if alibi is not None:
+        kpos, slopes = alibi
+        rc = load().pc_attn_fwd_alibi(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
+                                      _ptr(out), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, _ptr(workspace), ws_bytes,
+                                      _ptr(past_len_dev), _ptr(fh), _ptr(fl), kpos.data_ptr(), kpos.stride(0),
+                                      slopes.data_ptr(), current_stream() if stream is None else stream)
+        check(rc, "pc_attn_fwd_alibi")
+        return
     rc = load().pc_attn_fwd(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, _ptr(out),
                             o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, _ptr(workspace), ws_bytes,
                             _ptr(past_len_dev), _ptr(fh), _ptr(fl), current_stream() if stream is None else stream)
@@ -159,14 +171,14 @@ def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_
 
 
 def layernorm(x_f32, weight, bias, out, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
-    rc = load().pc_layernorm(x_f32.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, hidden, eps,
+    rc = load().pc_layernorm(x_f32.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), rows, hidden, eps,
                              current_stream() if stream is None else stream)
     check(rc, "pc_layernorm")
 
 
 def layernorm_frag(x_f32, weight, bias, xf_hi, xf_lo, rows: int, hidden: int, eps: float, slabs=None, nslabs: int = 0,
                    stream: Optional[int] = None) -> None:
-    rc = load().pc_layernorm_frag(x_f32.data_ptr(), weight.data_ptr(), bias.data_ptr(), xf_hi.data_ptr(), xf_lo.data_ptr(),
+    rc = load().pc_layernorm_frag(x_f32.data_ptr(), weight.data_ptr(), _ptr(bias), xf_hi.data_ptr(), xf_lo.data_ptr(),
                                   rows, hidden, eps, _ptr(slabs), nslabs, current_stream() if stream is None else stream)
     check(rc, "pc_layernorm_frag")
 

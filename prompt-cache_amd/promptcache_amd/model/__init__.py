@@ -130,6 +130,13 @@ def _falcon_formatter() -> PreprocessorList:
     return PreprocessorList([rep, conv])
 
 
+def _mpt_formatter() -> FormatConversation:
+    """Reference :269-272."""
+    return FormatConversation(system=("<|im_start|>system\n", "<|im_end|>\n", ""),
+                              user=("<|im_start|>user\n", "<|im_end|>\n<|im_start|>assistant\n"),
+                              assistant=("", "<|im_end|>\n"))
+
+
 class _LlamaFamily(LanguageModel):
     """Shared constructor: a local HF checkpoint directory when one exists, else (explicitly requested)
     seeded random weights at the named shape with the deterministic stand-in tokenizer -- the build and

@@ -90,6 +90,77 @@ def make_falcon_weights_np(cfg, seed: int = 0, scale: float = 1.0) -> Dict[str, 
     return out
 
 
+def mpt_weight_shapes(cfg) -> Dict[str, tuple]:
+    """Key names for the MPT adapter: ``embed``, ``l{i}.ln1|wqkv|wo|ln2|w1|w2``, ``lnf``, ``lm_head``; ``wqkv`` is
+    ``Wqkv`` [3*hid, hid] = all query heads, then all key heads, then all value heads (``mpt.py:144``)."""
+    hid = cfg.hidden_size
+    shapes = {"embed": (cfg.vocab_size, hid)}
+    for i in range(cfg.num_hidden_layers):
+        shapes[f"l{i}.ln1"] = (hid,)
+        shapes[f"l{i}.wqkv"] = (3 * hid, hid)
+        shapes[f"l{i}.wo"] = (hid, hid)
+        shapes[f"l{i}.ln2"] = (hid,)
+        shapes[f"l{i}.w1"] = (4 * hid, hid)
+        shapes[f"l{i}.w2"] = (hid, 4 * hid)
+    shapes["lnf"] = (hid,)
+    shapes["lm_head"] = (cfg.vocab_size, hid)
+    return shapes
+
+
+def make_mpt_weights_np(cfg, seed: int = 0, scale: float = 1.0) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in mpt_weight_shapes(cfg).items():
+        if len(shp) == 1:
+            w = 1.0 + 0.1 * rng.standard_normal(shp, dtype=np.float32)
+        else:
+            w = (cfg.initializer_range * scale) * rng.standard_normal(shp, dtype=np.float32)
+        out[name] = w.astype(np.float16)
+    if cfg.tie_word_embeddings:
+        out["lm_head"] = out["embed"]
+    return out
+
+
+def random_mpt_weights_device(cfg, device, dtype, seed: int = 0):
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    for name, shp in mpt_weight_shapes(cfg).items():
+        if len(shp) == 1:
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        else:
+            w = torch.empty(shp, device=device, dtype=torch.float32).normal_(0.0, cfg.initializer_range, generator=g)
+        out[name] = w.to(dtype)
+        del w
+    if cfg.tie_word_embeddings:
+        out["lm_head"] = out["embed"]
+    return out
+
+
+def load_mpt_safetensors(path: str, cfg):
+    """HF mpt-7b-class checkpoint directory -> the key layout of ``mpt_weight_shapes``."""
+    from safetensors import safe_open
+
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    raw = {}
+    for fn in files:
+        with safe_open(fn, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                raw[k] = f.get_tensor(k)
+    out = {"embed": raw["transformer.wte.weight"], "lnf": raw["transformer.norm_f.weight"]}
+    out["lm_head"] = raw.get("lm_head.weight", out["embed"])
+    names = {"ln1": "norm_1.weight", "wqkv": "attn.Wqkv.weight", "wo": "attn.out_proj.weight", "ln2": "norm_2.weight",
+             "w1": "ffn.up_proj.weight", "w2": "ffn.down_proj.weight"}
+    for i in range(cfg.num_hidden_layers):
+        for k, hf in names.items():
+            out[f"l{i}.{k}"] = raw[f"transformer.blocks.{i}.{hf}"]
+    return out
+
+
 _HF_MAP = {
     "ln1": "input_layernorm.weight", "wq": "self_attn.q_proj.weight", "wk": "self_attn.k_proj.weight",
     "wv": "self_attn.v_proj.weight", "wo": "self_attn.o_proj.weight",

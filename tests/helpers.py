@@ -7,6 +7,19 @@ import numpy as np
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["tiny_trip", "tiny_trip2", "mid_trip", "mid_mha_doc", "tiny_personalike"]
 FALCON_CASES = ["falcon_tiny_trip", "falcon_mid_doc"]     # reference Falcon adapter: multi-query cache (L, 1, D)
+MPT_CASES = ["mpt_tiny_trip", "mpt_mid_doc"]              # reference Mpt adapter: ALiBi at the keys' position ids
+
+
+def is_mpt(g) -> bool:
+    return str(g["shape_name"]).startswith("mpt")
+
+
+def full_positions(g, used, pos):
+    """Position ids handed to the model: MPT wants one per KEY (staged segments in staging order, then the new tokens,
+    cache_engine.py:517-519); everyone else the new tokens only."""
+    if not is_mpt(g):
+        return list(pos)
+    return [p for u in used for p in u.position_ids()] + list(pos)
 
 
 def is_falcon(g) -> bool:
@@ -14,8 +27,9 @@ def is_falcon(g) -> bool:
 
 
 def shape_for_case(g):
-    from promptcache_amd.model.config import FALCON_SHAPES, SHAPES
-    return (FALCON_SHAPES if is_falcon(g) else SHAPES)[str(g["shape_name"])]
+    from promptcache_amd.model.config import FALCON_SHAPES, MPT_SHAPES, SHAPES
+    name = str(g["shape_name"])
+    return (FALCON_SHAPES if name.startswith("falcon") else MPT_SHAPES if name.startswith("mpt") else SHAPES)[name]
 
 
 def load_case(name):
@@ -42,8 +56,8 @@ def llama_formatter():
 
 
 def formatter_for_case(g):
-    from promptcache_amd.model import _falcon_formatter
-    return _falcon_formatter() if is_falcon(g) else llama_formatter()
+    from promptcache_amd.model import _falcon_formatter, _mpt_formatter
+    return _falcon_formatter() if is_falcon(g) else _mpt_formatter() if is_mpt(g) else llama_formatter()
 
 
 def assemble(schema, prompt, lm):
@@ -87,7 +101,14 @@ def layout_for_case(g):
 
 def oracle_for_case(g, shape):
     from oracle.llama_oracle import LlamaOracle, OracleConfig
-    from promptcache_amd.model.weights import make_falcon_weights_np, make_weights_np
+    from promptcache_amd.model.weights import make_falcon_weights_np, make_mpt_weights_np, make_weights_np
+    if is_mpt(g):
+        from oracle.mpt_oracle import MptOracle, MptOracleConfig
+        w16 = make_mpt_weights_np(shape, int(g["seed"]), float(g["scale"]))
+        cfg = MptOracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size,
+                              num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                              layer_norm_epsilon=shape.layer_norm_epsilon, alibi_bias_max=shape.alibi_bias_max)
+        return MptOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()}), w16
     if is_falcon(g):
         from oracle.falcon_oracle import FalconOracle, FalconOracleConfig
         w16 = make_falcon_weights_np(shape, int(g["seed"]), float(g["scale"]))

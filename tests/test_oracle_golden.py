@@ -7,12 +7,13 @@ from oracle import engine_oracle as eo
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("case", H.MODEL_CASES + H.FALCON_CASES)
+@pytest.mark.parametrize("case", H.MODEL_CASES + H.FALCON_CASES + H.MPT_CASES)
 def test_oracle_reproduces_reference_outputs(case):
     g = H.load_case(case)
     shape, schema, jobs, prompt, used, ids, pos = H.layout_for_case(g)
     # integer layout first (bit-exact)
     assert ids == g["input_ids"].tolist()
+    pos = H.full_positions(g, used, pos)
     assert pos == g["position_ids"].tolist()
     assert [[u.offset, len(u)] for u in used] == g["seg_table"].tolist()
     model, _ = H.oracle_for_case(g, shape)
@@ -37,11 +38,11 @@ def test_oracle_reproduces_reference_outputs(case):
     np.testing.assert_allclose(present[0][0][0, :, S:], g["new_k0"], atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(logits[0], g["logits_cached"], atol=2e-3, rtol=1e-3)
     assert np.abs(logits[0] - g["logits_cached"]).max() < 2e-3
-    toks = eo.generate_greedy(model, logits, present, pos, len(g["greedy"]))
+    toks = eo.generate_greedy(model, logits, present, pos, len(g["greedy"]), use_full_position_ids=H.is_mpt(g))
     assert toks == g["greedy"].tolist()
 
 
-@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "falcon_mid_doc"])
+@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "falcon_mid_doc", "mpt_mid_doc"])
 def test_oracle_nocache_path(case):
     from promptcache_amd.pml import Prompt
     g = H.load_case(case)

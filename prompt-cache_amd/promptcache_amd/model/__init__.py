@@ -6,7 +6,8 @@ Mirrors ``promptcache/model/__init__.py`` of the reference: ``FormatConversation
 ``LlamaHIP`` forward makes the whole path run on the HIP kernels.
 
 ``Falcon`` (reference :206-258) runs the same kernels through ``falcon_hip.FalconHIP`` (multi-query cache shape
-``(L, 1, D)``).  The MPT adapter (reference :261-288, ALiBi) is outside this build.
+``(L, 1, D)``) and ``Mpt`` (reference :261-288) through ``mpt_hip.MptHIP`` (ALiBi at the keys' position ids,
+``use_full_position_ids``).
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ from typing import Callable, List, Optional, Tuple
 import torch
 
 from ..pml import Preprocessor, PreprocessorList, escape_xml  # noqa: F401  (re-exported like the reference)
-from .config import FALCON_SHAPES, SHAPES, FalconShape, LlamaShape
+from .config import FALCON_SHAPES, MPT_SHAPES, SHAPES, FalconShape, LlamaShape, MptShape
 from .tokenizer import StandInTokenizer
 
 # HF hub ids the reference's drivers use (demo.py:27, eval.py:36, config/*.json) -> shape presets
@@ -230,3 +231,50 @@ class Falcon(LanguageModel):
     def get_cache_shape(self) -> Tuple[int, int, int]:
         c = self.hf_model.config
         return c.num_hidden_layers, 1, c.head_dim
+
+
+class Mpt(LanguageModel):
+    """Reference ``Mpt`` adapter (:261-288): ChatML-style chat strings, stop tokens [50278, 0], and
+    ``use_full_position_ids = True`` -- drivers pass ``return_full_position_ids`` / ``use_full_position_ids`` to the
+    engines (demo.py:81-84) so the model sees the position id of every cached key (ALiBi, mpt.py:172)."""
+
+    _default_name = "mosaicml/mpt-7b-chat"
+    use_full_position_ids = True
+
+    def __init__(self, name: Optional[str] = None, device: str = "cuda:0", shape: Optional[MptShape] = None,
+                 weights=None, tokenizer=None, random_init: bool = False, seed: int = 0, **_hf_kwargs):
+        from .mpt_hip import MptHIP
+        from . import weights as W
+
+        name = name or self._default_name
+        if weights is not None:
+            assert shape is not None, "pass shape= together with weights="
+        elif os.path.isdir(name):
+            shape = shape or MptShape.from_hf_dir(name)
+            weights = W.load_mpt_safetensors(name, shape)
+            if tokenizer is None:
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(name)
+        else:
+            key = {"mosaicml/mpt-7b-chat": "mpt-7b", "mosaicml/mpt-7b": "mpt-7b", "mosaicml/mpt-7b-instruct": "mpt-7b"}.get(name, name)
+            if shape is None:
+                if key not in MPT_SHAPES:
+                    raise ValueError(f"unknown model {name!r}: pass a checkpoint directory or one of {sorted(MPT_SHAPES)}")
+                shape = MPT_SHAPES[key]
+            if not random_init:
+                raise FileNotFoundError(
+                    f"no checkpoint directory {name!r} (there is no network here); pass random_init=True to use "
+                    f"seeded N(0, {shape.initializer_range}) weights at the {shape.name} shape")
+            weights = W.random_mpt_weights_device(shape, device, torch.float16, seed)
+        if tokenizer is None:
+            tokenizer = StandInTokenizer(shape.vocab_size)
+        model = MptHIP(shape, weights, device=device)
+        self.formatter = _mpt_formatter()
+        super().__init__(name, model, tokenizer, [50278, 0], [])
+
+    def get_formatter(self) -> Callable[[str], str]:
+        return self.formatter
+
+    def get_cache_shape(self) -> Tuple[int, int, int]:
+        c = self.hf_model.config
+        return c.num_hidden_layers, c.num_attention_heads, c.head_dim

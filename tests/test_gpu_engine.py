@@ -15,10 +15,13 @@ LOGIT_TOL = 1e-2
 
 def build_product(g):
     from promptcache_amd import CacheEngine
-    from promptcache_amd.model import Falcon, Llama2
-    from promptcache_amd.model.weights import make_falcon_weights_np, make_weights_np
+    from promptcache_amd.model import Falcon, Llama2, Mpt
+    from promptcache_amd.model.weights import make_falcon_weights_np, make_mpt_weights_np, make_weights_np
     shape = H.shape_for_case(g)
-    if H.is_falcon(g):
+    if H.is_mpt(g):
+        lm = Mpt(name="golden", shape=shape, weights=make_mpt_weights_np(shape, int(g["seed"]), float(g["scale"])),
+                 device="cuda:0")
+    elif H.is_falcon(g):
         lm = Falcon(name="golden", shape=shape, weights=make_falcon_weights_np(shape, int(g["seed"]), float(g["scale"])),
                     device="cuda:0")
     else:
@@ -30,14 +33,14 @@ def build_product(g):
     return lm, eng
 
 
-@pytest.mark.parametrize("case", H.MODEL_CASES + H.FALCON_CASES)
+@pytest.mark.parametrize("case", H.MODEL_CASES + H.FALCON_CASES + H.MPT_CASES)
 def test_cached_prefill_matches_reference_golden(case):
     from promptcache_amd import Prompt
     g = H.load_case(case)
     lm, eng = build_product(g)
     assert np.array_equal(lm.hf_model.inv_freq_cpu.numpy(), g["inv_freq"])   # same RoPE constants as the reference
     prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
-    ids, pos, cache_ms, cache = eng.process(prompt)
+    ids, pos, cache_ms, cache = eng.process(prompt, return_full_position_ids=lm.use_full_position_ids)
     assert ids == g["input_ids"].tolist() and pos == g["position_ids"].tolist()
     assert [[m.token_sequence.offset, len(m)] for m in eng.prompt_cache.staged] == g["seg_table"].tolist()
     S = int(g["S"])
@@ -59,15 +62,17 @@ def test_cached_prefill_matches_reference_golden(case):
     np.testing.assert_allclose(out.past_key_values[0][0][0, :, S:].float().cpu().numpy(), g["new_k0"], atol=1.5e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "tiny_personalike", "falcon_tiny_trip", "falcon_mid_doc"])
+@pytest.mark.parametrize("case", ["tiny_trip", "mid_mha_doc", "tiny_personalike", "falcon_tiny_trip", "falcon_mid_doc",
+                                  "mpt_tiny_trip", "mpt_mid_doc"])
 def test_generate_greedy_and_nocache_match_reference_golden(case):
     from promptcache_amd import GenerationEngine, GenerationParameters, Prompt
     g = H.load_case(case)
     lm, eng = build_product(g)
     prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
-    ids, pos, _, cache = eng.process(prompt)
+    full = lm.use_full_position_ids
+    ids, pos, _, cache = eng.process(prompt, return_full_position_ids=full)
     params = GenerationParameters(temperature=0.0, max_new_tokens=len(g["greedy"]), stop_token_ids=[], stop_str=[])
-    outs = list(GenerationEngine(lm).generate(ids, pos, params, cache, stream_interval=1))
+    outs = list(GenerationEngine(lm).generate(ids, pos, params, cache, stream_interval=1, use_full_position_ids=full))
     assert outs[-1].new_text == lm.decode(g["greedy"].tolist())
     assert outs[-1].elapsed_time > 0 and outs[-1].response_time >= outs[-1].elapsed_time
     nids, npos, _, none = eng.process(prompt, no_cache=True)

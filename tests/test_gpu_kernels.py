@@ -767,3 +767,43 @@ def test_gemm_gelu_epilogue(M, N, K):
     ref = torch.nn.functional.gelu(xin.double() @ w.double().t()).float()
     got = n.from_act_frags(oh, M).float() + n.from_act_frags(ol, M).float()
     assert (got - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# ALiBi attention (MPT): score += slope[h] * position_id[key]
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("B,H,D,q_len,past", [(1, 4, 32, 12, 100), (1, 8, 64, 1, 77), (2, 4, 64, 30, 5), (1, 32, 128, 12, 1725),
+                                              (1, 8, 64, 200, 300), (1, 4, 128, 70, 0)])
+def test_attn_alibi_matches_reference_math(B, H, D, q_len, past):
+    n = _n()
+    rng = np.random.default_rng(51)
+    kv = past + q_len
+    cap = kv + 3
+    q = torch.from_numpy(rng.standard_normal((B, q_len, H, D), dtype=np.float32)).to(DEV)
+    k = torch.from_numpy(rng.standard_normal((B, H, cap, D), dtype=np.float32)).to(DEV).half()
+    v = torch.from_numpy(rng.standard_normal((B, H, cap, D), dtype=np.float32)).to(DEV).half()
+    pos = torch.from_numpy(np.sort(rng.choice(4000, size=(B, kv), replace=True), axis=1).astype(np.int64)).to(DEV)
+    n2 = 2 ** int(np.ceil(np.log2(H)))
+    slopes = 1.0 / torch.pow(2, torch.arange(1, n2 + 1, dtype=torch.float32) * (8.0 / n2))
+    slopes = slopes[:H].to(DEV)
+    cols = (cap + 63) // 64 * 64 + 64
+    kpos = torch.zeros((B, cols), dtype=torch.float32, device=DEV)
+    kpos[:, :kv] = pos.float()
+    q16 = q.half().contiguous()
+    out = torch.empty((B, q_len, H * D), dtype=torch.float16, device=DEV)
+    ws_bytes = n.attn_workspace_bytes(B, H, D, q_len, kv)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=DEV)
+    n.attn_fwd(q16, q_len * H * D, H * D, k, v, H * cap * D, cap * D, out, q_len * H * D, H * D, B, H, H, D, q_len, past,
+               1.0 / np.sqrt(D), ws, alibi=(kpos, slopes * 1.4426950408889634))
+    # reference math (mpt.py:157-184) in fp64 on the fp16-rounded operands
+    qd, kd, vd = q16.double().permute(0, 2, 1, 3), k[:, :, :kv].double(), v[:, :, :kv].double()
+    s = qd @ kd.transpose(2, 3) / np.sqrt(D)
+    s = s + slopes.double()[None, :, None, None] * (pos.double()[:, None, None, :] - pos.max().double())
+    idx = torch.arange(q_len, device=DEV)
+    mask = torch.ones((q_len, kv), dtype=torch.bool, device=DEV)
+    mask[:, past:] = idx[None, :] <= idx[:, None]
+    s = s.masked_fill(~mask[None, None], float("-inf"))
+    ref = (torch.softmax(s, dim=-1) @ vd).permute(0, 2, 1, 3).reshape(B, q_len, H * D)
+    err = (out.double() - ref).abs().max().item()
+    assert err < (3e-3 if q_len > 64 else 2e-3), err

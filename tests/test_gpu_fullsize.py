@@ -157,3 +157,45 @@ def test_falcon_7b_shape_multi_query_cached_equals_nocache_and_oracle():
     oerr = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
     print(f"[falcon-7b shape] max|dlogit| vs numpy oracle = {oerr:.2e}")
     assert S2 == S and oerr < TOL
+
+
+def test_mpt_7b_shape_alibi_cached_equals_nocache_and_oracle():
+    """mpt-7b layer shape (hidden 4096, 32 heads, ALiBi), 2 layers, small vocab, full position ids: cached == no-cache
+    over a union-free schema and the cached logits match the numpy oracle on identical weights."""
+    from oracle import engine_oracle as eo
+    from oracle.mpt_oracle import MptOracle, MptOracleConfig
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Mpt
+    from promptcache_amd.model.config import MptShape
+    from promptcache_amd.model.weights import make_mpt_weights_np
+    shape = MptShape(vocab_size=4096, hidden_size=4096, num_hidden_layers=2, num_attention_heads=32, name="mpt-7b-2l")
+    w16 = make_mpt_weights_np(shape, 11, 1.0)
+    lm = Mpt(name="mpt-7b-2l", shape=shape, weights=w16, device="cuda:0")
+    assert lm.use_full_position_ids and lm.get_cache_shape() == (2, 32, 128)
+    sp, pp = synth.flat_docs("mdocs", 20, (150, 90, 200), 10, seed=4)
+    fmt = lm.get_formatter()
+    eng = CacheEngine(1024, lm)
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+    ids, pos, _, cache = eng.process(prompt, return_full_position_ids=True)
+    S = cache[0][0].shape[1]
+    assert len(pos) == S + len(ids)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    nids, npos, _, _ = eng.process(prompt, no_cache=True)
+    out_n = lm(input_ids=torch.tensor([list(nids)], device="cuda"), position_ids=torch.tensor([npos], device="cuda"), use_cache=True)
+    err = (out.logits[0] - out_n.logits[0, -len(ids):]).abs().max().item()
+    cfg = MptOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
+                          shape.layer_norm_epsilon, shape.alibi_bias_max)
+    model = MptOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
+    sc = eng.get_schema("mdocs")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S2, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 1024)
+    oerr = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    print(f"[mpt-7b shape] S={S} q={len(ids)} cached vs no-cache {err:.2e}, vs numpy oracle {oerr:.2e}")
+    assert S2 == S and err < TOL and oerr < TOL

@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "prompt-cache_amd"))
 from promptcache_amd import CacheEngine, Prompt, synth  # noqa: E402
-from promptcache_amd.model import Falcon, Llama2  # noqa: E402
+from promptcache_amd.model import Falcon, Llama2, Mpt  # noqa: E402
 
 
 def ttft(lm, eng, prompt, no_cache, reps=5):
@@ -24,7 +24,7 @@ def ttft(lm, eng, prompt, no_cache, reps=5):
     for _ in range(reps):
         eng.prompt_cache.reset()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        ids, pos, _, cache = eng.process(prompt, no_cache=no_cache)
+        ids, pos, _, cache = eng.process(prompt, no_cache=no_cache, return_full_position_ids=lm.use_full_position_ids)
         lm(input_ids=torch.tensor([list(ids)], device=lm.device), position_ids=torch.tensor([pos], device=lm.device),
            past_key_values=cache, use_cache=True)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
@@ -43,6 +43,9 @@ def run(cfg):
         rng = np.random.default_rng(0)
         cases = [(f"squad-like entry {i}", synth.flat_docs(f"squad{i}", 20, (int(rng.integers(100, 400)),), int(rng.integers(10, 30)), seed=i + 1), 1024)
                  for i in range(4)]
+    elif cfg == 6:       # not a BASELINE config: the MPT adapter (ALiBi, full position ids)
+        lm = Mpt("mpt-7b", random_init=True)
+        cases = [("mpt-7b, persona-structured schema", synth.persona_like(), 4096)]
     elif cfg == 5:       # not a BASELINE config: the Falcon adapter (multi-query KV: 8 KiB per token instead of 512 KiB)
         lm = Falcon("falcon-7b", random_init=True)
         cases = [("falcon-7b, persona-structured schema", synth.persona_like(), 4096),

@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=4096)        # config/llm_config_llama2_7b.json of the reference
     ap.add_argument("--cpu-layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-library", action="store_true", help="skip the schema-library encode leg (BASELINE config 5)")
     ap.add_argument("--no-context", action="store_true", help="skip the extra (untimed) no-cache / decode / GEMM-roofline runs")
     args = ap.parse_args()
 
@@ -219,6 +220,32 @@ def main():
               "first_call_seconds": t_first,
               "note": "second add_schema call (steady state); scaffold passes auto-packed into right-padded batches, "
                       "sharded over the ranks, module KV all-gathered"}
+
+    # ---- module-library encode (BASELINE config 5: a whole schema library, ~150 passes / ~100 k tokens) ----
+    # five persona-structured schemas of different sizes + three flat document schemas; every schema's passes are
+    # sharded over the ranks and its module KV all-gathered, exactly like the single schema above
+    library = None
+    if not args.no_library:
+        lib_schemas = [synth.persona_like(name=f"lib-persona-{i}", system_len=200 + 40 * i, seed=20 + i)[0] for i in range(5)]
+        lib_schemas += [synth.flat_docs(f"lib-docs-{i}", 30, lens, 8, seed=30 + i)[0]
+                        for i, lens in enumerate([(306, 76, 800, 800, 800), (1500, 1200), (400,) * 6])]
+        barrier()
+        t0 = time.perf_counter()
+        for text in lib_schemas:
+            eng.add_schema(fmt(text))
+        barrier()
+        t_lib = time.perf_counter() - t0
+        names = [n for n in eng.schemas if n.startswith("lib-")]
+        lib_tokens = sum(sum(len(j["token_ids"]) for j in eng.schemas[n]._plan()) for n in names)
+        lib_passes = sum(int(eng.schemas[n].encode_stats["total_passes"]) for n in names)
+        lib_cached = sum(int(eng.schemas[n].encode_stats["cached_tokens"]) for n in names)
+        library = {"schemas": len(names), "passes": lib_passes, "tokens": int(lib_tokens), "cached_tokens": lib_cached,
+                   "module_kv_bytes": int(lib_cached) * lm.hf_model.config.kv_bytes_per_token, "seconds": t_lib,
+                   "tokens_per_s": lib_tokens / t_lib, "sharded_over": world,
+                   "note": "BASELINE config 5 stand-in: synthetic schema library, add_schema per schema, passes sharded "
+                           "over the ranks + one all-gather of module KV per schema"}
+        for n in names:
+            eng.remove_schema(n)
 
     prompt = Prompt(prompt_pml, [fmt])
     pc = eng.prompt_cache
@@ -284,6 +311,7 @@ def main():
                      "min_launch_us": gather_us[0], "launches_timed": len(gather_us),
                      "how": "HIP events recorded on the launch stream immediately around the launch, every timed step"},
         "encode": encode,
+        "encode_library": library,
     }
     if rank == 0 and not args.no_context:
         result["roofline_gemm"] = gemm_roofline(lm, q)

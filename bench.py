@@ -131,7 +131,10 @@ def gemm_roofline(lm, T: int):
         for lw in m.layers:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=oh, of_lo=ol)
+            if T <= m.NORM_FUSED_MAX_ROWS and m.fuse_norm:      # what the timed step launches for this many rows
+                n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], c.rms_norm_eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=oh, of_lo=ol)
+            else:
+                n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=oh, of_lo=ol)
             e1.record()
             if rep_ > 0:
                 evs.append((e0, e1))
@@ -146,6 +149,41 @@ def gemm_roofline(lm, T: int):
             "launches_timed": len(us), "launches_per_step": c.num_hidden_layers,
             "how": "HIP events around eager launches on each layer's weights after the timed region (event pairs "
                    "include ~2 us of launch gap); the in-graph duration is in profiles/"}
+
+
+def attn_roofline(lm, staged, q_len: int):
+    """Event-time the cached-prefill attention (pc_attn_fwd + its split-KV merge) eagerly on every layer's staged K/V:
+    HBM-bound on the K/V stream, bytes = 2*Hkv*(S+q)*D*2 per layer."""
+    import torch
+    from promptcache_amd import _native as n
+    from promptcache_amd.model.kv_arena import arena_from_past
+    m = lm.hf_model
+    H, Hkv, D = m.H, m.Hkv, m.D
+    arena, S = arena_from_past(staged, m.L, Hkv, D)
+    q16 = torch.randn((q_len, H * D), device=m.device).half()
+    out = torch.empty_like(q16)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, S + q_len), 4) // 4, dtype=torch.float32, device=m.device)
+    evs = []
+    for rep_ in range(3):
+        for li in range(m.L):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n.attn_fwd(q16, q_len * H * D, H * D, arena.k_plane(li), arena.v_plane(li), arena.batch_stride, arena.head_stride,
+                       out, q_len * H * D, H * D, 1, H, Hkv, D, q_len, S, m.softmax_scale, ws, q_lo=q16)
+            e1.record()
+            if rep_ > 0:
+                evs.append((e0, e1))
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    avg = sum(us) / len(us)
+    nbytes = 2 * Hkv * (S + q_len) * D * 2 + 2 * H * q_len * D * 2
+    return {"kernel": "attn_fwd_kernel<128,HP> + attn_combine_kernel (pc_attn_fwd, cached prefill)", "bound": "hbm",
+            "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": avg, "min_launch_us": us[0],
+            "launches_timed": len(us), "launches_per_step": m.L,
+            "how": "HIP events around eager pc_attn_fwd calls (two kernels: split-KV attention + merge) on each layer's "
+                   "staged K/V after the timed region; latency-bound at this size (28.5 MB per launch), see DESIGN.md 3.2"}
 
 
 def main():
@@ -328,6 +366,7 @@ def main():
         result["no_cache"] = {"tokens": len(nids), "ttft_ms": min(ts[1:]) * 1e3,
                               "speedup_from_prompt_cache": min(ts[1:]) * 1e3 / ttft_ms}
         ids2, pos2, _, cache2 = eng.process(prompt)
+        result["roofline_attn"] = attn_roofline(lm, cache2, len(ids2))
         o2 = lm(input_ids=torch.tensor([ids2], device=device), position_ids=torch.tensor([pos2], device=device),
                 past_key_values=cache2, use_cache=True)
         past, tok, nstep = o2.past_key_values, int(torch.argmax(o2.logits[0, -1])), 32

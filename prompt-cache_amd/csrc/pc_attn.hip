@@ -308,6 +308,224 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large q (q_len > 64: schema encode, no-cache prefill, long questions): the MFMA-bound regime.
+// The 16-row-per-wave kernel above re-reads every K / V^T fragment from LDS once per 16 query rows: 32 KiB of LDS reads
+// per 32 MFMAs of 16 cycles, i.e. the LDS (128 B/clk/CU) is asked for twice what the MFMAs can consume.  This variant
+// gives a wave 32 query rows and uses mfma_f32_32x32x16_f16: the same operand bytes per MFMA feed twice the flops.
+//   workgroup = 4 waves = 128 query rows of one head; KV tile = 64 keys (same LDS tiles, swizzles and loaders);
+//   S^T[key][q] (32 x 32 blocks, A = K rows, B = Q^T), O^T[d][q] += V^T[d][key] . P^T[key][q] (A = V^T via
+//   ds_read_b64_tr_b16, B = P^T straight from the S^T accumulators).
+// 32x32 C/D map: lane l owns query column l & 31; register r holds row 8*(r/4) + 4*(l>>5) + (r%4).  A/B operand:
+// lane l holds row/column l & 31, k = 8*(l>>5) + j (j < 8).  As in the 16x16 kernel the key slots of the P^T operand
+// are DEFINED by where the S^T accumulators already sit: for the 16-key step (blk, hh) slot (l>>5, j) is key
+// 32 blk + 16 hh + (j < 4 ? 4 (l>>5) + j : 8 + 4 (l>>5) + j - 4) = accumulator registers 8 hh .. 8 hh + 7, and V^T is
+// read with the same permutation.
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int kQB32 = 128;
+
+template <int D, bool ALIBI = false>
+__global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p) {
+    constexpr int KS = D / 16;   // 16-wide k-steps across the head dim (QK^T)
+    constexpr int DB = D / 32;   // 32-wide head-dim blocks of O^T
+    constexpr int CPR = D / 8;
+    constexpr int LPT = kTK * CPR / kThreads;
+    // (two tile buffers with one barrier per tile measured 3 % slower than this single-buffered form)
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[kTK * D];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[kTK * D];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 31, kg = lane >> 5;
+    int qblk, h, b, split;
+    if (p.xcd_remap) {
+        const int nqb = p.nqblk, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int per_xcd = (p.H * p.nbatch + 7) >> 3;
+        const int pair = (slot / nqb) * 8 + xcd;
+        if (slot / nqb >= per_xcd || pair >= p.H * p.nbatch) return;
+        qblk = nqb - 1 - (slot % nqb);
+        b = pair / p.H; h = pair - b * p.H; split = 0;
+    } else {
+        qblk = blockIdx.x; h = blockIdx.y;
+        b = blockIdx.z / p.nsplit; split = blockIdx.z - b * p.nsplit;
+    }
+    const int hkv = h / (p.H / p.Hkv);
+    const int q_len = p.q_len;
+    const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int kv_len = past_len + q_len;
+    int kps = (kv_len + p.nsplit - 1) / p.nsplit;
+    kps = (kps + kTK - 1) / kTK * kTK;
+    const int ks0 = split * kps;
+    const int wg_rows_end = (qblk * kQB32 + kQB32 < q_len) ? qblk * kQB32 + kQB32 : q_len;
+    int kend = ks0 + kps;
+    kend = kend < kv_len ? kend : kv_len;
+    kend = kend < past_len + wg_rows_end ? kend : past_len + wg_rows_end;
+
+    const int qrow0 = qblk * kQB32 + wave * 32;
+    const int qi = qrow0 + n;
+    const bool wave_active = qrow0 < q_len;
+    const int wave_rows_end = (qrow0 + 32 < q_len) ? qrow0 + 32 : q_len;
+    const int wave_vis_end = past_len + wave_rows_end;
+    const int row_vis_end = (qi < q_len) ? past_len + qi + 1 : 0;
+
+    h8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[ks] = z;
+        if (wave_active && qi < q_len)
+            qf[ks] = *(const h8*)(p.q + b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 16 + kg * 8);
+    }
+    f16v o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = kNegBig, l_run = 0.f;
+    [[maybe_unused]] const float slope = ALIBI ? p.slopes[h] : 0.f;
+    [[maybe_unused]] const float* kpos = ALIBI ? p.key_pos + b * p.kp_bs : nullptr;
+
+    const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+    const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+    u32x4 kr[LPT], vr[LPT];
+    auto issue_loads = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int c = tid + i * kThreads;
+            const int row = c / CPR, col = c - row * CPR;
+            const int key = key0 + row;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            kr[i] = z; vr[i] = z;
+            if (key < kend) {
+                kr[i] = *(const u32x4*)(kbase + (int64_t)key * D + col * 8);
+                vr[i] = *(const u32x4*)(vbase + (int64_t)key * D + col * 8);
+            }
+        }
+    };
+    if (ks0 < kend) issue_loads(ks0);
+
+    for (int key0 = ks0; key0 < kend; key0 += kTK) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int c = tid + i * kThreads;
+            const int row = c / CPR, col = c - row * CPR;
+            *(u32x4*)(Kl + row * D + ((col ^ (row & (CPR - 1))) << 3)) = kr[i];
+            *(u32x4*)(Vl + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
+        }
+        __syncthreads();
+        if (key0 + kTK < kend) issue_loads(key0 + kTK);
+
+        if (wave_active && key0 < wave_vis_end) {
+            // ---- S^T = K . Q^T : two 32-key blocks ----
+            // tiles every row of this wave sees in full (all but the diagonal and the last tile) skip the mask tests
+            const bool full_tile = (key0 + kTK <= kend) && (key0 + kTK <= past_len + qrow0 + 1);
+            f16v sacc[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[blk][r] = 0.f;
+                const int row = blk * 32 + n;                    // A operand: key row of this lane
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int chunk = ks * 2 + kg;               // 16-byte chunk: d = 16 ks + 8 kg .. + 8
+                    const h8 a = *(const h8*)(Kl + row * D + ((chunk ^ (row & (CPR - 1))) << 3));
+                    sacc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], sacc[blk], 0, 0, 0);
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f4 kb4 = {0.f, 0.f, 0.f, 0.f};
+                    if (ALIBI) kb4 = *(const f4*)(kpos + key0 + blk * 32 + rg * 8 + kg * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = key0 + blk * 32 + rg * 8 + kg * 4 + j;
+                        float sc = sacc[blk][rg * 4 + j] * p.scale_log2;
+                        if (ALIBI) sc += slope * kb4[j];
+                        if (!full_tile) sc = (key < row_vis_end && key < kend) ? sc : -INFINITY;
+                        sacc[blk][rg * 4 + j] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = fast_exp2(m_run - m_new);
+            float rs = 0.f;
+            h8 pb[4];                                            // P^T operands of the four 16-key steps
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = fast_exp2(sacc[blk][r] - m_new);
+                    rs += e;
+                    pb[blk * 2 + (r >> 3)][r & 7] = (_Float16)e;
+                }
+            rs += __shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            if (__any(m_new > m_run)) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            }
+            m_run = m_new;
+            // ---- O^T += V^T . P^T : four 16-key steps x DB head-dim blocks ----
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k0 = t * 16 + kg * 4;                  // keys k0 .. k0+3 (slots j < 4) and k0+8 .. (j >= 4)
+                const int vrow = k0 + ((n & 15) >> 2);           // source row of this lane inside its 16-lane group
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int dcol = db * 32 + (n & 16) + (n & 3) * 4;
+                    const _Float16* vp = Vl + vrow * D + ((dcol + 16 * (vrow & 7)) & (D - 1));
+                    const h4 lo = lds_tr_read(vp);               // keys k0 .. k0+3 at d = db*32 + (n & 31)
+                    const h4 hi = lds_tr_read(vp + 8 * D);       // keys k0+8 .. : (vrow + 8) & 7 == vrow & 7, same rotation
+                    const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[t], o[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!(wave_active && qi < q_len)) return;
+    // lane holds O^T[d][qi] for d = db*32 + 8*rg + 4*kg + j
+    if (p.nsplit == 1) {
+        const float inv = 1.0f / l_run;
+        const int row = b * q_len + qi, KSo = p.H * D / 32;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = db * 32 + rg * 8 + kg * 4;
+                if (p.of_hi) {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 vh, vl;
+                        pc_split(o[db][rg * 4 + j] * inv, vh, vl);
+                        hi[j] = vh; lo[j] = vl;
+                    }
+                    const int64_t off = frag_off(row, h * D + d, KSo);
+                    *(h4*)(p.of_hi + off) = hi;
+                    *(h4*)(p.of_lo + off) = lo;
+                } else {
+                    h4 r = {(_Float16)(o[db][rg * 4] * inv), (_Float16)(o[db][rg * 4 + 1] * inv),
+                            (_Float16)(o[db][rg * 4 + 2] * inv), (_Float16)(o[db][rg * 4 + 3] * inv)};
+                    *(h4*)(p.out + b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + d) = r;
+                }
+            }
+    } else {
+        const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                f4 v = {o[db][rg * 4], o[db][rg * 4 + 1], o[db][rg * 4 + 2], o[db][rg * 4 + 3]};
+                *(f4*)(p.part_o + slot * D + db * 32 + rg * 8 + kg * 4) = v;
+            }
+        if (kg == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_run; }
+    }
+}
+
 // Merge split-KV partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i.
 // One workgroup per (query row, head), one thread per head dim.  (A variant with one workgroup per head and
 // float4 items measured 8.0 us vs 6.3 us per launch inside the captured forward: more parallel, shorter chains win.)
@@ -352,9 +570,19 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
     }
 }
 
+// The 32-rows-per-wave kernel (attn_fwd32_kernel) halves the LDS traffic per flop but also the number of workgroups:
+// it wins once 128-row q-blocks alone fill the chip (q = S = 1737: 81 -> 69 us, 4404: 322 -> 274 us) or when a long
+// staged past supplies the parallelism through KV splits (q = 260 over S = 8000: 144 -> 131 us); with fewer blocks the
+// causal triangle leaves too few, too unequal workgroups (q = S = 456: 16 -> 25 us).
+bool use_rows32(int B, int H, int q_len, int kv_len) {
+    static const bool off = [] { const char* e = getenv("PC_ATTN_NO32"); return e && e[0] == '1'; }();
+    if (off || q_len <= kQB) return false;
+    return B * H * pc_ceil_div(q_len, kQB32) >= 256 || kv_len >= 8 * q_len;
+}
+
 int choose_nsplit(int B, int H, int q_len, int kv_len) {
     static const int forced = [] { const char* e = getenv("PC_ATTN_NSPLIT"); return e ? atoi(e) : 0; }();
-    const int nqblk = pc_ceil_div(q_len, kQB);
+    const int nqblk = pc_ceil_div(q_len, use_rows32(B, H, q_len, kv_len) ? kQB32 : kQB);
     const int base = B * H * nqblk;
     // ~1.25 workgroups per CU: fewer, longer KV streams per workgroup beat many short ones (measured on the
     // persona shape: 10 splits x 32 heads = 18.7 us vs 13 splits 20.3 us vs 4 splits 23.8 us per layer)
@@ -370,12 +598,16 @@ template <int D>
 int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     AttnParams p = p0;
     static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
-    p.nqblk = pc_ceil_div(p.q_len, kQB);
+    const bool rows32 = use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
+    p.nqblk = pc_ceil_div(p.q_len, rows32 ? kQB32 : kQB);
     p.nbatch = B;
-    p.xcd_remap = (p.nsplit == 1 && p.nqblk >= 4 && !no_remap) ? 1 : 0;
+    p.xcd_remap = (p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
     if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
-    if (p.key_pos) {
+    if (rows32) {
+        if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
+    } else if (p.key_pos) {
         if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);

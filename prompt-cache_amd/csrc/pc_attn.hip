@@ -408,7 +408,11 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
             const int c = tid + i * kThreads;
             const int row = c / CPR, col = c - row * CPR;
             *(u32x4*)(Kl + row * D + ((col ^ (row & (CPR - 1))) << 3)) = kr[i];
-            *(u32x4*)(Vl + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
+            // V rows rotated by 64 B per row (mod 4 rows): ds_read_b64_tr_b16 serves lanes 0-31 in one LDS cycle and
+            // they touch 4 consecutive rows x 64 contiguous bytes here, which must fall into 4 disjoint 64-B windows
+            // of the 256-B bank row (the 32-B rotation of the 16-row kernel left them overlapping pairwise:
+            // SQ_LDS_BANK_CONFLICT = 24 % of SQ_LDS_IDX_ACTIVE)
+            *(u32x4*)(Vl + row * D + (((col + 4 * (row & 3)) & (CPR - 1)) << 3)) = vr[i];
         }
         __syncthreads();
         if (key0 + kTK < kend) issue_loads(key0 + kTK);
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
             f16v sacc[2];
             float mx = -INFINITY;
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+            for (int blk = 0; blk < 2; ++blk) {                  // (alternating the two accumulators per k-step: 6 % slower)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[blk][r] = 0.f;
                 const int row = blk * 32 + n;                    // A operand: key row of this lane
@@ -475,9 +479,9 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const int dcol = db * 32 + (n & 16) + (n & 3) * 4;
-                    const _Float16* vp = Vl + vrow * D + ((dcol + 16 * (vrow & 7)) & (D - 1));
+                    const _Float16* vp = Vl + vrow * D + ((dcol + 32 * (vrow & 3)) & (D - 1));
                     const h4 lo = lds_tr_read(vp);               // keys k0 .. k0+3 at d = db*32 + (n & 31)
-                    const h4 hi = lds_tr_read(vp + 8 * D);       // keys k0+8 .. : (vrow + 8) & 7 == vrow & 7, same rotation
+                    const h4 hi = lds_tr_read(vp + 8 * D);       // keys k0+8 .. : (vrow + 8) & 3 == vrow & 3, same rotation
                     const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[t], o[db], 0, 0, 0);
                 }

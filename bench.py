@@ -256,8 +256,12 @@ def main():
               "cached_tokens": int(sc.encode_stats["cached_tokens"]), "seconds": t_enc,
               "tokens_per_s": enc_tokens / t_enc, "sharded_over": world,
               "first_call_seconds": t_first,
-              "note": "second add_schema call (steady state); scaffold passes auto-packed into right-padded batches, "
-                      "sharded over the ranks, module KV all-gathered"}
+              "computed_tokens": int(sc.encode_stats["computed_tokens"]),
+              "trunk_shared_passes": int(sc.encode_stats["trunk_shared_passes"]),
+              "note": "second add_schema call (steady state); tokens = scaffold tokens as the reference encodes them "
+                      "(every scaffold in full); computed_tokens = what ran through the model: scaffolds sharing a "
+                      "prefix with the root scaffold are encoded as suffixes over its K/V; passes packed into "
+                      "right-padded batches, sharded over the ranks, module KV all-gathered"}
 
     # ---- module-library encode (BASELINE config 5: a whole schema library, ~150 passes / ~100 k tokens) ----
     # five persona-structured schemas of different sizes + three flat document schemas; every schema's passes are

@@ -17,6 +17,7 @@ Schema encode shards over the GPUs of a node when ``torch.distributed`` is initi
 from __future__ import annotations
 
 import gc
+import os
 import itertools
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -162,12 +163,56 @@ class SchemaCache:
         dev = lm.device
         jobs = self._plan()
         rank, world = parallel.rank_world()
-        shards = parallel.shard_jobs([len(j["token_ids"]) for j in jobs], world)   # world == 1 -> everything
+        # ---- trunk reuse.  Scaffolds are emitted in position order and differ from the root scaffold (job 0: every
+        # union at its default member) from the first token of their own union member on, so under the causal mask
+        # the K/V of their common prefix is the root pass's K/V.  Such a scaffold is encoded as "suffix over the
+        # trunk's prefix rows" -- the very cached-prefill the engine exists for -- instead of from scratch (the
+        # reference re-encodes every scaffold in full, cache_engine.py:221-248).
+        prefix = [0] * len(jobs)
+        if self.share_trunk and len(jobs) > 1:
+            t_ids, t_pos = jobs[0]["token_ids"], jobs[0]["position_ids"]
+            for i in range(1, len(jobs)):
+                ids, pos = jobs[i]["token_ids"], jobs[i]["position_ids"]
+                n = 0
+                lim = min(len(ids), len(t_ids)) - 1          # at least one token is always run
+                while n < lim and ids[n] == t_ids[n] and pos[n] == t_pos[n]:
+                    n += 1
+                if n >= self.share_trunk_min and n >= len(ids) // 5:
+                    prefix[i] = n
+        # shard by what a pass actually costs: its suffix behind the trunk prefix (world == 1 -> everything)
+        shards = parallel.shard_jobs([len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)], world)
         mine = shards[rank]
 
-        encoded_tokens = 0
+        encoded_tokens = computed_tokens = 0
         per_job: Dict[int, List[Tuple[TokenSequence, torch.Tensor]]] = {}
-        for idxs in self._pack(mine, [len(j["token_ids"]) for j in jobs], batch_size):
+        full_pos = bool(getattr(lm, "use_full_position_ids", False))
+
+        def store_owned(job_idx: int, arena: KVArena, row: int):
+            job = jobs[job_idx]
+            pos, owned = job["position_ids"], job["owned"]
+            # position ids of a scaffold may be interleaved, but each segment is contiguous (:275-279)
+            src_off = [pos.index(tc.offset) for tc in owned]
+            lens = [len(tc) for tc in owned]
+            stores = [torch.empty((L, 2, Hkv, n, D), dtype=torch.float16, device=dev) for n in lens]
+            _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
+            per_job[job_idx] = list(zip(owned, stores))
+
+        shared = [i for i in mine if prefix[i] > 0]
+        whole = [i for i in mine if prefix[i] == 0]
+        trunk_arena: Optional[KVArena] = None
+        if shared:
+            job = jobs[0]
+            out = lm(input_ids=torch.tensor([job["token_ids"]], device=dev, dtype=torch.long),
+                     position_ids=torch.tensor([job["position_ids"]], device=dev, dtype=torch.long), use_cache=True)
+            trunk_arena = out.past_key_values.arena
+            computed_tokens += len(job["token_ids"])
+            if 0 in whole:                                   # this rank also owns the root pass: store from the same run
+                whole.remove(0)
+                encoded_tokens += len(job["token_ids"])
+                store_owned(0, trunk_arena, 0)
+            del out
+
+        for idxs in self._pack(whole, [len(j["token_ids"]) for j in jobs], batch_size):
             group = [jobs[i] for i in idxs]
             ids_pad, mask = pad_batch([j["token_ids"] for j in group], lm.eos_token_id)
             pos_pad, _ = pad_batch([j["position_ids"] for j in group], 0)
@@ -176,17 +221,40 @@ class SchemaCache:
                      attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
                      use_cache=True)
             arena: KVArena = out.past_key_values.arena
-            for row, job in enumerate(group):
-                encoded_tokens += len(job["token_ids"])
-                pos = job["position_ids"]
-                owned = job["owned"]
-                # position ids of a scaffold may be interleaved, but each segment is contiguous (:275-279)
-                src_off = [pos.index(tc.offset) for tc in owned]
-                lens = [len(tc) for tc in owned]
-                stores = [torch.empty((L, 2, Hkv, n, D), dtype=torch.float16, device=dev) for n in lens]
-                _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
-                per_job[idxs[row]] = list(zip(owned, stores))
+            for row, i in enumerate(idxs):
+                encoded_tokens += len(jobs[i]["token_ids"])
+                computed_tokens += len(jobs[i]["token_ids"])
+                store_owned(i, arena, row)
             del out, arena
+
+        # scaffolds sharing the same trunk prefix length (the members of one union) go through one batched forward
+        by_prefix: Dict[int, List[int]] = {}
+        for i in shared:
+            by_prefix.setdefault(prefix[i], []).append(i)
+        for n_pre, members in sorted(by_prefix.items()):
+            suffix_len = [len(jobs[i]["token_ids"]) - n_pre for i in members]
+            for idxs in self._pack(members, [len(j["token_ids"]) - n_pre for j in jobs], batch_size):
+                group = [jobs[i] for i in idxs]
+                width = max(len(j["token_ids"]) for j in group) - n_pre
+                arena = KVArena(len(group), L, Hkv, n_pre + width, D, dev)
+                arena.buf[:, :, :, :, :n_pre].copy_(trunk_arena.buf[:, :, :, :, :n_pre].expand(len(group), -1, -1, -1, -1, -1))
+                arena.length = n_pre
+                ids_pad, mask = pad_batch([j["token_ids"][n_pre:] for j in group], lm.eos_token_id)
+                pos_pad, _ = pad_batch([j["position_ids"][n_pre:] for j in group], 0)
+                if full_pos:                                 # ALiBi models take the position id of every key
+                    pos_pad = [list(jobs[0]["position_ids"][:n_pre]) + row for row in pos_pad]
+                out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
+                         position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
+                         attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
+                         past_key_values=arena.views(), use_cache=True)
+                arena = out.past_key_values.arena
+                for row, i in enumerate(idxs):
+                    encoded_tokens += len(jobs[i]["token_ids"])
+                    computed_tokens += len(jobs[i]["token_ids"]) - n_pre
+                    store_owned(i, arena, row)
+                del out, arena
+            del suffix_len
+        del trunk_arena
         # ascending job order == the global segment order restricted to this rank (what the all-gather plan assumes)
         local_segments: List[Tuple[TokenSequence, torch.Tensor]] = [p for i in sorted(per_job) for p in per_job[i]]
 
@@ -203,11 +271,15 @@ class SchemaCache:
             for tc, store in local_segments:
                 self.cache_l1[id(tc)] = TokenSequenceCache(tc, store)
         self.encode_stats = dict(passes=len(mine), total_passes=len(jobs), encoded_tokens=encoded_tokens,
+                                 computed_tokens=computed_tokens, trunk_shared_passes=len(shared),
                                  cached_tokens=sum(len(c) for c in self.cache_l1.values()))
         gc.collect()
 
     # tokens (padding included) one encode forward may carry when scaffolds are packed into a batch
     encode_token_budget = 8192
+    # encode scaffolds as suffixes over the root scaffold's K/V where they share a prefix with it (see _process)
+    share_trunk = os.environ.get("PC_SHARE_TRUNK", "1") != "0"
+    share_trunk_min = 32
 
     def _pack(self, mine: List[int], lengths: List[int], batch_size: int) -> List[List[int]]:
         """Group this rank's scaffold passes into right-padded batches.  ``batch_size`` is the reference's knob

@@ -252,10 +252,19 @@ def main():
     t_enc = time.perf_counter() - t0
     sc = eng.schemas["persona"]
     enc_tokens = sum(len(j["token_ids"]) for j in sc._plan())
+    lib_ok = None
+    if world > 1:
+        # after the all-gather every rank must hold the same module library: compare a per-segment checksum
+        sig = torch.stack([c.store.float().abs().sum() + c.store.float().sum() * 3.0
+                           for _, c in sorted(sc.cache_l1.items(), key=lambda kv: (kv[1].token_sequence.offset, len(kv[1])))])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        lib_ok = bool(torch.equal(lo, hi))
     encode = {"passes": int(sc.encode_stats["total_passes"]), "tokens": int(enc_tokens),
               "cached_tokens": int(sc.encode_stats["cached_tokens"]), "seconds": t_enc,
               "tokens_per_s": enc_tokens / t_enc, "sharded_over": world,
-              "first_call_seconds": t_first,
+              "first_call_seconds": t_first, "library_identical_on_all_ranks": lib_ok,
               "computed_tokens": int(sc.encode_stats["computed_tokens"]),
               "trunk_shared_passes": int(sc.encode_stats["trunk_shared_passes"]),
               "note": "second add_schema call (steady state); tokens = scaffold tokens as the reference encodes them "

@@ -29,11 +29,7 @@ from .llama_hip import LlamaHIP
 class FalconHIP(LlamaHIP):
     def __init__(self, shape: FalconShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
                  skinny: bool = True):
-        _native.load()  # fail loudly if the extension is missing
-        self.config = shape
-        self.device = torch.device(device)
-        self.dtype = torch.float16
-        self.decode_headroom = decode_headroom
+        self._setup(shape, device, decode_headroom)
         c = shape
         self.H, self.Hkv, self.D, self.L = c.num_attention_heads, 1, c.head_dim, c.num_hidden_layers
         dev = self.device
@@ -66,12 +62,7 @@ class FalconHIP(LlamaHIP):
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
         self.softmax_scale = 1.0 / math.sqrt(self.D)        # inv_norm_factor, falcon.py:316
-        self._ws = None
-        self.kslices = 4
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
-        self.use_graphs = True
-        self._graphs = {}
-        self.max_graphs = 64
 
     # ------------------------------------------------------------------------------------------
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):

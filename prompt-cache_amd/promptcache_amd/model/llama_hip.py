@@ -50,13 +50,25 @@ class LlamaHIP:
     NORM_FUSED_MAX_ROWS = 16   # ... and at or below this the RMSNorms are folded into the projections
     MID_MAX_ROWS = 512     # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly
 
-    def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
-                 decode_headroom: int = 256, skinny: bool = True):
+    def _setup(self, shape, device, decode_headroom: int) -> None:
+        """State every architecture shares: device, KV-arena headroom, workspace and the hipGraph cache."""
         _native.load()  # fail loudly if the extension is missing
         self.config = shape
         self.device = torch.device(device)
         self.dtype = torch.float16
         self.decode_headroom = decode_headroom
+        self._ws = None
+        # hipGraph cache for the small-q (prefill over staged KV / decode) forward: one captured graph per
+        # (B, q_len, arena, split count); past_len, token ids and positions are read from device buffers so
+        # every decode step and every same-shaped prompt replays the same graph.
+        self.use_graphs = True
+        self._graphs = {}
+        self.max_graphs = 64
+        self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
+
+    def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
+                 decode_headroom: int = 256, skinny: bool = True):
+        self._setup(shape, device, decode_headroom)
         c = shape
         self.H, self.Hkv, self.D, self.L = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.num_hidden_layers
         dev = self.device
@@ -95,15 +107,7 @@ class LlamaHIP:
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
         self.softmax_scale = 1.0 / math.sqrt(self.D)
-        self._ws = None
-        # hipGraph cache for the small-q (prefill over staged KV / decode) forward: one captured graph per
-        # (B, q_len, arena, split count); past_len, token ids and positions are read from device buffers so
-        # every decode step and every same-shaped prompt replays the same graph.
-        self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
         self.fuse_norm = os.environ.get("PC_FUSE_NORM", "1") != "0"
-        self.use_graphs = True
-        self._graphs = {}
-        self.max_graphs = 64
 
     # ------------------------------------------------------------------------------------------
     def new_arena(self, batch: int, cap: int) -> KVArena:

@@ -38,11 +38,7 @@ def alibi_slopes(num_heads: int, alibi_bias_max: int = 8) -> torch.Tensor:
 class MptHIP(LlamaHIP):
     def __init__(self, shape: MptShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
                  skinny: bool = True):
-        _native.load()
-        self.config = shape
-        self.device = torch.device(device)
-        self.dtype = torch.float16
-        self.decode_headroom = decode_headroom
+        self._setup(shape, device, decode_headroom)
         c = shape
         self.H = self.Hkv = c.num_attention_heads
         self.D, self.L = c.head_dim, c.num_hidden_layers
@@ -75,12 +71,7 @@ class MptHIP(LlamaHIP):
         self.slopes_log2 = (alibi_slopes(self.H, c.alibi_bias_max) * _LOG2E).to(dev)
         self.inv_freq_cpu = torch.zeros(1)                      # no rotary table (kept for interface symmetry)
         self.softmax_scale = 1.0 / math.sqrt(self.D)            # mpt.py:139-140
-        self._ws = None
-        self.kslices = 4
-        self.fuse_norm = False
-        self.use_graphs = True
-        self._graphs = {}
-        self.max_graphs = 64
+        self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

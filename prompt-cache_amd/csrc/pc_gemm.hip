@@ -707,6 +707,9 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
         }
 }
 
+// (Tried and dropped: also splitting the rows of a column group over 2-4 workgroups placed on one XCD, with the shape
+// chosen by bytes-per-workgroup: 10-15 % faster on a few isolated shapes (7b q|k|v at 259 / 512 rows), but the forward
+// as a whole did not gain -- q = 98: 5.8 -> 6.2 ms, config 4: 19.4 -> 20.1 ms.)
 // Launch shape of the rows kernel.  Rows per compute wave: 32 while that needs <= 12 compute waves (M <= 384; more,
 // narrower waves hide the L2 latency of the activation loads and spread evenly over the four SIMDs), else 64.
 // Weight tiles per workgroup: the smallest of {3,4,6,8} ({2,3,4} gate/up pairs) that fits the grid into one round.

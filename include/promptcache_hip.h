@@ -220,6 +220,30 @@ int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, i
                       const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo, const float* key_pos,
                       int64_t key_pos_batch_stride, const float* slopes_log2, void* stream);
 
+/* Split-precision variants for the dense (many-row) path.  fp16 activations cost 2^-11 per projection input; over 32
+ * layers that alone moves 7b-shape logits by 2-3e-2 against the reference's fp32 path.  These write an activation as
+ * hi = fp16(v) and lo = fp16(v - hi); the caller stacks [hi; lo] along the rows of one GEMM and adds the two halves of
+ * the product (gate_up2 / x2 / pc_add3 take the second half):
+ *   pc_rmsnorm_split, pc_layernorm_split   norm -> (hi, lo) [rows][hidden]
+ *   pc_silu_mul_split   silu(g) * u of (gate_up + gate_up2) -> (hi, lo);  pc_gelu_split  gelu(x + x2) -> (hi, lo)
+ *   pc_add3             x += a + b  (fp32 residual stream)
+ *   pc_attn_fwd_ex      pc_attn_fwd / pc_attn_fwd_alibi with an optional row-major `out_lo` plane next to `out`
+ *                       (key_pos / slopes_log2 NULL: no ALiBi). */
+int pc_rmsnorm_split(const float* x, const void* weight, void* out_hi, void* out_lo, int32_t rows, int32_t hidden,
+                     float eps, void* stream);
+int pc_layernorm_split(const float* x, const void* weight, const void* bias, void* out_hi, void* out_lo, int32_t rows,
+                       int32_t hidden, float eps, void* stream);
+int pc_silu_mul_split(const float* gate_up, const float* gate_up2, void* out_hi, void* out_lo, int32_t rows,
+                      int32_t inter, void* stream);
+int pc_gelu_split(const float* x, const float* x2, void* out_hi, void* out_lo, int64_t n, void* stream);
+int pc_add3(float* x, const float* a, const float* b, int64_t n, void* stream);
+int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+                   const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out, void* out_lo,
+                   int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
+                   int32_t q_len, int32_t past_len, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                   const int32_t* past_len_dev, const float* key_pos, int64_t key_pos_batch_stride,
+                   const float* slopes_log2, void* stream);
+
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);

@@ -50,6 +50,7 @@ struct AttnParams {
     const _Float16* q_lo;   // optional low-order plane of q (same strides), consumed when HP
     const _Float16* k; const _Float16* v; int64_t kv_bs, kv_hs;
     _Float16* out; int64_t o_bs, o_ts;
+    _Float16* out_lo;       // optional: fp16 residual of `out` (same strides): split-precision row-major output
     _Float16* of_hi; _Float16* of_lo;   // optional: fragment-major split-precision output planes (pc_gemm.hip)
     float* part_o; float* part_ml;
     const int32_t* past_len_dev;
@@ -292,12 +293,18 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             }
             return;
         }
-        _Float16* op = p.out + b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + g * 4;
+        const int64_t ooff = b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + g * 4;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            h4 r = {(_Float16)(o[db][0] * inv), (_Float16)(o[db][1] * inv), (_Float16)(o[db][2] * inv),
-                    (_Float16)(o[db][3] * inv)};
-            *(h4*)(op + db * 16) = r;
+            h4 r, rl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 vh, vl;
+                pc_split(o[db][j] * inv, vh, vl);
+                r[j] = vh; rl[j] = vl;
+            }
+            *(h4*)(p.out + ooff + db * 16) = r;
+            if (p.out_lo) *(h4*)(p.out_lo + ooff + db * 16) = rl;
         }
     } else {
         const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
@@ -512,9 +519,16 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
                     *(h4*)(p.of_hi + off) = hi;
                     *(h4*)(p.of_lo + off) = lo;
                 } else {
-                    h4 r = {(_Float16)(o[db][rg * 4] * inv), (_Float16)(o[db][rg * 4 + 1] * inv),
-                            (_Float16)(o[db][rg * 4 + 2] * inv), (_Float16)(o[db][rg * 4 + 3] * inv)};
-                    *(h4*)(p.out + b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + d) = r;
+                    h4 r, rl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 vh, vl;
+                        pc_split(o[db][rg * 4 + j] * inv, vh, vl);
+                        r[j] = vh; rl[j] = vl;
+                    }
+                    const int64_t ooff = b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + d;
+                    *(h4*)(p.out + ooff) = r;
+                    if (p.out_lo) *(h4*)(p.out_lo + ooff) = rl;
                 }
             }
     } else {
@@ -537,7 +551,7 @@ template <int D, int NS>   // NS: compile-time bound on nsplit, so every partial
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                     _Float16* __restrict__ out, int64_t o_bs, int64_t o_ts,
                                     _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo, int H, int q_len,
-                                    int nsplit) {
+                                    int nsplit, _Float16* __restrict__ out_lo) {
     const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
     const int64_t base = ((int64_t)b * H + h) * nsplit;
     // one batch of independent loads (a loop over a runtime nsplit serialises them: max first, then one dependent
@@ -570,7 +584,11 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
         of_hi[off] = hi;
         of_lo[off] = lo;
     } else {
-        out[b * o_bs + (int64_t)qi * o_ts + (int64_t)h * D + d] = (_Float16)v;
+        _Float16 hi, lo;
+        pc_split(v, hi, lo);
+        const int64_t off = b * o_bs + (int64_t)qi * o_ts + (int64_t)h * D + d;
+        out[off] = hi;
+        if (out_lo) out_lo[off] = lo;
     }
 }
 
@@ -602,7 +620,9 @@ template <int D>
 int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     AttnParams p = p0;
     static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
-    const bool rows32 = use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
+    // a q_lo plane asks for split-precision Q and P at any q_len (the many-row path in its precise mode): 16-row kernel
+    const bool want_hp = p.q_len <= kQB || p.q_lo != nullptr;
+    const bool rows32 = !p.q_lo && use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
     p.nqblk = pc_ceil_div(p.q_len, rows32 ? kQB32 : kQB);
     p.nbatch = B;
     p.xcd_remap = (p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
@@ -612,16 +632,16 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.key_pos) {
-        if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
+        if (want_hp) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(kThreads), 0, stream, p);
-    } else if (p.q_len <= kQB) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
+    } else if (want_hp) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     int rc = pc_check_launch("attn_fwd_kernel");
     if (rc != PC_OK) return rc;
     if (p.nsplit > 1) {
 #define PC_COMBINE(NSV)                                                                                         \
         hipLaunchKernelGGL((attn_combine_kernel<D, NSV>), dim3(p.q_len, p.H, B), dim3(D), 0, stream, p.part_o,     \
-                           p.part_ml, p.out, p.o_bs, p.o_ts, p.of_hi, p.of_lo, p.H, p.q_len, p.nsplit)
+                           p.part_ml, p.out, p.o_bs, p.o_ts, p.of_hi, p.of_lo, p.H, p.q_len, p.nsplit, p.out_lo)
         if (p.nsplit <= 4) PC_COMBINE(4);
         else if (p.nsplit <= 8) PC_COMBINE(8);
         else if (p.nsplit <= 16) PC_COMBINE(16);
@@ -647,7 +667,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
                   int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
                   int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
-                  const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* stream) {
+                  const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo, void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -663,6 +683,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.q_lo = (const _Float16*)q_lo;
     p.k = (const _Float16*)k; p.v = (const _Float16*)v; p.kv_bs = kv_batch_stride; p.kv_hs = kv_head_stride;
     p.out = (_Float16*)out; p.o_bs = out_batch_stride; p.o_ts = out_token_stride;
+    p.out_lo = (_Float16*)out_lo;
     p.of_hi = (_Float16*)out_frag_hi; p.of_lo = (_Float16*)out_frag_lo;
     p.past_len_dev = past_len_dev;
     p.key_pos = key_pos; p.kp_bs = key_pos_batch_stride; p.slopes = slopes;
@@ -694,7 +715,7 @@ PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_strid
                           void* stream) {
     return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, nullptr, 0, nullptr, stream);
+                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, nullptr, 0, nullptr, nullptr, stream);
 }
 
 PC_EXPORT int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
@@ -709,5 +730,21 @@ PC_EXPORT int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch
     return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
                          workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
-                         slopes_log2, stream);
+                         slopes_log2, nullptr, stream);
+}
+
+PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
+                             const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
+                             void* out_lo, int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H,
+                             int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
+                             int64_t workspace_bytes, const int32_t* past_len_dev, const float* key_pos,
+                             int64_t key_pos_batch_stride, const float* slopes_log2, void* stream) {
+    PC_REQUIRE(out, PC_ERR_ARG, "pc_attn_fwd_ex: row-major output required");
+    PC_REQUIRE((key_pos == nullptr) == (slopes_log2 == nullptr), PC_ERR_ARG, "pc_attn_fwd_ex: key_pos and slopes go together");
+    PC_REQUIRE(!key_pos || (key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0), PC_ERR_ARG,
+               "pc_attn_fwd_ex: key_pos rows not 16-byte aligned");
+    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
+                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
+                         workspace_bytes, past_len_dev, nullptr, nullptr, key_pos, key_pos_batch_stride, slopes_log2,
+                         out_lo, stream);
 }

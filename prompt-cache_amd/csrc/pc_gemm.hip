@@ -558,13 +558,14 @@ int launch_T(const GemmParams& p, int T, int units, hipStream_t s) {
 //     activation loads: a wave's loads complete in order, so one wave issuing both would make every L2-hit
 //     activation load wait behind ~2 us HBM weight loads.
 // One raw s_barrier per stage (LDS-only wait: `__syncthreads()` would drain the prefetch queues).
-// Activations: the hi plane only (fp16 activations x fp16 weights -> fp32, the precision of the dense path).
+// Activations: hi and lo planes when the caller passes both (two MFMAs per weight fragment), the hi plane only when
+// xf_lo is NULL.
 constexpr int kStageWaves = 4;
 constexpr int kRowsMaxM = 512;
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int TT, int EPI, int MTW>
+template <int TT, int EPI, int MTW, bool TWO>
 __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const GemmParams p) {
     constexpr int T = (EPI == EPI_SILU) ? TT / 2 : TT;   // output units (tiles, or gate/up pairs) per workgroup
     constexpr int KC = (TT <= 4) ? 8 : 4;                // k-steps per stage
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
     // clamped to the last one, pad rows inside it are read as they are -- output column m depends on
     // activation row m only, and rows >= M are never stored.
     const _Float16* xa[MTW];
+    const int64_t lo_delta = TWO ? (p.xf_lo - p.xf_hi) : 0;          // lo plane = hi plane + lo_delta (same layout)
     const int mt_last = ((p.M + 15) >> 4) - 1;
 #pragma unroll
     for (int a = 0; a < MTW; ++a) {
@@ -668,13 +670,16 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
     const int klast = kq1 - 1 - kq0;                     // last valid k-step, relative to kq0
     // k-step (relative to kq0) loaded for sequence position i; positions past the end repeat the last one
     auto kseq = [&](int i) { return i < klast ? i : klast; };
-    h8 xs[NX][MTW];
+    h8 xs[NX][MTW], xsl[TWO ? NX : 1][MTW];
     if (nst > 0) {                                       // (an empty K slice stores zeros below)
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
             const int kn = kseq(d);
 #pragma unroll
-            for (int a = 0; a < MTW; ++a) xs[d][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+            for (int a = 0; a < MTW; ++a) {
+                xs[d][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+                if (TWO) xsl[d][a] = ldg_h8(xa[a] + lo_delta + (int64_t)kn * 512);
+            }
         }
     }
     for (int st = 0; st < nst; ++st) {
@@ -685,7 +690,10 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
             // prefetch the activation fragments PD k-steps ahead (clamped at the end of the K range)
             const int kn = kseq(st * KC + j + PD);
 #pragma unroll
-            for (int a = 0; a < MTW; ++a) xs[(j + PD) % NX][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+            for (int a = 0; a < MTW; ++a) {
+                xs[(j + PD) % NX][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+                if (TWO) xsl[(j + PD) % NX][a] = ldg_h8(xa[a] + lo_delta + (int64_t)kn * 512);
+            }
             __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead of this k-step's MFMAs (see k_block)
             h8 w[TT];
 #pragma unroll
@@ -693,8 +701,10 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
 #pragma unroll
             for (int t = 0; t < TT; ++t)
 #pragma unroll
-                for (int a = 0; a < MTW; ++a)
+                for (int a = 0; a < MTW; ++a) {
                     acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xs[j % NX][a], acc[a][t], 0, 0, 0);
+                    if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xsl[j % NX][a], acc[a][t], 0, 0, 0);
+                }
         }
     }
 #pragma unroll
@@ -718,24 +728,30 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("PC_GEMM_ROWS_TT"); return e ? atoi(e) : 0; }();
     const GemmParams& p = p_in;
     const bool narrow = pc_ceil_div(p.M, 32) <= 12;
+    const bool two = p.xf_lo != nullptr;                 // split-precision activations: <= 4 tiles per workgroup (registers)
     const int RW = narrow ? pc_ceil_div(p.M, 32) : pc_ceil_div(p.M, 64);
     const dim3 block((RW + kStageWaves) * 64);
 #define PC_ROWS(TTV)                                                                                       \
     do {                                                                                                   \
         constexpr int TV = (EPI == EPI_SILU) ? (TTV) / 2 : (TTV);                                          \
         const dim3 grid(pc_ceil_div(units, TV), p.kslices);                                                \
-        if (narrow) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 2>), grid, block, 0, s, p);             \
-        else if constexpr ((TTV) <= 6) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4>), grid, block, 0, s, p); \
+        if (two) {                                                                                         \
+            if constexpr ((TTV) <= 4) {                                                                    \
+                if (narrow) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 2, true>), grid, block, 0, s, p); \
+                else hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4, true>), grid, block, 0, s, p);      \
+            }                                                                                              \
+        } else if (narrow) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 2, false>), grid, block, 0, s, p); \
+        else if constexpr ((TTV) <= 6) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4, false>), grid, block, 0, s, p); \
         return pc_check_launch("gemm_rows_kernel");                                                        \
     } while (0)
     const int work = units * p.kslices;
     if constexpr (EPI == EPI_SILU) {
-        if (forced == 4 || (!forced && pc_ceil_div(work, 2) <= 256)) PC_ROWS(4);
+        if (forced == 4 || two || (!forced && pc_ceil_div(work, 2) <= 256)) PC_ROWS(4);
         if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(6);
         PC_ROWS(8);
     } else {
         if (forced == 3 || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(3);
-        if (forced == 4 || (!forced && pc_ceil_div(work, 4) <= 256)) PC_ROWS(4);
+        if (forced == 4 || two || (!forced && pc_ceil_div(work, 4) <= 256)) PC_ROWS(4);
         if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 6) <= 256)) PC_ROWS(6);
         PC_ROWS(8);
     }

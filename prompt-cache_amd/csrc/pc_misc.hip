@@ -41,7 +41,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // parity target, so rounding there would only add error.)
 template <bool XF32>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ xin, const _Float16* __restrict__ w,
-                                                      _Float16* __restrict__ out, int hidden, float eps) {
+                                                      _Float16* __restrict__ out, int hidden, float eps,
+                                                      _Float16* __restrict__ out_lo = nullptr) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = hidden >> 3;
@@ -68,10 +69,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ x
         if (XF32) {
             const f4* p = (const f4*)((const float*)xin + (int64_t)row * hidden + i * 8);
             const f4 a = p[0], b = p[1];
+            if (out_lo) {      // split-precision output: hi to `out`, the fp16 residual to `out_lo`
+                h8 ol;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (_Float16)((float)g[e] * (a[e] * rs));
-                o[e + 4] = (_Float16)((float)g[e + 4] * (b[e] * rs));
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 vh, vl;
+                    pc_split((float)g[e] * ((e < 4 ? a[e] : b[e - 4]) * rs), vh, vl);
+                    o[e] = vh; ol[e] = vl;
+                }
+                *(h8*)(out_lo + (int64_t)row * hidden + i * 8) = ol;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (_Float16)((float)g[e] * (a[e] * rs));
+                    o[e + 4] = (_Float16)((float)g[e + 4] * (b[e] * rs));
+                }
             }
         } else {
             const h8 a = *(const h8*)((const _Float16*)xin + (int64_t)row * hidden + i * 8);
@@ -86,7 +98,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ x
 // fp32 math, one fp16 rounding.
 template <bool F32>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const void* __restrict__ gu, _Float16* __restrict__ out,
-                                                       int inter) {
+                                                       int inter, const float* __restrict__ gu2 = nullptr,
+                                                       _Float16* __restrict__ out_lo = nullptr) {
     const int row = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i * 8 >= inter) return;
@@ -96,6 +109,12 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const void* __restrict__ 
         const f4 a = *(const f4*)g, b = *(const f4*)(g + 4), c = *(const f4*)(g + inter), d = *(const f4*)(g + inter + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gt[e] = a[e]; gt[e + 4] = b[e]; up[e] = c[e]; up[e + 4] = d[e]; }
+        if (gu2) {             // second addend (the lo-plane half of a split-precision projection)
+            const float* g2 = gu2 + (int64_t)row * 2 * inter + i * 8;
+            const f4 a2 = *(const f4*)g2, b2 = *(const f4*)(g2 + 4), c2 = *(const f4*)(g2 + inter), d2 = *(const f4*)(g2 + inter + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gt[e] += a2[e]; gt[e + 4] += b2[e]; up[e] += c2[e]; up[e + 4] += d2[e]; }
+        }
     } else {
         const _Float16* g = (const _Float16*)gu + (int64_t)row * 2 * inter + i * 8;
         const h8 a = *(const h8*)g, c = *(const h8*)(g + inter);
@@ -103,8 +122,19 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const void* __restrict__ 
         for (int e = 0; e < 8; ++e) { gt[e] = (float)a[e]; up[e] = (float)c[e]; }
     }
     h8 o;
+    if (out_lo) {
+        h8 ol;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((gt[e] / (1.0f + __expf(-gt[e]))) * up[e]);
+        for (int e = 0; e < 8; ++e) {
+            _Float16 vh, vl;
+            pc_split((gt[e] / (1.0f + __expf(-gt[e]))) * up[e], vh, vl);
+            o[e] = vh; ol[e] = vl;
+        }
+        *(h8*)(out_lo + (int64_t)row * inter + i * 8) = ol;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((gt[e] / (1.0f + __expf(-gt[e]))) * up[e]);
+    }
     *(h8*)(out + (int64_t)row * inter + i * 8) = o;
 }
 
@@ -112,7 +142,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const void* __restrict__ 
 // sum of squares -- no E[x^2] - mean^2 cancellation), affine in fp32, one fp16 rounding.  x fp32 [rows][hidden].
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const _Float16* __restrict__ w,
                                                         const _Float16* __restrict__ b, _Float16* __restrict__ out,
-                                                        int hidden, float eps) {
+                                                        int hidden, float eps, _Float16* __restrict__ out_lo) {
     __shared__ float red[2][4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = hidden >> 3;
@@ -141,28 +171,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const h8 g = *(const h8*)(w + i * 8);
         h8 bb = {0, 0, 0, 0, 0, 0, 0, 0};
         if (b) bb = *(const h8*)(b + i * 8);       // MPT's LayerNorm has no bias (mpt.py:207, :215)
-        h8 o;
+        h8 o, ol;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[e] = (_Float16)((a[e] - mu) * rs * (float)g[e] + (float)bb[e]);
-            o[e + 4] = (_Float16)((c[e] - mu) * rs * (float)g[e + 4] + (float)bb[e + 4]);
+        for (int e = 0; e < 8; ++e) {
+            const float v = ((e < 4 ? a[e] : c[e - 4]) - mu) * rs * (float)g[e] + (float)bb[e];
+            _Float16 vh, vl;
+            pc_split(v, vh, vl);
+            o[e] = vh; ol[e] = vl;
         }
         *(h8*)(out + (int64_t)row * hidden + i * 8) = o;
+        if (out_lo) *(h8*)(out_lo + (int64_t)row * hidden + i * 8) = ol;
     }
 }
 
 // nn.GELU() (falcon.py:726), the exact erf form: fp32 in -> fp16 out
-__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n8) {
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n8,
+                                                   const float* __restrict__ x2, _Float16* __restrict__ out_lo) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
-    const f4 a = *(const f4*)(x + i * 8), c = *(const f4*)(x + i * 8 + 4);
-    h8 o;
+    f4 a = *(const f4*)(x + i * 8), c = *(const f4*)(x + i * 8 + 4);
+    if (x2) {
+        const f4 a2 = *(const f4*)(x2 + i * 8), c2 = *(const f4*)(x2 + i * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        o[e] = (_Float16)(0.5f * a[e] * (1.0f + erff(a[e] * 0.70710678118654752f)));
-        o[e + 4] = (_Float16)(0.5f * c[e] * (1.0f + erff(c[e] * 0.70710678118654752f)));
+        for (int e = 0; e < 4; ++e) { a[e] += a2[e]; c[e] += c2[e]; }
+    }
+    h8 o, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? a[e] : c[e - 4];
+        _Float16 vh, vl;
+        pc_split(0.5f * v * (1.0f + erff(v * 0.70710678118654752f)), vh, vl);
+        o[e] = vh; ol[e] = vl;
     }
     *(h8*)(out + i * 8) = o;
+    if (out_lo) *(h8*)(out_lo + i * 8) = ol;
+}
+
+// x += a + b (fp32): the two halves of a split-precision projection folded into the residual stream in one pass
+__global__ __launch_bounds__(256) void add3_kernel(float* __restrict__ x, const float* __restrict__ a,
+                                                   const float* __restrict__ b, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f4 v = *(const f4*)(x + i * 4);
+    const f4 p = *(const f4*)(a + i * 4), q = *(const f4*)(b + i * 4);
+    v[0] += p[0] + q[0]; v[1] += p[1] + q[1]; v[2] += p[2] + q[2]; v[3] += p[3] + q[3];
+    *(f4*)(x + i * 4) = v;
 }
 
 __global__ __launch_bounds__(256) void embed_gather_kernel(const _Float16* __restrict__ table,
@@ -215,6 +268,36 @@ PC_EXPORT int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t r
     return pc_check_launch("rmsnorm_kernel");
 }
 
+PC_EXPORT int pc_rmsnorm_split(const float* x, const void* weight, void* out_hi, void* out_lo, int32_t rows, int32_t hidden,
+                               float eps, void* stream) {
+    PC_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0, PC_ERR_ARG, "pc_rmsnorm_split: hidden must be a multiple of 8");
+    if (rows == 0) return PC_OK;
+    PC_REQUIRE(x && weight && out_hi && out_lo, PC_ERR_ARG, "pc_rmsnorm_split: null pointer");
+    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const void*)x,
+                       (const _Float16*)weight, (_Float16*)out_hi, hidden, eps, (_Float16*)out_lo);
+    return pc_check_launch("rmsnorm_kernel");
+}
+
+PC_EXPORT int pc_silu_mul_split(const float* gate_up, const float* gate_up2, void* out_hi, void* out_lo, int32_t rows,
+                                int32_t inter, void* stream) {
+    PC_REQUIRE(rows >= 0 && inter > 0 && inter % 8 == 0, PC_ERR_ARG, "pc_silu_mul_split: inter must be a multiple of 8");
+    if (rows == 0) return PC_OK;
+    PC_REQUIRE(gate_up && out_hi && out_lo, PC_ERR_ARG, "pc_silu_mul_split: null pointer");
+    dim3 grid(pc_ceil_div(inter / 8, 256), rows);
+    hipLaunchKernelGGL(silu_mul_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const void*)gate_up, (_Float16*)out_hi,
+                       inter, gate_up2, (_Float16*)out_lo);
+    return pc_check_launch("silu_mul_kernel");
+}
+
+PC_EXPORT int pc_add3(float* x, const float* a, const float* b, int64_t n, void* stream) {
+    PC_REQUIRE(n >= 0 && n % 4 == 0, PC_ERR_ARG, "pc_add3: element count must be a multiple of 4");
+    if (n == 0) return PC_OK;
+    PC_REQUIRE(x && a && b, PC_ERR_ARG, "pc_add3: null pointer");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, a, b, n4);
+    return pc_check_launch("add3_kernel");
+}
+
 PC_EXPORT int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, int32_t in_is_f32, void* stream) {
     PC_REQUIRE(rows >= 0 && inter > 0 && inter % 8 == 0, PC_ERR_ARG, "pc_silu_mul: inter must be a multiple of 8");
     if (rows == 0) return PC_OK;
@@ -233,7 +316,17 @@ PC_EXPORT int pc_layernorm(const float* x, const void* weight, const void* bias,
     if (rows == 0) return PC_OK;
     PC_REQUIRE(x && weight && out, PC_ERR_ARG, "pc_layernorm: null pointer");   /* bias may be NULL */
     hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
-                       (const _Float16*)bias, (_Float16*)out, hidden, eps);
+                       (const _Float16*)bias, (_Float16*)out, hidden, eps, (_Float16*)nullptr);
+    return pc_check_launch("layernorm_kernel");
+}
+
+PC_EXPORT int pc_layernorm_split(const float* x, const void* weight, const void* bias, void* out_hi, void* out_lo,
+                                 int32_t rows, int32_t hidden, float eps, void* stream) {
+    PC_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0, PC_ERR_ARG, "pc_layernorm_split: hidden must be a multiple of 8");
+    if (rows == 0) return PC_OK;
+    PC_REQUIRE(x && weight && out_hi && out_lo, PC_ERR_ARG, "pc_layernorm_split: null pointer");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)weight,
+                       (const _Float16*)bias, (_Float16*)out_hi, hidden, eps, (_Float16*)out_lo);
     return pc_check_launch("layernorm_kernel");
 }
 
@@ -242,7 +335,18 @@ PC_EXPORT int pc_gelu(const float* x, void* out, int64_t n, void* stream) {
     if (n == 0) return PC_OK;
     PC_REQUIRE(x && out, PC_ERR_ARG, "pc_gelu: null pointer");
     const int64_t n8 = n / 8;
-    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out, n8);
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out, n8,
+                       (const float*)nullptr, (_Float16*)nullptr);
+    return pc_check_launch("gelu_kernel");
+}
+
+PC_EXPORT int pc_gelu_split(const float* x, const float* x2, void* out_hi, void* out_lo, int64_t n, void* stream) {
+    PC_REQUIRE(n >= 0 && n % 8 == 0, PC_ERR_ARG, "pc_gelu_split: element count must be a multiple of 8");
+    if (n == 0) return PC_OK;
+    PC_REQUIRE(x && out_hi && out_lo, PC_ERR_ARG, "pc_gelu_split: null pointer");
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out_hi,
+                       n8, x2, (_Float16*)out_lo);
     return pc_check_launch("gelu_kernel");
 }
 

@@ -29,6 +29,13 @@ SIGNATURES = {
                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pc_attn_fwd_alibi": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "pc_attn_fwd_ex": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,
+                                 _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "pc_rmsnorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "pc_layernorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "pc_silu_mul_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pc_gelu_split": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "pc_add3": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -132,11 +139,20 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None) -> None:
+             alibi=None, out_lo=None) -> None:
     """``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
     ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi)."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
+    if out_lo is not None:
+        kpos, slopes = (None, None) if alibi is None else alibi
+        rc = load().pc_attn_fwd_ex(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
+                                   out.data_ptr(), out_lo.data_ptr(), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
+                                   _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(kpos),
+                                   0 if kpos is None else kpos.stride(0), _ptr(slopes),
+                                   current_stream() if stream is None else stream)
+        check(rc, "pc_attn_fwd_ex")
+        return
     if alibi is not None:
         kpos, slopes = alibi
         rc = load().pc_attn_fwd_alibi(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
@@ -262,6 +278,35 @@ def silu_mul(gate_up, out, rows: int, inter: int, in_is_f32: bool = False, strea
     rc = load().pc_silu_mul(gate_up.data_ptr(), out.data_ptr(), rows, inter, int(in_is_f32),
                             current_stream() if stream is None else stream)
     check(rc, "pc_silu_mul")
+
+
+def rmsnorm_split(x_f32, weight, out_hi, out_lo, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
+    rc = load().pc_rmsnorm_split(x_f32.data_ptr(), weight.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), rows, hidden, eps,
+                                 current_stream() if stream is None else stream)
+    check(rc, "pc_rmsnorm_split")
+
+
+def layernorm_split(x_f32, weight, bias, out_hi, out_lo, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
+    rc = load().pc_layernorm_split(x_f32.data_ptr(), weight.data_ptr(), _ptr(bias), out_hi.data_ptr(), out_lo.data_ptr(), rows,
+                                   hidden, eps, current_stream() if stream is None else stream)
+    check(rc, "pc_layernorm_split")
+
+
+def silu_mul_split(gate_up, gate_up2, out_hi, out_lo, rows: int, inter: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_silu_mul_split(gate_up.data_ptr(), _ptr(gate_up2), out_hi.data_ptr(), out_lo.data_ptr(), rows, inter,
+                                  current_stream() if stream is None else stream)
+    check(rc, "pc_silu_mul_split")
+
+
+def gelu_split(x, x2, out_hi, out_lo, n: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_gelu_split(x.data_ptr(), _ptr(x2), out_hi.data_ptr(), out_lo.data_ptr(), n,
+                              current_stream() if stream is None else stream)
+    check(rc, "pc_gelu_split")
+
+
+def add3(x, a, b, n: int, stream: Optional[int] = None) -> None:
+    rc = load().pc_add3(x.data_ptr(), a.data_ptr(), b.data_ptr(), n, current_stream() if stream is None else stream)
+    check(rc, "pc_add3")
 
 
 def embed_gather(table, ids_i64, out, n_tok: int, hidden: int, vocab: int, stream: Optional[int] = None) -> None:

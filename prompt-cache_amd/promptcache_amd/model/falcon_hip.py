@@ -66,6 +66,8 @@ class FalconHIP(LlamaHIP):
 
     # ------------------------------------------------------------------------------------------
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        if self.precise_dense:
+            return self._forward_dense_split(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
         n = _native
         dev = self.device
         c = self.config
@@ -103,6 +105,54 @@ class FalconHIP(LlamaHIP):
             return torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
         n.layernorm(x, self.lnf_w, self.lnf_b, h16, T, hid, eps)
         return torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)
+
+    def _forward_dense_split(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Many-row path with split-precision activations (see LlamaHIP._forward_dense_split)."""
+        n = _native
+        dev = self.device
+        c = self.config
+        H, D, hid = self.H, self.D, c.hidden_size
+        T = B * q_len
+        W = (H + 2) * D
+        eps = c.layer_norm_epsilon
+        f32 = torch.float32
+        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h2[0], T, hid, c.vocab_size)
+        x = h2[0].float()
+        attn2 = torch.empty((2, T, H * D), dtype=self.dtype, device=dev)
+        act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            n.layernorm_split(x, lw["ln_w"], lw["ln_b"], h2[0], h2[1], T, hid, eps)
+            qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
+            torch.add(qkv2[:T], qkv2[T:], out=qkv)
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
+                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True,
+                          q_out_lo=q16l)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
+                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l, out_lo=attn2[1])
+            h4 = torch.mm(h2.view(2 * T, hid), lw["w1"].t(), out_dtype=f32)
+            n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
+            o2 = torch.mm(attn2.view(2 * T, H * D), lw["wo"].t(), out_dtype=f32)
+            n.add3(x, o2[:T], o2[T:], T * hid)
+            d2 = torch.mm(act2.view(2 * T, 4 * hid), lw["w2"].t(), out_dtype=f32)
+            n.add3(x, d2[:T], d2[T:], T * hid)
+        if last_token_only:
+            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)
+            n.layernorm_split(xl, self.lnf_w, self.lnf_b, hl[0], hl[1], B, hid, eps)
+            lg = torch.mm(hl.view(2 * B, hid), self.lm_head.t(), out_dtype=f32)
+            return (lg[:B] + lg[B:]).view(B, 1, -1)
+        n.layernorm_split(x, self.lnf_w, self.lnf_b, h2[0], h2[1], T, hid, eps)
+        lg = torch.mm(h2.view(2 * T, hid), self.lm_head.t(), out_dtype=f32)
+        return (lg[:T] + lg[T:]).view(B, q_len, -1)
 
     def _forward_skinny(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
         """T <= 512 rows: weight-streaming projections (pc_gemm.hip).  The o_proj and dense_4h_to_h launches both leave

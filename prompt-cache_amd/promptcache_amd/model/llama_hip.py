@@ -65,6 +65,9 @@ class LlamaHIP:
         self._graphs = {}
         self.max_graphs = 64
         self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
+        # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
+        # full-depth parity for 2x fewer GEMM flops
+        self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True):
@@ -188,6 +191,8 @@ class LlamaHIP:
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
         """Layer stack for many rows (schema encode, no-cache prefill): hipBLASLt projections with fp32 outputs, HIP
         kernels for everything between them."""
+        if self.precise_dense:
+            return self._forward_dense_split(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
         n = _native
         dev = self.device
         H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
@@ -234,6 +239,61 @@ class LlamaHIP:
             n.rmsnorm(x, self.norm, h16, T, hid, eps, True)
             logits = torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)   # llama2.py:1050-1051
         return logits
+
+    def _forward_dense_split(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        """The dense layer stack with split-precision activations.  An fp16 activation costs 2^-11 per projection
+        input; through 32 layers that alone moves 7b-shape logits by 2-3e-2 against the reference's fp32 path (the
+        module KV an encode stores drifts the same way).  Here every projection input is a (hi, lo) fp16 pair stacked
+        along the rows of ONE hipBLASLt GEMM ([hi; lo] @ W^T, fp32 out) whose two halves are added by the consumer:
+        twice the GEMM flops, fp32-level activations."""
+        n = _native
+        dev = self.device
+        H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
+        inter = self.config.intermediate_size
+        T = B * q_len
+        W = (H + 2 * Hkv) * D
+        eps = self.config.rms_norm_eps
+        f32 = torch.float32
+        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)          # [hi; lo] of the normalised stream
+        n.embed_gather(self.embed, ids, h2[0], T, hid, self.config.vocab_size)
+        x = h2[0].float()  # fp32 residual stream
+        attn2 = torch.empty((2, T, H * D), dtype=self.dtype, device=dev)
+        act2 = torch.empty((2, T, inter), dtype=self.dtype, device=dev)
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            n.rmsnorm_split(x, lw["ln1"], h2[0], h2[1], T, hid, eps)
+            qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
+            torch.add(qkv2[:T], qkv2[T:], out=qkv)
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
+                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
+                          q_out_lo=q16l)
+            # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
+                       q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
+                       out_lo=attn2[1])
+            o2 = torch.mm(attn2.view(2 * T, H * D), lw["wo"].t(), out_dtype=f32)
+            n.add3(x, o2[:T], o2[T:], T * hid)
+            n.rmsnorm_split(x, lw["ln2"], h2[0], h2[1], T, hid, eps)
+            gu2 = torch.mm(h2.view(2 * T, hid), lw["wgu"].t(), out_dtype=f32)
+            n.silu_mul_split(gu2[:T], gu2[T:], act2[0], act2[1], T, inter)
+            d2 = torch.mm(act2.view(2 * T, inter), lw["wdown"].t(), out_dtype=f32)
+            n.add3(x, d2[:T], d2[T:], T * hid)
+        if last_token_only:
+            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)
+            n.rmsnorm_split(xl, self.norm, hl[0], hl[1], B, hid, eps)
+            lg = torch.mm(hl.view(2 * B, hid), self.lm_head.t(), out_dtype=f32)
+            return (lg[:B] + lg[B:]).view(B, 1, -1)
+        n.rmsnorm_split(x, self.norm, h2[0], h2[1], T, hid, eps)
+        lg = torch.mm(h2.view(2 * T, hid), self.lm_head.t(), out_dtype=f32)
+        return (lg[:T] + lg[T:]).view(B, q_len, -1)
 
     # ------------------------------------------------------------------------------------------
     def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,

@@ -152,6 +152,8 @@ class MptHIP(LlamaHIP):
 
     # ------------------------------------------------------------------------------------------
     def _forward_dense(self, ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers):
+        if self.precise_dense:
+            return self._forward_dense_split(ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers)
         n = _native
         dev = self.device
         c = self.config
@@ -190,6 +192,56 @@ class MptHIP(LlamaHIP):
             return torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
         n.layernorm(x, self.lnf, None, h16, T, hid, eps)
         return torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)
+
+    def _forward_dense_split(self, ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Many-row path with split-precision activations (see LlamaHIP._forward_dense_split)."""
+        n = _native
+        dev = self.device
+        c = self.config
+        H, D, hid = self.H, self.D, c.hidden_size
+        T = B * q_len
+        W = 3 * hid
+        eps = c.layer_norm_epsilon
+        f32 = torch.float32
+        cs = self._identity_rotation(T)
+        h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h2[0], T, hid, c.vocab_size)
+        x = h2[0].float()
+        attn2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)
+        act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
+        q16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        alibi = (kpos, self.slopes_log2)
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            n.layernorm_split(x, lw["ln1"], None, h2[0], h2[1], T, hid, eps)
+            qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
+            torch.add(qkv2[:T], qkv2[T:], out=qkv)
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            n.rope_append(qkv, q_len * W, W, q16, q_len * hid, hid, qkv[:, hid:], qkv[:, 2 * hid:], q_len * W, W,
+                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, H, D, q_len, past_len, arena.cap, True,
+                          q_out_lo=q16l)
+            n.attn_fwd(q16, q_len * hid, hid, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
+                       q_len * hid, hid, B, H, H, D, q_len, past_len, self.softmax_scale, ws, alibi=alibi, q_lo=q16l,
+                       out_lo=attn2[1])
+            o2 = torch.mm(attn2.view(2 * T, hid), lw["wo"].t(), out_dtype=f32)
+            n.add3(x, o2[:T], o2[T:], T * hid)
+            n.layernorm_split(x, lw["ln2"], None, h2[0], h2[1], T, hid, eps)
+            h4 = torch.mm(h2.view(2 * T, hid), lw["w1"].t(), out_dtype=f32)
+            n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
+            d2 = torch.mm(act2.view(2 * T, 4 * hid), lw["w2"].t(), out_dtype=f32)
+            n.add3(x, d2[:T], d2[T:], T * hid)
+        if last_token_only:
+            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)
+            n.layernorm_split(xl, self.lnf, None, hl[0], hl[1], B, hid, eps)
+            lg = torch.mm(hl.view(2 * B, hid), self.lm_head.t(), out_dtype=f32)
+            return (lg[:B] + lg[B:]).view(B, 1, -1)
+        n.layernorm_split(x, self.lnf, None, h2[0], h2[1], T, hid, eps)
+        lg = torch.mm(h2.view(2 * T, hid), self.lm_head.t(), out_dtype=f32)
+        return (lg[:T] + lg[T:]).view(B, q_len, -1)
 
     def _forward_skinny(self, ids, kpos, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
         n = _native

@@ -8,6 +8,7 @@ these sizes in seconds), checked through size-independent properties of the path
 * prefill + one decode step == prefill of the longer prompt (in-place KV append, hipGraph decode).
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -199,3 +200,50 @@ def test_mpt_7b_shape_alibi_cached_equals_nocache_and_oracle():
     oerr = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
     print(f"[mpt-7b shape] S={S} q={len(ids)} cached vs no-cache {err:.2e}, vs numpy oracle {oerr:.2e}")
     assert S2 == S and err < TOL and oerr < TOL
+
+
+@pytest.mark.skipif(os.environ.get("PC_FULL_PARITY", "0") != "1",
+                    reason="minutes of host BLAS time: set PC_FULL_PARITY=1 (result recorded in profiles/r01_full_depth_parity.txt)")
+def test_full_depth_7b_end_to_end_vs_numpy_oracle():
+    """All 32 layers at the true llama2-7b shape, end to end: schema encode (trunk reuse, dense + weight-streaming
+    paths), gather, cached prefill -- against the numpy oracle doing the reference's full per-scaffold encode in
+    fp32 on the host.  Small persona-structured schema so the oracle finishes in minutes."""
+    import time
+    from oracle import engine_oracle as eo
+    from oracle.llama_oracle import LlamaOracle, OracleConfig
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import random_weights_device
+    shape = SHAPES["llama2-7b"]
+    w = random_weights_device(shape, "cuda:0", torch.float16, seed=5)
+    lm = Llama2(name="llama2-7b", shape=shape, weights=w, device="cuda:0")
+    sp, pp = synth.persona_like("p7", system_len=120, intro_len=30,
+                                traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))), question_len=8, seed=9)
+    fmt = lm.get_formatter()
+    eng = CacheEngine(2048, lm)
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+    ids, pos, _, cache = eng.process(prompt)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    got = out.logits[0].cpu().numpy()
+    t0 = time.perf_counter()
+    cfg = OracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, intermediate_size=shape.intermediate_size,
+                       num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                       num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
+                       rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
+    model = LlamaOracle(cfg, {k: v.float().cpu().numpy() for k, v in w.items()})
+    sc = eng.get_schema("p7")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
+    err = np.abs(got - logits[0]).max()
+    st = eng.schemas["p7"].encode_stats
+    print(f"[full depth 7b] L=32 S={S} q={len(ids)} passes={st['total_passes']} (trunk-shared {st['trunk_shared_passes']}) "
+          f"max|dlogit| vs numpy oracle = {err:.2e}  (max|logit| {np.abs(logits).max():.2f}; oracle {time.perf_counter() - t0:.0f} s)")
+    assert err < TOL

@@ -48,7 +48,10 @@ class LlamaHIP:
 
     SKINNY_MAX_ROWS = 64   # B*q_len at or below this: split-precision weight-streaming kernels inside one hipGraph
     NORM_FUSED_MAX_ROWS = 16   # ... and at or below this the RMSNorms are folded into the projections
-    MID_MAX_ROWS = 512     # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly
+    # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly; above, the stacked
+    # [hi; lo] hipBLASLt projections of the many-row path are faster (crossover measured at ~256 rows: q = 130:
+    # 9.5 vs 9.8 ms, q = 258: 13.9 vs 13.9 ms, q = 402: 17.8 vs 17.2 ms; the kernel itself takes up to 512)
+    MID_MAX_ROWS = int(os.environ.get("PC_MID_MAX_ROWS", "256"))
 
     def _setup(self, shape, device, decode_headroom: int) -> None:
         """State every architecture shares: device, KV-arena headroom, workspace and the hipGraph cache."""

@@ -228,7 +228,7 @@ int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, i
  *   pc_silu_mul_split   silu(g) * u of (gate_up + gate_up2) -> (hi, lo);  pc_gelu_split  gelu(x + x2) -> (hi, lo)
  *   pc_add3             x += a + b  (fp32 residual stream)
  *   pc_attn_fwd_ex      pc_attn_fwd / pc_attn_fwd_alibi with an optional row-major `out_lo` plane next to `out`
- *                       (key_pos / slopes_log2 NULL: no ALiBi). */
+ *                       (key_pos / slopes_log2 NULL: no ALiBi) and optional k_lo / v_lo residual planes, see below. */
 int pc_rmsnorm_split(const float* x, const void* weight, void* out_hi, void* out_lo, int32_t rows, int32_t hidden,
                      float eps, void* stream);
 int pc_layernorm_split(const float* x, const void* weight, const void* bias, void* out_hi, void* out_lo, int32_t rows,
@@ -242,7 +242,20 @@ int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int6
                    int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
                    int32_t q_len, int32_t past_len, float softmax_scale, void* workspace, int64_t workspace_bytes,
                    const int32_t* past_len_dev, const float* key_pos, int64_t key_pos_batch_stride,
-                   const float* slopes_log2, void* stream);
+                   const float* slopes_log2, const void* k_lo, const void* v_lo, int64_t lo_batch_stride,
+                   int64_t lo_head_stride, int32_t lo_row0, void* stream);
+/* pc_rope_append_ex -- pc_rope_append that also writes the fp16 residuals of the appended K / V rows (k_lo, v_lo,
+ *   both or neither: [B][Hkv][rows][D] with the given strides, row = key index - lo_row0; lo_row0 = past_len for a
+ *   compact buffer of the new rows, 0 for an arena-shaped one that also carries residuals of earlier rows).  pc_attn_fwd_ex consumes them: the keys / values a pass appends enter
+ *   its own attention in split precision, as in the reference's fp32 pass (llama2.py:361-388), while the arena keeps the
+ *   fp16 value the reference stages (cache_engine.py:105-106).  Staged rows (< past_len) have no residual. */
+int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                      int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new, const void* v_new,
+                      int64_t kv_new_batch_stride, int64_t kv_new_token_stride, void* k_arena, void* v_arena,
+                      int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
+                      int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
+                      const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
+                      int64_t lo_head_stride, int32_t lo_row0, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

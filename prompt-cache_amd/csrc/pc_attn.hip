@@ -57,6 +57,9 @@ struct AttnParams {
     // ALiBi (MPT, promptcache/model/mpt.py:90-110, :160-175): score += slope[h] * key_pos[b][key]; both pre-scaled to
     // the log2 domain by the host (slope * log2 e), key_pos = the POSITION ID of each cached / new key
     const float* key_pos; int64_t kp_bs; const float* slopes;
+    // optional fp16 residuals of the NEW keys / values of this pass (rows past_len ..), compact [B][Hkv][q_len][D]:
+    // the pass's own K/V then enter the MFMAs in split precision (staged rows are exact fp16 as the reference stages them)
+    const _Float16* k_lo; const _Float16* v_lo; int64_t lo_bs, lo_hs; int32_t lo_row0;   // row = key - lo_row0
     int32_t H, Hkv, q_len, past_len, nsplit;
     int32_t xcd_remap, nqblk, nbatch;
     float scale_log2;
@@ -89,8 +92,9 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
 // enter the MFMAs as split-precision pairs (hi = fp16(x), lo = fp16(x - hi)), i.e. two MFMAs per fragment.
 // Against the reference's fp32 CPU path this removes the two largest rounding terms of the kernel (fp16 Q:
 // 2.5e-3, fp16 P: 1.7e-3 max |delta logit| on a 7b-shaped layer); K/V stay fp16 as staged.
-template <int D, bool HP, bool ALIBI = false>
+template <int D, bool HP, bool ALIBI = false, bool KVLO = false>
 __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
+    static_assert(!KVLO || HP, "K/V residual planes go with split-precision Q and P");
     constexpr int KS = D / 32;   // MFMA k-steps across the head dim (QK^T)
     constexpr int DB = D / 16;   // 16-wide head-dim blocks of O^T
     constexpr int CPR = D / 8;   // 16-byte chunks per K/V row
@@ -99,6 +103,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
 
     __shared__ __attribute__((aligned(16))) _Float16 Kl[kTK * D];
     __shared__ __attribute__((aligned(16))) _Float16 Vl[kTK * D];
+    __shared__ __attribute__((aligned(16))) _Float16 Kll[KVLO ? kTK * D : 8];     // residual tiles (KVLO)
+    __shared__ __attribute__((aligned(16))) _Float16 Vll[KVLO ? kTK * D : 8];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     int qblk, h, b, split;
@@ -164,6 +170,10 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     // Register-staged, software-pipelined tiles: the global loads of tile i+1 are issued right after tile i
     // has been written to LDS and stay in flight while tile i is consumed (HBM latency hides under the MFMAs).
     u32x4 kr[LPT], vr[LPT];
+    [[maybe_unused]] u32x4 krl[KVLO ? LPT : 1], vrl[KVLO ? LPT : 1];
+    [[maybe_unused]] const _Float16* klb = KVLO ? p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
+    [[maybe_unused]] const _Float16* vlb = KVLO ? p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
+    [[maybe_unused]] const int lo_row0 = KVLO ? p.lo_row0 : 0;
     auto issue_loads = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -172,9 +182,14 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             const int key = key0 + row;
             u32x4 z = {0u, 0u, 0u, 0u};
             kr[i] = z; vr[i] = z;   // zero-fill rows at/after kend: a garbage V row would turn 0 * NaN into NaN
+            if (KVLO) { krl[i] = z; vrl[i] = z; }
             if (key < kend) {
                 kr[i] = *(const u32x4*)(kbase + (int64_t)key * D + col * 8);
                 vr[i] = *(const u32x4*)(vbase + (int64_t)key * D + col * 8);
+                if (KVLO && key >= lo_row0) {            // rows before lo_row0 are exact fp16 (staged module KV)
+                    krl[i] = *(const u32x4*)(klb + (int64_t)(key - lo_row0) * D + col * 8);
+                    vrl[i] = *(const u32x4*)(vlb + (int64_t)(key - lo_row0) * D + col * 8);
+                }
             }
         }
     };
@@ -190,8 +205,13 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             // touches then sit in 8 different 32-B windows of the 256-B bank row instead of the same one (the
             // unrotated tile measured SQ_LDS_BANK_CONFLICT = 68 % of SQ_LDS_IDX_ACTIVE: an 8-way conflict)
             *(u32x4*)(Vl + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
+            if (KVLO) {
+                *(u32x4*)(Kll + row * D + ((col ^ (row & (CPR - 1))) << 3)) = krl[i];
+                *(u32x4*)(Vll + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vrl[i];
+            }
         }
         __syncthreads();
+        [[maybe_unused]] const bool tile_lo = KVLO && key0 + kTK > lo_row0;       // any key with a residual in the tile
         if (key0 + kTK < kend) issue_loads(key0 + kTK);
 
         if (wave_active && key0 < wave_vis_end) {
@@ -208,6 +228,12 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
                     const h8 a = *(const h8*)(Kl + row * D + ((chunk ^ (row & (CPR - 1))) << 3));
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], acc, 0, 0, 0);
                     if (HP) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qfl[ks], acc, 0, 0, 0);
+                    if (KVLO) {
+                        if (tile_lo) {
+                            const h8 al = *(const h8*)(Kll + row * D + ((chunk ^ (row & (CPR - 1))) << 3));
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qf[ks], acc, 0, 0, 0);
+                        }
+                    }
                 }
                 f4 kb4 = {0.f, 0.f, 0.f, 0.f};
                 if (ALIBI) {        // positions of this lane's 4 keys (rows past kend are masked below; the buffer
@@ -266,6 +292,15 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
                     const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
                     if (HP) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
+                    if (KVLO) {
+                        if (tile_lo) {
+                            const _Float16* vpl = Vll + (vp - Vl);
+                            const h4 llo = lds_tr_read(vpl);
+                            const h4 lhi = lds_tr_read(vpl + 16 * D);
+                            const h8 al = {llo[0], llo[1], llo[2], llo[3], lhi[0], lhi[1], lhi[2], lhi[3]};
+                            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, pb[t], o[db], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -622,7 +657,7 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
     // a q_lo plane asks for split-precision Q and P at any q_len (the many-row path in its precise mode): 16-row kernel
     const bool want_hp = p.q_len <= kQB || p.q_lo != nullptr;
-    const bool rows32 = !p.q_lo && use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
+    const bool rows32 = !p.q_lo && !p.k_lo && use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
     p.nqblk = pc_ceil_div(p.q_len, rows32 ? kQB32 : kQB);
     p.nbatch = B;
     p.xcd_remap = (p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
@@ -631,6 +666,9 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     if (rows32) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
+    } else if (p.k_lo) {
+        if (p.key_pos) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true, true>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, true>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.key_pos) {
         if (want_hp) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(kThreads), 0, stream, p);
@@ -667,7 +705,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
                   int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
                   int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
-                  const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo, void* stream) {
+                  const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo,
+                  const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -687,6 +726,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.of_hi = (_Float16*)out_frag_hi; p.of_lo = (_Float16*)out_frag_lo;
     p.past_len_dev = past_len_dev;
     p.key_pos = key_pos; p.kp_bs = key_pos_batch_stride; p.slopes = slopes;
+    p.k_lo = (const _Float16*)k_lo; p.v_lo = (const _Float16*)v_lo; p.lo_bs = lo_bs; p.lo_hs = lo_hs; p.lo_row0 = lo_row0;
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
@@ -715,7 +755,8 @@ PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_strid
                           void* stream) {
     return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, nullptr, 0, nullptr, nullptr, stream);
+                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, nullptr, 0, nullptr, nullptr, nullptr,
+                         nullptr, 0, 0, 0, stream);
 }
 
 PC_EXPORT int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
@@ -730,7 +771,7 @@ PC_EXPORT int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch
     return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
                          workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
-                         slopes_log2, nullptr, stream);
+                         slopes_log2, nullptr, nullptr, nullptr, 0, 0, 0, stream);
 }
 
 PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
@@ -738,13 +779,18 @@ PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_st
                              void* out_lo, int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H,
                              int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
                              int64_t workspace_bytes, const int32_t* past_len_dev, const float* key_pos,
-                             int64_t key_pos_batch_stride, const float* slopes_log2, void* stream) {
+                             int64_t key_pos_batch_stride, const float* slopes_log2, const void* k_lo, const void* v_lo,
+                             int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0, void* stream) {
     PC_REQUIRE(out, PC_ERR_ARG, "pc_attn_fwd_ex: row-major output required");
+    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || (q_lo && past_len_dev == nullptr)), PC_ERR_ARG,
+               "pc_attn_fwd_ex: k_lo / v_lo go together, need q_lo (split-precision Q) and a host past_len");
+    PC_REQUIRE(!k_lo || (lo_row0 >= 0 && lo_row0 <= past_len && lo_head_stride % 8 == 0), PC_ERR_ARG,
+               "pc_attn_fwd_ex: lo_row0 must lie in [0, past_len] and the lo strides keep 16-byte alignment");
     PC_REQUIRE((key_pos == nullptr) == (slopes_log2 == nullptr), PC_ERR_ARG, "pc_attn_fwd_ex: key_pos and slopes go together");
     PC_REQUIRE(!key_pos || (key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0), PC_ERR_ARG,
                "pc_attn_fwd_ex: key_pos rows not 16-byte aligned");
     return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
                          workspace_bytes, past_len_dev, nullptr, nullptr, key_pos, key_pos_batch_stride, slopes_log2,
-                         out_lo, stream);
+                         out_lo, k_lo, v_lo, lo_batch_stride, lo_head_stride, lo_row0, stream);
 }

@@ -57,7 +57,11 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
     const TIn* __restrict__ k_new, const TIn* __restrict__ v_new, int64_t n_bs, int64_t n_ts,
     _Float16* __restrict__ k_arena, _Float16* __restrict__ v_arena, int64_t a_bs, int64_t a_hs,
     const float2* __restrict__ cs, int H, int Hkv, int D, int q_len, int past_len,
-    const int32_t* __restrict__ past_len_dev) {
+    const int32_t* __restrict__ past_len_dev, _Float16* __restrict__ k_lo, _Float16* __restrict__ v_lo, int64_t lo_bs,
+    int64_t lo_hs, int lo_row0) {
+    // k_lo / v_lo (optional): fp16 residuals of the appended K / V rows, [B][Hkv][rows][D] with strides lo_bs / lo_hs,
+    // row = key index - lo_row0 (lo_row0 = past_len: compact, new rows only; 0: arena-shaped) -- the pass's own
+    // keys in split precision for the attention of that pass (the arena keeps the fp16 value the reference stages)
     const int t = blockIdx.x, b = blockIdx.y;
     if (past_len_dev) past_len = *past_len_dev;
     const int half = D >> 1;
@@ -95,16 +99,25 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
                 *(h8*)(dl + c * 8) = rlo;
                 *(h8*)(dl + half + c * 8) = rhi;
             }
+            if (!is_q && k_lo) {
+                _Float16* dl = k_lo + b * lo_bs + h * lo_hs + (int64_t)(past_len + t - lo_row0) * D;
+                *(h8*)(dl + c * 8) = rlo;
+                *(h8*)(dl + half + c * 8) = rhi;
+            }
         } else {
             const int j = it - nq - nk;
             const int cpv = D >> 3;
             const int h = j / cpv, c = j - h * cpv;
             float x[8];
             load8<TIn>(v_new + b * n_bs + t * n_ts + (int64_t)h * D + c * 8, x);
-            h8 o;
+            h8 o, ol;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)x[e];
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (_Float16)x[e];
+                ol[e] = (_Float16)(x[e] - (float)o[e]);
+            }
             *(h8*)(v_arena + b * a_bs + h * a_hs + (int64_t)(past_len + t) * D + c * 8) = o;
+            if (v_lo) *(h8*)(v_lo + b * lo_bs + h * lo_hs + (int64_t)(past_len + t - lo_row0) * D + c * 8) = ol;
         }
     }
 }
@@ -122,13 +135,14 @@ PC_EXPORT int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs
     return pc_check_launch("rope_table_kernel");
 }
 
-PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
-                             int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
-                             const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
-                             void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
-                             const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                             int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
-                             void* stream) {
+namespace {
+int rope_append_impl(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                     int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
+                     const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
+                     void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                     const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                     int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
+                     void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG, "pc_rope_append: bad sizes");
     PC_REQUIRE(D > 0 && D % 16 == 0, PC_ERR_ARG, "pc_rope_append: head_dim must be a multiple of 16");
     if (q_len == 0) return PC_OK;
@@ -142,12 +156,45 @@ PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_to
                            (const float*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, (_Float16*)q_out_lo, qo_batch_stride,
                            qo_token_stride, (const float*)k_new, (const float*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
-                           arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev);
+                           arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev, (_Float16*)k_lo,
+                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0);
     else
         hipLaunchKernelGGL(rope_append_kernel<_Float16>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
                            (const _Float16*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, (_Float16*)q_out_lo, qo_batch_stride,
                            qo_token_stride, (const _Float16*)k_new, (const _Float16*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
-                           arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev);
+                           arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev, (_Float16*)k_lo,
+                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0);
     return pc_check_launch("rope_append_kernel");
+}
+}  // namespace
+
+PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                             int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
+                             const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
+                             void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                             const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                             int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
+                             void* stream) {
+    return rope_append_impl(q, q_batch_stride, q_token_stride, q_out, q_out_lo, qo_batch_stride, qo_token_stride, k_new, v_new,
+                            kv_new_batch_stride, kv_new_token_stride, k_arena, v_arena, arena_batch_stride,
+                            arena_head_stride, cs, B, H, Hkv, D, q_len, past_len, cap, in_is_f32, past_len_dev, nullptr,
+                            nullptr, 0, 0, 0, stream);
+}
+
+PC_EXPORT int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                                int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
+                                const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
+                                void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                                const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                                int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
+                                void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0,
+                                void* stream) {
+    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr), PC_ERR_ARG, "pc_rope_append_ex: k_lo and v_lo go together");
+    PC_REQUIRE(!k_lo || (lo_row0 >= 0 && lo_row0 <= past_len && lo_head_stride % 8 == 0), PC_ERR_ARG,
+               "pc_rope_append_ex: lo_row0 must lie in [0, past_len] and the lo strides keep 16-byte alignment");
+    return rope_append_impl(q, q_batch_stride, q_token_stride, q_out, q_out_lo, qo_batch_stride, qo_token_stride, k_new, v_new,
+                            kv_new_batch_stride, kv_new_token_stride, k_arena, v_arena, arena_batch_stride,
+                            arena_head_stride, cs, B, H, Hkv, D, q_len, past_len, cap, in_is_f32, past_len_dev, k_lo, v_lo,
+                            lo_batch_stride, lo_head_stride, lo_row0, stream);
 }

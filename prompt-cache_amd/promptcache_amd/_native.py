@@ -30,7 +30,9 @@ SIGNATURES = {
     "pc_attn_fwd_alibi": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "pc_attn_fwd_ex": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,
-                                 _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+                                 _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "pc_rope_append_ex": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
+                                    _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_rmsnorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_layernorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_silu_mul_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -125,7 +127,15 @@ def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Opt
 
 def rope_append(q, q_bs, q_ts, q_out, qo_bs, qo_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs,
                 B, H, Hkv, D, q_len, past_len, cap, in_is_f32: bool, past_len_dev=None, q_out_lo=None,
-                stream: Optional[int] = None) -> None:
+                stream: Optional[int] = None, kv_lo=None) -> None:
+    if kv_lo is not None:
+        rc = load().pc_rope_append_ex(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
+                                      v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
+                                      cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), _ptr(past_len_dev),
+                                      kv_lo[0].data_ptr(), kv_lo[1].data_ptr(), kv_lo[2], kv_lo[3], kv_lo[4],
+                                      current_stream() if stream is None else stream)
+        check(rc, "pc_rope_append_ex")
+        return
     rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
                                v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
                                cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), _ptr(past_len_dev),
@@ -139,9 +149,11 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None, out_lo=None) -> None:
+             alibi=None, out_lo=None, kv_lo=None) -> None:
     """``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
-    ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi)."""
+    ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi).
+    ``out_lo``: row-major residual plane of ``out``; ``kv_lo=(k_lo, v_lo, batch_stride, head_stride, row0)``: residuals of K/V rows from key index row0 on
+    (written by ``rope_append(..., kv_lo=...)``), both via pc_attn_fwd_ex."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
     if out_lo is not None:
@@ -150,6 +162,8 @@ def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q
                                    out.data_ptr(), out_lo.data_ptr(), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
                                    _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(kpos),
                                    0 if kpos is None else kpos.stride(0), _ptr(slopes),
+                                   None if kv_lo is None else kv_lo[0].data_ptr(), None if kv_lo is None else kv_lo[1].data_ptr(),
+                                   0 if kv_lo is None else kv_lo[2], 0 if kv_lo is None else kv_lo[3], 0 if kv_lo is None else kv_lo[4],
                                    current_stream() if stream is None else stream)
         check(rc, "pc_attn_fwd_ex")
         return

@@ -203,7 +203,8 @@ class SchemaCache:
         if shared:
             job = jobs[0]
             out = lm(input_ids=torch.tensor([job["token_ids"]], device=dev, dtype=torch.long),
-                     position_ids=torch.tensor([job["position_ids"]], device=dev, dtype=torch.long), use_cache=True)
+                     position_ids=torch.tensor([job["position_ids"]], device=dev, dtype=torch.long), use_cache=True,
+                     many_rows=True)
             trunk_arena = out.past_key_values.arena
             computed_tokens += len(job["token_ids"])
             if 0 in whole:                                   # this rank also owns the root pass: store from the same run
@@ -219,7 +220,7 @@ class SchemaCache:
             out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                      position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
                      attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
-                     use_cache=True)
+                     use_cache=True, many_rows=True)
             arena: KVArena = out.past_key_values.arena
             for row, i in enumerate(idxs):
                 encoded_tokens += len(jobs[i]["token_ids"])
@@ -238,6 +239,10 @@ class SchemaCache:
                 width = max(len(j["token_ids"]) for j in group) - n_pre
                 arena = KVArena(len(group), L, Hkv, n_pre + width, D, dev)
                 arena.buf[:, :, :, :, :n_pre].copy_(trunk_arena.buf[:, :, :, :, :n_pre].expand(len(group), -1, -1, -1, -1, -1))
+                if trunk_arena.lo is not None and trunk_arena.lo_len >= n_pre:   # the trunk's keys stay split-precision
+                    arena.with_lo().lo[:, :, :, :, :n_pre].copy_(
+                        trunk_arena.lo[:, :, :, :, :n_pre].expand(len(group), -1, -1, -1, -1, -1))
+                    arena.lo_len = n_pre
                 arena.length = n_pre
                 ids_pad, mask = pad_batch([j["token_ids"][n_pre:] for j in group], lm.eos_token_id)
                 pos_pad, _ = pad_batch([j["position_ids"][n_pre:] for j in group], 0)
@@ -246,7 +251,7 @@ class SchemaCache:
                 out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                          position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
                          attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
-                         past_key_values=arena.views(), use_cache=True)
+                         past_key_values=arena.views(), use_cache=True, many_rows=True)
                 arena = out.past_key_values.arena
                 for row, i in enumerate(idxs):
                     encoded_tokens += len(jobs[i]["token_ids"])

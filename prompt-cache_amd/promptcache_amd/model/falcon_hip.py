@@ -125,6 +125,12 @@ class FalconHIP(LlamaHIP):
         act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        # fp16 residuals of the K / V rows this pass appends (consumed by the same layer's attention, then overwritten)
+        lo_k = torch.empty((B, 1, q_len, D), dtype=self.dtype, device=dev)
+        lo_v = torch.empty((B, 1, q_len, D), dtype=self.dtype, device=dev)
+        # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
+        full_lo = arena.lo is not None and arena.lo_len == past_len
+        compact_lo = (lo_k, lo_v, 1 * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
         qkv = torch.empty((T, W), dtype=f32, device=dev)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
@@ -133,17 +139,20 @@ class FalconHIP(LlamaHIP):
             qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
             torch.add(qkv2[:T], qkv2[T:], out=qkv)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kv_lo = arena.lo_planes(li) if full_lo else compact_lo
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l)
+                          q_out_lo=q16l, kv_lo=kv_lo)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
-                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l, out_lo=attn2[1])
+                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l, out_lo=attn2[1], kv_lo=kv_lo)
             h4 = torch.mm(h2.view(2 * T, hid), lw["w1"].t(), out_dtype=f32)
             n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
             o2 = torch.mm(attn2.view(2 * T, H * D), lw["wo"].t(), out_dtype=f32)
             n.add3(x, o2[:T], o2[T:], T * hid)
             d2 = torch.mm(act2.view(2 * T, 4 * hid), lw["w2"].t(), out_dtype=f32)
             n.add3(x, d2[:T], d2[T:], T * hid)
+        if full_lo:
+            arena.lo_len = past_len + q_len
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)

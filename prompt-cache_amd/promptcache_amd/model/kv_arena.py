@@ -23,6 +23,20 @@ class KVArena:
         self.B, self.L, self.Hkv, self.cap, self.D = batch, n_layers, n_kv_heads, cap, head_dim
         self.buf = torch.empty((batch, n_layers, 2, n_kv_heads, cap, head_dim), device=device, dtype=dtype)
         self.length = 0
+        # optional second buffer of the same shape: the fp16 residuals (value - fp16(value)) of the rows a schema-encode
+        # pass appended, so that later rows of that pass -- and scaffolds encoded as suffixes over this pass's prefix --
+        # see those keys / values in split precision.  Never stored, never staged: the module KV is `buf`.
+        self.lo: Optional[torch.Tensor] = None
+        self.lo_len = 0               # rows [0, lo_len) of `lo` hold valid residuals
+
+    def with_lo(self) -> "KVArena":
+        if self.lo is None:
+            self.lo = torch.empty_like(self.buf)
+        return self
+
+    def lo_planes(self, layer: int):
+        """(k_lo, v_lo, batch_stride, head_stride, row0) for pc_rope_append_ex / pc_attn_fwd_ex."""
+        return (self.lo[:, layer, 0], self.lo[:, layer, 1], self.batch_stride, self.head_stride, 0)
 
     # strides in elements
     @property
@@ -48,6 +62,9 @@ class KVArena:
         """A larger arena holding the same ``length`` rows (rare path: generation ran past ``cap``)."""
         a = KVArena(self.B, self.L, self.Hkv, new_cap, self.D, self.buf.device, self.buf.dtype)
         a.buf[:, :, :, :, :self.length].copy_(self.buf[:, :, :, :, :self.length])
+        if self.lo is not None:
+            a.with_lo().lo[:, :, :, :, :self.length].copy_(self.lo[:, :, :, :, :self.length])
+            a.lo_len = self.lo_len
         a.length = self.length
         return a
 
@@ -113,6 +130,7 @@ def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Opti
             st, k0.storage_offset(), (B, n_layers, 2, Hkv, cap, D),
             (n_layers * 2 * plane, 2 * plane, plane, cap * D, D, 1))
         a.length = S
+        a.lo, a.lo_len = None, 0
         return a, S
     except Exception:
         return None

@@ -156,12 +156,18 @@ class LlamaHIP:
     @torch.inference_mode()
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                  past_key_values=None, attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True,
-                 last_token_only: bool = False, num_layers: Optional[int] = None, **_unused) -> CausalLMOutput:
+                 last_token_only: bool = False, num_layers: Optional[int] = None, many_rows: bool = False,
+                 **_unused) -> CausalLMOutput:
+        """``many_rows``: take the stacked-GEMM path for more than 64 rows even where the row-split kernel would be
+        faster -- it alone keeps the pass's own K/V in split precision, which is what a schema encode wants (its K/V
+        are the product)."""
         n = _native
         dev = self.device
         input_ids = input_ids.to(dev)
         B, q_len = input_ids.shape
         arena, past_len = self._resolve_arena(past_key_values, B, q_len)
+        if many_rows and self.precise_dense and past_key_values is None:
+            arena.with_lo()           # a schema-encode pass: keep the residuals of every row it appends
         if position_ids is None:  # llama2.py:859-864
             position_ids = torch.arange(past_len, past_len + q_len, device=dev).unsqueeze(0).expand(B, q_len)
         position_ids = position_ids.to(dev).view(-1, q_len)
@@ -181,7 +187,7 @@ class LlamaHIP:
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
-        if self.skinny and T <= self.MID_MAX_ROWS:
+        if self.skinny and T <= self.MID_MAX_ROWS and not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS):
             logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
             arena.length = past_len + q_len
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
@@ -266,6 +272,12 @@ class LlamaHIP:
         act2 = torch.empty((2, T, inter), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        # fp16 residuals of the K / V rows this pass appends (consumed by the same layer's attention, then overwritten)
+        lo_k = torch.empty((B, Hkv, q_len, D), dtype=self.dtype, device=dev)
+        lo_v = torch.empty((B, Hkv, q_len, D), dtype=self.dtype, device=dev)
+        # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
+        full_lo = arena.lo is not None and arena.lo_len == past_len
+        compact_lo = (lo_k, lo_v, Hkv * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
         qkv = torch.empty((T, W), dtype=f32, device=dev)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
@@ -274,13 +286,14 @@ class LlamaHIP:
             qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
             torch.add(qkv2[:T], qkv2[T:], out=qkv)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kv_lo = arena.lo_planes(li) if full_lo else compact_lo
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l)
+                          q_out_lo=q16l, kv_lo=kv_lo)
             # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
-                       out_lo=attn2[1])
+                       out_lo=attn2[1], kv_lo=kv_lo)
             o2 = torch.mm(attn2.view(2 * T, H * D), lw["wo"].t(), out_dtype=f32)
             n.add3(x, o2[:T], o2[T:], T * hid)
             n.rmsnorm_split(x, lw["ln2"], h2[0], h2[1], T, hid, eps)
@@ -288,6 +301,8 @@ class LlamaHIP:
             n.silu_mul_split(gu2[:T], gu2[T:], act2[0], act2[1], T, inter)
             d2 = torch.mm(act2.view(2 * T, inter), lw["wdown"].t(), out_dtype=f32)
             n.add3(x, d2[:T], d2[T:], T * hid)
+        if full_lo:
+            arena.lo_len = past_len + q_len
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)

@@ -81,11 +81,13 @@ class MptHIP(LlamaHIP):
     @torch.inference_mode()
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None, past_key_values=None,
                  attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True, last_token_only: bool = False,
-                 num_layers: Optional[int] = None, **_unused) -> CausalLMOutput:
+                 num_layers: Optional[int] = None, many_rows: bool = False, **_unused) -> CausalLMOutput:
         dev = self.device
         input_ids = input_ids.to(dev)
         B, q_len = input_ids.shape
         arena, past_len = self._resolve_arena(past_key_values, B, q_len)
+        if many_rows and self.precise_dense and past_key_values is None:
+            arena.with_lo()
         kv_len = past_len + q_len
         if position_ids is None:
             if past_len:
@@ -109,7 +111,7 @@ class MptHIP(LlamaHIP):
         else:
             kpos = torch.zeros((B, self._kpos_cols(arena.cap)), dtype=torch.float32, device=dev)
             kpos[:, :kv_len] = position_ids.to(torch.float32)
-            if self.skinny and T <= self.MID_MAX_ROWS:
+            if self.skinny and T <= self.MID_MAX_ROWS and not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS):
                 logits = self._forward_skinny(ids, kpos, None, arena, B, q_len, past_len, last_token_only, num_layers)
             else:
                 logits = self._forward_dense(ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers)
@@ -211,6 +213,12 @@ class MptHIP(LlamaHIP):
         act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        # fp16 residuals of the K / V rows this pass appends (consumed by the same layer's attention, then overwritten)
+        lo_k = torch.empty((B, H, q_len, D), dtype=self.dtype, device=dev)
+        lo_v = torch.empty((B, H, q_len, D), dtype=self.dtype, device=dev)
+        # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
+        full_lo = arena.lo is not None and arena.lo_len == past_len
+        compact_lo = (lo_k, lo_v, H * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
         qkv = torch.empty((T, W), dtype=f32, device=dev)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         alibi = (kpos, self.slopes_log2)
@@ -220,12 +228,13 @@ class MptHIP(LlamaHIP):
             qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
             torch.add(qkv2[:T], qkv2[T:], out=qkv)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kv_lo = arena.lo_planes(li) if full_lo else compact_lo
             n.rope_append(qkv, q_len * W, W, q16, q_len * hid, hid, qkv[:, hid:], qkv[:, 2 * hid:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, H, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l)
+                          q_out_lo=q16l, kv_lo=kv_lo)
             n.attn_fwd(q16, q_len * hid, hid, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * hid, hid, B, H, H, D, q_len, past_len, self.softmax_scale, ws, alibi=alibi, q_lo=q16l,
-                       out_lo=attn2[1])
+                       out_lo=attn2[1], kv_lo=kv_lo)
             o2 = torch.mm(attn2.view(2 * T, hid), lw["wo"].t(), out_dtype=f32)
             n.add3(x, o2[:T], o2[T:], T * hid)
             n.layernorm_split(x, lw["ln2"], None, h2[0], h2[1], T, hid, eps)
@@ -233,6 +242,8 @@ class MptHIP(LlamaHIP):
             n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
             d2 = torch.mm(act2.view(2 * T, 4 * hid), lw["w2"].t(), out_dtype=f32)
             n.add3(x, d2[:T], d2[T:], T * hid)
+        if full_lo:
+            arena.lo_len = past_len + q_len
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)

@@ -72,5 +72,12 @@ def main(layers=32, qlen=8):
     print(f"(b) prefill on oracle-staged KV  max|dlogit| = {np.abs(out2.logits[0].cpu().numpy() - logits[0]).max():.3e}")
 
 
+    # (d) the no-cache path: every token re-encoded, positions range(N) (cache_engine.py:476-493)
+    nids, npos, _, _ = eng.process(prompt, no_cache=True)
+    out3 = lm(input_ids=torch.tensor([list(nids)], device="cuda"), position_ids=torch.tensor([npos], device="cuda"), use_cache=True)
+    lg3, _ = model.forward(np.asarray([list(nids)]), np.asarray([npos]))
+    print(f"(d) no-cache, {len(nids)} tokens      max|dlogit| = {np.abs(out3.logits[0].cpu().numpy() - lg3[0]).max():.3e}")
+
+
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 8)

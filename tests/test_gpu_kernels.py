@@ -807,3 +807,92 @@ def test_attn_alibi_matches_reference_math(B, H, D, q_len, past):
     ref = (torch.softmax(s, dim=-1) @ vd).permute(0, 2, 1, 3).reshape(B, q_len, H * D)
     err = (out.double() - ref).abs().max().item()
     assert err < (3e-3 if q_len > 64 else 2e-3), err
+
+
+# ---------------------------------------------------------------------------------------------------
+# split-precision many-row path: elementwise ops with (hi, lo) outputs, K/V residual planes in the attention
+# ---------------------------------------------------------------------------------------------------
+
+def test_split_elementwise_ops():
+    n = _n()
+    rng = np.random.default_rng(61)
+    T, hid, inter = 37, 512, 1376
+    x = torch.from_numpy((2.0 * rng.standard_normal((T, hid), dtype=np.float32) + 0.3)).to(DEV)
+    w = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(hid, dtype=np.float32)).astype(np.float16)).to(DEV)
+    b = torch.from_numpy((0.3 * rng.standard_normal(hid, dtype=np.float32)).astype(np.float16)).to(DEV)
+    hi = torch.empty((T, hid), dtype=torch.float16, device=DEV); lo = torch.empty_like(hi)
+    n.rmsnorm_split(x, w, hi, lo, T, hid, 1e-5)
+    xd = x.double()
+    ref = xd * torch.rsqrt((xd * xd).mean(1, keepdim=True) + 1e-5) * w.double()
+    assert ((hi.double() + lo.double()) - ref).abs().max().item() < 2e-6 * float(ref.abs().max())
+    assert (hi.double() - ref).abs().max().item() > 1e-4           # the hi plane alone is only fp16-accurate
+    n.layernorm_split(x, w, b, hi, lo, T, hid, 1e-5)
+    assert ((hi.double() + lo.double()) - _ln_ref(x, w.float(), b.float(), 1e-5)).abs().max().item() < 5e-6 * 5
+    # silu(g)*u of the sum of two addends
+    a1 = torch.from_numpy(rng.standard_normal((T, 2 * inter), dtype=np.float32)).to(DEV)
+    a2 = torch.from_numpy((1e-3 * rng.standard_normal((T, 2 * inter), dtype=np.float32))).to(DEV)
+    oh = torch.empty((T, inter), dtype=torch.float16, device=DEV); ol = torch.empty_like(oh)
+    n.silu_mul_split(a1, a2, oh, ol, T, inter)
+    gsum = (a1 + a2).double()
+    ref = torch.nn.functional.silu(gsum[:, :inter]) * gsum[:, inter:]
+    assert ((oh.double() + ol.double()) - ref).abs().max().item() < 3e-6 * max(1.0, float(ref.abs().max()))
+    gh = torch.empty((T, 2 * inter), dtype=torch.float16, device=DEV); gl = torch.empty_like(gh)
+    n.gelu_split(a1, a2, gh, gl, T * 2 * inter)
+    ref = torch.nn.functional.gelu(gsum)
+    assert ((gh.double() + gl.double()) - ref).abs().max().item() < 3e-6 * max(1.0, float(ref.abs().max()))
+    y = x.clone()
+    p1, p2 = torch.randn((T, hid), device=DEV), torch.randn((T, hid), device=DEV)
+    n.add3(y, p1, p2, T * hid)
+    assert torch.allclose(y, x + p1 + p2, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past", [(1, 4, 4, 128, 300, 0), (1, 4, 2, 128, 100, 70), (2, 2, 2, 64, 70, 33), (1, 8, 8, 128, 16, 200)])
+def test_attn_split_precision_qkv(B, H, Hkv, D, q_len, past):
+    """pc_rope_append_ex + pc_attn_fwd_ex: Q, P and the pass's own K/V rows in split precision.  Against fp64 attention
+    over the un-rounded new K/V (staged rows are fp16 as the reference stages them) the error must be far below what
+    fp16 K/V of the new rows costs."""
+    n = _n()
+    rng = np.random.default_rng(62)
+    T, cap, Wd = B * q_len, past + q_len + 5, (H + 2 * Hkv) * D
+    qkv = torch.from_numpy(rng.standard_normal((T, Wd), dtype=np.float32)).to(DEV)
+    arena = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    arena[:, :, :, :past] = torch.from_numpy(rng.standard_normal((B, 2, Hkv, past, D), dtype=np.float32)).to(DEV).half()
+    pos = torch.from_numpy(np.tile(np.arange(past, past + q_len, dtype=np.int32), B)).to(DEV)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(pos, _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    q16 = torch.empty((T, H * D), dtype=torch.float16, device=DEV); q16l = torch.empty_like(q16)
+    klo = torch.empty((B, Hkv, q_len, D), dtype=torch.float16, device=DEV); vlo = torch.empty_like(klo)
+    lo = (klo, vlo, Hkv * q_len * D, q_len * D, past)
+    n.rope_append(qkv, q_len * Wd, Wd, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * Wd, Wd,
+                  arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, cs, B, H, Hkv, D, q_len, past, cap, True,
+                  q_out_lo=q16l, kv_lo=lo)
+    out = torch.empty((B, q_len, H * D), dtype=torch.float16, device=DEV); out_lo = torch.empty_like(out)
+    ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, past + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+    n.attn_fwd(q16, q_len * H * D, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, out, q_len * H * D, H * D,
+               B, H, Hkv, D, q_len, past, 1.0 / np.sqrt(D), ws, q_lo=q16l, out_lo=out_lo, kv_lo=lo)
+    # fp64 reference on the exact rotated q / new k / new v
+    def rot(t):   # [T, heads, D]
+        c, s_ = cs[..., 0].double(), cs[..., 1].double()
+        c, s_ = torch.cat([c, c], 1)[:, None], torch.cat([s_, s_], 1)[:, None]
+        return t * c + torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1) * s_
+    qd = rot(qkv[:, :H * D].double().view(T, H, D)).view(B, q_len, H, D).permute(0, 2, 1, 3)
+    kn = rot(qkv[:, H * D:(H + Hkv) * D].double().view(T, Hkv, D)).view(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    vn = qkv[:, (H + Hkv) * D:].double().view(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    K = torch.cat([arena[:, 0, :, :past].double(), kn], 2).repeat_interleave(H // Hkv, 1)
+    V = torch.cat([arena[:, 1, :, :past].double(), vn], 2).repeat_interleave(H // Hkv, 1)
+    s = qd @ K.transpose(2, 3) / np.sqrt(D)
+    idx = torch.arange(q_len, device=DEV)
+    mask = torch.ones((q_len, past + q_len), dtype=torch.bool, device=DEV)
+    mask[:, past:] = idx[None, :] <= idx[:, None]
+    ref = (torch.softmax(s.masked_fill(~mask, float("-inf")), -1) @ V).permute(0, 2, 1, 3).reshape(B, q_len, H * D)
+    err = ((out.double() + out_lo.double()) - ref).abs().max().item()
+    # what rounding the new K/V to fp16 alone would cost
+    Kh = torch.cat([arena[:, 0, :, :past].double(), kn.half().double()], 2).repeat_interleave(H // Hkv, 1)
+    Vh = torch.cat([arena[:, 1, :, :past].double(), vn.half().double()], 2).repeat_interleave(H // Hkv, 1)
+    s2 = qd @ Kh.transpose(2, 3) / np.sqrt(D)
+    ref16 = (torch.softmax(s2.masked_fill(~mask, float("-inf")), -1) @ Vh).permute(0, 2, 1, 3).reshape(B, q_len, H * D)
+    floor16 = (ref16 - ref).abs().max().item()
+    assert err < 3e-5 and err < 0.25 * floor16, (err, floor16)
+    # the arena itself holds the fp16 value (what gets stored / staged)
+    assert torch.equal(arena[:, 0, :, past:past + q_len], kn.half()[:, :, :, :].to(arena.dtype)) or \
+        (arena[:, 0, :, past:past + q_len].double() - kn).abs().max().item() < 4e-3

@@ -247,3 +247,53 @@ def test_full_depth_7b_end_to_end_vs_numpy_oracle():
     print(f"[full depth 7b] L=32 S={S} q={len(ids)} passes={st['total_passes']} (trunk-shared {st['trunk_shared_passes']}) "
           f"max|dlogit| vs numpy oracle = {err:.2e}  (max|logit| {np.abs(logits).max():.2f}; oracle {time.perf_counter() - t0:.0f} s)")
     assert err < TOL
+
+
+@pytest.mark.skipif(os.environ.get("PC_FULL_PARITY", "0") != "1", reason="minutes of host BLAS time: set PC_FULL_PARITY=1")
+@pytest.mark.parametrize("family", ["falcon", "mpt"])
+def test_full_depth_falcon_mpt_end_to_end_vs_numpy_oracle(family):
+    """32 layers at the true falcon-7b / mpt-7b layer shapes (small vocab), end to end against the numpy oracles."""
+    import time
+    from oracle import engine_oracle as eo
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Falcon, Mpt
+    from promptcache_amd.model.config import FalconShape, MptShape
+    from promptcache_amd.model.weights import make_falcon_weights_np, make_mpt_weights_np
+    if family == "falcon":
+        from oracle.falcon_oracle import FalconOracle, FalconOracleConfig
+        shape = FalconShape(vocab_size=4096, hidden_size=4544, num_hidden_layers=32, num_attention_heads=71, name="falcon-7b-32l")
+        w16 = make_falcon_weights_np(shape, 21, 1.0)
+        lm = Falcon(name=shape.name, shape=shape, weights=w16, device="cuda:0")
+        model = FalconOracle(FalconOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
+                                                shape.layer_norm_epsilon, shape.rope_theta, lm.hf_model.inv_freq_cpu.numpy()),
+                             {k: v.astype(np.float32) for k, v in w16.items()})
+    else:
+        from oracle.mpt_oracle import MptOracle, MptOracleConfig
+        shape = MptShape(vocab_size=4096, hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, name="mpt-7b-32l")
+        w16 = make_mpt_weights_np(shape, 22, 1.0)
+        lm = Mpt(name=shape.name, shape=shape, weights=w16, device="cuda:0")
+        model = MptOracle(MptOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
+                                          shape.layer_norm_epsilon, shape.alibi_bias_max), {k: v.astype(np.float32) for k, v in w16.items()})
+    sp, pp = synth.persona_like("pf", system_len=100, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57))),
+                                question_len=8, seed=10)
+    fmt = lm.get_formatter()
+    eng = CacheEngine(2048, lm)
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+    full = lm.use_full_position_ids
+    ids, pos, _, cache = eng.process(prompt, return_full_position_ids=full)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    t0 = time.perf_counter()
+    sc = eng.get_schema("pf")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
+    err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    print(f"[full depth {family}] L=32 S={S} q={len(ids)} max|dlogit| vs numpy oracle = {err:.2e} "
+          f"(max|logit| {np.abs(logits).max():.2f}; oracle {time.perf_counter() - t0:.0f} s)")
+    assert err < TOL

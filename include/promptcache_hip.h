@@ -170,12 +170,15 @@ int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t
  *            features 8j..8j+7 followed by their rotary partners D/2+8j..D/2+8j+7
  *            (perm[h*D + 16j + r] = h*D + 8j + r for r < 8, h*D + D/2 + 8j + r - 8 otherwise).
  *   outputs: rotated q as split-precision planes q_hi/q_lo [B*q_len][H*D] (token stride q_token_stride);
- *            rotated k and v written in place at rows [past_len, past_len+q_len) of the arena planes. */
+ *            rotated k and v written in place at rows [past_len, past_len+q_len) of the arena planes.
+ *            k_lo / v_lo (both or NULL): fp16 residuals (value - fp16(value)) of those new K / V rows, compact
+ *            [B][Hkv][q_len][D] with the given strides, for pc_attn_fwd_ex(lo_row0 = -1): the rows a prefill pass
+ *            appends enter its own attention in split precision, as in the reference's fp32 pass. */
 int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, int32_t M, int32_t K,
                      const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
                      int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
                      int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
-                     void* stream);
+                     void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
 int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
                     float eps, const float* slabs, int32_t nslabs, void* stream);
 /* Fused-RMSNorm variants for M <= 16 rows: the activation operand is the fp32 residual stream x [M][K] itself; the
@@ -189,7 +192,7 @@ int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_
                           const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
                           int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
                           int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
-                          void* stream);
+                          void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Falcon adapter (promptcache/model/falcon.py; multi-query, parallel attention + MLP): the ops the Llama path does
@@ -228,7 +231,12 @@ int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, i
  *   pc_silu_mul_split   silu(g) * u of (gate_up + gate_up2) -> (hi, lo);  pc_gelu_split  gelu(x + x2) -> (hi, lo)
  *   pc_add3             x += a + b  (fp32 residual stream)
  *   pc_attn_fwd_ex      pc_attn_fwd / pc_attn_fwd_alibi with an optional row-major `out_lo` plane next to `out`
- *                       (key_pos / slopes_log2 NULL: no ALiBi) and optional k_lo / v_lo residual planes, see below. */
+ *                       (key_pos / slopes_log2 NULL: no ALiBi) and optional k_lo / v_lo residual planes, see below;
+ *                       lo_row0 = -1 means "the rows of this pass" (= past_len, read from past_len_dev when given):
+ *                       passes of <= 16 rows then run with one extra KV split whose workgroup computes the attention
+ *                       over the pass's own rows in fp32 (size the workspace with pc_attn_workspace_bytes, it
+ *                       accounts for that split);
+ *                       out_frag_hi / out_frag_lo as in pc_attn_fwd (then `out` may be NULL). */
 int pc_rmsnorm_split(const float* x, const void* weight, void* out_hi, void* out_lo, int32_t rows, int32_t hidden,
                      float eps, void* stream);
 int pc_layernorm_split(const float* x, const void* weight, const void* bias, void* out_hi, void* out_lo, int32_t rows,
@@ -243,7 +251,7 @@ int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int6
                    int32_t q_len, int32_t past_len, float softmax_scale, void* workspace, int64_t workspace_bytes,
                    const int32_t* past_len_dev, const float* key_pos, int64_t key_pos_batch_stride,
                    const float* slopes_log2, const void* k_lo, const void* v_lo, int64_t lo_batch_stride,
-                   int64_t lo_head_stride, int32_t lo_row0, void* stream);
+                   int64_t lo_head_stride, int32_t lo_row0, void* out_frag_hi, void* out_frag_lo, void* stream);
 /* pc_rope_append_ex -- pc_rope_append that also writes the fp16 residuals of the appended K / V rows (k_lo, v_lo,
  *   both or neither: [B][Hkv][rows][D] with the given strides, row = key index - lo_row0; lo_row0 = past_len for a
  *   compact buffer of the new rows, 0 for an arena-shaped one that also carries residuals of earlier rows).  pc_attn_fwd_ex consumes them: the keys / values a pass appends enter

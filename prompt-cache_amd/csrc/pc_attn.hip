@@ -61,6 +61,10 @@ struct AttnParams {
     // the pass's own K/V then enter the MFMAs in split precision (staged rows are exact fp16 as the reference stages them)
     const _Float16* k_lo; const _Float16* v_lo; int64_t lo_bs, lo_hs; int32_t lo_row0;   // row = key - lo_row0
     int32_t H, Hkv, q_len, past_len, nsplit;
+    // tail != 0 (lo_row0 < 0 and q_len <= kTailMax: prefill of a short prompt over a staged cache): splits
+    // 0 .. nsplit-2 stream the STAGED keys [0, past_len) only; the workgroup of split nsplit-1 computes the attention over
+    // the rows this pass appended in fp32 (attn_tail_block) and leaves it as one more partial for the merge kernel.
+    int32_t tail;
     int32_t xcd_remap, nqblk, nbatch;
     float scale_log2;
 };
@@ -79,6 +83,93 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     // addressed by lanes {i/4, 4+i/4, 8+i/4, 12+i/4} (verified by pc_probe_layouts on hardware).
     s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p));
     return __builtin_bit_cast(h4, r);
+}
+
+constexpr int kTailMax = 16;       // rows of one prefill pass the tail workgroup handles
+
+// The attention of <= 16 new query rows over the <= 16 rows their own pass appended (keys past_len + j, j <= qi), for one
+// head, as a split-KV partial (m, l, O) in the log2 domain.  All fp32 FMAs on (q_hi + q_lo), (K + K_lo), (V + V_lo): the
+// reference computes the pass in fp32 (llama2.py:361-388), only the STAGED rows are fp16 there.  It runs in the
+// workgroup of an extra split while the other splits stream the staged keys, so its ~2 us hide under their ~10 us.
+// (Residual tiles inside the streaming kernel instead cost 32 VGPRs -- the second resident workgroup per CU, or spills --
+// and a straggler split: 13.3 -> 15.9 .. 25 us per launch on the persona prompt; the same arithmetic inside the merge
+// kernel lengthened the serial merge by 1.1 us per layer.)
+// LDS: qs/ks/vs are [16][D] fp32 with the float4 column XOR-swizzled by the row (16 lanes read 16 different rows of one
+// column; unswizzled they share a bank), ps is [16][16].
+template <int D, bool ALIBI>
+__device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __restrict__ qs, float* __restrict__ ks,
+                                                float* __restrict__ vs, float* __restrict__ ps, int b, int h, int split) {
+    constexpr int CPR = D / 8;             // 16-byte fp16 chunks per row
+    constexpr int F4R = D / 4;             // float4 columns per fp32 row
+    constexpr int SWZ = F4R >= 16 ? 15 : F4R - 1;
+    constexpr int DPT = D / 16;            // output dims per thread in the O phase
+    const int tid = threadIdx.x, q_len = p.q_len;
+    const int past = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int hkv = h / (p.H / p.Hkv);
+    const _Float16* kb = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs + (int64_t)past * D;
+    const _Float16* vb = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs + (int64_t)past * D;
+    const _Float16* klb = p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs;
+    const _Float16* vlb = p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs;
+    for (int idx = tid; idx < kTailMax * CPR; idx += kThreads) {
+        const int row = idx / CPR, c = idx - row * CPR;
+        const int rc = row < q_len ? row : q_len - 1;          // clamped: unconditional loads
+        const int64_t qoff = b * p.q_bs + (int64_t)rc * p.q_ts + (int64_t)h * D + c * 8;
+        const h8 qh = *(const h8*)(p.q + qoff);
+        h8 ql = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.q_lo) ql = *(const h8*)(p.q_lo + qoff);
+        const h8 kk = *(const h8*)(kb + (int64_t)rc * D + c * 8), kl = *(const h8*)(klb + (int64_t)rc * D + c * 8);
+        const h8 vv = *(const h8*)(vb + (int64_t)rc * D + c * 8), vl = *(const h8*)(vlb + (int64_t)rc * D + c * 8);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f4 q4, k4, v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q4[e] = (float)qh[half * 4 + e] + (float)ql[half * 4 + e];
+                k4[e] = (float)kk[half * 4 + e] + (float)kl[half * 4 + e];
+                v4[e] = (float)vv[half * 4 + e] + (float)vl[half * 4 + e];
+            }
+            const int col = ((2 * c + half) ^ (row & SWZ)) * 4;
+            *(f4*)(qs + row * D + col) = q4;
+            *(f4*)(ks + row * D + col) = k4;
+            *(f4*)(vs + row * D + (2 * c + half) * 4) = v4;      // read row-wise below: no swizzle
+        }
+    }
+    __syncthreads();
+    const int qi = tid >> 4, j = tid & 15;                       // 256 threads = 16 x 16 (query row, key) pairs
+    float acc = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < F4R; ++d4) {
+        const f4 a = *(const f4*)(qs + qi * D + ((d4 ^ (qi & SWZ)) * 4));
+        const f4 k4 = *(const f4*)(ks + j * D + ((d4 ^ (j & SWZ)) * 4));
+        acc += a[0] * k4[0] + a[1] * k4[1] + a[2] * k4[2] + a[3] * k4[3];
+    }
+    float sv = acc * p.scale_log2;
+    if (ALIBI) sv += p.slopes[h] * p.key_pos[b * p.kp_bs + past + (j < q_len ? j : q_len - 1)];
+    const bool vis = qi < q_len && j <= qi;                      // causal inside the pass
+    float m = vis ? sv : kNegBig;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float pj = vis ? exp2f(sv - m) : 0.f;
+    float l = pj;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off);
+    ps[qi * 16 + j] = pj;
+    const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
+    if (j == 0 && qi < q_len) { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
+    __syncthreads();
+    float o[DPT];
+#pragma unroll
+    for (int e = 0; e < DPT; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < kTailMax; ++jj) {
+        const float w = ps[qi * 16 + jj];
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) o[e] += w * vs[jj * D + j * DPT + e];
+    }
+    if (qi < q_len) {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) p.part_o[slot * D + j * DPT + e] = o[e];
+    }
 }
 
 // (Tried and dropped for q_len <= 16: the four waves of a workgroup taking different key tiles -- four tiles in
@@ -126,10 +217,23 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
     const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
-    const int kv_len = past_len + q_len;
+    int nsp = p.nsplit;
+    if constexpr (HP && !KVLO) {
+        if (p.tail) {
+            nsp = p.nsplit - 1;
+            if (split == nsp) {           // workgroup-uniform: the extra split takes the pass's own rows
+                static_assert(sizeof(Kl) >= 2 * kTailMax * D * sizeof(float) && sizeof(Vl) >= (kTailMax * D + 256) * sizeof(float),
+                              "tail buffers live in the K / V tiles");
+                attn_tail_block<D, ALIBI>(p, (float*)Kl, (float*)Kl + kTailMax * D, (float*)Vl, (float*)Vl + kTailMax * D,
+                                          b, h, split);
+                return;
+            }
+        }
+    }
+    const int kv_len = p.tail ? past_len : past_len + q_len;   // tail mode: staged keys only, all visible to every row
 
     // this split's key range (tile-aligned) clipped by what the workgroup can causally see
-    int kps = (kv_len + p.nsplit - 1) / p.nsplit;
+    int kps = (kv_len + nsp - 1) / nsp;
     kps = (kps + kTK - 1) / kTK * kTK;
     const int ks0 = split * kps;
     const int wg_rows_end = (qblk * kQB + kQB < q_len) ? qblk * kQB + kQB : q_len;
@@ -141,8 +245,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     const int qi = qrow0 + n;                       // this lane's query row (new-token index)
     const bool wave_active = qrow0 < q_len;         // wave-uniform
     const int wave_rows_end = (qrow0 + 16 < q_len) ? qrow0 + 16 : q_len;
-    const int wave_vis_end = past_len + wave_rows_end;
-    const int row_vis_end = (qi < q_len) ? past_len + qi + 1 : 0;  // keys [0, row_vis_end) are visible
+    const int wave_vis_end = p.tail ? past_len : past_len + wave_rows_end;
+    const int row_vis_end = (qi < q_len) ? (p.tail ? past_len : past_len + qi + 1) : 0;  // keys [0, row_vis_end) are visible
 
     h8 qf[KS], qfl[HP ? KS : 1];
 #pragma unroll
@@ -173,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     [[maybe_unused]] u32x4 krl[KVLO ? LPT : 1], vrl[KVLO ? LPT : 1];
     [[maybe_unused]] const _Float16* klb = KVLO ? p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
     [[maybe_unused]] const _Float16* vlb = KVLO ? p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
-    [[maybe_unused]] const int lo_row0 = KVLO ? p.lo_row0 : 0;
+    [[maybe_unused]] const int lo_row0 = KVLO ? (p.lo_row0 < 0 ? past_len : p.lo_row0) : 0;   // < 0: the new rows
     auto issue_loads = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -666,7 +770,7 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     if (rows32) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
-    } else if (p.k_lo) {
+    } else if (p.k_lo && !p.tail) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, true>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.key_pos) {
@@ -694,7 +798,9 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
 
 PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max) {
     if (B <= 0 || H <= 0 || D <= 0 || q_len <= 0) return 0;
-    const int ns = choose_nsplit(B, H, q_len, kv_len_max);
+    int ns = choose_nsplit(B, H, q_len, kv_len_max);
+    // passes of <= kTailMax rows may run in tail mode (pc_attn_fwd_ex with lo_row0 = -1): one more split, always merged
+    if (q_len <= kTailMax) ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
     if (ns <= 1) return 0;
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
@@ -730,6 +836,14 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
+    p.tail = (k_lo && lo_row0 < 0 && q_len <= kTailMax) ? 1 : 0;
+    if (p.tail) {
+        // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
+        // next instantiation of the merge kernel (4 / 8 / 16 / 32 partials per row)
+        int ms = p.nsplit;
+        if (ms >= 4 && (ms & (ms - 1)) == 0) ms -= 1;
+        p.nsplit = ms + 1;
+    }
     p.part_o = nullptr; p.part_ml = nullptr;
     if (p.nsplit > 1) {
         const int64_t slots = (int64_t)B * H * p.nsplit * q_len;
@@ -780,17 +894,18 @@ PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_st
                              int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
                              int64_t workspace_bytes, const int32_t* past_len_dev, const float* key_pos,
                              int64_t key_pos_batch_stride, const float* slopes_log2, const void* k_lo, const void* v_lo,
-                             int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0, void* stream) {
-    PC_REQUIRE(out, PC_ERR_ARG, "pc_attn_fwd_ex: row-major output required");
-    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || (q_lo && past_len_dev == nullptr)), PC_ERR_ARG,
-               "pc_attn_fwd_ex: k_lo / v_lo go together, need q_lo (split-precision Q) and a host past_len");
-    PC_REQUIRE(!k_lo || (lo_row0 >= 0 && lo_row0 <= past_len && lo_head_stride % 8 == 0), PC_ERR_ARG,
-               "pc_attn_fwd_ex: lo_row0 must lie in [0, past_len] and the lo strides keep 16-byte alignment");
+                             int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0, void* out_frag_hi,
+                             void* out_frag_lo, void* stream) {
+    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || q_lo), PC_ERR_ARG,
+               "pc_attn_fwd_ex: k_lo / v_lo go together and need q_lo (split-precision Q)");
+    PC_REQUIRE(!k_lo || (lo_row0 < 0 || (lo_row0 <= past_len && past_len_dev == nullptr)), PC_ERR_ARG,
+               "pc_attn_fwd_ex: lo_row0 must be -1 (= past_len) or lie in [0, past_len] of a host past_len");
+    PC_REQUIRE(!k_lo || lo_head_stride % 8 == 0, PC_ERR_ARG, "pc_attn_fwd_ex: the lo strides must keep 16-byte alignment");
     PC_REQUIRE((key_pos == nullptr) == (slopes_log2 == nullptr), PC_ERR_ARG, "pc_attn_fwd_ex: key_pos and slopes go together");
     PC_REQUIRE(!key_pos || (key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0), PC_ERR_ARG,
                "pc_attn_fwd_ex: key_pos rows not 16-byte aligned");
     return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, past_len_dev, nullptr, nullptr, key_pos, key_pos_batch_stride, slopes_log2,
-                         out_lo, k_lo, v_lo, lo_batch_stride, lo_head_stride, lo_row0, stream);
+                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
+                         slopes_log2, out_lo, k_lo, v_lo, lo_batch_stride, lo_head_stride, lo_row0, stream);
 }

@@ -58,6 +58,7 @@ struct RopeEpi {          // EPI_ROPE outputs
     const float2* cs;     // [B*q_len][D/2] (cos, sin) from pc_rope_table
     _Float16* q_hi; _Float16* q_lo; int64_t q_ts;        // [B*q_len][H*D] planes, token stride q_ts
     _Float16* k_arena; _Float16* v_arena; int64_t a_bs, a_hs;
+    _Float16* k_lo; _Float16* v_lo; int64_t lo_bs, lo_hs;   // optional fp16 residuals of the new K / V rows, [B][Hkv][q_len][D]
     const int32_t* past_len_dev;
     int32_t H, Hkv, D, q_len, past_len;
 };
@@ -274,11 +275,19 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
                 } else {
                     const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
                     *(h4*)(e.k_arena + bb * e.a_bs + (int64_t)(hh - e.H) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hi;
+                    if (e.k_lo) *(h4*)(e.k_lo + bb * e.lo_bs + (int64_t)(hh - e.H) * e.lo_hs + (int64_t)tt * e.D + d0) = lo;
                 }
             } else {
                 const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
-                h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                h4 hv, lv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 oh, ol;
+                    pc_split(v[r], oh, ol);
+                    hv[r] = oh; lv[r] = ol;
+                }
                 *(h4*)(e.v_arena + bb * e.a_bs + (int64_t)(hh - e.H - e.Hkv) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hv;
+                if (e.v_lo) *(h4*)(e.v_lo + bb * e.lo_bs + (int64_t)(hh - e.H - e.Hkv) * e.lo_hs + (int64_t)tt * e.D + d0) = lv;
             }
         }
     }
@@ -822,7 +831,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                       const int32_t* past_len_dev, void* stream);
+                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream);
 }  // namespace
 
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
@@ -843,22 +852,24 @@ PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const voi
                                const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena,
                                void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                                int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                               const int32_t* past_len_dev, void* stream) {
+                               const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
+                               int64_t lo_head_stride, void* stream) {
     PC_REQUIRE(xf_hi, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
     return gemm_qkv_rope_impl(wf_perm, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
                               v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, stream);
+                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream);
 }
 
 PC_EXPORT int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_weight, float eps, int32_t M,
                                     int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
                                     void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
                                     int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
-                                    int32_t cap, const int32_t* past_len_dev, void* stream) {
+                                    int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
+                                    int64_t lo_batch_stride, int64_t lo_head_stride, void* stream) {
     PC_REQUIRE(x && norm_weight && M <= 16, PC_ERR_ARG, "pc_gemm_qkv_rope_norm: needs x, the norm weight and M <= 16");
     return gemm_qkv_rope_impl(wf_perm, nullptr, nullptr, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
                               v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, stream);
+                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream);
 }
 
 namespace {
@@ -866,7 +877,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                       const int32_t* past_len_dev, void* stream) {
+                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream) {
     const int N = (H + 2 * Hkv) * D;
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
@@ -883,6 +894,9 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
     p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
     p.rope.k_arena = (_Float16*)k_arena; p.rope.v_arena = (_Float16*)v_arena; p.rope.a_bs = arena_batch_stride;
     p.rope.a_hs = arena_head_stride; p.rope.past_len_dev = past_len_dev;
+    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || lo_hs % 4 == 0), PC_ERR_ARG,
+               "pc_gemm_qkv_rope: k_lo / v_lo go together, strides must keep 8-byte alignment");
+    p.rope.k_lo = (_Float16*)k_lo; p.rope.v_lo = (_Float16*)v_lo; p.rope.lo_bs = lo_bs; p.rope.lo_hs = lo_hs;
     p.rope.H = H; p.rope.Hkv = Hkv; p.rope.D = D; p.rope.q_len = q_len; p.rope.past_len = past_len;
     return launch_MT<EPI_ROPE>(p, choose_T(p.ntiles), p.ntiles, (hipStream_t)stream);
 }

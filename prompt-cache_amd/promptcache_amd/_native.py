@@ -30,7 +30,8 @@ SIGNATURES = {
     "pc_attn_fwd_alibi": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "pc_attn_fwd_ex": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,
-                                 _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+                                 _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
+                                 _vp, _vp, _vp]),
     "pc_rope_append_ex": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_rmsnorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
@@ -40,11 +41,11 @@ SIGNATURES = {
     "pc_add3": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
-                                   _i32, _i32, _i32, _i32, _vp, _vp]),
+                                   _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "pc_gemm_skinny_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "pc_gemm_qkv_rope_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
-                                        _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+                                        _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "pc_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_layernorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
@@ -156,15 +157,15 @@ def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q
     (written by ``rope_append(..., kv_lo=...)``), both via pc_attn_fwd_ex."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
-    if out_lo is not None:
+    if out_lo is not None or kv_lo is not None:
         kpos, slopes = (None, None) if alibi is None else alibi
         rc = load().pc_attn_fwd_ex(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
-                                   out.data_ptr(), out_lo.data_ptr(), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
+                                   _ptr(out), _ptr(out_lo), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
                                    _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(kpos),
                                    0 if kpos is None else kpos.stride(0), _ptr(slopes),
                                    None if kv_lo is None else kv_lo[0].data_ptr(), None if kv_lo is None else kv_lo[1].data_ptr(),
                                    0 if kv_lo is None else kv_lo[2], 0 if kv_lo is None else kv_lo[3], 0 if kv_lo is None else kv_lo[4],
-                                   current_stream() if stream is None else stream)
+                                   _ptr(fh), _ptr(fl), current_stream() if stream is None else stream)
         check(rc, "pc_attn_fwd_ex")
         return
     if alibi is not None:
@@ -193,10 +194,14 @@ def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None,
 
 
 def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,
-                  past_len, cap, past_len_dev=None, stream: Optional[int] = None) -> None:
+                  past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None) -> None:
+    """``kv_lo=(k_lo, v_lo, batch_stride, head_stride)``: also write the fp16 residuals of the new K / V rows (compact
+    ``[B][Hkv][q_len][D]``) for ``attn_fwd(..., kv_lo=(k_lo, v_lo, bs, hs, -1))``."""
+    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
     rc = load().pc_gemm_qkv_rope(wf_perm.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, K, cs.data_ptr(), q_hi.data_ptr(),
                                  q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D,
-                                 q_len, past_len, cap, _ptr(past_len_dev), current_stream() if stream is None else stream)
+                                 q_len, past_len, cap, _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3],
+                                 current_stream() if stream is None else stream)
     check(rc, "pc_gemm_qkv_rope")
 
 
@@ -227,11 +232,12 @@ def gemm_skinny_norm(wf, x_f32, norm_weight, eps: float, M: int, N: int, K: int,
 
 
 def gemm_qkv_rope_norm(wf_perm, x_f32, norm_weight, eps: float, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H,
-                       Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None) -> None:
+                       Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None) -> None:
+    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
     rc = load().pc_gemm_qkv_rope_norm(wf_perm.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, K, cs.data_ptr(),
                                       q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs,
-                                      a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
-                                      current_stream() if stream is None else stream)
+                                      a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]),
+                                      lo[2], lo[3], current_stream() if stream is None else stream)
     check(rc, "pc_gemm_qkv_rope_norm")
 
 

@@ -160,61 +160,6 @@ MPT_SHAPES = {
     "mpt-7b": MptShape(name="mpt-7b"),
 }
 
-@dataclass
-class MptShape:
-    """MPT-7b-class decoder (``promptcache/model/mpt.py``): multi-head attention with ALiBi position biases (no
-    rotary), fused ``Wqkv`` = [q | k | v], bias-free LayerNorms, GELU MLP of width 4*d_model, lm_head tied to the
-    embedding.  The reference reads these from ``MptConfig``; its cache shape is ``(n_layers, n_heads, head_dim)``
-    (``promptcache/model/__init__.py:284-286``)."""
-    vocab_size: int = 50432
-    hidden_size: int = 4096
-    num_hidden_layers: int = 32
-    num_attention_heads: int = 32
-    layer_norm_epsilon: float = 1e-5
-    alibi_bias_max: int = 8
-    initializer_range: float = 0.02
-    tie_word_embeddings: bool = False
-    name: str = "mpt"
-
-    @property
-    def num_key_value_heads(self) -> int:
-        return self.num_attention_heads
-
-    @property
-    def head_dim(self) -> int:
-        return self.hidden_size // self.num_attention_heads
-
-    @property
-    def intermediate_size(self) -> int:
-        return 4 * self.hidden_size
-
-    @property
-    def kv_bytes_per_token(self) -> int:
-        return 2 * self.num_hidden_layers * self.num_attention_heads * self.head_dim * 2
-
-    def to_dict(self):
-        return asdict(self)
-
-    @classmethod
-    def from_hf_dir(cls, path: str) -> "MptShape":
-        with open(os.path.join(path, "config.json")) as f:
-            c = json.load(f)
-        ac = c.get("attn_config", {})
-        if not ac.get("alibi", True) or not c.get("no_bias", True) or ac.get("clip_qkv") or ac.get("qk_ln"):
-            raise ValueError("only the mpt-7b architecture (alibi, no biases, no qkv clipping / qk layernorm) is supported")
-        return cls(vocab_size=c["vocab_size"], hidden_size=c["d_model"], num_hidden_layers=c["n_layers"],
-                   num_attention_heads=c["n_heads"], layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-5),
-                   alibi_bias_max=ac.get("alibi_bias_max", 8), tie_word_embeddings=True,
-                   name=os.path.basename(os.path.normpath(path)))
-
-
-MPT_SHAPES = {
-    "mpt-tiny": MptShape(vocab_size=1024, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, name="mpt-tiny"),
-    # head_dim 64.  (Head counts must be powers of two: the reference's slope table raises otherwise, mpt.py:104.)
-    "mpt-mid": MptShape(vocab_size=2048, hidden_size=512, num_hidden_layers=2, num_attention_heads=8, name="mpt-mid"),
-    "mpt-7b": MptShape(name="mpt-7b"),
-}
-
 SHAPES = {
     # test-sized
     "tiny": LlamaShape(vocab_size=1024, hidden_size=128, intermediate_size=344, num_hidden_layers=2,

@@ -195,15 +195,16 @@ class FalconHIP(LlamaHIP):
         KQ = self.kslices
         slabs = torch.empty((2 * KQ, T, hid), dtype=f32, device=dev)      # [0:KQ] attention branch, [KQ:] MLP branch
         pending = 0
+        kvlo = self._new_kv_lo(B, 1, q_len, D)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_frag(x, lw["ln_w"], lw["ln_b"], xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
-                            arena.head_stride, B, H, 1, D, q_len, past_len, arena.cap, past_dev)
+                            arena.head_stride, B, H, 1, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, 1, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l)
+                       q_lo=q16l, kv_lo=kvlo)
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs[:KQ], ldy=hid, kslices=KQ)
             n.gemm_skinny(lw["w1_f"], xh, xl, T, inter, hid, n.EPI_GELU, of_hi=ch, of_lo=cl)
             n.gemm_skinny(lw["w2_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs[KQ:], ldy=hid, kslices=KQ)

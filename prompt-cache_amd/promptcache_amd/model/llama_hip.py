@@ -71,6 +71,10 @@ class LlamaHIP:
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops
         self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
+        # weight-streaming regimes (<= MID_MAX_ROWS rows): keep the fp16 residuals of the K / V rows a prefill pass appends
+        # and feed them to that pass's own attention (the reference computes the pass in fp32, llama2.py:361-388; the
+        # arena still holds the fp16 values).  Off for single-row decode steps.
+        self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True):
@@ -118,6 +122,14 @@ class LlamaHIP:
     # ------------------------------------------------------------------------------------------
     def new_arena(self, batch: int, cap: int) -> KVArena:
         return KVArena(batch, self.L, self.Hkv, cap, self.D, self.device, self.dtype)
+
+    def _new_kv_lo(self, B: int, Hkv: int, q_len: int, D: int):
+        """(k_lo, v_lo, batch_stride, head_stride, -1): compact residual planes for the K / V rows of one prefill pass
+        (shared by all layers: each layer's attention consumes them before the next layer overwrites them)."""
+        if not self.new_kv_lo or q_len <= 1:
+            return None
+        lo = torch.empty((2, B, Hkv, q_len, D), dtype=self.dtype, device=self.device)
+        return (lo[0], lo[1], Hkv * q_len * D, q_len * D, -1)
 
     def _workspace(self, nbytes: int) -> Optional[torch.Tensor]:
         if nbytes <= 0:
@@ -315,7 +327,7 @@ class LlamaHIP:
 
     # ------------------------------------------------------------------------------------------
     def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
-                           last_token_only):
+                           last_token_only, kvlo=None):
         """T <= 16 rows: six launches per layer.  Both RMSNorms are folded into the projections that consume them
         (pc_gemm_*_norm read the fp32 residual stream directly) and both residual adds into the o_proj / down_proj
         epilogues, so x is the only activation that round-trips through memory in fp32."""
@@ -326,10 +338,11 @@ class LlamaHIP:
         for li, lw in enumerate(layers):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
-                                 arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev)
+                                 arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
+                                 kv_lo=kvlo and kvlo[:4])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l)
+                       q_lo=q16l, kv_lo=kvlo)
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)                   # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)
             n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)                # x += act @ Wd^T
@@ -393,6 +406,7 @@ class LlamaHIP:
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)       # low-order plane of the split-precision q
         ws_bytes = n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len)
         ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
+        kvlo = self._new_kv_lo(B, Hkv, q_len, D)
 
         def planes(k):
             return (torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev),
@@ -409,16 +423,16 @@ class LlamaHIP:
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         if T <= self.NORM_FUSED_MAX_ROWS and self.fuse_norm:
             return self._layers_norm_fused(x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
-                                           last_token_only)
+                                           last_token_only, kvlo)
         for li, lw in enumerate(layers):
             n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             # q|k|v projection + RoPE + in-place KV append in one weight-streaming launch
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
-                            arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev)
+                            arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l)
+                       q_lo=q16l, kv_lo=kvlo)
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ)   # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm
             n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)  # silu(g)*u

@@ -284,15 +284,16 @@ class MptHIP(LlamaHIP):
         KQ = self.kslices
         slabs = torch.empty((KQ, T, hid), dtype=f32, device=dev)
         pending = 0
+        kvlo = self._new_kv_lo(B, H, q_len, D)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_frag(x, lw["ln1"], None, xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, hid, kp, vp, arena.batch_stride,
-                            arena.head_stride, B, H, H, D, q_len, past_len, arena.cap, past_dev)
+                            arena.head_stride, B, H, H, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4])
             n.attn_fwd(q16, q_len * hid, hid, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, H, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, alibi=alibi)
+                       q_lo=q16l, alibi=alibi, kv_lo=kvlo)
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, hid, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ)
             n.layernorm_frag(x, lw["ln2"], None, xh, xl, T, hid, eps, slabs, KQ)
             n.gemm_skinny(lw["w1_f"], xh, xl, T, inter, hid, n.EPI_GELU, of_hi=ch, of_lo=cl)

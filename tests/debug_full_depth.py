@@ -70,6 +70,13 @@ def main(layers=32, qlen=8):
     out2 = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
               past_key_values=arena.views(), use_cache=True)
     print(f"(b) prefill on oracle-staged KV  max|dlogit| = {np.abs(out2.logits[0].cpu().numpy() - logits[0]).max():.3e}")
+    # (b') the same through the stacked-GEMM many-row path (no weight-streaming kernels)
+    lm.hf_model.skinny = False
+    arena.length = S
+    out2b = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+               past_key_values=arena.views(S), use_cache=True)
+    lm.hf_model.skinny = True
+    print(f"(b') same, many-row path          max|dlogit| = {np.abs(out2b.logits[0].cpu().numpy() - logits[0]).max():.3e}")
 
 
     # (d) the no-cache path: every token re-encoded, positions range(N) (cache_engine.py:476-493)

@@ -896,3 +896,66 @@ def test_attn_split_precision_qkv(B, H, Hkv, D, q_len, past):
     # the arena itself holds the fp16 value (what gets stored / staged)
     assert torch.equal(arena[:, 0, :, past:past + q_len], kn.half()[:, :, :, :].to(arena.dtype)) or \
         (arena[:, 0, :, past:past + q_len].double() - kn).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 70, 512), (1, 8, 1, 64, 40, 130, 512),
+                                                       (1, 4, 4, 128, 104, 90, 512)])
+def test_weight_streaming_prefill_keeps_new_kv_residuals(B, H, Hkv, D, q_len, past, hid):
+    """pc_gemm_qkv_rope(k_lo, v_lo) + pc_attn_fwd_ex(lo_row0 = -1, device past_len, fragment output): the K / V rows the
+    pass appends reach its own attention in split precision.  (a) arena + lo planes reproduce the fp32 projection;
+    (b) the attention output is far closer to fp64 attention over the un-rounded new rows than fp16 new rows allow."""
+    n = _n()
+    rng = np.random.default_rng(77)
+    T, W, cap = B * q_len, (H + 2 * Hkv) * D, past + q_len + 3
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((T, hid), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    pos = torch.from_numpy(np.tile(np.arange(past, past + q_len, dtype=np.int32), B)).to(DEV)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(pos, _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    arena = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    arena[:, :, :, :past] = torch.from_numpy(rng.standard_normal((B, 2, Hkv, past, D), dtype=np.float32)).to(DEV).half()
+    perm = n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)
+    q16 = torch.empty((T, H * D), dtype=torch.float16, device=DEV); q16l = torch.empty_like(q16)
+    klo = torch.full((B, Hkv, q_len, D), 7.0, dtype=torch.float16, device=DEV); vlo = torch.full_like(klo, 7.0)
+    past_dev = torch.tensor([past], dtype=torch.int32, device=DEV)
+    # host past_len deliberately wrong (0): the kernels must take it from the device word
+    n.gemm_qkv_rope(n.to_weight_frags(w[perm].contiguous()), hi, lo, T, hid, cs, q16, q16l, H * D, arena[:, 0], arena[:, 1],
+                    2 * Hkv * cap * D, cap * D, B, H, Hkv, D, q_len, 0, cap, past_dev,
+                    kv_lo=(klo, vlo, Hkv * q_len * D, q_len * D))
+    # fp64 projection + rotation of the same operands
+    xd = (n.from_act_frags(hi, T).double() + n.from_act_frags(lo, T).double())
+    qkv = xd @ w.double().T
+    def rot(t):
+        c, s_ = cs[..., 0].double(), cs[..., 1].double()
+        c, s_ = torch.cat([c, c], 1)[:, None], torch.cat([s_, s_], 1)[:, None]
+        return t * c + torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1) * s_
+    kn = rot(qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)).view(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    vn = qkv[:, (H + Hkv) * D:].view(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    k_rec = arena[:, 0, :, past:past + q_len].double() + klo.double()
+    v_rec = arena[:, 1, :, past:past + q_len].double() + vlo.double()
+    scale_k, scale_v = float(kn.abs().max()), float(vn.abs().max())
+    assert (k_rec - kn).abs().max().item() < 2e-6 * max(1.0, scale_k)
+    assert (v_rec - vn).abs().max().item() < 2e-6 * max(1.0, scale_v)
+    assert (arena[:, 0, :, past:past + q_len].double() - kn).abs().max().item() < 1e-3 * max(1.0, scale_k)   # arena = fp16(value)
+    # attention: fragment-plane output, lo_row0 = -1
+    mt = (T + 15) // 16
+    fh = torch.zeros((mt, H * D // 32, 64, 8), dtype=torch.float16, device=DEV); fl = torch.zeros_like(fh)
+    ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, past + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+    n.attn_fwd(q16, q_len * H * D, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, None, 0, 0,
+               B, H, Hkv, D, q_len, past, 1.0 / np.sqrt(D), ws, past_len_dev=past_dev, out_frag=(fh, fl), q_lo=q16l,
+               kv_lo=(klo, vlo, Hkv * q_len * D, q_len * D, -1))
+    got = (n.from_act_frags(fh, T).double() + n.from_act_frags(fl, T).double()).view(B, q_len, H * D)
+    qd = rot(qkv[:, :H * D].view(T, H, D)).view(B, q_len, H, D).permute(0, 2, 1, 3)
+    idx = torch.arange(q_len, device=DEV)
+    mask = torch.ones((q_len, past + q_len), dtype=torch.bool, device=DEV)
+    mask[:, past:] = idx[None, :] <= idx[:, None]
+    def attn(kx, vx):
+        K = torch.cat([arena[:, 0, :, :past].double(), kx], 2).repeat_interleave(H // Hkv, 1)
+        V = torch.cat([arena[:, 1, :, :past].double(), vx], 2).repeat_interleave(H // Hkv, 1)
+        s = qd @ K.transpose(2, 3) / np.sqrt(D)
+        return (torch.softmax(s.masked_fill(~mask, float("-inf")), -1) @ V).permute(0, 2, 1, 3).reshape(B, q_len, H * D)
+    ref = attn(kn, vn)
+    floor16 = (attn(kn.half().double(), vn.half().double()) - ref).abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, scale_v) and err < 0.25 * floor16, (err, floor16)

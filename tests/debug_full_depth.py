@@ -70,6 +70,23 @@ def main(layers=32, qlen=8):
     out2 = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
               past_key_values=arena.views(), use_cache=True)
     print(f"(b) prefill on oracle-staged KV  max|dlogit| = {np.abs(out2.logits[0].cpu().numpy() - logits[0]).max():.3e}")
+    # (e) decode steps after (b), teacher-forced with the oracle's greedy tokens (generation_engine.py:123-147: the i-th
+    #     decoded token sits at position max(position_ids) + 1 + i)
+    steps = int(os.environ.get("PC_DBG_DECODE", "6"))
+    if steps:
+        _, present = model.forward(np.asarray([ids]), np.asarray([pos]), past=[(k[None], v[None]) for k, v in staged])
+        olog, gpast, worst = logits, out2.past_key_values, 0.0
+        for i in range(steps):
+            tok = int(np.argmax(olog[0, -1]))
+            p1 = max(pos) + 1 + i
+            olog, present = model.forward(np.array([[tok]]), np.array([[p1]]), past=present)
+            go = lm(input_ids=torch.tensor([[tok]], device="cuda"), position_ids=torch.tensor([[p1]], device="cuda"),
+                    past_key_values=gpast, use_cache=True)
+            gpast = go.past_key_values
+            d = np.abs(go.logits[0, -1].cpu().numpy() - olog[0, -1]).max()
+            worst = max(worst, d)
+            print(f"(e) decode step {i}: max|dlogit| = {d:.3e}  argmax equal: {int(np.argmax(olog[0, -1])) == int(go.logits[0, -1].argmax())}")
+        arena.length = S
     # (b') the same through the stacked-GEMM many-row path (no weight-streaming kernels)
     lm.hf_model.skinny = False
     arena.length = S

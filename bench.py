@@ -393,6 +393,29 @@ def main():
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
         result["decode"] = {"tokens_per_s": nstep / dt, "ms_per_token": dt / nstep * 1e3, "kv_len": S + q + 2 * nstep,
                             "how": "greedy steps through lm(), hipGraph replay per step (second block of 32 timed)"}
+    if rank == 0 and not args.no_context:
+        # context: the same step with this prompt's modules in the HOST tier (pinned host memory, the reference's default
+        # placement, cache_engine.py:283-296) -- pc_kv_gather then reads them in place over PCIe.  Never `value`.
+        used = list(pc.staged)
+        for m in used:
+            m.free()
+        torch.cuda.synchronize()
+        hs, hg = [], []
+        for i in range(6):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            step(False)
+            torch.cuda.synchronize(); hs.append((time.perf_counter() - t0) * 1e3)
+            a, b = pc.last_gather_events
+            hg.append(a.elapsed_time(b))
+        host_gather_ms = min(hg[1:])
+        result["host_tier"] = {"ttft_ms": min(hs[1:]), "gather_ms": host_gather_ms,
+                               "pcie_read_GBps": S * (2 * L * Hkv * D * 2) / (host_gather_ms * 1e-3) / 1e9,
+                               "bytes_over_pcie": S * (2 * L * Hkv * D * 2),
+                               "what": "module KV of the staged segments in pinned host memory (TokenSequenceCache.free()); "
+                                       "same pc_kv_gather launch, sources read over PCIe; modules uploaded back afterwards"}
+        for m in used:
+            m.upload(device)
+        torch.cuda.synchronize()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline_and_parity(lm, eng, prompt, ids, pos, args.cpu_layers)
         result["cpu_baseline"] = base

@@ -40,20 +40,68 @@ def pad_batch(batch_list: List[List[int]], pad_id: int) -> Tuple[List[List[int]]
 
 
 class TokenSequenceCache:
-    """Module KV of one text segment, resident in HBM: ``store`` is ``[L][2][Hkv][len][D]`` fp16."""
+    """Module KV of one text segment: one ``[L][2][Hkv][len][D]`` fp16 tensor.
+
+    Two tiers, as in the reference (``host_cache`` / ``device_cache``, ``upload`` / ``free``, :50-83), with the
+    defaults turned around for a 288 GB part: the store is born in HBM and stays there; a library that does not fit
+    moves segments to PINNED host memory (``offload``), from where ``pc_kv_gather`` reads them in place over PCIe --
+    pinned allocations are mapped into the device address space, so a staged prompt may mix HBM and host segments
+    in the one gather launch.  ``upload`` brings a segment back, ``free`` drops the HBM copy."""
 
     def __init__(self, seq: TokenSequence, store: torch.Tensor):
         self.token_sequence = seq
-        self.store = store
         self.usage_counter = 0
+        self.device_store: Optional[torch.Tensor] = store if store.is_cuda else None
+        self.host_store: Optional[torch.Tensor] = None if store.is_cuda else self._pinned(store)
+
+    @staticmethod
+    def _pinned(t: torch.Tensor) -> torch.Tensor:
+        if t.is_cuda or not t.is_pinned():
+            out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            out.copy_(t)                      # device -> pinned host: synchronous on the current stream
+            return out
+        return t
 
     def inc_usage_counter(self):
         self.usage_counter += 1
 
     @property
+    def store(self) -> torch.Tensor:
+        """The copy a gather reads: HBM when resident, else the pinned host tensor."""
+        return self.device_store if self.device_store is not None else self.host_store
+
+    def offload(self) -> None:
+        """Move the segment to the host tier (keeps an existing host copy; drops the HBM copy)."""
+        if self.host_store is None:
+            self.host_store = self._pinned(self.device_store)
+        self.device_store = None
+
+    def upload(self, device=None) -> None:
+        """Reference :65-68: make the segment HBM-resident (no-op when it already is)."""
+        if self.device_store is None:
+            self.device_store = self.host_store.to(device if device is not None else "cuda", non_blocking=True)
+
+    def free(self) -> None:
+        """Reference :70-73: release the HBM copy; the segment stays usable from the host tier."""
+        if self.device_store is not None:
+            self.offload()
+
+    @staticmethod
+    def _views(store: torch.Tensor) -> KVCache:
+        return [(store[i, 0], store[i, 1]) for i in range(store.shape[0])]
+
+    @property
+    def host_cache(self) -> Optional[KVCache]:
+        return None if self.host_store is None else self._views(self.host_store)
+
+    @property
+    def device_cache(self) -> Optional[KVCache]:
+        return None if self.device_store is None else self._views(self.device_store)
+
+    @property
     def cache(self) -> KVCache:
-        """Per-layer ``(K, V)`` views ``[Hkv, len, D]`` (the reference's ``host_cache`` layout)."""
-        return [(self.store[i, 0], self.store[i, 1]) for i in range(self.store.shape[0])]
+        """Per-layer ``(K, V)`` views ``[Hkv, len, D]``, device copy first (the reference's ``cache``, :75-80)."""
+        return self._views(self.store)
 
     def __len__(self):
         return len(self.token_sequence)
@@ -124,15 +172,21 @@ class PromptCache:
 
 
 class SchemaCache:
-    def __init__(self, schema: Schema, lm: LanguageModel, batch_size: int = 1, target_device=None, no_cache=False):
+    def __init__(self, schema: Schema, lm: LanguageModel, batch_size: int = 1, target_device=None, no_cache=False,
+                 module_memory: str = "device"):
         self.schema = schema
         self.lm = lm
+        self.module_memory = module_memory
         self.cache_l1: Dict[int, TokenSequenceCache] = {}
         self.cache_l2: Dict[Tuple[int, int], Tuple[TokenSequenceCache, TokenSequenceCache]] = {}
         self.target_device = lm.device if target_device is None else target_device
         self.encode_stats: Dict[str, float] = {}
         if not no_cache:
             self._process(batch_size)
+            if module_memory == "host":
+                for c in self.cache_l1.values():
+                    c.offload()
+                gc.collect()
 
     # ------------------------------------------------------------------------------------------
     def _plan(self):
@@ -314,8 +368,14 @@ class SchemaCache:
 
 
 class CacheEngine:
-    def __init__(self, max_ctx_length: int, lm: LanguageModel, target_device=None):
+    def __init__(self, max_ctx_length: int, lm: LanguageModel, target_device=None, module_memory: Optional[str] = None):
+        """``module_memory``: where add_schema leaves the module KV -- ``"device"`` (HBM, default) or ``"host"`` (pinned
+        host memory, gathered over PCIe: the reference's default placement, :283-296; for libraries beyond HBM).
+        Individual segments move with ``TokenSequenceCache.upload`` / ``free``.  Env default: PC_MODULE_MEMORY."""
         _native.load()
+        self.module_memory = module_memory or os.environ.get("PC_MODULE_MEMORY", "device")
+        if self.module_memory not in ("device", "host"):
+            raise ValueError(f"module_memory must be 'device' or 'host', not {self.module_memory!r}")
         self.lm = lm
         self.schemas: Dict[str, SchemaCache] = {}
         self.target_device = lm.device if target_device is None else target_device
@@ -330,7 +390,7 @@ class CacheEngine:
         if schema.name in self.schemas:
             raise ValueError(f"There is already a schema named {schema.name} in the cache")
         self.schemas[schema.name] = SchemaCache(schema, self.lm, batch_size, target_device=self.target_device,
-                                                no_cache=no_cache)
+                                                no_cache=no_cache, module_memory=self.module_memory)
 
     def get_schema(self, name: str) -> Optional[Schema]:
         return self.schemas[name].schema if name in self.schemas else None

@@ -295,3 +295,56 @@ def test_deep_stack_parity_vs_live_oracle(q_words):
     err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
     print(f"[24 layers, q={len(ids)}] max|dlogit| vs live oracle = {err:.2e} (max|logit| {np.abs(logits).max():.1f})")
     assert err < LOGIT_TOL
+
+
+def test_host_memory_tier_stages_the_same_bytes_and_logits():
+    """Module KV in pinned host memory (the reference's default placement, cache_engine.py:283-296; ``upload`` / ``free``
+    :65-73): pc_kv_gather reads the pinned stores in place.  Staged bytes and logits must equal the all-HBM engine's
+    bit for bit, for an all-host library, a mixed one, and after upload()."""
+    from promptcache_amd import CacheEngine, Prompt
+    g = H.load_case("mid_mha_doc")
+    lm, eng = build_product(g)                                   # module_memory="device"
+    fmt = lm.get_formatter()
+    prompt = Prompt(str(g["prompt_text"]), [fmt])
+    ids, pos, _, cache = eng.process(prompt)
+    S = cache[0][0].shape[1]
+    want_arena = eng.prompt_cache.arena.buf[0, :, :, :, :S].clone()
+    want = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+              past_key_values=cache, use_cache=True).logits.clone()
+
+    mt = int(g["max_tokens"])
+    host = CacheEngine(int(g["max_ctx"]), lm, module_memory="host")
+    host.add_schema(fmt(str(g["schema_text"])), max_tokens=None if mt < 0 else mt)
+    segs = list(host.schemas[list(host.schemas)[0]].cache_l1.values())
+    assert segs and all(c.device_store is None and c.host_store.is_pinned() and not c.host_store.is_cuda for c in segs)
+    assert all(c.host_cache is not None and c.device_cache is None for c in segs)
+
+    def run(engine):
+        engine.prompt_cache.reset()
+        i2, p2, ms, c2 = engine.process(Prompt(str(g["prompt_text"]), [fmt]))
+        assert i2 == ids and p2 == pos and ms >= 0.0
+        assert torch.equal(engine.prompt_cache.arena.buf[0, :, :, :, :S], want_arena)
+        out = lm(input_ids=torch.tensor([i2], device="cuda"), position_ids=torch.tensor([p2], device="cuda"),
+                 past_key_values=c2, use_cache=True).logits
+        assert torch.equal(out, want)
+
+    run(host)                                                    # every segment read over PCIe
+    for c in segs[::2]:
+        c.upload(lm.device)                                      # mixed HBM / host segment table in one launch
+    torch.cuda.synchronize()
+    assert all(c.device_store is not None and c.device_store.is_cuda for c in segs[::2])
+    run(host)
+    for c in segs:
+        c.upload(lm.device)
+    run(host)
+    for c in segs:
+        c.free()                                                 # back to the host tier, still usable
+    assert all(c.device_store is None for c in segs)
+    run(host)
+    # an HBM-born segment can be evicted too: free() first makes the pinned copy
+    dsegs = list(eng.schemas[list(eng.schemas)[0]].cache_l1.values())
+    dsegs[0].free()
+    assert dsegs[0].device_store is None and dsegs[0].host_store.is_pinned()
+    run(eng)
+    with pytest.raises(ValueError):
+        CacheEngine(64, lm, module_memory="disk")

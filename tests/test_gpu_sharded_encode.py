@@ -1,0 +1,95 @@
+"""The N > 1 path of the cache engine END TO END on one GPU box: two processes (both on cuda:0, ``gloo`` for the exchange
+because RCCL wants one device per rank) shard a schema's scaffold passes, run their share through the HIP forward, and
+all-gather the module KV (``SchemaCache._process`` with ``world == 2``, ``parallel.allgather_segments`` on device
+tensors).  Every rank must end with the whole library, equal to the single-process library, and a prompt served from it
+must give the single-process logits."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    try:
+        shape = SHAPES["mid"]
+        lm = Llama2(name="mid", shape=shape, weights=make_weights_np(shape, 11, 0.05), device="cuda:0")
+        fmt = lm.get_formatter()
+        sp, pp = synth.persona_like("shard", system_len=60, intro_len=20,
+                                    traits=(("age", (30, 25, 34)), ("home", (40, 32, 37)), ("job", (25, 30, 21))),
+                                    question_len=9, seed=4)
+
+        def serve(engine):
+            prompt = Prompt(pp, [fmt])
+            ids, pos, _, cache = engine.process(prompt)
+            out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+                     past_key_values=cache, use_cache=True)
+            return out.logits[0].float().cpu()
+
+        def library(engine):
+            sc = engine.schemas["shard"]
+            return sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in sc.cache_l1.values()),
+                          key=lambda t: (t[0], t[1])), dict(sc.encode_stats)
+
+        solo = CacheEngine(1024, lm)
+        solo.add_schema(fmt(sp))                                   # world == 1: everything on this process
+        lib1, st1 = library(solo)
+        logits1 = serve(solo)
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        eng = CacheEngine(1024, lm)
+        eng.add_schema(fmt(sp))                                    # world == 2: sharded passes + all-gather
+        lib2, st2 = library(eng)
+        logits2 = serve(eng)
+        dist.barrier()
+        dist.destroy_process_group()
+
+        assert st2["total_passes"] == st1["total_passes"] and 0 < st2["passes"] < st1["passes"], (st1, st2)
+        assert [(o, n) for o, n, _ in lib1] == [(o, n) for o, n, _ in lib2]
+        worst = max(float((a - b).abs().max()) for (_, _, a), (_, _, b) in zip(lib1, lib2))
+        # same arithmetic per pass; only the batch a pass travels in differs between the two plans
+        assert worst < 4e-3, worst
+        dl = float((logits1 - logits2).abs().max())
+        assert dl < 2e-3, dl
+        q.put((rank, "ok", st2["passes"], worst, dl))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), 0.0, 0.0))
+        raise e
+
+
+def test_two_rank_sharded_encode_on_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    passes = sorted(r[2] for r in res)
+    print(f"[sharded encode, 2 ranks on one GPU] passes per rank {passes}, max|dKV| vs solo {max(r[3] for r in res):.2e}, "
+          f"max|dlogit| {max(r[4] for r in res):.2e}")
+    assert all(r[0] in (0, 1) for r in res) and all(p.exitcode == 0 for p in procs)

@@ -233,7 +233,7 @@ int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, i
  *   pc_attn_fwd_ex      pc_attn_fwd / pc_attn_fwd_alibi with an optional row-major `out_lo` plane next to `out`
  *                       (key_pos / slopes_log2 NULL: no ALiBi) and optional k_lo / v_lo residual planes, see below;
  *                       lo_row0 = -1 means "the rows of this pass" (= past_len, read from past_len_dev when given):
- *                       passes of <= 16 rows then run with one extra KV split whose workgroup computes the attention
+ *                       passes of <= 32 rows then run with one extra KV split whose workgroup computes the attention
  *                       over the pass's own rows in fp32 (size the workspace with pc_attn_workspace_bytes, it
  *                       accounts for that split);
  *                       out_frag_hi / out_frag_lo as in pc_attn_fwd (then `out` may be NULL). */

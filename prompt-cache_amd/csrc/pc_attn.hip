@@ -85,24 +85,28 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     return __builtin_bit_cast(h4, r);
 }
 
-constexpr int kTailMax = 16;       // rows of one prefill pass the tail workgroup handles
+constexpr int kTailMax = 32;       // most rows of one prefill pass the tail workgroup handles (NT = 16 or 32 below)
 
-// The attention of <= 16 new query rows over the <= 16 rows their own pass appended (keys past_len + j, j <= qi), for one
+// The attention of <= NT new query rows over the <= NT rows their own pass appended (keys past_len + j, j <= qi), for one
 // head, as a split-KV partial (m, l, O) in the log2 domain.  All fp32 FMAs on (q_hi + q_lo), (K + K_lo), (V + V_lo): the
 // reference computes the pass in fp32 (llama2.py:361-388), only the STAGED rows are fp16 there.  It runs in the
-// workgroup of an extra split while the other splits stream the staged keys, so its ~2 us hide under their ~10 us.
+// workgroup of an extra split while the other splits stream the staged keys, so its 2-5 us hide under their ~10 us.
 // (Residual tiles inside the streaming kernel instead cost 32 VGPRs -- the second resident workgroup per CU, or spills --
 // and a straggler split: 13.3 -> 15.9 .. 25 us per launch on the persona prompt; the same arithmetic inside the merge
 // kernel lengthened the serial merge by 1.1 us per layer.)
-// LDS: qs/ks/vs are [16][D] fp32 with the float4 column XOR-swizzled by the row (16 lanes read 16 different rows of one
-// column; unswizzled they share a bank), ps is [16][16].
-template <int D, bool ALIBI>
+// 256 threads = NT rows x LPR lanes; a lane owns JPT = NT / LPR keys in the score phase and D / LPR output dims after it.
+// LDS: qs / ks / vs are [NT][D] fp32 (qs, ks with the float4 column XOR-swizzled by the row: the lanes of a row group
+// read different rows of one column; unswizzled they share a bank), ps is [NT][NT].
+template <int D, int NT, bool ALIBI>
 __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __restrict__ qs, float* __restrict__ ks,
                                                 float* __restrict__ vs, float* __restrict__ ps, int b, int h, int split) {
     constexpr int CPR = D / 8;             // 16-byte fp16 chunks per row
     constexpr int F4R = D / 4;             // float4 columns per fp32 row
     constexpr int SWZ = F4R >= 16 ? 15 : F4R - 1;
-    constexpr int DPT = D / 16;            // output dims per thread in the O phase
+    constexpr int LPR = kThreads / NT;     // lanes per query row (16 / 8)
+    constexpr int JPT = NT / LPR;          // keys per lane (1 / 4)
+    constexpr int DPT = D / LPR;           // output dims per lane in the O phase
+    static_assert(NT * LPR == kThreads && JPT * LPR == NT && DPT * LPR == D && DPT % 2 == 0, "tail thread map");
     const int tid = threadIdx.x, q_len = p.q_len;
     const int past = p.past_len_dev ? *p.past_len_dev : p.past_len;
     const int hkv = h / (p.H / p.Hkv);
@@ -110,7 +114,7 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
     const _Float16* vb = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs + (int64_t)past * D;
     const _Float16* klb = p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs;
     const _Float16* vlb = p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs;
-    for (int idx = tid; idx < kTailMax * CPR; idx += kThreads) {
+    for (int idx = tid; idx < NT * CPR; idx += kThreads) {
         const int row = idx / CPR, c = idx - row * CPR;
         const int rc = row < q_len ? row : q_len - 1;          // clamped: unconditional loads
         const int64_t qoff = b * p.q_bs + (int64_t)rc * p.q_ts + (int64_t)h * D + c * 8;
@@ -135,40 +139,58 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
         }
     }
     __syncthreads();
-    const int qi = tid >> 4, j = tid & 15;                       // 256 threads = 16 x 16 (query row, key) pairs
-    float acc = 0.f;
+    const int qi = tid / LPR, jl = tid - qi * LPR;               // (query row, lane in the row group)
+    float acc[JPT];
 #pragma unroll
+    for (int u = 0; u < JPT; ++u) acc[u] = 0.f;
+#pragma unroll 8
     for (int d4 = 0; d4 < F4R; ++d4) {
         const f4 a = *(const f4*)(qs + qi * D + ((d4 ^ (qi & SWZ)) * 4));
-        const f4 k4 = *(const f4*)(ks + j * D + ((d4 ^ (j & SWZ)) * 4));
-        acc += a[0] * k4[0] + a[1] * k4[1] + a[2] * k4[2] + a[3] * k4[3];
+#pragma unroll
+        for (int u = 0; u < JPT; ++u) {
+            const int j = jl + u * LPR;
+            const f4 k4 = *(const f4*)(ks + j * D + ((d4 ^ (j & SWZ)) * 4));
+            acc[u] += a[0] * k4[0] + a[1] * k4[1] + a[2] * k4[2] + a[3] * k4[3];
+        }
     }
-    float sv = acc * p.scale_log2;
-    if (ALIBI) sv += p.slopes[h] * p.key_pos[b * p.kp_bs + past + (j < q_len ? j : q_len - 1)];
-    const bool vis = qi < q_len && j <= qi;                      // causal inside the pass
-    float m = vis ? sv : kNegBig;
+    float sv[JPT];
+    float m = kNegBig;
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    const float pj = vis ? exp2f(sv - m) : 0.f;
-    float l = pj;
+    for (int u = 0; u < JPT; ++u) {
+        const int j = jl + u * LPR;
+        sv[u] = acc[u] * p.scale_log2;
+        if (ALIBI) sv[u] += p.slopes[h] * p.key_pos[b * p.kp_bs + past + (j < q_len ? j : q_len - 1)];
+        const bool vis = qi < q_len && j <= qi;                  // causal inside the pass
+        sv[u] = vis ? sv[u] : kNegBig;
+        m = fmaxf(m, sv[u]);
+    }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off);
-    ps[qi * 16 + j] = pj;
+    for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float l = 0.f;
+#pragma unroll
+    for (int u = 0; u < JPT; ++u) {
+        const int j = jl + u * LPR;
+        const float pj = (qi < q_len && j <= qi) ? exp2f(sv[u] - m) : 0.f;
+        l += pj;
+        ps[qi * NT + j] = pj;
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) l += __shfl_xor(l, off);
     const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
-    if (j == 0 && qi < q_len) { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
+    if (jl == 0 && qi < q_len) { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
     __syncthreads();
     float o[DPT];
 #pragma unroll
     for (int e = 0; e < DPT; ++e) o[e] = 0.f;
+#pragma unroll 4
+    for (int jj = 0; jj < NT; ++jj) {
+        const float w = ps[qi * NT + jj];
 #pragma unroll
-    for (int jj = 0; jj < kTailMax; ++jj) {
-        const float w = ps[qi * 16 + jj];
-#pragma unroll
-        for (int e = 0; e < DPT; ++e) o[e] += w * vs[jj * D + j * DPT + e];
+        for (int e = 0; e < DPT; ++e) o[e] += w * vs[jj * D + jl * DPT + e];
     }
     if (qi < q_len) {
 #pragma unroll
-        for (int e = 0; e < DPT; ++e) p.part_o[slot * D + j * DPT + e] = o[e];
+        for (int e = 0; e < DPT; ++e) p.part_o[slot * D + jl * DPT + e] = o[e];
     }
 }
 
@@ -192,8 +214,12 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     constexpr int LPT = kTK * CPR / kThreads;  // 16-byte loads per thread per tile per tensor
     static_assert(LPT >= 1, "tile too small for 256 threads");
 
-    __shared__ __attribute__((aligned(16))) _Float16 Kl[kTK * D];
-    __shared__ __attribute__((aligned(16))) _Float16 Vl[kTK * D];
+    // (the split-precision variants without residual tiles also host attn_tail_block's fp32 buffers in these two)
+    constexpr int kKlElems = (HP && !KVLO && 4 * kTailMax * D > kTK * D) ? 4 * kTailMax * D : kTK * D;
+    constexpr int kVlElems = (HP && !KVLO && 2 * (kTailMax * D + kTailMax * kTailMax) > kTK * D)
+                                 ? 2 * (kTailMax * D + kTailMax * kTailMax) : kTK * D;
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[kKlElems];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[kVlElems];
     __shared__ __attribute__((aligned(16))) _Float16 Kll[KVLO ? kTK * D : 8];     // residual tiles (KVLO)
     __shared__ __attribute__((aligned(16))) _Float16 Vll[KVLO ? kTK * D : 8];
 
@@ -222,10 +248,12 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
         if (p.tail) {
             nsp = p.nsplit - 1;
             if (split == nsp) {           // workgroup-uniform: the extra split takes the pass's own rows
-                static_assert(sizeof(Kl) >= 2 * kTailMax * D * sizeof(float) && sizeof(Vl) >= (kTailMax * D + 256) * sizeof(float),
-                              "tail buffers live in the K / V tiles");
-                attn_tail_block<D, ALIBI>(p, (float*)Kl, (float*)Kl + kTailMax * D, (float*)Vl, (float*)Vl + kTailMax * D,
-                                          b, h, split);
+                static_assert(sizeof(Kl) >= 2 * kTailMax * D * sizeof(float) &&
+                              sizeof(Vl) >= (kTailMax * D + kTailMax * kTailMax) * sizeof(float), "tail buffers live in the K / V tiles");
+                if (q_len <= 16)
+                    attn_tail_block<D, 16, ALIBI>(p, (float*)Kl, (float*)Kl + 16 * D, (float*)Vl, (float*)Vl + 16 * D, b, h, split);
+                else
+                    attn_tail_block<D, 32, ALIBI>(p, (float*)Kl, (float*)Kl + 32 * D, (float*)Vl, (float*)Vl + 32 * D, b, h, split);
                 return;
             }
         }

@@ -899,7 +899,8 @@ def test_attn_split_precision_qkv(B, H, Hkv, D, q_len, past):
 
 
 @pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 70, 512), (1, 8, 1, 64, 40, 130, 512),
-                                                       (1, 4, 4, 128, 104, 90, 512)])
+                                                       (1, 4, 4, 128, 104, 90, 512), (1, 32, 32, 128, 26, 300, 4096), (2, 8, 1, 64, 31, 5, 512),
+                                                       (1, 4, 4, 32, 32, 0, 128), (1, 4, 2, 128, 17, 1000, 512), (1, 4, 4, 128, 16, 64, 512)])
 def test_weight_streaming_prefill_keeps_new_kv_residuals(B, H, Hkv, D, q_len, past, hid):
     """pc_gemm_qkv_rope(k_lo, v_lo) + pc_attn_fwd_ex(lo_row0 = -1, device past_len, fragment output): the K / V rows the
     pass appends reach its own attention in split precision.  (a) arena + lo planes reproduce the fp32 projection;

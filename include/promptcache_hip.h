@@ -255,6 +255,8 @@ int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int6
 /* pc_rope_append_ex -- pc_rope_append that also writes the fp16 residuals of the appended K / V rows (k_lo, v_lo,
  *   both or neither: [B][Hkv][rows][D] with the given strides, row = key index - lo_row0; lo_row0 = past_len for a
  *   compact buffer of the new rows, 0 for an arena-shaped one that also carries residuals of earlier rows).  pc_attn_fwd_ex consumes them: the keys / values a pass appends enter
+ *   (in2_offset != 0: every q / k_new / v_new input element is x[i] + x[i + in2_offset], the two row halves a stacked
+ *   [hi; lo] projection leaves)
  *   its own attention in split precision, as in the reference's fp32 pass (llama2.py:361-388), while the arena keeps the
  *   fp16 value the reference stages (cache_engine.py:105-106).  Staged rows (< past_len) have no residual. */
 int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
@@ -263,7 +265,7 @@ int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_str
                       int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
                       int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
-                      int64_t lo_head_stride, int32_t lo_row0, void* stream);
+                      int64_t lo_head_stride, int32_t lo_row0, int64_t in2_offset, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

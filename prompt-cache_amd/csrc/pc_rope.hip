@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
     _Float16* __restrict__ k_arena, _Float16* __restrict__ v_arena, int64_t a_bs, int64_t a_hs,
     const float2* __restrict__ cs, int H, int Hkv, int D, int q_len, int past_len,
     const int32_t* __restrict__ past_len_dev, _Float16* __restrict__ k_lo, _Float16* __restrict__ v_lo, int64_t lo_bs,
-    int64_t lo_hs, int lo_row0) {
+    int64_t lo_hs, int lo_row0, int64_t in2) {
+    // in2 != 0: every input element is the SUM x[i] + x[i + in2] -- the two row halves a stacked [hi; lo] projection leaves
     // k_lo / v_lo (optional): fp16 residuals of the appended K / V rows, [B][Hkv][rows][D] with strides lo_bs / lo_hs,
     // row = key index - lo_row0 (lo_row0 = past_len: compact, new rows only; 0: arena-shaped) -- the pass's own
     // keys in split precision for the attention of that pass (the arena keeps the fp16 value the reference stages)
@@ -80,6 +81,13 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
             float lo[8], hi[8];
             load8<TIn>(src + c * 8, lo);
             load8<TIn>(src + half + c * 8, hi);
+            if (in2) {
+                float lo2[8], hi2[8];
+                load8<TIn>(src + in2 + c * 8, lo2);
+                load8<TIn>(src + in2 + half + c * 8, hi2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { lo[e] += lo2[e]; hi[e] += hi2[e]; }
+            }
             h8 olo, ohi, rlo, rhi;   // r*: low-order residuals (second plane of the split-precision q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -110,6 +118,12 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
             const int h = j / cpv, c = j - h * cpv;
             float x[8];
             load8<TIn>(v_new + b * n_bs + t * n_ts + (int64_t)h * D + c * 8, x);
+            if (in2) {
+                float x2[8];
+                load8<TIn>(v_new + in2 + b * n_bs + t * n_ts + (int64_t)h * D + c * 8, x2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += x2[e];
+            }
             h8 o, ol;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -142,7 +156,7 @@ int rope_append_impl(const void* q, int64_t q_batch_stride, int64_t q_token_stri
                      void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
                      const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
                      int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
-                     void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream) {
+                     void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, int64_t in2, void* stream) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG, "pc_rope_append: bad sizes");
     PC_REQUIRE(D > 0 && D % 16 == 0, PC_ERR_ARG, "pc_rope_append: head_dim must be a multiple of 16");
     if (q_len == 0) return PC_OK;
@@ -157,14 +171,14 @@ int rope_append_impl(const void* q, int64_t q_batch_stride, int64_t q_token_stri
                            qo_token_stride, (const float*)k_new, (const float*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
                            arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev, (_Float16*)k_lo,
-                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0);
+                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0, in2);
     else
         hipLaunchKernelGGL(rope_append_kernel<_Float16>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
                            (const _Float16*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, (_Float16*)q_out_lo, qo_batch_stride,
                            qo_token_stride, (const _Float16*)k_new, (const _Float16*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
                            arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev, (_Float16*)k_lo,
-                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0);
+                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0, in2);
     return pc_check_launch("rope_append_kernel");
 }
 }  // namespace
@@ -179,7 +193,7 @@ PC_EXPORT int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_to
     return rope_append_impl(q, q_batch_stride, q_token_stride, q_out, q_out_lo, qo_batch_stride, qo_token_stride, k_new, v_new,
                             kv_new_batch_stride, kv_new_token_stride, k_arena, v_arena, arena_batch_stride,
                             arena_head_stride, cs, B, H, Hkv, D, q_len, past_len, cap, in_is_f32, past_len_dev, nullptr,
-                            nullptr, 0, 0, 0, stream);
+                            nullptr, 0, 0, 0, 0, stream);
 }
 
 PC_EXPORT int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
@@ -189,12 +203,13 @@ PC_EXPORT int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q
                                 const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
                                 int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
                                 void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0,
-                                void* stream) {
+                                int64_t in2_offset, void* stream) {
     PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr), PC_ERR_ARG, "pc_rope_append_ex: k_lo and v_lo go together");
+    PC_REQUIRE(in2_offset % 8 == 0, PC_ERR_ARG, "pc_rope_append_ex: in2_offset must keep 16-byte alignment");
     PC_REQUIRE(!k_lo || (lo_row0 >= 0 && lo_row0 <= past_len && lo_head_stride % 8 == 0), PC_ERR_ARG,
                "pc_rope_append_ex: lo_row0 must lie in [0, past_len] and the lo strides keep 16-byte alignment");
     return rope_append_impl(q, q_batch_stride, q_token_stride, q_out, q_out_lo, qo_batch_stride, qo_token_stride, k_new, v_new,
                             kv_new_batch_stride, kv_new_token_stride, k_arena, v_arena, arena_batch_stride,
                             arena_head_stride, cs, B, H, Hkv, D, q_len, past_len, cap, in_is_f32, past_len_dev, k_lo, v_lo,
-                            lo_batch_stride, lo_head_stride, lo_row0, stream);
+                            lo_batch_stride, lo_head_stride, lo_row0, in2_offset, stream);
 }

@@ -33,7 +33,7 @@ SIGNATURES = {
                                  _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
                                  _vp, _vp, _vp]),
     "pc_rope_append_ex": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
-                                    _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+                                    _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp]),
     "pc_rmsnorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_layernorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_silu_mul_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -128,15 +128,17 @@ def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Opt
 
 def rope_append(q, q_bs, q_ts, q_out, qo_bs, qo_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs,
                 B, H, Hkv, D, q_len, past_len, cap, in_is_f32: bool, past_len_dev=None, q_out_lo=None,
-                stream: Optional[int] = None, kv_lo=None) -> None:
+                stream: Optional[int] = None, kv_lo=None, in2_offset: int = 0) -> None:
+    """``in2_offset`` (elements, with ``kv_lo``): inputs are ``x[i] + x[i + in2_offset]`` (the halves of a [hi; lo] GEMM)."""
     if kv_lo is not None:
         rc = load().pc_rope_append_ex(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
                                       v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
                                       cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), _ptr(past_len_dev),
-                                      kv_lo[0].data_ptr(), kv_lo[1].data_ptr(), kv_lo[2], kv_lo[3], kv_lo[4],
+                                      kv_lo[0].data_ptr(), kv_lo[1].data_ptr(), kv_lo[2], kv_lo[3], kv_lo[4], in2_offset,
                                       current_stream() if stream is None else stream)
         check(rc, "pc_rope_append_ex")
         return
+    assert in2_offset == 0, "in2_offset goes through pc_rope_append_ex (pass kv_lo)"
     rc = load().pc_rope_append(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
                                v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
                                cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), _ptr(past_len_dev),

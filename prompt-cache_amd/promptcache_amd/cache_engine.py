@@ -258,7 +258,7 @@ class SchemaCache:
             job = jobs[0]
             out = lm(input_ids=torch.tensor([job["token_ids"]], device=dev, dtype=torch.long),
                      position_ids=torch.tensor([job["position_ids"]], device=dev, dtype=torch.long), use_cache=True,
-                     many_rows=True)
+                     many_rows=True, kv_only=True)
             trunk_arena = out.past_key_values.arena
             computed_tokens += len(job["token_ids"])
             if 0 in whole:                                   # this rank also owns the root pass: store from the same run
@@ -274,7 +274,7 @@ class SchemaCache:
             out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                      position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
                      attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
-                     use_cache=True, many_rows=True)
+                     use_cache=True, many_rows=True, kv_only=True)
             arena: KVArena = out.past_key_values.arena
             for row, i in enumerate(idxs):
                 encoded_tokens += len(jobs[i]["token_ids"])
@@ -305,7 +305,7 @@ class SchemaCache:
                 out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                          position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
                          attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
-                         past_key_values=arena.views(), use_cache=True, many_rows=True)
+                         past_key_values=arena.views(), use_cache=True, many_rows=True, kv_only=True)
                 arena = out.past_key_values.arena
                 for row, i in enumerate(idxs):
                     encoded_tokens += len(jobs[i]["token_ids"])

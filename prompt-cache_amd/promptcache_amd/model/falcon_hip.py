@@ -92,12 +92,16 @@ class FalconHIP(LlamaHIP):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True)
+            if self._kv_only and li == len(layers) - 1:
+                break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
                        q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws)
             h4 = torch.mm(h16, lw["w1"].t(), out_dtype=f32)                                       # same LayerNorm output (:798)
             n.gelu(h4, act, T * 4 * hid)
             x.add_(torch.mm(attn, lw["wo"].t(), out_dtype=f32))
             x.add_(torch.mm(act, lw["w2"].t(), out_dtype=f32))
+        if self._kv_only:
+            return None
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
@@ -131,18 +135,18 @@ class FalconHIP(LlamaHIP):
         # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
         full_lo = arena.lo is not None and arena.lo_len == past_len
         compact_lo = (lo_k, lo_v, 1 * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
-        qkv = torch.empty((T, W), dtype=f32, device=dev)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_split(x, lw["ln_w"], lw["ln_b"], h2[0], h2[1], T, hid, eps)
-            qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
-            torch.add(qkv2[:T], qkv2[T:], out=qkv)
+            qkv = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)      # rows [0, T): hi part, [T, 2T): lo part
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = arena.lo_planes(li) if full_lo else compact_lo
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo)
+                          q_out_lo=q16l, kv_lo=kv_lo, in2_offset=T * W)
+            if self._kv_only and li == len(layers) - 1:
+                break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l, out_lo=attn2[1], kv_lo=kv_lo)
             h4 = torch.mm(h2.view(2 * T, hid), lw["w1"].t(), out_dtype=f32)
@@ -153,6 +157,8 @@ class FalconHIP(LlamaHIP):
             n.add3(x, d2[:T], d2[T:], T * hid)
         if full_lo:
             arena.lo_len = past_len + q_len
+        if self._kv_only:
+            return None
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)

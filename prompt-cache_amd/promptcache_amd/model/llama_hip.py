@@ -75,6 +75,7 @@ class LlamaHIP:
         # and feed them to that pass's own attention (the reference computes the pass in fp32, llama2.py:361-388; the
         # arena still holds the fp16 values).  Off for single-row decode steps.
         self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
+        self._kv_only = False      # set per call (see __call__)
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True):
@@ -169,8 +170,10 @@ class LlamaHIP:
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                  past_key_values=None, attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True,
                  last_token_only: bool = False, num_layers: Optional[int] = None, many_rows: bool = False,
-                 **_unused) -> CausalLMOutput:
-        """``many_rows``: take the stacked-GEMM path for more than 64 rows even where the row-split kernel would be
+                 kv_only: bool = False, **_unused) -> CausalLMOutput:
+        """``kv_only`` (many-row path): stop after the last layer's K / V are in the arena and return no logits -- all a
+        schema-encode pass is run for (the reference discards the rest, cache_engine.py:243-296).
+        ``many_rows``: take the stacked-GEMM path for more than 64 rows even where the row-split kernel would be
         faster -- it alone keeps the pass's own K/V in split precision, which is what a schema encode wants (its K/V
         are the product)."""
         n = _native
@@ -190,6 +193,7 @@ class LlamaHIP:
                 raise NotImplementedError("left / interior padding masks are not supported by the HIP path")
 
         T = B * q_len
+        self._kv_only = bool(kv_only)
         if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
             # the graph's static int64 / int32 input buffers are filled straight from the caller's tensors
             # (copy_ converts), so no separate dtype-conversion launches sit in front of the replay
@@ -243,6 +247,8 @@ class LlamaHIP:
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, k_new, v_new, q_len * W, W, kp, vp,
                           arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True)
+            if self._kv_only and li == len(layers) - 1:
+                break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws)
             x.add_(torch.mm(attn, lw["wo"].t(), out_dtype=f32))
@@ -251,6 +257,8 @@ class LlamaHIP:
             n.silu_mul(gu, act, T, inter, True)
             x.add_(torch.mm(act, lw["wdown"].t(), out_dtype=f32))
 
+        if self._kv_only:
+            return None
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
@@ -290,18 +298,19 @@ class LlamaHIP:
         # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
         full_lo = arena.lo is not None and arena.lo_len == past_len
         compact_lo = (lo_k, lo_v, Hkv * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
-        qkv = torch.empty((T, W), dtype=f32, device=dev)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.rmsnorm_split(x, lw["ln1"], h2[0], h2[1], T, hid, eps)
-            qkv2 = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)
-            torch.add(qkv2[:T], qkv2[T:], out=qkv)
+            qkv = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)      # rows [0, T): hi part, [T, 2T): lo part
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = arena.lo_planes(li) if full_lo else compact_lo
+            # the two halves are summed inside the RoPE / append kernel (in2_offset)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo)
+                          q_out_lo=q16l, kv_lo=kv_lo, in2_offset=T * W)
+            if self._kv_only and li == len(layers) - 1:
+                break             # schema encode: the K / V of the last layer are written; nothing after them is used
             # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
@@ -315,6 +324,8 @@ class LlamaHIP:
             n.add3(x, d2[:T], d2[T:], T * hid)
         if full_lo:
             arena.lo_len = past_len + q_len
+        if self._kv_only:
+            return None
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
             hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)

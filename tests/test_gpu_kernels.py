@@ -960,3 +960,28 @@ def test_weight_streaming_prefill_keeps_new_kv_residuals(B, H, Hkv, D, q_len, pa
     floor16 = (attn(kn.half().double(), vn.half().double()) - ref).abs().max().item()
     err = (got - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, scale_v) and err < 0.25 * floor16, (err, floor16)
+
+
+def test_rope_append_sums_the_two_halves_of_a_stacked_projection():
+    """pc_rope_append_ex(in2_offset): inputs are x[i] + x[i + in2_offset] -- identical to adding the halves first."""
+    n = _n()
+    rng = np.random.default_rng(91)
+    B, H, Hkv, D, q_len, past = 2, 4, 2, 64, 37, 11
+    T, W, cap = B * q_len, (H + 2 * Hkv) * D, past + q_len + 3
+    x2 = torch.from_numpy(rng.standard_normal((2 * T, W), dtype=np.float32)).to(DEV)
+    xs = (x2[:T] + x2[T:]).contiguous()
+    pos = torch.from_numpy(rng.integers(0, 4000, size=T).astype(np.int32)).to(DEV)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(pos, _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    outs = []
+    for src, off in ((xs, 0), (x2, T * W)):
+        arena = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+        q16 = torch.zeros((T, H * D), dtype=torch.float16, device=DEV); q16l = torch.zeros_like(q16)
+        klo = torch.zeros((B, Hkv, q_len, D), dtype=torch.float16, device=DEV); vlo = torch.zeros_like(klo)
+        n.rope_append(src, q_len * W, W, q16, q_len * H * D, H * D, src[:, H * D:], src[:, (H + Hkv) * D:], q_len * W, W,
+                      arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, cs, B, H, Hkv, D, q_len, past, cap, True,
+                      q_out_lo=q16l, kv_lo=(klo, vlo, Hkv * q_len * D, q_len * D, past), in2_offset=off)
+        outs.append((arena, q16, q16l, klo, vlo))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

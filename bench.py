@@ -189,8 +189,8 @@ def attn_roofline(lm, staged, q_len: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="llama2-7b")
     ap.add_argument("--max-ctx", type=int, default=4096)        # config/llm_config_llama2_7b.json of the reference
     ap.add_argument("--cpu-layers", type=int, default=4)

@@ -85,7 +85,10 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     return __builtin_bit_cast(h4, r);
 }
 
-constexpr int kTailMax = 32;       // most rows of one prefill pass the tail workgroup handles (NT = 16 or 32 below)
+#ifndef PC_TAIL_MAX
+#define PC_TAIL_MAX 32
+#endif
+constexpr int kTailMax = PC_TAIL_MAX;   // most rows of one prefill pass the tail workgroup handles (NT = 16 or 32 below)
 
 // The attention of <= NT new query rows over the <= NT rows their own pass appended (keys past_len + j, j <= qi), for one
 // head, as a split-KV partial (m, l, O) in the log2 domain.  All fp32 FMAs on (q_hi + q_lo), (K + K_lo), (V + V_lo): the
@@ -250,10 +253,10 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             if (split == nsp) {           // workgroup-uniform: the extra split takes the pass's own rows
                 static_assert(sizeof(Kl) >= 2 * kTailMax * D * sizeof(float) &&
                               sizeof(Vl) >= (kTailMax * D + kTailMax * kTailMax) * sizeof(float), "tail buffers live in the K / V tiles");
-                if (q_len <= 16)
+                if (q_len <= 16 || kTailMax == 16)
                     attn_tail_block<D, 16, ALIBI>(p, (float*)Kl, (float*)Kl + 16 * D, (float*)Vl, (float*)Vl + 16 * D, b, h, split);
                 else
-                    attn_tail_block<D, 32, ALIBI>(p, (float*)Kl, (float*)Kl + 32 * D, (float*)Vl, (float*)Vl + 32 * D, b, h, split);
+                    attn_tail_block<D, kTailMax, ALIBI>(p, (float*)Kl, (float*)Kl + kTailMax * D, (float*)Vl, (float*)Vl + kTailMax * D, b, h, split);
                 return;
             }
         }

@@ -144,7 +144,10 @@ def gemm_roofline(lm, T: int):
     nbytes = 2 * inter * hid * 2
     return {"kernel": "gemm_skinny_kernel<EPI_SILU> (gate|up projection, pc_gemm_skinny)", "bound": "hbm",
             "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            # FETCH_SIZE x 2 (gfx950) + WRITE_SIZE of this kernel at this shape, separate rocprofv3 --pmc passes
+            "traffic": 182116147 + 528384 if (T, hid, inter) == (12, 4096, 11008) else None,
+            "traffic_source": "profiles/r01_pmc_gemm_attn_cached.txt",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": avg, "min_launch_us": us[0],
             "launches_timed": len(us), "launches_per_step": c.num_hidden_layers,
             "how": "HIP events around eager launches on each layer's weights after the timed region (event pairs "
@@ -179,7 +182,10 @@ def attn_roofline(lm, staged, q_len: int):
     nbytes = 2 * Hkv * (S + q_len) * D * 2 + 2 * H * q_len * D * 2
     return {"kernel": "attn_fwd_kernel<128,HP> + attn_combine_kernel (pc_attn_fwd, cached prefill)", "bound": "hbm",
             "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            # both kernels, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc passes at this shape
+            "traffic": (28696576 + 1997107 + 2446336 + 98304) if (H, Hkv, D, q_len, S) == (32, 32, 128, 12, 1725) else None,
+            "traffic_source": "profiles/r01_pmc_gemm_attn_cached.txt",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": avg, "min_launch_us": us[0],
             "launches_timed": len(us), "launches_per_step": m.L,
             "how": "HIP events around eager pc_attn_fwd calls (two kernels: split-KV attention + merge) on each layer's "

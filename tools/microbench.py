@@ -94,6 +94,22 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         print("gather-only done: algorithmic bytes per launch", 2 * sum(PERSONA) * 32 * 2 * 32 * 128 * 2)
         sys.exit(0)
+    if "--gemm-only" in sys.argv:        # PMC passes: the kernel of bench.py's roofline_gemm (norm-fused gate|up, 12 rows, 7b)
+        hid, inter, T = 4096, 11008, 12
+        ncopy = 5                                             # 5 x 180 MB > the 256 MB Infinity Cache
+        ws = [n.to_weight_frags(torch.randn(2 * inter, hid, device=DEV).half() * 0.05) for _ in range(ncopy)]
+        x = torch.randn(T, hid, device=DEV)
+        g = torch.ones(hid, dtype=torch.float16, device=DEV)
+        oh = torch.empty((1, inter // 32, 64, 8), dtype=torch.float16, device=DEV); ol = torch.empty_like(oh)
+        for i in range(10):
+            n.gemm_skinny_norm(ws[i % ncopy], x, g, 1e-5, T, 2 * inter, hid, n.EPI_SILU, of_hi=oh, of_lo=ol)
+        torch.cuda.synchronize()
+        print("gemm-only done: algorithmic weight bytes per launch", 2 * inter * hid * 2)
+        sys.exit(0)
+    if "--attn-cached-only" in sys.argv:  # PMC passes: the cached-prefill attention of the persona prompt (q = 12 over S = 1725)
+        for _ in range(2):
+            bench_attn("persona cached", 32, 32, 128, 12, 1725)
+        sys.exit(0)
     if "--attn-only" in sys.argv:        # PMC passes: a few launches of the large-q (MFMA-bound) attention shapes
         for _ in range(2):
             bench_attn("nocache 4404", 32, 32, 128, 4404, 0)

@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--cpu-layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-library", action="store_true", help="skip the schema-library encode leg (BASELINE config 5)")
+    ap.add_argument("--no-int8", action="store_true", help="skip the int8-weight context leg (builds a second model)")
     ap.add_argument("--no-context", action="store_true", help="skip the extra (untimed) no-cache / decode / GEMM-roofline runs")
     args = ap.parse_args()
 
@@ -422,6 +423,35 @@ def main():
         for m in used:
             m.upload(device)
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_context and not args.no_int8:
+        # context: the reference's GPU configs load the model with load_in_8bit=True (config/llm_config_llama2_7b.json:5).
+        # Weight-only int8 here: same prompt, same staged module KV (bit-identical gather), the
+        # decoder linears streamed as int8 fragment images.  A different numeric mode: never `value`.
+        lm8 = Llama2(args.model, device=device, random_init=True, seed=0, load_in_8bit=True)
+        ids8, pos8, _, cache8 = eng.process(prompt)
+        i8_t = torch.tensor([ids8], device=device, dtype=torch.long)
+        p8_t = torch.tensor([pos8], device=device, dtype=torch.long)
+        ts8 = []
+        for _ in range(12):
+            pc.reset()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _, _, _, cache8 = eng.process(prompt)
+            o8 = lm8(input_ids=i8_t, position_ids=p8_t, past_key_values=cache8, use_cache=True)
+            torch.cuda.synchronize(); ts8.append((time.perf_counter() - t0) * 1e3)
+        past8, tok8 = o8.past_key_values, int(torch.argmax(o8.logits[0, -1]))
+        for phase in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(32):
+                o8 = lm8(input_ids=torch.tensor([[tok8]], device=device),
+                         position_ids=torch.tensor([[max(pos8) + 2 + phase * 32 + i]], device=device),
+                         past_key_values=past8, use_cache=True)
+                past8, tok8 = o8.past_key_values, int(torch.argmax(o8.logits[0, -1]))
+            torch.cuda.synchronize(); dt8 = time.perf_counter() - t0
+        result["int8_weights"] = {"ttft_ms": sorted(ts8[2:])[len(ts8[2:]) // 2], "decode_tokens_per_s": 32 / dt8,
+                                  "what": "load_in_8bit=True: row-wise absmax int8 decoder linears (weight-only, exact "
+                                          "arithmetic on the dequantised values), lm_head fp16; module KV from the fp16 engine"}
+        del lm8, o8, past8, cache8
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline_and_parity(lm, eng, prompt, ids, pos, args.cpu_layers)
         result["cpu_baseline"] = base

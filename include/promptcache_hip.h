@@ -267,6 +267,31 @@ int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_str
                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
                       int64_t lo_head_stride, int32_t lo_row0, int64_t in2_offset, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * int8 weights (the reference's GPU configs pass load_in_8bit=True to from_pretrained,
+ * config/llm_config_*.json:5, eval.py:36-42 -- bitsandbytes LLM.int8, a dependency that is not in the tree).
+ * This is WEIGHT-ONLY int8: q[n][k] = round(w[n][k] / scale[n]), scale[n] = absmax_k |w[n][k]| / 127 (the row-wise
+ * absmax quantiser LLM.int8 applies to weights); activations stay split-precision fp16 pairs, accumulation fp32, so a
+ * launch returns scale[n] * sum_k q[n][k] * x[k] -- what an fp32 GEMM over the dequantised weights gives -- while
+ * streaming half the weight bytes.  wf8: fragment image [N/16][K/64][64][16] of offset-binary bytes (q + 128), a lane's
+ * 16 bytes = its 8 values of k-step 2s then of k-step 2s + 1 (K % 64 == 0);
+ * w_scale: fp32 [N] in the row order of the image (16-byte aligned).  M <= 64.  Other arguments as in the fp16 entries;
+ * pc_gemm_qkv_rope_w8 takes either the activation planes (x = norm_weight = NULL) or the fused-RMSNorm source
+ * (xf_hi = xf_lo = NULL, M <= 16).
+ * ------------------------------------------------------------------------------------------- */
+int pc_gemm_skinny_w8(const void* wf8, const float* w_scale, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N,
+                      int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
+                      void* stream);
+int pc_gemm_skinny_norm_w8(const void* wf8, const float* w_scale, const float* x, const void* norm_weight, float eps,
+                           int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi,
+                           void* of_lo, void* stream);
+int pc_gemm_qkv_rope_w8(const void* wf8_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo,
+                        const float* x, const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs,
+                        void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
+                        int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
+                        int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
+                        int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
+
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);

@@ -73,12 +73,31 @@ struct GemmParams {
     int32_t kslices; int64_t slab_stride;   // EPI_STORE only: grid.y K-slices, slice s writes y + s*slab_stride
     // NORM activation source (M <= 16): the fp32 residual stream itself; RMSNorm is folded into the launch
     const float* xn; const _Float16* gamma; float eps;
+    // int8 weights (W8 kernels, M <= 64): wf is the fragment image of OFFSET-BINARY bytes (q + 128), 8 B per lane per
+    // k-step, wscale[n] the fp32 scale of output feature n (row order of the image); y = scale * sum_k q[n][k] x[k]
+    const float* wscale; int32_t w8;
     RopeEpi rope;
 };
 
 __device__ __forceinline__ h8 ldg_h8(const _Float16* p) { return *(const h8*)p; }
 __device__ __forceinline__ h8 ldg_h8_nt(const _Float16* p) {
     return __builtin_bit_cast(h8, __builtin_nontemporal_load((const u32x4*)p));
+}
+
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// int8 weights: 8 offset-binary bytes (two dwords, one k-step of this lane) -> fp16, exactly: the byte u goes under the
+// exponent of 1024.0 (0x6400 | u = 1024 + u), then 1152 = 1024 + 128 is subtracted (v_perm_b32 + v_pk_add_f16: 8 VALU
+// ops per fragment next to two 8-pass MFMAs).
+__device__ __forceinline__ h8 cvt_w8(uint32_t d0, uint32_t d1) {
+    const h2v bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+    const h2v a0 = __builtin_bit_cast(h2v, __builtin_amdgcn_perm(0x64646464u, d0, 0x04010400u)) - bias;
+    const h2v b0 = __builtin_bit_cast(h2v, __builtin_amdgcn_perm(0x64646464u, d0, 0x04030402u)) - bias;
+    const h2v a1 = __builtin_bit_cast(h2v, __builtin_amdgcn_perm(0x64646464u, d1, 0x04010400u)) - bias;
+    const h2v b1 = __builtin_bit_cast(h2v, __builtin_amdgcn_perm(0x64646464u, d1, 0x04030402u)) - bias;
+    const h8 out = {a0[0], a0[1], b0[0], b0[1], a1[0], a1[1], b1[0], b1[1]};
+    return out;
 }
 
 // position of element (row m, feature k) in a fragment-major plane with KS k-steps
@@ -93,17 +112,28 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
 // TAIL: the last, partial block of a wave's K range (nvalid < U k-steps): the missing steps re-read the last
 // valid one and their weight fragments are zeroed, so the tail keeps the same load depth as a full block
 // instead of degenerating into nvalid serial load->wait->MFMA round trips.
-template <int MT, int TT, bool TWO, int U, bool TAIL>
+template <int MT, int TT, bool TWO, int U, bool TAIL, bool W8 = false>
 __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], const _Float16* xh_base,
                                         const _Float16* xl_base, int KS, int ks, int nvalid, const bool (&row_ok)[MT],
                                         f4 (&acc)[MT][TT]) {
-    h8 w[U][TT], xh[U][MT], xl[U][MT];
+    // W8: the image holds k-step PAIRS -- a lane's 16 bytes are its 8 values of k-step 2s and of 2s + 1 -- so one
+    // global_load_dwordx4 feeds four MFMAs; ks, nvalid and U are even (the K ranges are cut on pair boundaries).  The
+    // raw bytes wait in registers (half of what fp16 fragments take) and are converted right before their MFMAs.
+    constexpr int NW = W8 ? U / 2 : U;
+    static_assert(!W8 || U % 2 == 0, "int8 weights come in k-step pairs");
+    h8 w[W8 ? 1 : U][TT], xh[U][MT], xl[U][MT];
+    u32x4 raw[W8 ? NW : 1][TT];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < NW; ++u)
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
-            w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + uu) * 512);   // 1 KiB / wave, streamed once
+            if constexpr (W8) {
+                const int uu = (TAIL && 2 * u >= nvalid) ? nvalid / 2 - 1 : u;
+                raw[u][t] = __builtin_nontemporal_load((const u32x4*)(wbase[t] + (int64_t)((ks >> 1) + uu) * 512));
+            } else {
+                const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+                w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + uu) * 512);   // 1 KiB / wave, streamed once
+            }
         }
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
@@ -126,7 +156,7 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
     // keep the whole block's loads in flight: hipcc otherwise sinks each load next to its MFMA and waits
     // vmcnt(0) per k-step (measured in the ISA), which turns a streaming kernel into a latency chain
     __builtin_amdgcn_sched_barrier(0);
-    if (TAIL) {
+    if (TAIL && !W8) {
 #pragma unroll
         for (int u = 1; u < U; ++u)
             if (u >= nvalid) {
@@ -136,14 +166,20 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
             }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+        if (W8 && TAIL && u >= nvalid) continue;          // (wave-uniform) the re-read pair contributes nothing
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
+        for (int t = 0; t < TT; ++t) {
+            h8 wv;
+            if constexpr (W8) wv = (u & 1) ? cvt_w8(raw[u >> 1][t][2], raw[u >> 1][t][3]) : cvt_w8(raw[u >> 1][t][0], raw[u >> 1][t][1]);
+            else wv = w[u][t];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], xh[u][a], acc[a][t], 0, 0, 0);
-                if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], xl[u][a], acc[a][t], 0, 0, 0);
+                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xh[u][a], acc[a][t], 0, 0, 0);
+                if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xl[u][a], acc[a][t], 0, 0, 0);
             }
+        }
+    }
 }
 
 // NORM variant of k_block for M <= 16: the activation operand is produced on the fly from the fp32 residual stream
@@ -151,17 +187,25 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
 // planes), forms g*x as a split-precision pair and accumulates sum(x^2) of its K slice in `ss`.  The 1/rms factor
 // is a per-row scalar and the GEMM is linear in the activations, so it is applied to the reduced tile in the
 // epilogue -- LlamaRMSNorm (llama2.py:103-108) costs no launch and no pass over x of its own.  Needs |g*x| < 65504.
-template <int TT, int U, bool TAIL>
+template <int TT, int U, bool TAIL, bool W8 = false>
 __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT], const float* xrow, const _Float16* gam,
                                              int ks, int nvalid, bool row_ok, f4 (&acc)[1][TT], float& ss) {
-    h8 w[U][TT], gw[U];
+    constexpr int NW = W8 ? U / 2 : U;                   // W8: k-step pairs per 16-byte load, see k_block
+    static_assert(!W8 || U % 2 == 0, "int8 weights come in k-step pairs");
+    h8 w[W8 ? 1 : U][TT], gw[U];
+    u32x4 raw[W8 ? NW : 1][TT];
     f4 xa[U][2];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < NW; ++u)
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
-            w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + uu) * 512);
+            if constexpr (W8) {
+                const int uu = (TAIL && 2 * u >= nvalid) ? nvalid / 2 - 1 : u;
+                raw[u][t] = __builtin_nontemporal_load((const u32x4*)(wbase[t] + (int64_t)((ks >> 1) + uu) * 512));
+            } else {
+                const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+                w[u][t] = ldg_h8_nt(wbase[t] + (int64_t)(ks + uu) * 512);
+            }
         }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -194,8 +238,11 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
         }
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], hi, acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], lo, acc[0][t], 0, 0, 0);
+            h8 wv;
+            if constexpr (W8) wv = (u & 1) ? cvt_w8(raw[u >> 1][t][2], raw[u >> 1][t][3]) : cvt_w8(raw[u >> 1][t][0], raw[u >> 1][t][1]);
+            else wv = w[u][t];
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, hi, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, lo, acc[0][t], 0, 0, 0);
         }
     }
 }
@@ -206,6 +253,14 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
 template <int EPI>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, int row, int unit, int g, int slice) {
     const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
+    if (p.wscale && unit < nunits) {        // int8 weights: per-output-feature scale (linear, so K-sliced partials scale too)
+        const f4 sv = *(const f4*)(p.wscale + unit * 16 + g * 4);
+        v[0] *= sv[0]; v[1] *= sv[1]; v[2] *= sv[2]; v[3] *= sv[3];
+        if (EPI == EPI_SILU) {
+            const f4 su = *(const f4*)(p.wscale + (p.npairs + unit) * 16 + g * 4);
+            u[0] *= su[0]; u[1] *= su[1]; u[2] *= su[2]; u[3] *= su[3];
+        }
+    }
     if (unit < nunits && row < p.M) {
         if (EPI == EPI_SILU) {
             const int j0 = unit * 16 + g * 4;   // intermediate feature index of v[0]
@@ -293,7 +348,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
     }
 }
 
-template <int MT, int T, int EPI, bool TWO, int U, bool NORM = false>
+template <int MT, int T, int EPI, bool TWO, int U, bool NORM = false, bool W8 = false>
 __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams p) {
     static_assert(!NORM || (MT == 1 && TWO), "the fused-RMSNorm source is for one row tile");
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
@@ -307,10 +362,12 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     const int KS = p.KS;
     // K range of this workgroup (grid.y slices K across workgroups; partial sums then go to per-slice slabs
     // that the consumer -- pc_rmsnorm_frag -- adds up in fixed order), then eight ways across the waves
-    const int ksq = (KS + p.kslices - 1) / p.kslices;
+    int ksq = (KS + p.kslices - 1) / p.kslices;
+    if (W8) ksq = (ksq + 1) & ~1;                         // int8 images are cut on k-step pairs (KS is even)
     const int kq0 = blockIdx.y * ksq;
     const int kq1 = (kq0 + ksq < KS) ? kq0 + ksq : KS;
-    const int ksw = (kq1 - kq0 + kWaves - 1) / kWaves;
+    int ksw = (kq1 - kq0 + kWaves - 1) / kWaves;
+    if (W8) ksw = (ksw + 1) & ~1;
     const int ks0 = kq0 + wave * ksw;
     const int ks1 = (ks0 + ksw < kq1) ? ks0 + ksw : kq1;
 
@@ -336,7 +393,8 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 
     const _Float16* wbase[TT];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) wbase[t] = p.wf + ((int64_t)tile[t] * KS * 64 + lane) * 8;
+    // (W8: [tile][KS/2][64][16 B] -- the same 512 halfs per unit as fp16, the unit being a k-step pair)
+    for (int t = 0; t < TT; ++t) wbase[t] = p.wf + ((int64_t)tile[t] * (W8 ? KS / 2 : KS) * 64 + lane) * 8;
     const _Float16* xh_base = p.xf_hi + lane * 8;
     const _Float16* xl_base = TWO ? p.xf_lo + lane * 8 : nullptr;
 
@@ -349,14 +407,14 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     if constexpr (NORM) {
         const float* xrow = p.xn + (int64_t)m * (KS * 32) + g * 8;
         const _Float16* gam = p.gamma + g * 8;
-        for (; ks + U <= ks1; ks += U) k_block_norm<TT, U, false>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss);
-        if (ks < ks1) k_block_norm<TT, U, true>(wbase, xrow, gam, ks, ks1 - ks, row_ok[0], acc, ss);
+        for (; ks + U <= ks1; ks += U) k_block_norm<TT, U, false, W8>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss);
+        if (ks < ks1) k_block_norm<TT, U, true, W8>(wbase, xrow, gam, ks, ks1 - ks, row_ok[0], acc, ss);
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         if (g == 0) ssl[wave][m] = ss;                   // this wave's share of sum(x^2) of row m
     } else {
-        for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
-        if (ks < ks1) k_block<MT, TT, TWO, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+        for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U, false, W8>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
+        if (ks < ks1) k_block<MT, TT, TWO, U, true, W8>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
     }
 
     // ---- split-K reduction through LDS, fixed order ----
@@ -518,6 +576,17 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
     const bool two = p.xf_lo != nullptr;
 #define PC_GO(UV)                                                                                     \
     do {                                                                                              \
+        if (p.w8) {   /* int8 weights: split-precision activations only; twice the k-steps per block = the same bytes */ \
+            constexpr int UW = ((UV) * 2 > 8) ? 8 : (UV) * 2;                                         \
+            if constexpr (MT == 1 && EPI != EPI_ADD) {                                                \
+                if (p.xn) {                                                                           \
+                    hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, true, true>), grid, block, 0, s, p); \
+                    break;                                                                            \
+                }                                                                                     \
+            }                                                                                         \
+            hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, false, true>), grid, block, 0, s, p); \
+            break;                                                                                    \
+        }                                                                                             \
         if constexpr (MT == 1 && EPI != EPI_ADD) {                                                    \
             if (p.xn) {                                                                               \
                 hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UV, true>), grid, block, 0, s, p); \
@@ -793,7 +862,7 @@ int choose_T(int units) {
 namespace {
 int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma, float eps,
                      int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
-                     int32_t kslices, void* stream) {
+                     int32_t kslices, void* stream, const float* wscale = nullptr) {
     PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
@@ -803,6 +872,9 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
     memset(&p, 0, sizeof(p));
     p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
     p.wf = (const _Float16*)wf; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
+    PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
+               "pc_gemm_skinny_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
+    p.wscale = wscale; p.w8 = wscale ? 1 : 0;
     p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
     PC_REQUIRE(kslices >= 1 && kslices <= 16 && (kslices == 1 || epilogue == EPI_STORE), PC_ERR_ARG,
@@ -831,7 +903,8 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream);
+                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
+                       const float* wscale = nullptr);
 }  // namespace
 
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
@@ -877,7 +950,8 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream) {
+                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
+                       const float* wscale) {
     const int N = (H + 2 * Hkv) * D;
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
@@ -889,6 +963,9 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
     memset(&p, 0, sizeof(p));
     p.wf = (const _Float16*)wf_perm; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
     p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
+    PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
+               "pc_gemm_qkv_rope_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
+    p.wscale = wscale; p.w8 = wscale ? 1 : 0;
     p.y = nullptr; p.ldy = 0; p.of_hi = nullptr; p.of_lo = nullptr; p.KSo = 0;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.kslices = 1; p.slab_stride = 0;
     p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
@@ -932,4 +1009,39 @@ PC_EXPORT int pc_layernorm_frag(float* x, const void* weight, const void* bias, 
     if (groups <= 1) PC_LN(1); else if (groups <= 2) PC_LN(2); else if (groups <= 4) PC_LN(4); else PC_LN(8);
 #undef PC_LN
     return pc_check_launch("layernorm_frag_kernel");
+}
+
+// ---- int8 weights (the reference's GPU configs load the model with load_in_8bit) ----------------
+// Weight-only int8: wf8 is the fragment image [N/16][K/64][64][16] of OFFSET-BINARY bytes -- a lane's 16 bytes are its 8
+// values of k-step 2s followed by those of k-step 2s + 1 -- (q + 128, q = round(w / scale)
+// per output row, scale = absmax / 127), w_scale[N] fp32 in the row order of the image.  Activations stay split-precision
+// fp16 pairs and accumulation fp32, so y = scale[n] * sum_k q[n][k] * x[k] exactly as an fp32 GEMM over the dequantised
+// weights would give it -- half the weight bytes per launch.  M <= 64 (the weight-streaming regime proper).
+PC_EXPORT int pc_gemm_skinny_w8(const void* wf8, const float* w_scale, const void* xf_hi, const void* xf_lo, int32_t M,
+                                int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
+                                int32_t kslices, void* stream) {
+    PC_REQUIRE(xf_hi && xf_lo && w_scale, PC_ERR_ARG, "pc_gemm_skinny_w8: null pointer");
+    return gemm_skinny_impl(wf8, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, kslices, stream,
+                            w_scale);
+}
+
+PC_EXPORT int pc_gemm_skinny_norm_w8(const void* wf8, const float* w_scale, const float* x, const void* norm_weight, float eps,
+                                     int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi,
+                                     void* of_lo, void* stream) {
+    PC_REQUIRE(x && norm_weight && w_scale, PC_ERR_ARG, "pc_gemm_skinny_norm_w8: null pointer");
+    return gemm_skinny_impl(wf8, nullptr, nullptr, x, norm_weight, eps, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream,
+                            w_scale);
+}
+
+PC_EXPORT int pc_gemm_qkv_rope_w8(const void* wf8_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo,
+                                  const float* x, const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs,
+                                  void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
+                                  int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
+                                  int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
+                                  void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream) {
+    PC_REQUIRE(w_scale_perm && ((xf_hi && xf_lo && !x) || (x && norm_weight && !xf_hi && M <= 16)), PC_ERR_ARG,
+               "pc_gemm_qkv_rope_w8: pass either the activation planes or (x, norm_weight) with M <= 16");
+    return gemm_qkv_rope_impl(wf8_perm, xf_hi, xf_lo, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
+                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
+                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm);
 }

@@ -42,6 +42,10 @@ SIGNATURES = {
     "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "pc_gemm_skinny_w8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "pc_gemm_skinny_norm_w8": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "pc_gemm_qkv_rope_w8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
+                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "pc_gemm_skinny_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "pc_gemm_qkv_rope_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
@@ -188,18 +192,32 @@ EPI_STORE, EPI_ADD, EPI_SILU, EPI_GELU = 0, 1, 2, 4
 
 
 def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0, of_hi=None, of_lo=None,
-                kslices: int = 1, stream: Optional[int] = None) -> None:
-    """``kslices > 1`` (plain-store epilogue): ``y`` is ``[kslices][M][ldy]`` slabs of partial sums."""
+                kslices: int = 1, stream: Optional[int] = None, wscale=None) -> None:
+    """``kslices > 1`` (plain-store epilogue): ``y`` is ``[kslices][M][ldy]`` slabs of partial sums.
+    ``wscale`` (fp32 [N]): ``wf`` is an int8 fragment image (``to_weight_frags_i8``) -> pc_gemm_skinny_w8."""
+    if wscale is not None:
+        rc = load().pc_gemm_skinny_w8(wf.data_ptr(), wscale.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue,
+                                      _ptr(y), ldy, _ptr(of_hi), _ptr(of_lo), kslices,
+                                      current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_skinny_w8")
+        return
     rc = load().pc_gemm_skinny(wf.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue, _ptr(y), ldy,
                                _ptr(of_hi), _ptr(of_lo), kslices, current_stream() if stream is None else stream)
     check(rc, "pc_gemm_skinny")
 
 
 def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,
-                  past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None) -> None:
+                  past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None, wscale=None) -> None:
     """``kv_lo=(k_lo, v_lo, batch_stride, head_stride)``: also write the fp16 residuals of the new K / V rows (compact
     ``[B][Hkv][q_len][D]``) for ``attn_fwd(..., kv_lo=(k_lo, v_lo, bs, hs, -1))``."""
     lo = (None, None, 0, 0) if kv_lo is None else kv_lo
+    if wscale is not None:
+        rc = load().pc_gemm_qkv_rope_w8(wf_perm.data_ptr(), wscale.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), None, None, 0.0,
+                                        M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
+                                        v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
+                                        _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_qkv_rope_w8")
+        return
     rc = load().pc_gemm_qkv_rope(wf_perm.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, K, cs.data_ptr(), q_hi.data_ptr(),
                                  q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D,
                                  q_len, past_len, cap, _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3],
@@ -226,16 +244,31 @@ def gelu(x_f32, out, n: int, stream: Optional[int] = None) -> None:
 
 
 def gemm_skinny_norm(wf, x_f32, norm_weight, eps: float, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,
-                     of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
+                     of_hi=None, of_lo=None, stream: Optional[int] = None, wscale=None) -> None:
     """RMSNorm folded into the projection (M <= 16): y = W . (norm_weight * x) * rsqrt(mean(x^2) + eps)."""
+    if wscale is not None:
+        rc = load().pc_gemm_skinny_norm_w8(wf.data_ptr(), wscale.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, N,
+                                           K, epilogue, _ptr(y), ldy, _ptr(of_hi), _ptr(of_lo),
+                                           current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_skinny_norm_w8")
+        return
     rc = load().pc_gemm_skinny_norm(wf.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, N, K, epilogue, _ptr(y),
                                     ldy, _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
     check(rc, "pc_gemm_skinny_norm")
 
 
 def gemm_qkv_rope_norm(wf_perm, x_f32, norm_weight, eps: float, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H,
-                       Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None) -> None:
+                       Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None,
+                       wscale=None) -> None:
     lo = (None, None, 0, 0) if kv_lo is None else kv_lo
+    if wscale is not None:
+        rc = load().pc_gemm_qkv_rope_w8(wf_perm.data_ptr(), wscale.data_ptr(), None, None, x_f32.data_ptr(),
+                                        norm_weight.data_ptr(), eps, M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts,
+                                        k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap,
+                                        _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3],
+                                        current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_qkv_rope_w8")
+        return
     rc = load().pc_gemm_qkv_rope_norm(wf_perm.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, K, cs.data_ptr(),
                                       q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs,
                                       a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]),
@@ -268,6 +301,37 @@ def to_weight_frags(w):
     N, K = w.shape
     assert N % 16 == 0 and K % 32 == 0, (N, K)
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def quantize_rows_int8(w):
+    """Row-wise absmax int8 (the weight quantiser of LLM.int8): ``q = round_half_even(w * (127 / absmax_row))`` in
+    [-127, 127], ``scale = absmax_row / 127`` (all-zero row: q = 0, scale = 1).  The two per-row divisions are done on
+    the host in IEEE fp32 (a GPU's fp32 division is not correctly rounded), the per-element step is one correctly
+    rounded fp32 product, so the result is bit-identical to ``oracle/int8_oracle.py`` on any device.
+    Returns ``(q int8 [N, K], scale fp32 [N])`` on the weight's device."""
+    import torch
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).cpu()
+    ok = amax > 0
+    one = torch.ones_like(amax)
+    c127 = torch.full_like(amax, 127.0)
+    safe = torch.where(ok, amax, one)
+    # tensor / tensor: true IEEE division on the CPU (scalar / tensor is evaluated as reciprocal * scalar: 1 ulp off)
+    scale = torch.where(ok, safe / c127, one)
+    inv = torch.where(ok, c127 / safe, torch.zeros_like(amax))
+    q = torch.round(wf * inv.to(w.device)[:, None]).clamp_(-127, 127).to(torch.int8)
+    return q, scale.to(w.device).contiguous()
+
+
+def to_weight_frags_i8(q):
+    """int8 weight [N, K] -> fragment-major image [N/16][K/64][64][16] of OFFSET-BINARY bytes (q + 128) for the W8 kernels:
+    lane 16 g + m of tile t holds, for the k-step pair s, row 16 t + m's features 64 s + 8 g .. + 7 followed by
+    64 s + 32 + 8 g .. + 7 (one 16-byte load feeds two k-steps).  Returned as ``[N/16][K/64][4][16][2][8]``."""
+    import torch
+    N, K = q.shape
+    assert N % 16 == 0 and K % 64 == 0 and q.dtype == torch.int8, (N, K, q.dtype)
+    u = (q.to(torch.int16) + 128).to(torch.uint8)
+    return u.view(N // 16, 16, K // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous()
 
 
 def to_act_frags(x):

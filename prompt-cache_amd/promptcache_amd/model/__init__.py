@@ -172,7 +172,8 @@ class _LlamaFamily(LanguageModel):
             weights = W.random_weights_device(shape, device, torch.float16, seed)
         if tokenizer is None:
             tokenizer = StandInTokenizer(shape.vocab_size)
-        model = LlamaHIP(shape, weights, device=device)
+        # load_in_8bit (the reference's GPU configs, config/llm_config_*.json:5): weight-only int8 for the decoder linears
+        model = LlamaHIP(shape, weights, device=device, int8_weights=bool(_hf_kwargs.get("load_in_8bit", False)))
         self.formatter = _llama_formatter()
         super().__init__(name, model, tokenizer, [tokenizer.eos_token_id], ["</s>"])
 

@@ -168,6 +168,11 @@ SHAPES = {
     # get_cache_shape returns num_attention_heads, promptcache/model/__init__.py:110-114)
     "mid": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1376, num_hidden_layers=3,
                       num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-5, name="mid"),
+    # every GEMM K a multiple of 64 (what the int8-weight images need), D = 128, MHA and GQA
+    "mid64": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1408, num_hidden_layers=3,
+                        num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-5, name="mid64"),
+    "mid64_gqa": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1408, num_hidden_layers=3,
+                            num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid64_gqa"),
     # GQA 2:1 so the head-broadcast index math is exercised (oracle-checked only)
     "mid_gqa": LlamaShape(vocab_size=2048, hidden_size=512, intermediate_size=1376, num_hidden_layers=3,
                           num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, name="mid_gqa"),

@@ -78,7 +78,11 @@ class LlamaHIP:
         self._kv_only = False      # set per call (see __call__)
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
-                 decode_headroom: int = 256, skinny: bool = True):
+                 decode_headroom: int = 256, skinny: bool = True, int8_weights: bool = False):
+        """``int8_weights`` (the adapters' ``load_in_8bit=True``): the decoder-layer linears are quantised row-wise to
+        int8 (``_native.quantize_rows_int8``); passes of <= 64 rows stream the int8 fragment images (half the bytes, exact
+        arithmetic on the dequantised values); longer passes run the hipBLASLt path on the dequantised weights rounded
+        to fp16."""
         self._setup(shape, device, decode_headroom)
         c = shape
         self.H, self.Hkv, self.D, self.L = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.num_hidden_layers
@@ -102,18 +106,37 @@ class LlamaHIP:
         fr = _native.to_weight_frags if self.skinny else (lambda t: None)
         self.lm_head_f = fr(self.lm_head)
         self.layers = []
+        # (the int8 images are cut on pairs of 32-feature k-steps: every GEMM K must be a multiple of 64)
+        self.int8_weights = bool(int8_weights) and self.skinny and c.hidden_size % 64 == 0 and \
+            c.intermediate_size % 64 == 0 and (self.H * self.D) % 64 == 0
+        if self.int8_weights:
+            self.MID_MAX_ROWS = self.SKINNY_MAX_ROWS      # the row-split kernel has no int8 variant: 65+ rows go dense
+
+        def prep(wt, perm=None):
+            """-> (row-major fp16 for the dense path, fragment image for the streaming kernels, fp32 scales | None)"""
+            if not self.int8_weights:
+                src = wt if perm is None else wt[perm].contiguous()
+                return wt, fr(src), None
+            q, sc = _native.quantize_rows_int8(wt)
+            dense = (q.float() * sc[:, None]).to(self.dtype)              # dequantised, rounded to fp16 (many-row paths)
+            if perm is not None:
+                q, sc = q[perm].contiguous(), sc[perm].contiguous()
+            return dense, _native.to_weight_frags_i8(q), sc
+
         for i in range(self.L):
             wqkv = torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous()
             wgu = torch.cat([w(f"l{i}.gate"), w(f"l{i}.up")], dim=0).contiguous()
             wo, wdown = w(f"l{i}.wo"), w(f"l{i}.down")
-            if self.skinny:
-                if i == 0:
-                    self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2 * self.Hkv, self.D).to(dev)
-                wqkv_f = fr(wqkv[self._qkv_perm].contiguous())     # rotary pairs share a 16-row tile (pc_gemm_qkv_rope)
-            else:
-                wqkv_f = None
+            if self.skinny and i == 0:
+                self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2 * self.Hkv, self.D).to(dev)
+            # q|k|v fragment image: rotary pairs share a 16-row tile (pc_gemm_qkv_rope)
+            wqkv, wqkv_f, wqkv_s = prep(wqkv, self._qkv_perm if self.skinny else None)
+            wo, wo_f, wo_s = prep(wo)
+            wgu, wgu_f, wgu_s = prep(wgu)
+            wdown, wdown_f, wdown_s = prep(wdown)
             self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown,
-                                    wqkv_f=wqkv_f, wo_f=fr(wo), wgu_f=fr(wgu), wdown_f=fr(wdown)))
+                                    wqkv_f=wqkv_f, wo_f=wo_f, wgu_f=wgu_f, wdown_f=wdown_f,
+                                    wqkv_s=wqkv_s, wo_s=wo_s, wgu_s=wgu_s, wdown_s=wdown_s))
         # exactly the reference formula, evaluated on the CPU like the reference does (llama2.py:121)
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
@@ -350,13 +373,14 @@ class LlamaHIP:
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                                  arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
-                                 kv_lo=kvlo and kvlo[:4])
+                                 kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)
-            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)                   # x += attn @ Wo^T
-            n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)
-            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)                # x += act @ Wd^T
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"])  # x += attn @ Wo^T
+            n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
+                               wscale=lw["wgu_s"])
+            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wdown_s"])  # x += act @ Wd^T
         if last_token_only:
             xs = x.view(B, q_len, hid)[:, -1, :].contiguous()
             logits = torch.empty((B, V), dtype=torch.float32, device=self.device)
@@ -440,14 +464,17 @@ class LlamaHIP:
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             # q|k|v projection + RoPE + in-place KV append in one weight-streaming launch
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
-                            arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4])
+                            arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
+                            wscale=lw["wqkv_s"])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)
-            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ)   # attn @ Wo^T
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
+                          wscale=lw["wo_s"])                                                    # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm
-            n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)  # silu(g)*u
-            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ)  # act @ Wd^T
+            n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl, wscale=lw["wgu_s"])  # silu(g)*u
+            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
+                          wscale=lw["wdown_s"])                                                 # act @ Wd^T
             pending = KQ
         V = c.vocab_size
         if last_token_only:

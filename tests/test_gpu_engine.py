@@ -348,3 +348,73 @@ def test_host_memory_tier_stages_the_same_bytes_and_logits():
     run(eng)
     with pytest.raises(ValueError):
         CacheEngine(64, lm, module_memory="disk")
+
+
+@pytest.mark.parametrize("shape_name,seed", [("mid64", 21), ("mid64_gqa", 22)])
+def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed):
+    """``load_in_8bit=True`` (the reference's GPU configs): weight-only int8 for the decoder linears.  The oracle runs the
+    ordinary fp32 path over the DEQUANTISED weights (oracle/int8_oracle.py); cached prefill and greedy decode stream the
+    int8 fragment images, the schema encode runs hipBLASLt on the dequantised weights rounded to fp16."""
+    from promptcache_amd import CacheEngine, Prompt
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    from oracle.llama_oracle import LlamaOracle, OracleConfig
+    from oracle import int8_oracle as io
+    g = H.load_case("tiny_trip")
+    shape = SHAPES[shape_name]
+    w16 = make_weights_np(shape, seed, 2.0)
+    lm = Llama2(name="x", shape=shape, weights=w16, device="cuda:0", load_in_8bit=True)
+    assert lm.hf_model.int8_weights and lm.hf_model.layers[0]["wqkv_s"] is not None
+    eng = CacheEngine(256, lm)
+    eng.add_schema(lm.get_formatter()(str(g["schema_text"])))
+    prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    cfg = OracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, intermediate_size=shape.intermediate_size,
+                       num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                       num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
+                       rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
+    wd = io.dequantized_llama_weights({k: v.astype(np.float32) for k, v in w16.items()})
+    assert not np.array_equal(wd["l0.wq"], w16["l0.wq"].astype(np.float32)) and np.array_equal(wd["lm_head"], w16["lm_head"].astype(np.float32))
+    model = LlamaOracle(cfg, wd)
+    sc = eng.get_schema("trip")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    staged, S, (logits, present) = eo.cached_prefill(model, lib, used, ids, pos, 256)
+    err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    # the same prefill on the ORACLE's staged KV isolates the int8 streaming kernels from the fp16-weight encode
+    arena = eng.prompt_cache.arena
+    for l, (k, v) in enumerate(staged):
+        arena.buf[0, l, 0, :, :S] = torch.from_numpy(k).cuda()
+        arena.buf[0, l, 1, :, :S] = torch.from_numpy(v).cuda()
+    arena.length = S
+    out2 = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+              past_key_values=arena.views(S), use_cache=True)
+    err2 = np.abs(out2.logits[0].cpu().numpy() - logits[0]).max()
+    # what the quantisation itself moves (context for the numbers above)
+    ref16 = LlamaOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
+    lib16 = eo.encode_schema(ref16, jobs)
+    _, _, (logits16, _) = eo.cached_prefill(ref16, lib16, used, ids, pos, 256)
+    print(f"[int8 {shape_name}] end to end {err:.2e}; on oracle-staged KV {err2:.2e}; int8 vs fp16 weights (oracle) "
+          f"{np.abs(logits16 - logits).max():.2e}")
+    assert err < LOGIT_TOL and err2 < 2e-3
+    # four decode steps, teacher-forced with the oracle's greedy tokens (hipGraph replay, int8 images, M = 1)
+    past, olog = out2.past_key_values, logits
+    for i in range(4):
+        tok = int(np.argmax(olog[0, -1]))
+        p1 = max(pos) + 1 + i
+        olog, present = model.forward(np.array([[tok]]), np.array([[p1]]), past=present)
+        o = lm(input_ids=torch.tensor([[tok]], device="cuda"), position_ids=torch.tensor([[p1]], device="cuda"),
+               past_key_values=past, use_cache=True)
+        past = o.past_key_values
+        d = np.abs(o.logits[0, -1].cpu().numpy() - olog[0, -1]).max()
+        top2 = np.sort(olog[0, -1])[-2:]
+        assert d < LOGIT_TOL, (i, d)
+        if top2[1] - top2[0] > 4 * d:
+            assert int(o.logits[0, -1].argmax()) == int(np.argmax(olog[0, -1]))

@@ -985,3 +985,128 @@ def test_rope_append_sums_the_two_halves_of_a_stacked_projection():
     torch.cuda.synchronize()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# int8 weights (weight-only; pc_gemm_*_w8)
+# ---------------------------------------------------------------------------------------------------
+
+def test_int8_row_quantizer_is_bit_exact_with_the_oracle():
+    from oracle import int8_oracle as io
+    n = _n()
+    rng = np.random.default_rng(5)
+    w = (0.05 * rng.standard_normal((96, 192), dtype=np.float32)).astype(np.float16)
+    w[7] = 0                                                    # an all-zero row keeps scale 1
+    w[11, 3] = np.float16(0.31)                                 # an outlier sets its row's scale
+    for r in range(20, 60):                                     # exact ties: w = amax / 2 -> 63.5 before rounding; a 1-ulp
+        w[r, 5] = np.float16(-0.5) * np.abs(w[r]).max()         # error in 127 / amax flips the result (seen on real weights)
+    q, s = n.quantize_rows_int8(torch.from_numpy(w).to(DEV))
+    qo, so = io.quantize_rows_int8(w.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), qo) and np.array_equal(s.cpu().numpy(), so)
+    assert int(np.abs(qo).max()) == 127 and so[7] == 1.0
+    img = n.to_weight_frags_i8(q).cpu().numpy()
+    assert img.dtype == np.uint8 and img.shape == (6, 3, 4, 16, 2, 8)    # [tile][k-step pair][g][m][half][8]: lane = 16 g + m
+    # lane g*16+m of tile t, k-step s holds row 16t+m, features 32s+8g .. +7, offset binary
+    assert np.array_equal(img[2, 1, 1, 5, 1].astype(np.int16) - 128, qo[2 * 16 + 5, 3 * 32 + 8: 3 * 32 + 16].astype(np.int16))
+
+
+@pytest.mark.parametrize("M,N,K,epi,kq", [(12, 4096, 4096, 0, 1), (12, 4096, 11008, 0, 4), (1, 12288, 4096, 0, 1), (40, 4096, 4096, 1, 1),
+                                          (64, 512, 384, 0, 2), (16, 22016, 4096, 2, 1), (33, 1376 * 2, 512, 2, 1), (5, 2048, 512, 4, 1),
+                                          (3, 64, 64, 0, 1), (20, 4096, 1408, 0, 4), (1, 4096, 11008, 0, 4)])
+def test_gemm_skinny_w8_matches_fp64_on_dequantised_weights(M, N, K, epi, kq):
+    """y = scale[n] * sum_k q[n][k] * (x_hi + x_lo)[k]: exact integers times split-precision activations, fp32 sums."""
+    n = _n()
+    rng = np.random.default_rng(17)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    q, sc = n.quantize_rows_int8(w)
+    wf8 = n.to_weight_frags_i8(q)
+    wd = q.double() * sc.double()[:, None]
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    xd = n.from_act_frags(hi, M).double() + n.from_act_frags(lo, M).double()
+    ref = xd @ wd.T
+    mt = (M + 15) // 16
+    if epi in (0, 1):
+        y = torch.full((kq, M, N), 0.5, dtype=torch.float32, device=DEV) if epi == 1 else torch.empty((kq, M, N), dtype=torch.float32, device=DEV)
+        n.gemm_skinny(wf8, hi, lo, M, N, K, epi, y=y, ldy=N, kslices=kq, wscale=sc)
+        got = y.double().sum(0)
+        if epi == 1:
+            ref = ref + 0.5
+    else:
+        inter = N // 2 if epi == 2 else N
+        oh = torch.zeros((mt, inter // 32, 64, 8), dtype=torch.float16, device=DEV); ol = torch.zeros_like(oh)
+        n.gemm_skinny(wf8, hi, lo, M, N, K, epi, of_hi=oh, of_lo=ol, wscale=sc)
+        got = n.from_act_frags(oh, M).double() + n.from_act_frags(ol, M).double()
+        ref = torch.nn.functional.silu(ref[:, :inter]) * ref[:, inter:] if epi == 2 else torch.nn.functional.gelu(ref)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(12, 22016, 4096, 2), (7, 32000, 4096, 0), (16, 1024, 512, 0)])
+def test_gemm_skinny_norm_w8(M, N, K, epi):
+    n = _n()
+    rng = np.random.default_rng(23)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    q, sc = n.quantize_rows_int8(w)
+    wd = q.double() * sc.double()[:, None]
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    gam = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(K, dtype=np.float32)).astype(np.float16)).to(DEV)
+    xn = x.double() * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-5) * gam.double()
+    ref = xn @ wd.T
+    if epi == 0:
+        y = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        n.gemm_skinny_norm(n.to_weight_frags_i8(q), x, gam, 1e-5, M, N, K, 0, y=y, ldy=N, wscale=sc)
+        got = y.double()
+    else:
+        inter = N // 2
+        oh = torch.zeros((1, inter // 32, 64, 8), dtype=torch.float16, device=DEV); ol = torch.zeros_like(oh)
+        n.gemm_skinny_norm(n.to_weight_frags_i8(q), x, gam, 1e-5, M, N, K, 2, of_hi=oh, of_lo=ol, wscale=sc)
+        got = n.from_act_frags(oh, M).double() + n.from_act_frags(ol, M).double()
+        ref = torch.nn.functional.silu(ref[:, :inter]) * ref[:, inter:]
+    err = (got - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid,norm", [(1, 32, 32, 128, 12, 100, 4096, True), (1, 32, 32, 128, 40, 9, 4096, False),
+                                                            (2, 4, 2, 64, 5, 7, 256, True)])
+def test_gemm_qkv_rope_w8(B, H, Hkv, D, q_len, past, hid, norm):
+    """The int8 fused q|k|v projection against the fp16 fused projection run on the DEQUANTISED weights -- those are
+    exactly representable here only approximately (q * scale rounds in fp16), so the comparison is against fp64 math."""
+    n = _n()
+    rng = np.random.default_rng(29)
+    T, W, cap = B * q_len, (H + 2 * Hkv) * D, past + q_len + 2
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    q8, sc = n.quantize_rows_int8(w)
+    wd = q8.double() * sc.double()[:, None]
+    perm = n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((T, hid), dtype=np.float32)).to(DEV)
+    gam = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(hid, dtype=np.float32)).astype(np.float16)).to(DEV)
+    pos = torch.from_numpy(rng.integers(0, 3000, size=T).astype(np.int32)).to(DEV)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(pos, _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    arena = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    q16 = torch.zeros((T, H * D), dtype=torch.float16, device=DEV); q16l = torch.zeros_like(q16)
+    klo = torch.zeros((B, Hkv, q_len, D), dtype=torch.float16, device=DEV); vlo = torch.zeros_like(klo)
+    kv_lo = (klo, vlo, Hkv * q_len * D, q_len * D)
+    wf8, scp = n.to_weight_frags_i8(q8[perm].contiguous()), sc[perm].contiguous()
+    if norm:
+        n.gemm_qkv_rope_norm(wf8, x, gam, 1e-5, T, hid, cs, q16, q16l, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D,
+                             B, H, Hkv, D, q_len, past, cap, kv_lo=kv_lo, wscale=scp)
+        xd = x.double() * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-5) * gam.double()
+    else:
+        hi, lo = n.to_act_frags(x)
+        n.gemm_qkv_rope(wf8, hi, lo, T, hid, cs, q16, q16l, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D,
+                        B, H, Hkv, D, q_len, past, cap, kv_lo=kv_lo, wscale=scp)
+        xd = n.from_act_frags(hi, T).double() + n.from_act_frags(lo, T).double()
+    qkv = xd @ wd.T
+    def rot(t):
+        c, s_ = cs[..., 0].double(), cs[..., 1].double()
+        c, s_ = torch.cat([c, c], 1)[:, None], torch.cat([s_, s_], 1)[:, None]
+        return t * c + torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1) * s_
+    qd = rot(qkv[:, :H * D].view(T, H, D)).reshape(T, H * D)
+    kn = rot(qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)).view(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    vn = qkv[:, (H + Hkv) * D:].view(B, q_len, Hkv, D).permute(0, 2, 1, 3)
+    tol = 3e-5 * max(1.0, float(qkv.abs().max()))
+    assert ((q16.double() + q16l.double()) - qd).abs().max().item() < tol
+    assert ((arena[:, 0, :, past:past + q_len].double() + klo.double()) - kn).abs().max().item() < tol
+    assert ((arena[:, 1, :, past:past + q_len].double() + vlo.double()) - vn).abs().max().item() < tol

@@ -110,6 +110,33 @@ if __name__ == "__main__":
         for _ in range(2):
             bench_attn("persona cached", 32, 32, 128, 12, 1725)
         sys.exit(0)
+    if "--gemm-w8" in sys.argv:          # int8 weight images vs fp16, the four projection shapes of a 7b layer at 12 rows
+        def w8(name, M, N, K, epi, kq=1, norm=False):
+            ncopy = max(2, int(700e6 / (N * K)) + 1)
+            qs = [n.quantize_rows_int8(torch.randn(N, K, device=DEV).half() * 0.05) for _ in range(2)]
+            ws = [(n.to_weight_frags_i8(qs[i % 2][0]), qs[i % 2][1]) for i in range(ncopy)]
+            x = torch.randn(M, K, device=DEV); hi, lo = n.to_act_frags(x)
+            g = torch.ones(K, dtype=torch.float16, device=DEV)
+            mt = (M + 15) // 16
+            y = torch.zeros((kq, M, N), dtype=torch.float32, device=DEV)
+            oh = torch.empty((mt, max(N // 64, 1), 64, 8), dtype=torch.float16, device=DEV); ol = torch.empty_like(oh)
+            i = [0]
+            def fn():
+                i[0] = (i[0] + 1) % ncopy
+                wf, sc = ws[i[0]]
+                if norm:
+                    n.gemm_skinny_norm(wf, x, g, 1e-5, M, N, K, epi, y=y if epi == 0 else None, ldy=N, of_hi=oh, of_lo=ol, wscale=sc)
+                elif epi == 2:
+                    n.gemm_skinny(wf, hi, lo, M, N, K, 2, of_hi=oh, of_lo=ol, wscale=sc)
+                else:
+                    n.gemm_skinny(wf, hi, lo, M, N, K, epi, y=y, ldy=N, kslices=kq, wscale=sc)
+            med, best = timeit(fn, iters=40)
+            print(f"w8 {name}{' norm' if norm else ''}: M={M} N={N} K={K} epi={epi} kq={kq}  med {med*1e3:.1f} us (best {best*1e3:.1f})  int8 weights {N*K/med/1e6:.0f} GB/s")
+        M = 12
+        w8("gate_up", M, 22016, 4096, 2); w8("gate_up", M, 22016, 4096, 2, norm=True)
+        w8("qkv", M, 12288, 4096, 0); w8("o", M, 4096, 4096, 0, 4); w8("down", M, 4096, 11008, 0, 4)
+        bench_gemm("gate_up fp16", M, 22016, 4096, 2); bench_gemm("down fp16", M, 4096, 11008, 0, 4)
+        sys.exit(0)
     if "--attn-only" in sys.argv:        # PMC passes: a few launches of the large-q (MFMA-bound) attention shapes
         for _ in range(2):
             bench_attn("nocache 4404", 32, 32, 128, 4404, 0)

@@ -459,6 +459,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        barrier()                      # the other ranks wait for rank 0's (untimed) context legs before tearing down
         dist.destroy_process_group()
 
 

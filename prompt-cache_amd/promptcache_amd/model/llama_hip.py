@@ -81,8 +81,8 @@ class LlamaHIP:
                  decode_headroom: int = 256, skinny: bool = True, int8_weights: bool = False):
         """``int8_weights`` (the adapters' ``load_in_8bit=True``): the decoder-layer linears are quantised row-wise to
         int8 (``_native.quantize_rows_int8``); passes of <= 64 rows stream the int8 fragment images (half the bytes, exact
-        arithmetic on the dequantised values); longer passes run the hipBLASLt path on the dequantised weights rounded
-        to fp16."""
+        arithmetic on the dequantised values); longer passes run hipBLASLt on the int8 codes held in fp16 (exact) and
+        scale the product per output feature (``_mm``)."""
         self._setup(shape, device, decode_headroom)
         c = shape
         self.H, self.Hkv, self.D, self.L = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.num_hidden_layers
@@ -116,12 +116,13 @@ class LlamaHIP:
             """-> (row-major fp16 for the dense path, fragment image for the streaming kernels, fp32 scales | None)"""
             if not self.int8_weights:
                 src = wt if perm is None else wt[perm].contiguous()
-                return wt, fr(src), None
+                return wt, fr(src), (None, None)
             q, sc = _native.quantize_rows_int8(wt)
-            dense = (q.float() * sc[:, None]).to(self.dtype)              # dequantised, rounded to fp16 (many-row paths)
+            dense = q.to(self.dtype)                      # the int8 codes, exact in fp16; _mm applies the scales (many-row paths)
+            dsc = sc
             if perm is not None:
                 q, sc = q[perm].contiguous(), sc[perm].contiguous()
-            return dense, _native.to_weight_frags_i8(q), sc
+            return dense, _native.to_weight_frags_i8(q), (sc, dsc)
 
         for i in range(self.L):
             wqkv = torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous()
@@ -136,7 +137,8 @@ class LlamaHIP:
             wdown, wdown_f, wdown_s = prep(wdown)
             self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown,
                                     wqkv_f=wqkv_f, wo_f=wo_f, wgu_f=wgu_f, wdown_f=wdown_f,
-                                    wqkv_s=wqkv_s, wo_s=wo_s, wgu_s=wgu_s, wdown_s=wdown_s))
+                                    wqkv_s=wqkv_s[0], wo_s=wo_s[0], wgu_s=wgu_s[0], wdown_s=wdown_s[0],
+                                    wqkv_ds=wqkv_s[1], wo_ds=wo_s[1], wgu_ds=wgu_s[1], wdown_ds=wdown_s[1]))
         # exactly the reference formula, evaluated on the CPU like the reference does (llama2.py:121)
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
@@ -154,6 +156,17 @@ class LlamaHIP:
             return None
         lo = torch.empty((2, B, Hkv, q_len, D), dtype=self.dtype, device=self.device)
         return (lo[0], lo[1], Hkv * q_len * D, q_len * D, -1)
+
+    @staticmethod
+    def _mm(a: torch.Tensor, lw: dict, key: str) -> torch.Tensor:
+        """``a @ W^T`` in fp32 on hipBLASLt.  int8 mode: ``lw[key]`` holds the int8 codes as fp16 (exact) and the per-output
+        scales are applied to the product -- the many-row paths then compute with exactly the dequantised weights the
+        streaming kernels use, instead of an fp16 rounding of them (2e-2 on 32-layer logits)."""
+        y = torch.mm(a, lw[key].t(), out_dtype=torch.float32)
+        sc = lw.get(key + "_ds")
+        if sc is not None:
+            y.mul_(sc)
+        return y
 
     def _workspace(self, nbytes: int) -> Optional[torch.Tensor]:
         if nbytes <= 0:
@@ -264,7 +277,7 @@ class LlamaHIP:
             n.rmsnorm(x, lw["ln1"], h16, T, hid, eps, True)
             # projections keep fp32 outputs (fp16 x fp16 -> fp32 accumulate -> fp32 store): one rounding less
             # per stage against the reference's fp32 CPU path
-            qkv = torch.mm(h16, lw["wqkv"].t(), out_dtype=f32)       # [T, (H+2Hkv)*D]
+            qkv = self._mm(h16, lw, "wqkv")       # [T, (H+2Hkv)*D]
             k_new = qkv[:, H * D:]
             v_new = qkv[:, (H + Hkv) * D:]
             kp, vp = arena.k_plane(li), arena.v_plane(li)
@@ -274,11 +287,11 @@ class LlamaHIP:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws)
-            x.add_(torch.mm(attn, lw["wo"].t(), out_dtype=f32))
+            x.add_(self._mm(attn, lw, "wo"))
             n.rmsnorm(x, lw["ln2"], h16, T, hid, eps, True)
-            gu = torch.mm(h16, lw["wgu"].t(), out_dtype=f32)         # [T, 2*inter]
+            gu = self._mm(h16, lw, "wgu")         # [T, 2*inter]
             n.silu_mul(gu, act, T, inter, True)
-            x.add_(torch.mm(act, lw["wdown"].t(), out_dtype=f32))
+            x.add_(self._mm(act, lw, "wdown"))
 
         if self._kv_only:
             return None
@@ -325,7 +338,7 @@ class LlamaHIP:
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.rmsnorm_split(x, lw["ln1"], h2[0], h2[1], T, hid, eps)
-            qkv = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)      # rows [0, T): hi part, [T, 2T): lo part
+            qkv = self._mm(h2.view(2 * T, hid), lw, "wqkv")      # rows [0, T): hi part, [T, 2T): lo part
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = arena.lo_planes(li) if full_lo else compact_lo
             # the two halves are summed inside the RoPE / append kernel (in2_offset)
@@ -338,12 +351,12 @@ class LlamaHIP:
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
                        out_lo=attn2[1], kv_lo=kv_lo)
-            o2 = torch.mm(attn2.view(2 * T, H * D), lw["wo"].t(), out_dtype=f32)
+            o2 = self._mm(attn2.view(2 * T, H * D), lw, "wo")
             n.add3(x, o2[:T], o2[T:], T * hid)
             n.rmsnorm_split(x, lw["ln2"], h2[0], h2[1], T, hid, eps)
-            gu2 = torch.mm(h2.view(2 * T, hid), lw["wgu"].t(), out_dtype=f32)
+            gu2 = self._mm(h2.view(2 * T, hid), lw, "wgu")
             n.silu_mul_split(gu2[:T], gu2[T:], act2[0], act2[1], T, inter)
-            d2 = torch.mm(act2.view(2 * T, inter), lw["wdown"].t(), out_dtype=f32)
+            d2 = self._mm(act2.view(2 * T, inter), lw, "wdown")
             n.add3(x, d2[:T], d2[T:], T * hid)
         if full_lo:
             arena.lo_len = past_len + q_len

@@ -24,7 +24,8 @@ def main(layers=32, qlen=8):
     from promptcache_amd.model.weights import random_weights_device
     shape = dataclasses.replace(SHAPES["llama2-7b"], num_hidden_layers=layers)
     w = random_weights_device(shape, "cuda:0", torch.float16, seed=5)
-    lm = Llama2(name="llama2-7b", shape=shape, weights=w, device="cuda:0")
+    int8 = os.environ.get("PC_DBG_INT8") == "1"          # load_in_8bit: the oracle then runs on the dequantised weights
+    lm = Llama2(name="llama2-7b", shape=shape, weights=w, device="cuda:0", load_in_8bit=int8)
     if os.environ.get("PC_DBG_BENCH_WORKLOAD") == "1":     # the bench.py workload itself: 29 passes, S = 1725, q = 12
         sp, pp = synth.persona_like("p7")
     else:
@@ -43,7 +44,11 @@ def main(layers=32, qlen=8):
                        num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
                        num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
                        rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
-    model = LlamaOracle(cfg, {k: v.float().cpu().numpy() for k, v in w.items()})
+    wnp = {k: v.float().cpu().numpy() for k, v in w.items()}
+    if int8:
+        from oracle import int8_oracle as io
+        wnp = io.dequantized_llama_weights(wnp)
+    model = LlamaOracle(cfg, wnp)
     sc = eng.get_schema("p7")
     jobs = []
     for p in sc.encode_paths():

@@ -232,7 +232,8 @@ int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, i
  *   pc_add3             x += a + b  (fp32 residual stream)
  *   pc_attn_fwd_ex      pc_attn_fwd / pc_attn_fwd_alibi with an optional row-major `out_lo` plane next to `out`
  *                       (key_pos / slopes_log2 NULL: no ALiBi) and optional k_lo / v_lo residual planes, see below;
- *                       lo_row0 = -1 means "the rows of this pass" (= past_len, read from past_len_dev when given):
+ *                       lo_row0 = -2: the residual tail starts at key past_len_dev[1] (decode steps, see
+ *                       pc_gemm_qkv_rope_ex); lo_row0 = -1 means "the rows of this pass" (= past_len, read from past_len_dev when given):
  *                       passes of <= 32 rows then run with one extra KV split whose workgroup computes the attention
  *                       over the pass's own rows in fp32 (size the workspace with pc_attn_workspace_bytes, it
  *                       accounts for that split);
@@ -291,6 +292,19 @@ int pc_gemm_qkv_rope_w8(const void* wf8_perm, const float* w_scale_perm, const v
                         int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
                         int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
                         int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
+
+/* pc_gemm_qkv_rope_ex -- the union of the q|k|v entry points (fp16 weights: w_scale_perm = NULL, int8: not NULL;
+ *   activation planes, or x + norm_weight for the fused-RMSNorm source) plus lo_base: where the residual row of token tt
+ *   goes in k_lo / v_lo -- tt (-1: a buffer of this pass's rows), past_len + tt - lo_base (>= 0), or
+ *   past_len + tt - past_len_dev[1] (-2).  The last two keep ONE residual tail per layer across a prefill and the decode
+ *   steps after it (llama2.py:361-388 keeps those K / V rows in fp32 for the whole generation, generation_engine.py:123-147);
+ *   pc_attn_fwd_ex(lo_row0 = -2) reads it, lo_row0 coming from the same device word. */
+int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo, const float* x,
+                        const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo,
+                        int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
+                        int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                        int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
+                        int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (see csrc/pc_probe.hip). */

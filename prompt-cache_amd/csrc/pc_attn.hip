@@ -308,7 +308,9 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     [[maybe_unused]] u32x4 krl[KVLO ? LPT : 1], vrl[KVLO ? LPT : 1];
     [[maybe_unused]] const _Float16* klb = KVLO ? p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
     [[maybe_unused]] const _Float16* vlb = KVLO ? p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
-    [[maybe_unused]] const int lo_row0 = KVLO ? (p.lo_row0 < 0 ? past_len : p.lo_row0) : 0;   // < 0: the new rows
+    // lo_row0: -1 = the rows of this pass (past_len); -2 = the device word next to past_len (decode over a residual tail
+    // that started at an earlier pass; hipGraph replays read both from the same static buffer)
+    [[maybe_unused]] const int lo_row0 = !KVLO ? 0 : (p.lo_row0 == -2 ? p.past_len_dev[1] : (p.lo_row0 < 0 ? past_len : p.lo_row0));
     auto issue_loads = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -867,7 +869,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
-    p.tail = (k_lo && lo_row0 < 0 && q_len <= kTailMax) ? 1 : 0;
+    p.tail = (k_lo && lo_row0 == -1 && q_len <= kTailMax) ? 1 : 0;
     if (p.tail) {
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
         // next instantiation of the merge kernel (4 / 8 / 16 / 32 partials per row)
@@ -929,8 +931,8 @@ PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_st
                              void* out_frag_lo, void* stream) {
     PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || q_lo), PC_ERR_ARG,
                "pc_attn_fwd_ex: k_lo / v_lo go together and need q_lo (split-precision Q)");
-    PC_REQUIRE(!k_lo || (lo_row0 < 0 || (lo_row0 <= past_len && past_len_dev == nullptr)), PC_ERR_ARG,
-               "pc_attn_fwd_ex: lo_row0 must be -1 (= past_len) or lie in [0, past_len] of a host past_len");
+    PC_REQUIRE(!k_lo || lo_row0 == -1 || (lo_row0 == -2 && past_len_dev) || (lo_row0 >= 0 && lo_row0 <= past_len && !past_len_dev),
+               PC_ERR_ARG, "pc_attn_fwd_ex: lo_row0 must be -1 (= past_len), -2 (= past_len_dev[1]) or lie in [0, past_len] of a host past_len");
     PC_REQUIRE(!k_lo || lo_head_stride % 8 == 0, PC_ERR_ARG, "pc_attn_fwd_ex: the lo strides must keep 16-byte alignment");
     PC_REQUIRE((key_pos == nullptr) == (slopes_log2 == nullptr), PC_ERR_ARG, "pc_attn_fwd_ex: key_pos and slopes go together");
     PC_REQUIRE(!key_pos || (key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0), PC_ERR_ARG,

@@ -58,7 +58,8 @@ struct RopeEpi {          // EPI_ROPE outputs
     const float2* cs;     // [B*q_len][D/2] (cos, sin) from pc_rope_table
     _Float16* q_hi; _Float16* q_lo; int64_t q_ts;        // [B*q_len][H*D] planes, token stride q_ts
     _Float16* k_arena; _Float16* v_arena; int64_t a_bs, a_hs;
-    _Float16* k_lo; _Float16* v_lo; int64_t lo_bs, lo_hs;   // optional fp16 residuals of the new K / V rows, [B][Hkv][q_len][D]
+    _Float16* k_lo; _Float16* v_lo; int64_t lo_bs, lo_hs;   // optional fp16 residuals of the new K / V rows, [B][Hkv][rows][D]
+    int32_t lo_base;      // residual row of token tt: tt (lo_base = -1), past + tt - lo_base (>= 0), past + tt - past_len_dev[1] (-2)
     const int32_t* past_len_dev;
     int32_t H, Hkv, D, q_len, past_len;
 };
@@ -330,7 +331,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
                 } else {
                     const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
                     *(h4*)(e.k_arena + bb * e.a_bs + (int64_t)(hh - e.H) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hi;
-                    if (e.k_lo) *(h4*)(e.k_lo + bb * e.lo_bs + (int64_t)(hh - e.H) * e.lo_hs + (int64_t)tt * e.D + d0) = lo;
+                    if (e.k_lo) {
+                        const int lr = e.lo_base == -1 ? tt : past + tt - (e.lo_base == -2 ? e.past_len_dev[1] : e.lo_base);
+                        *(h4*)(e.k_lo + bb * e.lo_bs + (int64_t)(hh - e.H) * e.lo_hs + (int64_t)lr * e.D + d0) = lo;
+                    }
                 }
             } else {
                 const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
@@ -342,7 +346,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
                     hv[r] = oh; lv[r] = ol;
                 }
                 *(h4*)(e.v_arena + bb * e.a_bs + (int64_t)(hh - e.H - e.Hkv) * e.a_hs + (int64_t)(past + tt) * e.D + d0) = hv;
-                if (e.v_lo) *(h4*)(e.v_lo + bb * e.lo_bs + (int64_t)(hh - e.H - e.Hkv) * e.lo_hs + (int64_t)tt * e.D + d0) = lv;
+                if (e.v_lo) {
+                    const int lr = e.lo_base == -1 ? tt : past + tt - (e.lo_base == -2 ? e.past_len_dev[1] : e.lo_base);
+                    *(h4*)(e.v_lo + bb * e.lo_bs + (int64_t)(hh - e.H - e.Hkv) * e.lo_hs + (int64_t)lr * e.D + d0) = lv;
+                }
             }
         }
     }
@@ -905,7 +912,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                        const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
-                       const float* wscale = nullptr);
+                       const float* wscale = nullptr, int32_t lo_base = -1);
 }  // namespace
 
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
@@ -952,7 +959,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                        const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
-                       const float* wscale) {
+                       const float* wscale, int32_t lo_base) {
     const int N = (H + 2 * Hkv) * D;
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
@@ -975,6 +982,9 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
     PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || lo_hs % 4 == 0), PC_ERR_ARG,
                "pc_gemm_qkv_rope: k_lo / v_lo go together, strides must keep 8-byte alignment");
     p.rope.k_lo = (_Float16*)k_lo; p.rope.v_lo = (_Float16*)v_lo; p.rope.lo_bs = lo_bs; p.rope.lo_hs = lo_hs;
+    PC_REQUIRE(lo_base >= -2 && (lo_base != -2 || past_len_dev) && (lo_base < 0 || lo_base <= past_len), PC_ERR_ARG,
+               "pc_gemm_qkv_rope: lo_base must be -1 (pass-relative rows), -2 (past_len_dev[1]) or lie in [0, past_len]");
+    p.rope.lo_base = lo_base;
     p.rope.H = H; p.rope.Hkv = Hkv; p.rope.D = D; p.rope.q_len = q_len; p.rope.past_len = past_len;
     return launch_MT<EPI_ROPE>(p, choose_T(p.ntiles), p.ntiles, (hipStream_t)stream);
 }
@@ -1045,4 +1055,21 @@ PC_EXPORT int pc_gemm_qkv_rope_w8(const void* wf8_perm, const float* w_scale_per
     return gemm_qkv_rope_impl(wf8_perm, xf_hi, xf_lo, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
                               v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
                               past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm);
+}
+
+// pc_gemm_qkv_rope_ex: the union of the q|k|v entry points (fp16 or int8 weights: w_scale_perm NULL or not; activation
+// planes or the fused-RMSNorm source) plus lo_base, which places the residual rows in a buffer that outlives the pass:
+// row of token tt = tt (-1), past_len + tt - lo_base (>= 0) or past_len + tt - past_len_dev[1] (-2, decode under a hipGraph).
+PC_EXPORT int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo,
+                                  const float* x, const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs,
+                                  void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
+                                  int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
+                                  int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
+                                  void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base,
+                                  void* stream) {
+    PC_REQUIRE((xf_hi && !x) || (x && norm_weight && !xf_hi && M <= 16), PC_ERR_ARG,
+               "pc_gemm_qkv_rope_ex: pass either the activation planes or (x, norm_weight) with M <= 16");
+    return gemm_qkv_rope_impl(wf_perm, xf_hi, xf_lo, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
+                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
+                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base);
 }

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pc_gemm_skinny_norm_w8": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "pc_gemm_qkv_rope_w8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
                                       _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "pc_gemm_qkv_rope_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
+                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "pc_gemm_skinny_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "pc_gemm_qkv_rope_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
@@ -207,10 +209,19 @@ def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None,
 
 
 def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,
-                  past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None, wscale=None) -> None:
+                  past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None, wscale=None,
+                  lo_base: int = -1) -> None:
     """``kv_lo=(k_lo, v_lo, batch_stride, head_stride)``: also write the fp16 residuals of the new K / V rows (compact
     ``[B][Hkv][q_len][D]``) for ``attn_fwd(..., kv_lo=(k_lo, v_lo, bs, hs, -1))``."""
     lo = (None, None, 0, 0) if kv_lo is None else kv_lo
+    if lo_base != -1:            # a residual tail that outlives the pass (decode): pc_gemm_qkv_rope_ex
+        rc = load().pc_gemm_qkv_rope_ex(wf_perm.data_ptr(), _ptr(wscale), xf_hi.data_ptr(), _ptr(xf_lo), None, None, 0.0,
+                                        M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
+                                        v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
+                                        _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo_base,
+                                        current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_qkv_rope_ex")
+        return
     if wscale is not None:
         rc = load().pc_gemm_qkv_rope_w8(wf_perm.data_ptr(), wscale.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), None, None, 0.0,
                                         M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
@@ -259,8 +270,16 @@ def gemm_skinny_norm(wf, x_f32, norm_weight, eps: float, M: int, N: int, K: int,
 
 def gemm_qkv_rope_norm(wf_perm, x_f32, norm_weight, eps: float, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H,
                        Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None,
-                       wscale=None) -> None:
+                       wscale=None, lo_base: int = -1) -> None:
     lo = (None, None, 0, 0) if kv_lo is None else kv_lo
+    if lo_base != -1:
+        rc = load().pc_gemm_qkv_rope_ex(wf_perm.data_ptr(), _ptr(wscale), None, None, x_f32.data_ptr(), norm_weight.data_ptr(),
+                                        eps, M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
+                                        v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
+                                        _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo_base,
+                                        current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_qkv_rope_ex")
+        return
     if wscale is not None:
         rc = load().pc_gemm_qkv_rope_w8(wf_perm.data_ptr(), wscale.data_ptr(), None, None, x_f32.data_ptr(),
                                         norm_weight.data_ptr(), eps, M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts,

@@ -125,6 +125,7 @@ class PromptCache:
 
     def reset(self):
         self.staged, self.length = [], 0
+        self.arena.tail_base, self.arena.tail_len = -1, 0
 
     @torch.inference_mode()
     def update(self, modules: Sequence[TokenSequenceCache]):
@@ -162,6 +163,7 @@ class PromptCache:
         self.staged = list(ordered)
         self.length = offset
         a.length = offset
+        a.tail_base, a.tail_len = -1, 0          # a new staging: the residual tail of the previous generation is void
 
     def __len__(self):
         return self.length

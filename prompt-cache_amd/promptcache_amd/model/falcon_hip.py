@@ -62,6 +62,7 @@ class FalconHIP(LlamaHIP):
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
         self.softmax_scale = 1.0 / math.sqrt(self.D)        # inv_norm_factor, falcon.py:316
+        self.tail_supported = False  # (own layer loops: residuals of a pass's rows only, _new_kv_lo)
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
 
     # ------------------------------------------------------------------------------------------

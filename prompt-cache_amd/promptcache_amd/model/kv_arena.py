@@ -28,11 +28,28 @@ class KVArena:
         # see those keys / values in split precision.  Never stored, never staged: the module KV is `buf`.
         self.lo: Optional[torch.Tensor] = None
         self.lo_len = 0               # rows [0, lo_len) of `lo` hold valid residuals
+        # residual TAIL of a generation: fp16 residuals of the rows appended since the staged cache ended -- the prompt's
+        # own tokens and every decoded token -- [B][L][2][Hkv][tail_cap][D], row r = key index tail_base + r.  Valid
+        # while tail_base + tail_len == length.  The prefill writes rows [0, q), each decode step appends one.
+        self.tail_lo: Optional[torch.Tensor] = None
+        self.tail_base = -1
+        self.tail_len = 0
 
     def with_lo(self) -> "KVArena":
         if self.lo is None:
             self.lo = torch.empty_like(self.buf)
         return self
+
+    def ensure_tail(self, rows: int) -> None:
+        if self.tail_lo is None or self.tail_lo.shape[4] < rows:
+            self.tail_lo = torch.empty((self.B, self.L, 2, self.Hkv, rows, self.D), device=self.buf.device, dtype=self.buf.dtype)
+            self.tail_base, self.tail_len = -1, 0
+
+    def tail_planes(self, layer: int):
+        """(k_lo, v_lo, batch_stride, head_stride) of the residual tail for one layer."""
+        t = self.tail_lo
+        cap = t.shape[4]
+        return (t[:, layer, 0], t[:, layer, 1], self.L * 2 * self.Hkv * cap * self.D, cap * self.D)
 
     def lo_planes(self, layer: int):
         """(k_lo, v_lo, batch_stride, head_stride, row0) for pc_rope_append_ex / pc_attn_fwd_ex."""
@@ -66,6 +83,7 @@ class KVArena:
             a.with_lo().lo[:, :, :, :, :self.length].copy_(self.lo[:, :, :, :, :self.length])
             a.lo_len = self.lo_len
         a.length = self.length
+        a.tail_lo, a.tail_base, a.tail_len = self.tail_lo, self.tail_base, self.tail_len   # indexed by key, not by row capacity
         return a
 
 
@@ -131,6 +149,7 @@ def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Opti
             (n_layers * 2 * plane, 2 * plane, plane, cap * D, D, 1))
         a.length = S
         a.lo, a.lo_len = None, 0
+        a.tail_lo, a.tail_base, a.tail_len = None, -1, 0
         return a, S
     except Exception:
         return None

@@ -76,6 +76,7 @@ class LlamaHIP:
         # arena still holds the fp16 values).  Off for single-row decode steps.
         self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
         self._kv_only = False      # set per call (see __call__)
+        self.tail_supported = True  # subclasses with their own layer loops switch the per-arena residual tail off
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True, int8_weights: bool = False):
@@ -168,6 +169,35 @@ class LlamaHIP:
             y.mul_(sc)
         return y
 
+    TAIL_HEADROOM = 256     # decoded rows a generation's residual tail has room for past the prompt's own
+
+    def _tail_mode(self, arena: KVArena, q_len: int, past_len: int) -> int:
+        """How the weight-streaming paths treat the fp16 residuals of the rows they append (``KVArena.tail_lo``):
+        1 = a prefill pass starts a new tail at ``past_len`` (rows [0, q_len)); 2 = a decode step continues the tail the
+        prefill started, so every row since the staged cache ended -- prompt tokens and decoded tokens alike -- reaches
+        the attention in split precision, as in the reference's fp32 generation (generation_engine.py:123-147);
+        0 = no residuals (switched off, a tail that does not cover the rows since its base, or no room left)."""
+        if not self.new_kv_lo or not self.tail_supported:
+            return 0
+        if q_len > 1:
+            arena.ensure_tail(q_len + self.TAIL_HEADROOM)
+            return 1
+        t = arena.tail_lo
+        # (a caller may rewind the arena by a few rows: the tail then still covers [tail_base, past_len))
+        if t is not None and 0 <= arena.tail_base <= past_len <= arena.tail_base + arena.tail_len and \
+                past_len - arena.tail_base + 1 <= t.shape[4]:
+            return 2
+        return 0
+
+    @staticmethod
+    def _tail_done(arena: KVArena, mode: int, q_len: int, past_len: int) -> None:
+        if mode == 1:
+            arena.tail_base, arena.tail_len = past_len, q_len
+        elif mode == 2:
+            arena.tail_len = past_len + q_len - arena.tail_base
+        else:
+            arena.tail_base, arena.tail_len = -1, 0          # rows appended without residuals: the tail no longer covers
+
     def _workspace(self, nbytes: int) -> Optional[torch.Tensor]:
         if nbytes <= 0:
             return None
@@ -230,22 +260,28 @@ class LlamaHIP:
 
         T = B * q_len
         self._kv_only = bool(kv_only)
+        streaming = self.skinny and (T <= self.SKINNY_MAX_ROWS and self.use_graphs or T <= self.MID_MAX_ROWS and
+                                     not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS))
+        self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
         if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
             # the graph's static int64 / int32 input buffers are filled straight from the caller's tensors
             # (copy_ converts), so no separate dtype-conversion launches sit in front of the replay
             logits = self._graphed_skinny(input_ids.reshape(-1), position_ids.reshape(-1), arena, B, q_len, past_len,
                                           last_token_only, num_layers)
             arena.length = past_len + q_len
+            self._tail_done(arena, self._lo_mode, q_len, past_len)
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
         if self.skinny and T <= self.MID_MAX_ROWS and not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS):
             logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
             arena.length = past_len + q_len
+            self._tail_done(arena, self._lo_mode, q_len, past_len)
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
         logits = self._forward_dense(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
         arena.length = past_len + q_len
+        self._tail_done(arena, 0, q_len, past_len)
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
     # ------------------------------------------------------------------------------------------
@@ -374,7 +410,7 @@ class LlamaHIP:
 
     # ------------------------------------------------------------------------------------------
     def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
-                           last_token_only, kvlo=None):
+                           last_token_only, tail=None):
         """T <= 16 rows: six launches per layer.  Both RMSNorms are folded into the projections that consume them
         (pc_gemm_*_norm read the fp32 residual stream directly) and both residual adds into the o_proj / down_proj
         epilogues, so x is the only activation that round-trips through memory in fp32."""
@@ -384,9 +420,10 @@ class LlamaHIP:
         T, eps, V = B * q_len, c.rms_norm_eps, c.vocab_size
         for li, lw in enumerate(layers):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kvlo, lo_base = tail(li) if tail is not None else (None, -1)
             n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                                  arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
-                                 kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"])
+                                 kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"], lo_base=lo_base)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)
@@ -407,7 +444,9 @@ class LlamaHIP:
         """Replay (capturing on first use) the hipGraph of the small-q forward for this shape."""
         n = _native
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
-        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm)
+        mode = self._lo_mode
+        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm,
+               mode, arena.tail_lo.data_ptr() if mode else 0)
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= self.max_graphs:
@@ -415,8 +454,10 @@ class LlamaHIP:
             T = B * q_len
             st_ids = torch.zeros(T, dtype=torch.int64, device=self.device)
             st_pos = torch.zeros(T, dtype=torch.int32, device=self.device)
-            st_past = torch.zeros(1, dtype=torch.int32, device=self.device)
-            st_ids.copy_(ids); st_pos.copy_(pos32); st_past.fill_(past_len)
+            st_past = torch.zeros(2, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail}
+            st_ids.copy_(ids); st_pos.copy_(pos32); st_past[0:1].fill_(past_len)
+            if mode == 2:
+                st_past[1:2].fill_(arena.tail_base)
             # one eager pass first (loads code objects / sizes the allocator), then capture
             self._forward_skinny(st_ids, st_pos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
             torch.cuda.synchronize()
@@ -428,9 +469,19 @@ class LlamaHIP:
         g, st_ids, st_pos, st_past, out = ent
         st_ids.copy_(ids)
         st_pos.copy_(pos32)
-        st_past.fill_(past_len)
+        st_past[0:1].fill_(past_len)
+        if mode == 2:
+            st_past[1:2].fill_(arena.tail_base)
         g.replay()
         return out.clone()
+
+    def _tail_for(self, arena, past_dev):
+        """Per-layer ``((k_lo, v_lo, batch_stride, head_stride, lo_row0) | None, lo_base)`` for the current tail mode."""
+        mode = self._lo_mode
+        if mode == 0:
+            return lambda li: (None, -1)
+        base = -1 if mode == 1 else (-2 if past_dev is not None else arena.tail_base)
+        return lambda li: (arena.tail_planes(li) + (base,), base)
 
     def _forward_skinny(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
         """Layer stack for T = B*q_len <= 64 rows: every projection is a weight-streaming pc_gemm_skinny
@@ -454,7 +505,7 @@ class LlamaHIP:
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)       # low-order plane of the split-precision q
         ws_bytes = n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len)
         ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
-        kvlo = self._new_kv_lo(B, Hkv, q_len, D)
+        tail = self._tail_for(arena, past_dev)
 
         def planes(k):
             return (torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev),
@@ -471,14 +522,15 @@ class LlamaHIP:
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         if T <= self.NORM_FUSED_MAX_ROWS and self.fuse_norm:
             return self._layers_norm_fused(x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
-                                           last_token_only, kvlo)
+                                           last_token_only, tail)
         for li, lw in enumerate(layers):
             n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kvlo, lo_base = tail(li)
             # q|k|v projection + RoPE + in-place KV append in one weight-streaming launch
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                             arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
-                            wscale=lw["wqkv_s"])
+                            wscale=lw["wqkv_s"], lo_base=lo_base)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)

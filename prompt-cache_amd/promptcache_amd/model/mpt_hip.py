@@ -71,6 +71,7 @@ class MptHIP(LlamaHIP):
         self.slopes_log2 = (alibi_slopes(self.H, c.alibi_bias_max) * _LOG2E).to(dev)
         self.inv_freq_cpu = torch.zeros(1)                      # no rotary table (kept for interface symmetry)
         self.softmax_scale = 1.0 / math.sqrt(self.D)            # mpt.py:139-140
+        self.tail_supported = False  # (own layer loops: residuals of a pass's rows only, _new_kv_lo)
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
 
     # ------------------------------------------------------------------------------------------

@@ -23,14 +23,15 @@ def main(layers=32, qlen=8):
     from promptcache_amd.model.kv_arena import KVArena
     from promptcache_amd.model.weights import random_weights_device
     shape = dataclasses.replace(SHAPES["llama2-7b"], num_hidden_layers=layers)
-    w = random_weights_device(shape, "cuda:0", torch.float16, seed=5)
+    seed = int(os.environ.get("PC_DBG_SEED", "5"))
+    w = random_weights_device(shape, "cuda:0", torch.float16, seed=seed)
     int8 = os.environ.get("PC_DBG_INT8") == "1"          # load_in_8bit: the oracle then runs on the dequantised weights
     lm = Llama2(name="llama2-7b", shape=shape, weights=w, device="cuda:0", load_in_8bit=int8)
     if os.environ.get("PC_DBG_BENCH_WORKLOAD") == "1":     # the bench.py workload itself: 29 passes, S = 1725, q = 12
         sp, pp = synth.persona_like("p7")
     else:
         sp, pp = synth.persona_like("p7", system_len=120, intro_len=30,
-                                    traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))), question_len=qlen, seed=9)
+                                    traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))), question_len=qlen, seed=seed + 4)
     fmt = lm.get_formatter()
     eng = CacheEngine(4096 if os.environ.get('PC_DBG_BENCH_WORKLOAD') == '1' else 2048, lm)
     eng.add_schema(fmt(sp))

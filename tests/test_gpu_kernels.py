@@ -1110,3 +1110,66 @@ def test_gemm_qkv_rope_w8(B, H, Hkv, D, q_len, past, hid, norm):
     assert ((q16.double() + q16l.double()) - qd).abs().max().item() < tol
     assert ((arena[:, 0, :, past:past + q_len].double() + klo.double()) - kn).abs().max().item() < tol
     assert ((arena[:, 1, :, past:past + q_len].double() + vlo.double()) - vn).abs().max().item() < tol
+
+
+def test_residual_tail_outlives_the_pass_for_decode():
+    """pc_gemm_qkv_rope_ex(lo_base) + pc_attn_fwd_ex(lo_row0 = -2): a prefill writes tail rows [0, q), decode steps append
+    one row each at past_len - base (read from past_len_dev[1]), and the decode attention sees every row since `base` in
+    split precision: the result must beat what fp16 rows since `base` allow, against fp64 attention."""
+    n = _n()
+    rng = np.random.default_rng(101)
+    B, H, Hkv, D, hid, base, q0, steps = 1, 8, 4, 128, 512, 70, 9, 5
+    W, cap, tcap = (H + 2 * Hkv) * D, 128, 32
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    wf = n.to_weight_frags(w[n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)].contiguous())
+    arena = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    arena[:, :, :, :base] = torch.from_numpy(rng.standard_normal((B, 2, Hkv, base, D), dtype=np.float32)).to(DEV).half()
+    tail = torch.zeros((B, 2, Hkv, tcap, D), dtype=torch.float16, device=DEV)
+    kv_lo = (tail[:, 0], tail[:, 1], 2 * Hkv * tcap * D, tcap * D)
+    inv = _inv_freq(D, 10000.0).to(DEV)
+    Kd = [arena[0, 0, :, :base].double()]; Vd = [arena[0, 1, :, :base].double()]          # fp64 truth per row block
+
+    def rot(t, cs):
+        c, s_ = cs[..., 0].double(), cs[..., 1].double()
+        c, s_ = torch.cat([c, c], 1)[:, None], torch.cat([s_, s_], 1)[:, None]
+        return t * c + torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1) * s_
+
+    past = base
+    for step in range(steps + 1):
+        q_len = q0 if step == 0 else 1
+        x = torch.from_numpy(rng.standard_normal((q_len, hid), dtype=np.float32)).to(DEV)
+        hi, lo = n.to_act_frags(x)
+        pos = torch.arange(past, past + q_len, dtype=torch.int32, device=DEV)
+        cs = torch.empty((q_len, D // 2, 2), dtype=torch.float32, device=DEV)
+        n.rope_table(pos, inv, cs, q_len, D)
+        q16 = torch.zeros((q_len, H * D), dtype=torch.float16, device=DEV); q16l = torch.zeros_like(q16)
+        pdev = torch.tensor([past, base], dtype=torch.int32, device=DEV)
+        n.gemm_qkv_rope(wf, hi, lo, q_len, hid, cs, q16, q16l, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D,
+                        B, H, Hkv, D, q_len, 0, cap, pdev, kv_lo=kv_lo, lo_base=-1 if step == 0 else -2)
+        xd = n.from_act_frags(hi, q_len).double() + n.from_act_frags(lo, q_len).double()
+        qkv = xd @ w.double().T
+        Kd.append(rot(qkv[:, H * D:(H + Hkv) * D].view(q_len, Hkv, D), cs).permute(1, 0, 2))
+        Vd.append(qkv[:, (H + Hkv) * D:].view(q_len, Hkv, D).permute(1, 0, 2))
+        qd = rot(qkv[:, :H * D].view(q_len, H, D), cs).permute(1, 0, 2)                    # [H, q, D]
+        out = torch.zeros((1, q_len, H * D), dtype=torch.float16, device=DEV); out_lo = torch.zeros_like(out)
+        ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, past + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+        n.attn_fwd(q16, q_len * H * D, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, out, q_len * H * D, H * D,
+                   B, H, Hkv, D, q_len, 0, 1.0 / np.sqrt(D), ws, past_len_dev=pdev, q_lo=q16l, out_lo=out_lo,
+                   kv_lo=kv_lo + (-1 if step == 0 else -2,))
+        K = torch.cat(Kd, 1).repeat_interleave(H // Hkv, 0); V = torch.cat(Vd, 1).repeat_interleave(H // Hkv, 0)
+        idx = torch.arange(q_len, device=DEV)
+        mask = torch.ones((q_len, past + q_len), dtype=torch.bool, device=DEV)
+        mask[:, past:] = idx[None, :] <= idx[:, None]
+        def attn(K_, V_):
+            s_ = (qd @ K_.transpose(1, 2)) / np.sqrt(D)
+            return (torch.softmax(s_.masked_fill(~mask, float("-inf")), -1) @ V_).permute(1, 0, 2).reshape(q_len, H * D)
+        ref = attn(K, V)
+        K16 = torch.cat([Kd[0]] + [k.half().double() for k in Kd[1:]], 1).repeat_interleave(H // Hkv, 0)
+        V16 = torch.cat([Vd[0]] + [v.half().double() for v in Vd[1:]], 1).repeat_interleave(H // Hkv, 0)
+        floor16 = (attn(K16, V16) - ref).abs().max().item()
+        err = ((out[0].double() + out_lo[0].double()) - ref).abs().max().item()
+        assert err < 3e-5 and err < 0.25 * floor16, (step, err, floor16)
+        past += q_len
+    # the tail holds one residual row per appended key, in key order
+    rec = arena[0, 0, :, base:past].double() + tail[0, 0, :, :past - base].double()
+    assert (rec - torch.cat(Kd[1:], 1)).abs().max().item() < 1e-5

@@ -62,7 +62,6 @@ class FalconHIP(LlamaHIP):
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
         self.softmax_scale = 1.0 / math.sqrt(self.D)        # inv_norm_factor, falcon.py:316
-        self.tail_supported = False  # (own layer loops: residuals of a pass's rows only, _new_kv_lo)
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
 
     # ------------------------------------------------------------------------------------------
@@ -202,13 +201,15 @@ class FalconHIP(LlamaHIP):
         KQ = self.kslices
         slabs = torch.empty((2 * KQ, T, hid), dtype=f32, device=dev)      # [0:KQ] attention branch, [KQ:] MLP branch
         pending = 0
-        kvlo = self._new_kv_lo(B, 1, q_len, D)
+        tail = self._tail_for(arena, past_dev)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_frag(x, lw["ln_w"], lw["ln_b"], xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kvlo, lo_base = tail(li)
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
-                            arena.head_stride, B, H, 1, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4])
+                            arena.head_stride, B, H, 1, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
+                            lo_base=lo_base)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, 1, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)

@@ -76,7 +76,7 @@ class LlamaHIP:
         # arena still holds the fp16 values).  Off for single-row decode steps.
         self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
         self._kv_only = False      # set per call (see __call__)
-        self.tail_supported = True  # subclasses with their own layer loops switch the per-arena residual tail off
+        self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True, int8_weights: bool = False):
@@ -149,14 +149,6 @@ class LlamaHIP:
     # ------------------------------------------------------------------------------------------
     def new_arena(self, batch: int, cap: int) -> KVArena:
         return KVArena(batch, self.L, self.Hkv, cap, self.D, self.device, self.dtype)
-
-    def _new_kv_lo(self, B: int, Hkv: int, q_len: int, D: int):
-        """(k_lo, v_lo, batch_stride, head_stride, -1): compact residual planes for the K / V rows of one prefill pass
-        (shared by all layers: each layer's attention consumes them before the next layer overwrites them)."""
-        if not self.new_kv_lo or q_len <= 1:
-            return None
-        lo = torch.empty((2, B, Hkv, q_len, D), dtype=self.dtype, device=self.device)
-        return (lo[0], lo[1], Hkv * q_len * D, q_len * D, -1)
 
     @staticmethod
     def _mm(a: torch.Tensor, lw: dict, key: str) -> torch.Tensor:

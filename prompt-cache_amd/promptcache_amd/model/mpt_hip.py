@@ -71,7 +71,6 @@ class MptHIP(LlamaHIP):
         self.slopes_log2 = (alibi_slopes(self.H, c.alibi_bias_max) * _LOG2E).to(dev)
         self.inv_freq_cpu = torch.zeros(1)                      # no rotary table (kept for interface symmetry)
         self.softmax_scale = 1.0 / math.sqrt(self.D)            # mpt.py:139-140
-        self.tail_supported = False  # (own layer loops: residuals of a pass's rows only, _new_kv_lo)
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
 
     # ------------------------------------------------------------------------------------------
@@ -109,6 +108,9 @@ class MptHIP(LlamaHIP):
         # like the reference (mpt.py:97: arange(1 - max_len, 1)) the bias is slope * (pos - max_pos) <= 0: the keys that
         # carry the weight sit near max_pos, where the term is small and fp32 resolves it finely
         position_ids = position_ids - position_ids.amax(dim=1, keepdim=True)
+        streaming = self.skinny and (T <= self.SKINNY_MAX_ROWS and self.use_graphs or T <= self.MID_MAX_ROWS and
+                                     not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS))
+        self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
         if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
             logits = self._graphed_mpt(ids, position_ids, arena, B, q_len, past_len, last_token_only, num_layers)
         else:
@@ -119,13 +121,16 @@ class MptHIP(LlamaHIP):
             else:
                 logits = self._forward_dense(ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers)
         arena.length = kv_len
+        self._tail_done(arena, self._lo_mode, q_len, past_len)
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
     def _graphed_mpt(self, ids, position_ids, arena, B, q_len, past_len, last_token_only, num_layers):
         n = _native
         kv_len = past_len + q_len
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, kv_len)
-        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers)
+        mode = self._lo_mode
+        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, mode,
+               arena.tail_lo.data_ptr() if mode else 0)
         ent = self._graphs.get(key)
         fresh = ent is None
         if fresh:
@@ -133,12 +138,14 @@ class MptHIP(LlamaHIP):
                 self._graphs.pop(next(iter(self._graphs)))
             st_ids = torch.zeros(B * q_len, dtype=torch.int64, device=self.device)
             st_kpos = torch.zeros((B, self._kpos_cols(arena.cap)), dtype=torch.float32, device=self.device)
-            st_past = torch.zeros(1, dtype=torch.int32, device=self.device)
+            st_past = torch.zeros(2, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail}
             ent = [None, st_ids, st_kpos, st_past, None]
         _, st_ids, st_kpos, st_past, out = ent
         st_ids.copy_(ids)
         st_kpos[:, :kv_len].copy_(position_ids)           # int64 -> fp32 on the fly
-        st_past.fill_(past_len)
+        st_past[0:1].fill_(past_len)
+        if mode == 2:
+            st_past[1:2].fill_(arena.tail_base)
         if fresh:
             self._forward_skinny(st_ids, st_kpos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
             torch.cuda.synchronize()
@@ -293,13 +300,15 @@ class MptHIP(LlamaHIP):
         KQ = self.kslices
         slabs = torch.empty((KQ, T, hid), dtype=f32, device=dev)
         pending = 0
-        kvlo = self._new_kv_lo(B, H, q_len, D)
+        tail = self._tail_for(arena, past_dev)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_frag(x, lw["ln1"], None, xh, xl, T, hid, eps, slabs, pending)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kvlo, lo_base = tail(li)
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, hid, kp, vp, arena.batch_stride,
-                            arena.head_stride, B, H, H, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4])
+                            arena.head_stride, B, H, H, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
+                            lo_base=lo_base)
             n.attn_fwd(q16, q_len * hid, hid, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, H, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, alibi=alibi, kv_lo=kvlo)

@@ -129,19 +129,14 @@ class FalconHIP(LlamaHIP):
         act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        # fp16 residuals of the K / V rows this pass appends (consumed by the same layer's attention, then overwritten)
-        lo_k = torch.empty((B, 1, q_len, D), dtype=self.dtype, device=dev)
-        lo_v = torch.empty((B, 1, q_len, D), dtype=self.dtype, device=dev)
-        # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
-        full_lo = arena.lo is not None and arena.lo_len == past_len
-        compact_lo = (lo_k, lo_v, 1 * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
+        lo_for, full_lo = self._dense_pass_lo(arena, B, 1, q_len, past_len)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_split(x, lw["ln_w"], lw["ln_b"], h2[0], h2[1], T, hid, eps)
             qkv = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)      # rows [0, T): hi part, [T, 2T): lo part
             kp, vp = arena.k_plane(li), arena.v_plane(li)
-            kv_lo = arena.lo_planes(li) if full_lo else compact_lo
+            kv_lo = lo_for(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True,
                           q_out_lo=q16l, kv_lo=kv_lo, in2_offset=T * W)

@@ -181,6 +181,21 @@ class LlamaHIP:
             return 2
         return 0
 
+    def _dense_pass_lo(self, arena: KVArena, B: int, Hkv: int, q_len: int, past_len: int):
+        """Residual planes for the K / V rows a many-row pass appends: ``layer -> (k_lo, v_lo, bs, hs, row0)``.
+        An encode arena (``arena.lo``) keeps residuals for all of its rows; a prefill in front of a generation writes them
+        into the arena's residual tail so the decode steps after it find them (``_tail_mode``); a batch-padded or kv-only
+        pass gets a scratch buffer shared by the layers (each layer's attention consumes it before the next overwrites it)."""
+        if arena.lo is not None and arena.lo_len == past_len:
+            return (lambda li: arena.lo_planes(li)), True
+        if self.new_kv_lo and self.tail_supported and not self._kv_only:
+            arena.ensure_tail(q_len + self.TAIL_HEADROOM)
+            self._lo_mode = 1
+            return (lambda li: arena.tail_planes(li) + (past_len,)), False
+        lo = torch.empty((2, B, Hkv, q_len, self.D), dtype=self.dtype, device=self.device)
+        scratch = (lo[0], lo[1], Hkv * q_len * self.D, q_len * self.D, past_len)
+        return (lambda li: scratch), False
+
     @staticmethod
     def _tail_done(arena: KVArena, mode: int, q_len: int, past_len: int) -> None:
         if mode == 1:
@@ -273,7 +288,7 @@ class LlamaHIP:
 
         logits = self._forward_dense(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
         arena.length = past_len + q_len
-        self._tail_done(arena, 0, q_len, past_len)
+        self._tail_done(arena, self._lo_mode, q_len, past_len)       # (_dense_pass_lo sets mode 1 when it starts a tail)
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
     # ------------------------------------------------------------------------------------------
@@ -356,19 +371,14 @@ class LlamaHIP:
         act2 = torch.empty((2, T, inter), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        # fp16 residuals of the K / V rows this pass appends (consumed by the same layer's attention, then overwritten)
-        lo_k = torch.empty((B, Hkv, q_len, D), dtype=self.dtype, device=dev)
-        lo_v = torch.empty((B, Hkv, q_len, D), dtype=self.dtype, device=dev)
-        # an encode arena carries residuals for all of its rows (valid up to lo_len); otherwise only this pass's rows do
-        full_lo = arena.lo is not None and arena.lo_len == past_len
-        compact_lo = (lo_k, lo_v, Hkv * q_len * D, q_len * D, past_len)       # rows = this pass's own keys only
+        lo_for, full_lo = self._dense_pass_lo(arena, B, Hkv, q_len, past_len)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.rmsnorm_split(x, lw["ln1"], h2[0], h2[1], T, hid, eps)
             qkv = self._mm(h2.view(2 * T, hid), lw, "wqkv")      # rows [0, T): hi part, [T, 2T): lo part
             kp, vp = arena.k_plane(li), arena.v_plane(li)
-            kv_lo = arena.lo_planes(li) if full_lo else compact_lo
+            kv_lo = lo_for(li)
             # the two halves are summed inside the RoPE / append kernel (in2_offset)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,

@@ -291,10 +291,25 @@ def test_deep_stack_parity_vs_live_oracle(q_words):
         jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
     lib = eo.encode_schema(model, jobs)
     used = [m.token_sequence for m in eng.prompt_cache.staged]
-    _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
+    _, S, (logits, present) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
     err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
     print(f"[24 layers, q={len(ids)}] max|dlogit| vs live oracle = {err:.2e} (max|logit| {np.abs(logits).max():.1f})")
     assert err < LOGIT_TOL
+    # decode steps (hipGraph replay), teacher-forced with the oracle's greedy tokens: the rows since the staged cache ended
+    # keep their fp16 residuals (KVArena.tail_lo), so decode must not be worse than the prefill it follows
+    past, olog, worst = out.past_key_values, logits, 0.0
+    for i in range(6):
+        tok = int(np.argmax(olog[0, -1]))
+        p1 = max(pos) + 1 + i
+        olog, present = model.forward(np.array([[tok]]), np.array([[p1]]), past=present)
+        o = lm(input_ids=torch.tensor([[tok]], device="cuda"), position_ids=torch.tensor([[p1]], device="cuda"),
+               past_key_values=past, use_cache=True)
+        past = o.past_key_values
+        worst = max(worst, float(np.abs(o.logits[0, -1].cpu().numpy() - olog[0, -1]).max()))
+    arena = past.arena
+    print(f"[24 layers, q={len(ids)}] decode steps: max|dlogit| = {worst:.2e}; residual tail {arena.tail_len} rows from key {arena.tail_base}")
+    assert worst < max(2.0 * err, 2e-3)
+    assert arena.tail_base == S and arena.tail_len == len(ids) + 6        # every row regime starts the tail
 
 
 def test_host_memory_tier_stages_the_same_bytes_and_logits():

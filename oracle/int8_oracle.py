@@ -32,7 +32,14 @@ def dequantize(q: np.ndarray, scale: np.ndarray) -> np.ndarray:
     return q.astype(np.float32) * scale[:, None].astype(np.float32)
 
 
-LINEAR_KEYS = ("wq", "wk", "wv", "wo", "gate", "up", "down")      # the oracle's per-layer names: "l{i}.wq", ...
+LINEAR_KEYS = ("wq", "wk", "wv", "wo", "gate", "up", "down")      # the Llama oracle's per-layer names: "l{i}.wq", ...
+LINEAR_KEYS_FUSED = ("wqkv", "wo", "w1", "w2")                    # the Falcon / MPT oracles' ("l{i}.wqkv", ...)
+
+
+def dequantized_weights(weights: Dict[str, np.ndarray], keys=LINEAR_KEYS_FUSED) -> Dict[str, np.ndarray]:
+    """The same for any of the oracles' weight dicts: per-layer 2-D tensors named ``l{i}.<key>`` with ``key in keys``."""
+    return {k: (dequantize(*quantize_rows_int8(v)) if v.ndim == 2 and k.startswith("l") and k.split(".")[-1] in keys
+                else v.astype(np.float32)) for k, v in weights.items()}
 
 
 def dequantized_llama_weights(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:

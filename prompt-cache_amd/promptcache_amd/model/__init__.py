@@ -222,7 +222,7 @@ class Falcon(LanguageModel):
             weights = W.random_falcon_weights_device(shape, device, torch.float16, seed)
         if tokenizer is None:
             tokenizer = StandInTokenizer(shape.vocab_size)
-        model = FalconHIP(shape, weights, device=device)
+        model = FalconHIP(shape, weights, device=device, int8_weights=bool(_hf_kwargs.get("load_in_8bit", False)))
         self.formatter = _falcon_formatter()
         super().__init__(name, model, tokenizer, list(range(12)), ["<|endoftext|>", "\nUser"])
 
@@ -269,7 +269,7 @@ class Mpt(LanguageModel):
             weights = W.random_mpt_weights_device(shape, device, torch.float16, seed)
         if tokenizer is None:
             tokenizer = StandInTokenizer(shape.vocab_size)
-        model = MptHIP(shape, weights, device=device)
+        model = MptHIP(shape, weights, device=device, int8_weights=bool(_hf_kwargs.get("load_in_8bit", False)))
         self.formatter = _mpt_formatter()
         super().__init__(name, model, tokenizer, [50278, 0], [])
 

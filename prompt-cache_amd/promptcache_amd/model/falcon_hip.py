@@ -28,7 +28,7 @@ from .llama_hip import LlamaHIP
 
 class FalconHIP(LlamaHIP):
     def __init__(self, shape: FalconShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
-                 skinny: bool = True):
+                 skinny: bool = True, int8_weights: bool = False):
         self._setup(shape, device, decode_headroom)
         c = shape
         self.H, self.Hkv, self.D, self.L = c.num_attention_heads, 1, c.head_dim, c.num_hidden_layers
@@ -48,16 +48,18 @@ class FalconHIP(LlamaHIP):
         fr = _native.to_weight_frags if self.skinny else (lambda t: None)
         self.lm_head_f = fr(self.lm_head)
         self.layers = []
+        # load_in_8bit: weight-only int8 decoder linears, see LlamaHIP (every GEMM K must be a multiple of 64)
+        self.int8_weights = bool(int8_weights) and self.skinny and hid % 64 == 0 and (self.H * self.D) % 64 == 0
+        if self.int8_weights:
+            self.MID_MAX_ROWS = self.SKINNY_MAX_ROWS
         for i in range(self.L):
-            wqkv, wo, w1, w2 = w(f"l{i}.wqkv"), w(f"l{i}.wo"), w(f"l{i}.w1"), w(f"l{i}.w2")
-            if self.skinny:
-                if i == 0:
-                    self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2, self.D).to(dev)
-                wqkv_f = fr(wqkv[self._qkv_perm].contiguous())
-            else:
-                wqkv_f = None
-            self.layers.append(dict(ln_w=w(f"l{i}.ln_w"), ln_b=w(f"l{i}.ln_b"), wqkv=wqkv, wo=wo, w1=w1, w2=w2,
-                                    wqkv_f=wqkv_f, wo_f=fr(wo), w1_f=fr(w1), w2_f=fr(w2)))
+            if self.skinny and i == 0:
+                self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2, self.D).to(dev)
+            ent = dict(ln_w=w(f"l{i}.ln_w"), ln_b=w(f"l{i}.ln_b"))
+            ent.update(self._linear_entries("wqkv", self._prep_linear(w(f"l{i}.wqkv"), self._qkv_perm if self.skinny else None)))
+            for name in ("wo", "w1", "w2"):
+                ent.update(self._linear_entries(name, self._prep_linear(w(f"l{i}.{name}"))))
+            self.layers.append(ent)
         # falcon.py:99: the same formula as the Llama table, evaluated on the CPU in fp32
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
@@ -88,7 +90,7 @@ class FalconHIP(LlamaHIP):
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm(x, lw["ln_w"], lw["ln_b"], h16, T, hid, eps)                              # falcon.py:779
-            qkv = torch.mm(h16, lw["wqkv"].t(), out_dtype=f32)                                    # [T, (H+2)*D]
+            qkv = self._mm(h16, lw, "wqkv")                                    # [T, (H+2)*D]
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True)
@@ -96,10 +98,10 @@ class FalconHIP(LlamaHIP):
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
                        q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws)
-            h4 = torch.mm(h16, lw["w1"].t(), out_dtype=f32)                                       # same LayerNorm output (:798)
+            h4 = self._mm(h16, lw, "w1")                                       # same LayerNorm output (:798)
             n.gelu(h4, act, T * 4 * hid)
-            x.add_(torch.mm(attn, lw["wo"].t(), out_dtype=f32))
-            x.add_(torch.mm(act, lw["w2"].t(), out_dtype=f32))
+            x.add_(self._mm(attn, lw, "wo"))
+            x.add_(self._mm(act, lw, "w2"))
         if self._kv_only:
             return None
         if last_token_only:
@@ -134,7 +136,7 @@ class FalconHIP(LlamaHIP):
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         for li, lw in enumerate(layers):
             n.layernorm_split(x, lw["ln_w"], lw["ln_b"], h2[0], h2[1], T, hid, eps)
-            qkv = torch.mm(h2.view(2 * T, hid), lw["wqkv"].t(), out_dtype=f32)      # rows [0, T): hi part, [T, 2T): lo part
+            qkv = self._mm(h2.view(2 * T, hid), lw, "wqkv")      # rows [0, T): hi part, [T, 2T): lo part
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
@@ -144,11 +146,11 @@ class FalconHIP(LlamaHIP):
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l, out_lo=attn2[1], kv_lo=kv_lo)
-            h4 = torch.mm(h2.view(2 * T, hid), lw["w1"].t(), out_dtype=f32)
+            h4 = self._mm(h2.view(2 * T, hid), lw, "w1")
             n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
-            o2 = torch.mm(attn2.view(2 * T, H * D), lw["wo"].t(), out_dtype=f32)
+            o2 = self._mm(attn2.view(2 * T, H * D), lw, "wo")
             n.add3(x, o2[:T], o2[T:], T * hid)
-            d2 = torch.mm(act2.view(2 * T, 4 * hid), lw["w2"].t(), out_dtype=f32)
+            d2 = self._mm(act2.view(2 * T, 4 * hid), lw, "w2")
             n.add3(x, d2[:T], d2[T:], T * hid)
         if full_lo:
             arena.lo_len = past_len + q_len
@@ -204,13 +206,13 @@ class FalconHIP(LlamaHIP):
             kvlo, lo_base = tail(li)
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                             arena.head_stride, B, H, 1, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
-                            lo_base=lo_base)
+                            lo_base=lo_base, wscale=lw["wqkv_s"])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, 1, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)
-            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs[:KQ], ldy=hid, kslices=KQ)
-            n.gemm_skinny(lw["w1_f"], xh, xl, T, inter, hid, n.EPI_GELU, of_hi=ch, of_lo=cl)
-            n.gemm_skinny(lw["w2_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs[KQ:], ldy=hid, kslices=KQ)
+            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs[:KQ], ldy=hid, kslices=KQ, wscale=lw["wo_s"])
+            n.gemm_skinny(lw["w1_f"], xh, xl, T, inter, hid, n.EPI_GELU, of_hi=ch, of_lo=cl, wscale=lw["w1_s"])
+            n.gemm_skinny(lw["w2_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs[KQ:], ldy=hid, kslices=KQ, wscale=lw["w2_s"])
             pending = 2 * KQ
         V = c.vocab_size
         if last_token_only:

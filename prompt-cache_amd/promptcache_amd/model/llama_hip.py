@@ -113,17 +113,7 @@ class LlamaHIP:
         if self.int8_weights:
             self.MID_MAX_ROWS = self.SKINNY_MAX_ROWS      # the row-split kernel has no int8 variant: 65+ rows go dense
 
-        def prep(wt, perm=None):
-            """-> (row-major fp16 for the dense path, fragment image for the streaming kernels, fp32 scales | None)"""
-            if not self.int8_weights:
-                src = wt if perm is None else wt[perm].contiguous()
-                return wt, fr(src), (None, None)
-            q, sc = _native.quantize_rows_int8(wt)
-            dense = q.to(self.dtype)                      # the int8 codes, exact in fp16; _mm applies the scales (many-row paths)
-            dsc = sc
-            if perm is not None:
-                q, sc = q[perm].contiguous(), sc[perm].contiguous()
-            return dense, _native.to_weight_frags_i8(q), (sc, dsc)
+        prep = self._prep_linear
 
         for i in range(self.L):
             wqkv = torch.cat([w(f"l{i}.wq"), w(f"l{i}.wk"), w(f"l{i}.wv")], dim=0).contiguous()
@@ -149,6 +139,25 @@ class LlamaHIP:
     # ------------------------------------------------------------------------------------------
     def new_arena(self, batch: int, cap: int) -> KVArena:
         return KVArena(batch, self.L, self.Hkv, cap, self.D, self.device, self.dtype)
+
+    def _prep_linear(self, wt: torch.Tensor, perm=None):
+        """One projection -> (row-major image for the many-row GEMMs, fragment image for the streaming kernels,
+        (fragment-order scales, row-order scales) | (None, None)).  int8 mode: both images hold the int8 codes."""
+        fr = _native.to_weight_frags if self.skinny else (lambda t: None)
+        if not self.int8_weights:
+            src = wt if perm is None else wt[perm].contiguous()
+            return wt, fr(src), (None, None)
+        q, sc = _native.quantize_rows_int8(wt)
+        dense = q.to(self.dtype)                      # the int8 codes, exact in fp16; _mm applies the scales (many-row paths)
+        dsc = sc
+        if perm is not None:
+            q, sc = q[perm].contiguous(), sc[perm].contiguous()
+        return dense, _native.to_weight_frags_i8(q), (sc, dsc)
+
+    @staticmethod
+    def _linear_entries(name: str, prepped) -> dict:
+        dense, frag, (sc, dsc) = prepped
+        return {name: dense, name + "_f": frag, name + "_s": sc, name + "_ds": dsc}
 
     @staticmethod
     def _mm(a: torch.Tensor, lw: dict, key: str) -> torch.Tensor:

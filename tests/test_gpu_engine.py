@@ -433,3 +433,44 @@ def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed
         assert d < LOGIT_TOL, (i, d)
         if top2[1] - top2[0] > 4 * d:
             assert int(o.logits[0, -1].argmax()) == int(np.argmax(olog[0, -1]))
+
+
+@pytest.mark.parametrize("case", ["falcon_mid_doc", "mpt_mid_doc"])
+def test_int8_weight_mode_falcon_and_mpt(case):
+    """``load_in_8bit=True`` on the Falcon / MPT adapters: cached prefill over the schema's module KV and two decode steps
+    against the family's oracle on the dequantised weights."""
+    from promptcache_amd import CacheEngine, Prompt
+    from promptcache_amd.model import Falcon, Mpt
+    from oracle import int8_oracle as io
+    g = H.load_case(case)
+    shape = H.shape_for_case(g)
+    oracle16, w16 = H.oracle_for_case(g, shape)
+    model = type(oracle16)(oracle16.cfg, io.dequantized_weights({k: v.astype(np.float32) for k, v in w16.items()}))
+    lm = (Mpt if H.is_mpt(g) else Falcon)(name="golden", shape=shape, weights=w16, device="cuda:0", load_in_8bit=True)
+    assert lm.hf_model.int8_weights
+    fmt = lm.get_formatter()
+    eng = CacheEngine(int(g["max_ctx"]), lm)
+    mt = int(g["max_tokens"])
+    eng.add_schema(fmt(str(g["schema_text"])), max_tokens=None if mt < 0 else mt)
+    full = lm.use_full_position_ids
+    ids, pos, _, cache = eng.process(Prompt(str(g["prompt_text"]), [fmt]), return_full_position_ids=full)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    sc = eng.get_schema(list(eng.schemas)[0])
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in eng.prompt_cache.staged]
+    _, S, (logits, present) = eo.cached_prefill(model, lib, used, ids, pos, int(g["max_ctx"]))
+    err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    ref16_lib = eo.encode_schema(oracle16, jobs)
+    _, _, (logits16, _) = eo.cached_prefill(oracle16, ref16_lib, used, ids, pos, int(g["max_ctx"]))
+    print(f"[int8 {case}] end to end {err:.2e}; int8 vs fp16 weights (oracle) {np.abs(logits16 - logits).max():.2e}")
+    assert err < LOGIT_TOL
+    # and the generation loop runs on the int8 images (hipGraph replay per step)
+    from promptcache_amd import GenerationEngine, GenerationParameters
+    outs = list(GenerationEngine(lm).generate(ids, pos, GenerationParameters(temperature=0.0, max_new_tokens=3), cache,
+                                               stream_interval=1, use_full_position_ids=full))
+    assert outs, "no output"

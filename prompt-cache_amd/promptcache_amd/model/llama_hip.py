@@ -71,9 +71,10 @@ class LlamaHIP:
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops
         self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
-        # weight-streaming regimes (<= MID_MAX_ROWS rows): keep the fp16 residuals of the K / V rows a prefill pass appends
-        # and feed them to that pass's own attention (the reference computes the pass in fp32, llama2.py:361-388; the
-        # arena still holds the fp16 values).  Off for single-row decode steps.
+        # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
+        # decoded token -- in the arena's residual tail and feed them to the attention (the reference keeps those rows in
+        # fp32 for the whole generation, llama2.py:361-388, generation_engine.py:123-147; the arena still holds the fp16
+        # values).  See _tail_mode / _dense_pass_lo.
         self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
         self._kv_only = False      # set per call (see __call__)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off

@@ -41,7 +41,13 @@ class KVArena:
         return self
 
     def ensure_tail(self, rows: int) -> None:
+        """Room for ``rows`` residual rows.  Capacities come in buckets (320, 512, then powers of two): the captured
+        forwards hold the buffer's address, so a slightly longer prompt must not move it."""
         if self.tail_lo is None or self.tail_lo.shape[4] < rows:
+            cap = 320 if rows <= 320 else 512
+            while cap < rows:
+                cap *= 2
+            rows = cap
             self.tail_lo = torch.empty((self.B, self.L, 2, self.Hkv, rows, self.D), device=self.buf.device, dtype=self.buf.dtype)
             self.tail_base, self.tail_len = -1, 0
 

@@ -12,9 +12,15 @@ past in every layer of every call, ``promptcache/model/llama2.py:361-364``).
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
+
+# live arenas by the address of their buffer: a caller that hands back plain views (the reference's GenerationEngine
+# rebuilds the list with k.unsqueeze(0), generation_engine.py:101-102) gets the SAME arena object again -- with its
+# residual tail and the hipGraphs keyed on it -- instead of a fresh reconstruction per call
+_LIVE: "weakref.WeakValueDictionary[int, KVArena]" = weakref.WeakValueDictionary()
 
 
 class KVArena:
@@ -22,6 +28,7 @@ class KVArena:
                  dtype=torch.float16):
         self.B, self.L, self.Hkv, self.cap, self.D = batch, n_layers, n_kv_heads, cap, head_dim
         self.buf = torch.empty((batch, n_layers, 2, n_kv_heads, cap, head_dim), device=device, dtype=dtype)
+        _LIVE[self.buf.data_ptr()] = self
         self.length = 0
         # optional second buffer of the same shape: the fp16 residuals (value - fp16(value)) of the rows a schema-encode
         # pass appended, so that later rows of that pass -- and scaffolds encoded as suffixes over this pass's prefix --
@@ -148,6 +155,10 @@ def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Opti
         need_end = k0.storage_offset() + B * n_layers * 2 * plane
         if need_end * es > st.nbytes():
             return None
+        live = _LIVE.get(k0.data_ptr())
+        if live is not None and (live.B, live.L, live.Hkv, live.cap, live.D) == (B, n_layers, Hkv, cap, D) and \
+                live.buf.dtype == k0.dtype:
+            return live, S
         a = KVArena.__new__(KVArena)
         a.B, a.L, a.Hkv, a.cap, a.D = B, n_layers, Hkv, cap, D
         a.buf = torch.empty(0, dtype=k0.dtype, device=k0.device).set_(

@@ -40,3 +40,23 @@ def test_argument_errors_need_no_gpu():
     assert b"null pointer" in lib.pc_last_error_string()
     assert lib.pc_attn_workspace_bytes(1, 32, 128, 4390, 4390) == 0        # encode regime: no split
     assert lib.pc_attn_workspace_bytes(1, 32, 128, 12, 1737) > 0           # cached prefill: split-KV partials
+
+
+def _declared_arity():
+    """name -> number of parameters of every ``pc_*`` prototype in include/*.h."""
+    out = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for m in re.finditer(r"\b(pc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            params = m.group(2).strip()
+            out[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_ctypes_signatures_have_the_arity_of_the_header_prototypes():
+    """A parameter added on one side only would shift every later argument silently (ctypes does not check)."""
+    from promptcache_amd import _native
+    arity = _declared_arity()
+    assert sorted(arity) == _declared()
+    for name, (_, argtypes) in _native.SIGNATURES.items():
+        assert len(argtypes) == arity[name], (name, len(argtypes), arity[name])

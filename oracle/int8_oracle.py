@@ -6,7 +6,7 @@ NOT in ``/root/reference`` nor installed here).  What is restated is the publish
 row-wise absmax int8 (Dettmers et al., "LLM.int8()", 2022, section 3.1: ``X_i8 = round(127 / max|X_row| * X_row)``, dequantised with ``max|X_row| / 127``) -- and
 NOT its activation path: the build keeps activations in split-precision fp16 (weight-only int8), which is strictly closer
 to the fp32 reference than int8 activations are.  PARITY UNPINNED against bitsandbytes itself (no copy of it to run);
-pinned are (a) the quantiser, bit-exact between this numpy version and ``_native.quantize_rows_int8``, and (b) the
+pinned are (a) the quantiser, bit-exact between this numpy version (IEEE fp32 divisions) and ``_native.quantize_rows_int8``, and (b) the
 forward over the DEQUANTISED weights ``q * scale`` (fp32) through the ordinary oracle, which is what the W8 kernels must
 reproduce to the usual 1e-2.
 """

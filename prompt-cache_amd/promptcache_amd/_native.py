@@ -324,22 +324,23 @@ def to_weight_frags(w):
 
 def quantize_rows_int8(w):
     """Row-wise absmax int8 (the weight quantiser of LLM.int8): ``q = round_half_even(w * (127 / absmax_row))`` in
-    [-127, 127], ``scale = absmax_row / 127`` (all-zero row: q = 0, scale = 1).  The two per-row divisions are done on
-    the host in IEEE fp32 (a GPU's fp32 division is not correctly rounded), the per-element step is one correctly
-    rounded fp32 product, so the result is bit-identical to ``oracle/int8_oracle.py`` on any device.
-    Returns ``(q int8 [N, K], scale fp32 [N])`` on the weight's device."""
+    [-127, 127], ``scale = absmax_row / 127`` (all-zero row: q = 0, scale = 1), on the weight's device.  The two per-row
+    quotients are formed as tensor / tensor in fp64 and rounded to fp32 -- which is the correctly rounded fp32 quotient
+    (53 >= 2 * 24 + 2 bits) on any device; ``scalar / tensor`` would be lowered to ``reciprocal * scalar`` and lands one ulp
+    off often enough to flip exact ties (w = absmax / 2) on real weights.  The per-element step is one correctly rounded
+    fp32 product, so the result is bit-identical to ``oracle/int8_oracle.py``.
+    Returns ``(q int8 [N, K], scale fp32 [N])``."""
     import torch
     wf = w.float()
-    amax = wf.abs().amax(dim=1).cpu()
+    amax = wf.abs().amax(dim=1)
     ok = amax > 0
     one = torch.ones_like(amax)
-    c127 = torch.full_like(amax, 127.0)
-    safe = torch.where(ok, amax, one)
-    # tensor / tensor: true IEEE division on the CPU (scalar / tensor is evaluated as reciprocal * scalar: 1 ulp off)
-    scale = torch.where(ok, safe / c127, one)
-    inv = torch.where(ok, c127 / safe, torch.zeros_like(amax))
-    q = torch.round(wf * inv.to(w.device)[:, None]).clamp_(-127, 127).to(torch.int8)
-    return q, scale.to(w.device).contiguous()
+    safe = torch.where(ok, amax, one).double()
+    c127 = torch.full_like(safe, 127.0)
+    scale = torch.where(ok, (safe / c127).float(), one)
+    inv = torch.where(ok, (c127 / safe).float(), torch.zeros_like(amax))
+    q = torch.round(wf * inv[:, None]).clamp_(-127, 127).to(torch.int8)
+    return q, scale.contiguous()
 
 
 def to_weight_frags_i8(q):

@@ -501,15 +501,33 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
         }
     }
     if (nslabs > 0) {
-        for (int s = 0; s < nslabs; ++s) {
+        // CH slabs at a time: all of their loads are issued before the first add (clamped, unconditional), so a chunk
+        // costs one L2 round trip instead of one per slab (one workgroup per row: with 12..64 rows nothing else hides
+        // the latency -- 6.5 -> ~4 us per launch at 22 rows); the adds keep the fixed slab order
+        constexpr int CH = G <= 2 ? 4 : (G <= 4 ? 2 : 1);
+        for (int s0 = 0; s0 < nslabs; s0 += CH) {
+            f4 c[CH][G], d[CH][G];
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int i = tid + k * 256;
-                if (i < nv) {
-                    const float* sp = slabs + s * slab_stride + (int64_t)row * hidden + i * 8;
-                    const f4 c = *(const f4*)sp, d = *(const f4*)(sp + 4);
-                    va[k][0] += c[0]; va[k][1] += c[1]; va[k][2] += c[2]; va[k][3] += c[3];
-                    vb[k][0] += d[0]; vb[k][1] += d[1]; vb[k][2] += d[2]; vb[k][3] += d[3];
+            for (int j = 0; j < CH; ++j) {
+                const int sj = s0 + j < nslabs ? s0 + j : nslabs - 1;
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int i = tid + k * 256;
+                    const float* sp = slabs + sj * slab_stride + (int64_t)row * hidden + (i < nv ? i : nv - 1) * 8;
+                    c[j][k] = *(const f4*)sp;
+                    d[j][k] = *(const f4*)(sp + 4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (s0 + j < nslabs) {
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        if (tid + k * 256 < nv) {
+                            va[k][0] += c[j][k][0]; va[k][1] += c[j][k][1]; va[k][2] += c[j][k][2]; va[k][3] += c[j][k][3];
+                            vb[k][0] += d[j][k][0]; vb[k][1] += d[j][k][1]; vb[k][2] += d[j][k][2]; vb[k][3] += d[j][k][3];
+                        }
+                    }
                 }
             }
         }

@@ -66,7 +66,7 @@ class LlamaHIP:
         # every decode step and every same-shaped prompt replays the same graph.
         self.use_graphs = True
         self._graphs = {}
-        self.max_graphs = 64
+        self.max_graphs = 256   # one per (q_len, split count, mode): a serving mix of prompt lengths stays resident
         self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops

@@ -22,7 +22,7 @@ def main(layers=32, qlen=8):
     from promptcache_amd.model.config import SHAPES
     from promptcache_amd.model.kv_arena import KVArena
     from promptcache_amd.model.weights import random_weights_device
-    shape = dataclasses.replace(SHAPES["llama2-7b"], num_hidden_layers=layers)
+    shape = dataclasses.replace(SHAPES[os.environ.get("PC_DBG_SHAPE", "llama2-7b")], num_hidden_layers=layers)
     seed = int(os.environ.get("PC_DBG_SEED", "5"))
     w = random_weights_device(shape, "cuda:0", torch.float16, seed=seed)
     int8 = os.environ.get("PC_DBG_INT8") == "1"          # load_in_8bit: the oracle then runs on the dequantised weights

@@ -41,10 +41,12 @@ for _p in (ROOT, os.path.join(ROOT, "prompt-cache_amd")):
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
-def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: int = 2):
+def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: int = 2, parity_layers: int = 0):
     """Time the numpy oracle (oracle/, 'port' of the reference's CPU path) on the host cores on a bounded
     sample -- the full-size gather plus k of the 32 layers and lm_head, scaled by L/k -- and compare the
-    GPU logits of the same k-layer stack with the oracle's (identical weights and staged KV)."""
+    GPU logits of the FULL-depth stack (``parity_layers``, default all L) with the oracle's on identical weights and
+    staged KV: shallow stacks say little about parity, and the oracle's cost for the q new rows
+    is one pass over the fp32 weights per layer."""
     import numpy as np
     import torch
     from threadpoolctl import threadpool_info
@@ -57,7 +59,8 @@ def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: i
     w = {"embed": m.embed.float().cpu().numpy(), "norm": m.norm.float().cpu().numpy(),
          "lm_head": m.lm_head.float().cpu().numpy()}
     H, Hkv, D = m.H, m.Hkv, m.D
-    for i in range(k_layers):
+    p_layers = L if parity_layers <= 0 else min(parity_layers, L)
+    for i in range(max(k_layers, p_layers)):
         lw = m.layers[i]
         wqkv = lw["wqkv"].float().cpu().numpy()
         w[f"l{i}.wq"], w[f"l{i}.wk"], w[f"l{i}.wv"] = wqkv[:H * D], wqkv[H * D:(H + Hkv) * D], wqkv[(H + Hkv) * D:]
@@ -67,7 +70,7 @@ def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: i
             w[f"l{i}.{k}"] = lw[k].float().cpu().numpy()
         w[f"l{i}.down"] = lw["wdown"].float().cpu().numpy()
     cfg = OracleConfig(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
-                       num_hidden_layers=k_layers, num_attention_heads=H, num_key_value_heads=Hkv,
+                       num_hidden_layers=max(k_layers, p_layers), num_attention_heads=H, num_key_value_heads=Hkv,
                        rms_norm_eps=c.rms_norm_eps, rope_theta=c.rope_theta, inv_freq=m.inv_freq_cpu.numpy())
     oracle = LlamaOracle(cfg, w)
     # --- module KV of the used segments on the host (all layers: the gather is timed at full size) ---
@@ -85,7 +88,7 @@ def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: i
         staged, S = kv_gather(segs, max_ctx)                          # PromptCache.update on the CPU
         t1 = time.perf_counter()
         past = [(k[None], v[None]) for k, v in staged[:k_layers]]
-        logits, _ = oracle.forward(ids_np, pos_np, past=past)
+        logits, _ = oracle.forward(ids_np, pos_np, past=past, n_layers=k_layers)
         t2 = time.perf_counter()
         t_gather.append(t1 - t0)
         t_prefill.append(t2 - t1)
@@ -96,10 +99,15 @@ def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: i
     tp = min(t_prefill)
     ttft_cpu = min(t_gather) + (tp - t_head) * (L / k_layers) + t_head
     threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    # --- parity at the true layer shape: GPU k-layer stack vs oracle ---
+    # --- parity at the true shape AND depth: GPU cached prefill (the timed step's own forward) vs the oracle over the
+    # same staged KV, all p_layers layers ---
+    t0 = time.perf_counter()
+    staged, S = kv_gather(segs, max_ctx)
+    logits, _ = oracle.forward(ids_np, pos_np, past=[(k[None], v[None]) for k, v in staged[:p_layers]], n_layers=p_layers)
+    t_par = time.perf_counter() - t0
     ids2, pos2, _, cache = eng.process(prompt)
     out = lm(input_ids=torch.tensor([ids2], device=lm.device), position_ids=torch.tensor([pos2], device=lm.device),
-             past_key_values=cache, use_cache=True, num_layers=k_layers)
+             past_key_values=cache, use_cache=True, num_layers=None if p_layers == L else p_layers)
     err = float(np.abs(out.logits[0].float().cpu().numpy() - logits[0]).max())
     n_tok = S + len(ids)
     base = {"value": n_tok / ttft_cpu, "unit": "tokens/s", "cores": int(threads), "kind": "port",
@@ -107,8 +115,10 @@ def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: i
             "sample": (f"numpy oracle (oracle/llama_oracle.py), same persona-like prompt: full-size gather (L={L}) + "
                        f"{k_layers} of {L} layers at the 7b layer shape + lm_head, best of {repeats}; layer time scaled by "
                        f"{L}/{k_layers}")}
-    parity = {"max_abs_dlogit": err, "tol": 1e-2, "layers": k_layers,
-              "what": "GPU k-layer cached prefill vs numpy oracle, identical weights / staged KV / positions"}
+    parity = {"max_abs_dlogit": err, "tol": 1e-2, "layers": p_layers, "staged_tokens": int(S), "new_tokens": len(ids),
+              "max_abs_logit": float(np.abs(logits).max()), "oracle_seconds": t_par,
+              "what": "GPU cached prefill of the timed step (all layers) vs the numpy oracle on identical weights, "
+                      "staged module KV and positions; end-to-end parity incl. the encode: tests/test_gpu_fullsize.py"}
     return base, parity
 
 
@@ -199,7 +209,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="llama2-7b")
     ap.add_argument("--max-ctx", type=int, default=4096)        # config/llm_config_llama2_7b.json of the reference
-    ap.add_argument("--cpu-layers", type=int, default=4)
+    ap.add_argument("--cpu-layers", type=int, default=4, help="layers the cpu_baseline TIMING runs (scaled by L/k)")
+    ap.add_argument("--parity-layers", type=int, default=0, help="layers of the parity leg (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-library", action="store_true", help="skip the schema-library encode leg (BASELINE config 5)")
     ap.add_argument("--no-int8", action="store_true", help="skip the int8-weight context leg (builds a second model)")
@@ -453,7 +464,7 @@ def main():
         del lm8, o8, past8, cache8
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline_and_parity(lm, eng, prompt, ids, pos, args.cpu_layers)
+        base, parity = cpu_baseline_and_parity(lm, eng, prompt, ids, pos, args.cpu_layers, parity_layers=args.parity_layers)
         result["cpu_baseline"] = base
         result["parity"] = parity
     if rank == 0:

@@ -307,7 +307,7 @@ int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const vo
                         int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
- * map the attention kernel relies on (see csrc/pc_probe.hip). */
+ * map the attention kernel relies on (probe_kernel in csrc/pc_misc.hip). */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);
 
 #ifdef __cplusplus

@@ -446,6 +446,33 @@ def main():
     mpt_goldens(pc)
 
 
+
+SAMPLING_CASES = [
+    # temperature, repetition_penalty, top_p, top_k   (generation_engine.py:22-42)
+    (1.0, 1.0, 1.0, -1), (0.7, 1.0, 1.0, -1), (1.3, 1.2, 1.0, -1), (0.7, 1.0, 0.9, -1), (0.7, 1.0, 1.0, 5),
+    (0.5, 1.3, 0.8, 7), (1.0, 1.0, 0.5, 1), (0.0, 1.0, 1.0, -1), (1.0, 1.0, 1e-9, -1), (2.0, 1.5, 0.95, 40),
+]
+
+
+def sampling_goldens(pc):
+    """The reference's logits-processor chain (``GenerationParameters.get_logits_processor``, generation_engine.py:32-42,
+    applied as at :150-155) on seeded logits and a token history: processed logits per parameter set."""
+    import torch
+    GP = pc.generation_engine.GenerationParameters
+    rng = np.random.default_rng(77)
+    V = 96
+    logits = (3.0 * rng.standard_normal((len(SAMPLING_CASES), V))).astype(np.float32)
+    history = rng.integers(0, V, size=(len(SAMPLING_CASES), 11))
+    out = np.zeros_like(logits)
+    for i, (t, rp, tp, tk) in enumerate(SAMPLING_CASES):
+        params = GP(temperature=t, repetition_penalty=rp, top_p=tp, top_k=tk)
+        chain = params.get_logits_processor()
+        hist = torch.as_tensor([history[i].tolist()]) if rp > 1.0 else None
+        out[i] = chain(hist, torch.from_numpy(logits[i:i + 1].copy()))[0].numpy()
+    np.savez(os.path.join(GOLD, "sampling_chain.npz"), params=np.array(SAMPLING_CASES, dtype=np.float64), logits=logits,
+             history=history, processed=out)
+    print(f"[golden] sampling_chain: {len(SAMPLING_CASES)} parameter sets, V={V}")
+
 def falcon_goldens(pc):
     """Falcon adapter fixtures (reference FalconForCausalLM, multi-query cache shape (L, 1, D))."""
     model_golden(pc, "falcon_tiny_trip", "falcon-tiny", seed=5, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT,
@@ -463,6 +490,9 @@ def mpt_goldens(pc):
 
 
 if __name__ == "__main__":
+    if "--sampling-only" in sys.argv:
+        sampling_goldens(ref_shim.import_reference())
+        sys.exit(0)
     if "--mpt-only" in sys.argv:
         mpt_goldens(ref_shim.import_reference())
         sys.exit(0)

@@ -242,6 +242,8 @@ class SchemaCache:
         encoded_tokens = computed_tokens = 0
         per_job: Dict[int, List[Tuple[TokenSequence, torch.Tensor]]] = {}
         full_pos = bool(getattr(lm, "use_full_position_ids", False))
+        custom_store_hooks = (type(lm).store_k_hook is not LanguageModel.store_k_hook or
+                              type(lm).store_v_hook is not LanguageModel.store_v_hook)
 
         def store_owned(job_idx: int, arena: KVArena, row: int):
             job = jobs[job_idx]
@@ -251,6 +253,13 @@ class SchemaCache:
             lens = [len(tc) for tc in owned]
             stores = [torch.empty((L, 2, Hkv, n, D), dtype=torch.float16, device=dev) for n in lens]
             _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
+            if custom_store_hooks:
+                # an adapter that overrides store_k_hook / store_v_hook (reference :284-285) sees the per-layer
+                # [Hkv, len, D] slices exactly as the reference hands them over; identity hooks cost nothing
+                for st in stores:
+                    for li in range(L):
+                        st[li, 0].copy_(lm.store_k_hook(st[li, 0]))
+                        st[li, 1].copy_(lm.store_v_hook(st[li, 1]))
             per_job[job_idx] = list(zip(owned, stores))
 
         shared = [i for i in mine if prefix[i] > 0]
@@ -486,5 +495,9 @@ class CacheEngine:
         for i in range(len(cache)):
             cache[i] = (self.lm.read_k_hook(cache[i][0]), self.lm.read_v_hook(cache[i][1]))
         if return_full_position_ids:
-            position_ids = [p for s in used for p in s.position_ids()] + position_ids
+            # positions of the cached keys in the order they are STAGED (most-used first, PromptCache.update), not in the
+            # DFS order of `used`: an ALiBi model reads position_ids[:S] as the positions of arena rows [0, S).  (The
+            # reference returns the DFS order at :517-519 while staging the sorted order -- the two diverge as soon as
+            # the usage counters do; not reproduced.)
+            position_ids = [p for c in self.prompt_cache.staged for p in c.token_sequence.position_ids()] + position_ids
         return input_ids, position_ids, cache_time, cache

@@ -277,10 +277,16 @@ class LlamaHIP:
 
         T = B * q_len
         self._kv_only = bool(kv_only)
-        streaming = self.skinny and (T <= self.SKINNY_MAX_ROWS and self.use_graphs or T <= self.MID_MAX_ROWS and
-                                     not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS))
+        # a schema-encode pass (fresh arena, or a suffix over a trunk arena that carries residuals) always takes the
+        # many-row path, however few rows it has: that path alone reads the prefix's residual planes and stops after the
+        # last layer's K / V; and a pass that is not the serving prefill / decode must not capture a throwaway hipGraph
+        encode_pass = many_rows and self.precise_dense and (past_key_values is None or arena.lo is not None)
+        graphed = self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs and not many_rows and not kv_only
+        mid = self.skinny and not encode_pass and T <= self.MID_MAX_ROWS and \
+            not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS)
+        streaming = graphed or mid
         self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
-        if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
+        if graphed:
             # the graph's static int64 / int32 input buffers are filled straight from the caller's tensors
             # (copy_ converts), so no separate dtype-conversion launches sit in front of the replay
             logits = self._graphed_skinny(input_ids.reshape(-1), position_ids.reshape(-1), arena, B, q_len, past_len,
@@ -290,7 +296,7 @@ class LlamaHIP:
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
-        if self.skinny and T <= self.MID_MAX_ROWS and not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS):
+        if mid:
             logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
             arena.length = past_len + q_len
             self._tail_done(arena, self._lo_mode, q_len, past_len)
@@ -458,11 +464,13 @@ class LlamaHIP:
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
         mode = self._lo_mode
         key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm,
-               mode, arena.tail_lo.data_ptr() if mode else 0)
-        ent = self._graphs.get(key)
-        if ent is None:
+               mode, arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0)
+        ent = self._graphs.pop(key, None)
+        if ent is not None:
+            self._graphs[key] = ent                      # LRU: a hit moves the entry to the young end
+        else:
             if len(self._graphs) >= self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))
+                self._graphs.pop(next(iter(self._graphs)))   # evict the least recently used
             T = B * q_len
             st_ids = torch.zeros(T, dtype=torch.int64, device=self.device)
             st_pos = torch.zeros(T, dtype=torch.int32, device=self.device)

@@ -110,15 +110,19 @@ class MptHIP(LlamaHIP):
         # like the reference (mpt.py:97: arange(1 - max_len, 1)) the bias is slope * (pos - max_pos) <= 0: the keys that
         # carry the weight sit near max_pos, where the term is small and fp32 resolves it finely
         position_ids = position_ids - position_ids.amax(dim=1, keepdim=True)
-        streaming = self.skinny and (T <= self.SKINNY_MAX_ROWS and self.use_graphs or T <= self.MID_MAX_ROWS and
-                                     not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS))
-        self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
-        if self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs:
+        # (same routing as LlamaHIP.__call__: encode passes always take the many-row path, only the serving prefill and
+        # the decode steps capture hipGraphs)
+        encode_pass = many_rows and self.precise_dense and (past_key_values is None or arena.lo is not None)
+        graphed = self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs and not many_rows and not kv_only
+        mid = self.skinny and not encode_pass and T <= self.MID_MAX_ROWS and \
+            not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS)
+        self._lo_mode = self._tail_mode(arena, q_len, past_len) if (graphed or mid) else 0
+        if graphed:
             logits = self._graphed_mpt(ids, position_ids, arena, B, q_len, past_len, last_token_only, num_layers)
         else:
             kpos = torch.zeros((B, self._kpos_cols(arena.cap)), dtype=torch.float32, device=dev)
             kpos[:, :kv_len] = position_ids.to(torch.float32)
-            if self.skinny and T <= self.MID_MAX_ROWS and not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS):
+            if mid:
                 logits = self._forward_skinny(ids, kpos, None, arena, B, q_len, past_len, last_token_only, num_layers)
             else:
                 logits = self._forward_dense(ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers)
@@ -132,12 +136,14 @@ class MptHIP(LlamaHIP):
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, kv_len)
         mode = self._lo_mode
         key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, mode,
-               arena.tail_lo.data_ptr() if mode else 0)
-        ent = self._graphs.get(key)
+               arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0)
+        ent = self._graphs.pop(key, None)
         fresh = ent is None
-        if fresh:
+        if not fresh:
+            self._graphs[key] = ent                      # LRU: a hit moves the entry to the young end
+        else:
             if len(self._graphs) >= self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))
+                self._graphs.pop(next(iter(self._graphs)))   # evict the least recently used
             st_ids = torch.zeros(B * q_len, dtype=torch.int64, device=self.device)
             st_kpos = torch.zeros((B, self._kpos_cols(arena.cap)), dtype=torch.float32, device=self.device)
             st_past = torch.zeros(2, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail}

@@ -121,6 +121,28 @@ def make_mpt_weights_np(cfg, seed: int = 0, scale: float = 1.0) -> Dict[str, np.
     return out
 
 
+def read_checkpoint_dir(path: str):
+    """Every tensor of an HF checkpoint directory, by its HF name, on the host: the ``*.safetensors`` shards when
+    there are any, else the ``pytorch_model*.bin`` shards (``torch.load(weights_only=True)``) that older uploads of
+    the models the reference lists ship instead."""
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    raw = {}
+    if files:
+        from safetensors import safe_open
+        for fn in files:
+            with safe_open(fn, framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    raw[k] = f.get_tensor(k)
+        return raw
+    bins = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+    if not bins:
+        raise FileNotFoundError(f"no *.safetensors and no pytorch_model*.bin under {path}")
+    import torch
+    for fn in bins:
+        raw.update(torch.load(fn, map_location="cpu", weights_only=True))
+    return raw
+
+
 def random_mpt_weights_device(cfg, device, dtype, seed: int = 0):
     import torch
 
@@ -141,16 +163,7 @@ def random_mpt_weights_device(cfg, device, dtype, seed: int = 0):
 
 def load_mpt_safetensors(path: str, cfg):
     """HF mpt-7b-class checkpoint directory -> the key layout of ``mpt_weight_shapes``."""
-    from safetensors import safe_open
-
-    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
-    if not files:
-        raise FileNotFoundError(f"no *.safetensors under {path}")
-    raw = {}
-    for fn in files:
-        with safe_open(fn, framework="pt", device="cpu") as f:
-            for k in f.keys():
-                raw[k] = f.get_tensor(k)
+    raw = read_checkpoint_dir(path)
     out = {"embed": raw["transformer.wte.weight"], "lnf": raw["transformer.norm_f.weight"]}
     out["lm_head"] = raw.get("lm_head.weight", out["embed"])
     names = {"ln1": "norm_1.weight", "wqkv": "attn.Wqkv.weight", "wo": "attn.out_proj.weight", "ln2": "norm_2.weight",
@@ -171,17 +184,7 @@ _HF_MAP = {
 
 def load_hf_safetensors(path: str, cfg: LlamaShape, device, dtype):
     """Read an HF Llama checkpoint directory (``*.safetensors``) into the key layout above."""
-    import torch
-    from safetensors import safe_open
-
-    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
-    if not files:
-        raise FileNotFoundError(f"no *.safetensors under {path}")
-    raw = {}
-    for fn in files:
-        with safe_open(fn, framework="pt", device="cpu") as f:
-            for k in f.keys():
-                raw[k] = f.get_tensor(k)
+    raw = read_checkpoint_dir(path)
     out = {"embed": raw["model.embed_tokens.weight"], "norm": raw["model.norm.weight"],
            "lm_head": raw.get("lm_head.weight", raw["model.embed_tokens.weight"])}
     for i in range(cfg.num_hidden_layers):
@@ -231,16 +234,7 @@ def random_falcon_weights_device(cfg, device, dtype, seed: int = 0):
 def load_falcon_safetensors(path: str, cfg):
     """Read an HF falcon-7b-class checkpoint directory (``*.safetensors``) into the key layout of
     ``falcon_weight_shapes`` (HF names: ``transformer.h.{i}.self_attention.query_key_value`` etc.)."""
-    from safetensors import safe_open
-
-    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
-    if not files:
-        raise FileNotFoundError(f"no *.safetensors under {path}")
-    raw = {}
-    for fn in files:
-        with safe_open(fn, framework="pt", device="cpu") as f:
-            for k in f.keys():
-                raw[k] = f.get_tensor(k)
+    raw = read_checkpoint_dir(path)
     out = {"embed": raw["transformer.word_embeddings.weight"], "lnf_w": raw["transformer.ln_f.weight"],
            "lnf_b": raw["transformer.ln_f.bias"]}
     out["lm_head"] = raw.get("lm_head.weight", out["embed"])

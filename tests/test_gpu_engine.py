@@ -474,3 +474,96 @@ def test_int8_weight_mode_falcon_and_mpt(case):
     outs = list(GenerationEngine(lm).generate(ids, pos, GenerationParameters(temperature=0.0, max_new_tokens=3), cache,
                                                stream_interval=1, use_full_position_ids=full))
     assert outs, "no output"
+
+
+def test_mpt_full_position_ids_follow_the_staged_order_after_usage_counters_diverge():
+    """ALiBi reads position_ids[:S] as the positions of the STAGED rows.  Staging is most-used-first
+    (PromptCache.update), so after a first prompt has bumped some usage counters a second prompt's staged order
+    differs from its DFS order -- the positions handed back by process(return_full_position_ids=True) must follow
+    the staging.  Checked against the numpy MPT oracle on the second prompt."""
+    from oracle.mpt_oracle import MptOracle, MptOracleConfig
+    from promptcache_amd import CacheEngine, Prompt
+    from promptcache_amd.model import Mpt
+    from promptcache_amd.model.config import MPT_SHAPES
+    from promptcache_amd.model.weights import make_mpt_weights_np
+    shape = MPT_SHAPES["mpt-tiny"]
+    w16 = make_mpt_weights_np(shape, 13, 4.0)
+    lm = Mpt(name="x", shape=shape, weights=w16, device="cuda:0")
+    fmt = lm.get_formatter()
+    schema = ("<schema name='two'><system>You are terse and exact in every answer you give.</system>"
+              "<module name='a'>Alpha block: the quick brown fox jumps over the lazy dog again and again.</module>"
+              "<module name='b'>Beta block: pack my box with five dozen liquor jugs, then rest a while.</module>"
+              "<user>Question follows.</user></schema>")
+    eng = CacheEngine(512, lm)
+    eng.add_schema(fmt(schema))
+    # prompt 1 uses <a/> only: usage counters root 1, a 1, b 0
+    eng.process(Prompt("<prompt schema='two'><a/>first ask</prompt>", [fmt]), return_full_position_ids=True)
+    # prompt 2: the DFS (explicit stack, LIFO) visits root, b, a; the counters (root 2, a 2, b 1) stage root | a | b
+    p2 = Prompt("<prompt schema='two'><a/><b/>second ask now</prompt>", [fmt])
+    ids, pos, _, cache = eng.process(p2, return_full_position_ids=True)
+    staged = eng.prompt_cache.staged
+    S = cache[0][0].shape[1]
+    offs = [m.token_sequence.offset for m in staged]
+    assert offs == sorted(offs) and len(offs) >= 3, "expected the staging root | a | b (the DFS order is root | b | a)"
+    assert pos[:S] == [p for m in staged for p in m.token_sequence.position_ids()]
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    model = MptOracle(MptOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
+                                      shape.layer_norm_epsilon, shape.alibi_bias_max),
+                      {k: v.astype(np.float32) for k, v in w16.items()})
+    sc = eng.get_schema("two")
+    jobs = []
+    for p in sc.encode_paths():
+        sf = sc.get_scaffold(p)
+        jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
+    lib = eo.encode_schema(model, jobs)
+    used = [m.token_sequence for m in staged]
+    _, S2, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 512)
+    err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
+    print(f"[mpt staged-order positions] S={S} max|dlogit| vs oracle = {err:.2e}")
+    assert S2 == S and err < LOGIT_TOL
+
+
+def test_generate_sampling_branch_top_k_1_equals_greedy_and_is_seed_reproducible():
+    """The non-greedy branch of generate (reference generation_engine.py:161-163: softmax + multinomial over the processed
+    logits).  With top_k = 1 the processed distribution is one-hot, so sampling must reproduce the reference's greedy
+    golden tokens; with a real distribution the draw is a function of the torch seed only."""
+    from promptcache_amd import GenerationEngine, GenerationParameters, Prompt
+    g = H.load_case("tiny_trip")
+    lm, eng = build_product(g)
+    prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
+    n = len(g["greedy"])
+
+    def run(params, seed):
+        ids, pos, _, cache = eng.process(prompt)
+        torch.manual_seed(seed)
+        outs = list(GenerationEngine(lm).generate(ids, pos, params, cache, stream_interval=1))
+        return outs[-1].new_text
+
+    one_hot = GenerationParameters(temperature=0.7, top_k=1, repetition_penalty=1.0, max_new_tokens=n, stop_token_ids=[], stop_str=[])
+    assert not one_hot.greedy
+    assert run(one_hot, 0) == lm.decode(g["greedy"].tolist())
+    warm = GenerationParameters(temperature=1.5, top_p=0.95, top_k=50, repetition_penalty=1.2, max_new_tokens=8,
+                                stop_token_ids=[], stop_str=[])
+    a, b, c = run(warm, 123), run(warm, 123), [run(warm, s) for s in (1, 2, 3, 4)]
+    assert a == b and len(a) > 0
+    assert any(x != a for x in c), "four other seeds all reproduced the same 8 sampled tokens: the draw ignores the seed"
+
+
+def test_checkpoint_directory_path_equals_in_memory_weights(tmp_path):
+    """INTEGRATION.md's real-checkpoint route: Llama2(<HF dir>) -- config.json + safetensors shards -> LlamaShape.from_hf_dir
+    + load_hf_safetensors -> the same logits as the same tensors handed over in memory."""
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.tokenizer import StandInTokenizer
+    from promptcache_amd.model.weights import make_weights_np
+    from tests.test_loaders_cpu import _llama_dir
+    shape = SHAPES["mid_gqa"]
+    w16 = make_weights_np(shape, 21, 2.0)
+    _llama_dir(str(tmp_path), shape, w16, shards=2)
+    tok = StandInTokenizer(shape.vocab_size)
+    a = Llama2(name=str(tmp_path), device="cuda:0", tokenizer=tok)
+    b = Llama2(name="mem", shape=shape, weights=w16, device="cuda:0")
+    assert a.get_cache_shape() == b.get_cache_shape()
+    ids = torch.randint(3, shape.vocab_size, (1, 23), generator=torch.Generator().manual_seed(2)).cuda()
+    assert torch.equal(a(input_ids=ids, use_cache=True).logits, b(input_ids=ids, use_cache=True).logits)

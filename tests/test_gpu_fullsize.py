@@ -202,8 +202,12 @@ def test_mpt_7b_shape_alibi_cached_equals_nocache_and_oracle():
     assert S2 == S and err < TOL and oerr < TOL
 
 
-@pytest.mark.skipif(os.environ.get("PC_FULL_PARITY", "0") != "1",
-                    reason="minutes of host BLAS time: set PC_FULL_PARITY=1 (result recorded in profiles/r01_full_depth_parity.txt)")
+# Full-depth parity runs by default (shallow stacks hid a 2-3e-2 drift in round 1); each test spends
+# 1-2 minutes in the host oracle.  PC_SKIP_FULL_PARITY=1 opts out for quick local iterations.
+_skip_full = pytest.mark.skipif(os.environ.get("PC_SKIP_FULL_PARITY", "0") == "1", reason="PC_SKIP_FULL_PARITY=1")
+
+
+@_skip_full
 def test_full_depth_7b_end_to_end_vs_numpy_oracle():
     """All 32 layers at the true llama2-7b shape, end to end: schema encode (trunk reuse, dense + weight-streaming
     paths), gather, cached prefill -- against the numpy oracle doing the reference's full per-scaffold encode in
@@ -249,7 +253,7 @@ def test_full_depth_7b_end_to_end_vs_numpy_oracle():
     assert err < TOL
 
 
-@pytest.mark.skipif(os.environ.get("PC_FULL_PARITY", "0") != "1", reason="minutes of host BLAS time: set PC_FULL_PARITY=1")
+@_skip_full
 @pytest.mark.parametrize("family", ["falcon", "mpt"])
 def test_full_depth_falcon_mpt_end_to_end_vs_numpy_oracle(family):
     """32 layers at the true falcon-7b / mpt-7b layer shapes (small vocab), end to end against the numpy oracles."""

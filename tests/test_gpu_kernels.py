@@ -254,6 +254,12 @@ ATTN_CASES = [
     (1, 2, 1, 128, 456, 0),       # encode regime (q = S)
     (1, 8, 8, 128, 1, 1000),      # decode step
     (1, 40, 40, 128, 30, 511),    # 13b head count
+    # the 32-rows-per-wave kernel (attn_fwd32_kernel, mfma 32x32x16): dispatched when q_len > 64 and 128-row q-blocks fill
+    # the chip (B*H*ceil(q/128) >= 256) or the staged past is long (kv_len >= 8 q_len) -- pc_attn.hip use_rows32()
+    (1, 32, 32, 128, 1100, 0),    # 7b heads, encode regime: 288 q-blocks, ragged last block, causal diagonal
+    (2, 16, 8, 128, 1030, 5),     # batch + GQA, 288 q-blocks
+    (1, 8, 8, 128, 70, 600),      # long staged past (kv >= 8 q): KV splits + merge from the 32-row kernel
+    (1, 64, 64, 64, 600, 3),      # D = 64
 ]
 
 

@@ -306,6 +306,23 @@ int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const vo
                         int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
                         int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
 
+/* Many-row projection (schema encode / no-cache prefill / long questions; MFMA-bound), csrc/pc_gemm_dense.hip:
+ *     acc[m][n] = sum_k (x_hi[m][k] + x_lo[m][k]) * w[n][k]        fp16 operands, fp32 accumulation
+ * x_hi / x_lo: split-precision activation planes [M][K] (row stride ldx halfs; x_lo may be NULL), w: the nn.Linear
+ * weight [N][K] (row stride ldw), w_scale: optional fp32 per-output-row scale (int8 codes held in fp16).
+ * Replaces the nn.Linear calls of promptcache/model/llama2.py:345-347 (q|k|v), :405 (o_proj), :242 (gate / up / down),
+ * :1050 (lm_head) -- and falcon.py:393-405,:726-731 / mpt.py -- for passes of many rows, together with the ops
+ * that follow them:
+ *   epilogue 0  y[m][n]  = acc                                   (fp32, row stride ldy)
+ *   epilogue 1  y[m][n] += acc                                   residual add, llama2.py:638 / :644
+ *   epilogue 2  out[m][j] = silu(acc[m][j]) * acc[m][N/2 + j]    w = [gate; up] rows, llama2.py:242; out_hi / out_lo
+ *                                                                split-precision planes [M][N/2] (row stride ldo)
+ *   epilogue 4  out[m][n] = gelu(acc)                            nn.GELU(), falcon.py:726; planes [M][N]
+ * K % 8 == 0, N % 4 == 0; operands 16-byte aligned.  Returns 0 or a negative PC_ERR_* code. */
+int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw, const float* w_scale,
+                  int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
+                  int64_t ldo, void* stream);
+
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (probe_kernel in csrc/pc_misc.hip). */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);

@@ -1,0 +1,316 @@
+// Many-row projections (schema encode, no-cache prefill, long questions): the MFMA-bound regime of the path.
+//
+// Replaces  q_proj/k_proj/v_proj   promptcache/model/llama2.py:345-347   (one fused [q|k|v] GEMM)
+//           o_proj + residual       promptcache/model/llama2.py:405, :638
+//           gate/up + SiLU*up       promptcache/model/llama2.py:242
+//           down_proj + residual    promptcache/model/llama2.py:242, :644
+//           lm_head                 promptcache/model/llama2.py:1050
+//           (Falcon / MPT: query_key_value, dense, dense_h_to_4h + GELU, dense_4h_to_h; falcon.py:393-405, :726-731)
+// inside SchemaCache._process (cache_engine.py:243-248): the module-KV precompute.
+//
+// Y[m][n] = sum_k (Xhi[m][k] + Xlo[m][k]) * W[n][k]       X: split-precision fp16 planes [M][K] (hi = fp16(x),
+//                                                          lo = fp16(x - hi); lo optional), W: nn.Linear [N][K] fp16
+// Why two planes: an fp16 activation costs 2^-12 per projection input, and through 32 layers that alone moves
+// 7b-shape logits by 2-3e-2 against the reference's fp32 CPU path.  Round 1 ran [hi; lo] stacked
+// along the rows of a vendor GEMM and added the halves in separate fp32 passes.  Here both planes meet the SAME weight
+// fragment inside one tile pass: a weight fragment is read from LDS once and feeds the hi and the lo MFMA, the two
+// partial products meet in the fp32 accumulator, and the epilogue (residual add, SiLU*up, GELU, fp32 store) runs on the
+// accumulator tile -- no [2T][N] fp32 intermediate ever exists.
+//
+// Tile: workgroup = 8 waves (2 per SIMD), block tile 128 (M) x BN (N) x 64 (K), BN = 256 (waves 2 x 4, wave tile
+// 64 x 64) or 128 (waves 4 x 2, wave tile 32 x 64; for launches whose 256-wide grid would leave CUs idle).
+// mfma_f32_32x32x16_f16: per 16-deep k-slab a wave reads 2*MT activation fragments and 2 weight fragments (16 B per
+// lane each, ds_read_b128) for 4*MT MFMAs.
+// Staging: global_load_lds (16 B per lane, 1 KiB per wave-instruction = 8 rows x 128 B of a tile) straight into a
+// double-buffered LDS image, one barrier per K-step: the loads of K-step t+1 are in flight while step t is multiplied.
+// The LDS image keeps 128-byte rows; the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7), which
+// makes every ds_read_b128 lane group of a fragment read hit 16 distinct 16-byte bank slots (row-major 128-B rows
+// would be 8-way conflicted).  LDS-DMA writes lane-linearly, so the permutation is applied to the per-lane SOURCE
+// address and again on the read (guide: rule 21, both sides or neither).
+// Which global weight row lands in which LDS row is free as well (per-lane source address): the SiLU launch puts 32
+// gate rows and the 32 matching up rows side by side in one wave tile, so gate_j and up_j meet in the same lane.
+// Epilogue: the accumulator tile goes through the (now idle) LDS once so that every global store is 16 B per lane on
+// full rows.
+// Grid: 1-D, XCD-aware: block id b runs on XCD b % 8; an XCD owns the weight panels xcd, xcd + 8, ... and walks all
+// M-blocks of a panel before the next one, so a panel is fetched from HBM once and served from that XCD's L2.
+// Roofline: MFMA.  flops per launch = 2 * (TWO ? 2 : 1) * M * N * K against the 2.5 PFLOP/s dense fp16 peak.
+#include <hip/hip_fp16.h>
+#include <string.h>
+
+#include "pc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BK = 64;
+constexpr int kXT = BM * BK * 2;                 // bytes of one activation plane tile (16 KiB)
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2, EPI_GELU = 4 };
+
+struct DenseParams {
+    const _Float16* xh; const _Float16* xl; int64_t ldx;   // [M][K] planes (xl may be null), row stride in halfs
+    const _Float16* w; int64_t ldw;                        // [N][K]
+    const float* wscale;                                   // optional per-output-row scale (int8 codes held in fp16)
+    const _Float16* zeros;                                 // >= 16 B of zeros: source of activation chunks past K
+    float* y; int64_t ldy;                                 // EPI_STORE / EPI_ADD
+    _Float16* oh; _Float16* ol; int64_t ldo;               // EPI_SILU / EPI_GELU output planes
+    int32_t M, N, K, mb, nb, nfeat;                        // nfeat: SiLU features (= N / 2)
+};
+
+__device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int WM, int EPI, bool TWO>
+__global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
+    constexpr int WN = 8 / WM, MT = BM / (32 * WM), NT = 2, BN = 64 * WN;
+    constexpr int kWT = BN * BK * 2;             // bytes of the weight tile
+    constexpr int kStage = 2 * kXT + kWT;        // Xhi | Xlo | W
+    constexpr int NXI = 2, NWI = BN / 64;        // staging instructions per wave: 2 per activation plane, BN/64 for W
+    __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    // block -> (M-block, weight panel), XCD-aware
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nloc = slot / p.mb, mi = slot - nloc * p.mb, ni = nloc * 8 + xcd;
+    if (ni >= p.nb) return;
+    const int m0 = mi * BM;
+    const int K = p.K, nk = (K + BK - 1) / BK;
+
+    // global weight row of LDS weight-tile row r; -1 = past the end (clamped source, never stored)
+    auto wrow = [&](int r) -> int {
+        if (EPI == EPI_SILU) {
+            const int f = (ni * WN + (r >> 6)) * 32 + (r & 31);
+            return f < p.nfeat ? ((r >> 5) & 1) * p.nfeat + f : -1;
+        }
+        const int n = ni * BN + r;
+        return n < p.N ? n : -1;
+    };
+
+    // ---- staging sources: per lane one 16-byte chunk of one row per instruction ----
+    const int srow = lane >> 3, scp = lane & 7;          // row inside the 8-row group, chunk POSITION in the LDS row
+    const _Float16* gx[NXI];
+    const _Float16* gw[NWI];
+    int cx[NXI], cw[NWI];                                // source chunk index (for the K tail)
+    const int64_t lo_delta = TWO ? (p.xl - p.xh) : 0;
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+        const int r = wave * 16 + j * 8 + srow;
+        const int gm = (m0 + r < p.M) ? m0 + r : p.M - 1;
+        cx[j] = scp ^ ((r >> 1) & 7);
+        gx[j] = p.xh + (int64_t)gm * p.ldx + cx[j] * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NWI; ++j) {
+        const int r = wave * (BN / 8) + j * 8 + srow;
+        int gr = wrow(r);
+        gr = gr < 0 ? 0 : gr;
+        cw[j] = scp ^ ((r >> 1) & 7);
+        gw[j] = p.w + (int64_t)gr * p.ldw + cw[j] * 8;
+    }
+    auto stage = [&](int t, char* buf, bool tail) {
+        const int64_t ko = (int64_t)t * BK;
+        const int kchunks = tail ? (K - t * BK) / 8 : 8;          // valid 16-byte chunks in this K-step
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const bool ok = !tail || cx[j] < kchunks;
+            const _Float16* sh = ok ? gx[j] + ko : p.zeros;
+            glds16(sh, buf + (wave * 16 + j * 8) * 128);
+            if (TWO) glds16(ok ? gx[j] + lo_delta + ko : p.zeros, buf + kXT + (wave * 16 + j * 8) * 128);
+        }
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+            // chunks past K pair with zero activations: any finite weight bytes do (the row's first chunk)
+            const _Float16* sw = (!tail || cw[j] < kchunks) ? gw[j] + ko : gw[j] - cw[j] * 8;
+            glds16(sw, buf + 2 * kXT + (wave * (BN / 8) + j * 8) * 128);
+        }
+    };
+
+    // ---- fragment addressing: lane = (row fr of the 32-row subtile, k-half fh) ----
+    const int fr = lane & 31, fh = lane >> 5;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = fr * 128 + (((2 * ks + fh) ^ ((fr >> 1) & 7)) << 4);
+    const int a_base = (wm * 32 * MT) * 128;              // + 32*i rows, + kXT for the lo plane
+    const int b_base = 2 * kXT + (wn * 64) * 128;         // + 32*j rows
+
+    f16v acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool ktail = (K % BK) != 0;
+    stage(0, lds, ktail && nk == 1);
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed (this wave's LDS-DMA drained) and is visible to everyone; everyone is also done reading
+        // the other buffer (K-step t-1), which the next stage overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* cur = lds + (t & 1) * kStage;
+        if (t + 1 < nk) stage(t + 1, lds + ((t + 1) & 1) * kStage, ktail && t + 2 == nk);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            h8 ah[MT], al[TWO ? MT : 1], bw[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = *(const h8*)(cur + a_base + i * 32 * 128 + foff[ks]);
+                if (TWO) al[i] = *(const h8*)(cur + kXT + a_base + i * 32 * 128 + foff[ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bw[j] = *(const h8*)(cur + b_base + j * 32 * 128 + foff[ks]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
+                    if (TWO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: accumulators -> wave-private LDS tile [32*MT][64] fp32 -> full-row global stores ----
+    __syncthreads();                                       // every wave is done with the staging buffers
+    float* st = (float*)(lds + wave * (32 * MT * 64 * 4));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st[(32 * i + 8 * (r >> 2) + 4 * fh + (r & 3)) * 64 + 32 * j + fr] = acc[i][j][r];
+    const int mrow0 = m0 + wm * 32 * MT;
+    if (EPI == EPI_SILU) {
+        // the wave's 64 columns are [32 gate features | the same 32 up features]: 8 lanes per row, 4 features per lane
+        const int fbase = (ni * WN + wn) * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int it = 0; it < 4 * MT; ++it) {
+            const int row = it * 8 + (lane >> 3), m = mrow0 + row;
+            f4 g = *(const f4*)(st + row * 64 + (lane & 7) * 4);
+            f4 u = *(const f4*)(st + row * 64 + 32 + (lane & 7) * 4);
+            if (m < p.M && fbase < p.nfeat) {
+                if (p.wscale) {
+                    const f4 sg = *(const f4*)(p.wscale + fbase), su = *(const f4*)(p.wscale + p.nfeat + fbase);
+                    g[0] *= sg[0]; g[1] *= sg[1]; g[2] *= sg[2]; g[3] *= sg[3];
+                    u[0] *= su[0]; u[1] *= su[1]; u[2] *= su[2]; u[3] *= su[3];
+                }
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = (g[e] / (1.0f + __expf(-g[e]))) * u[e];      // act_fn(gate) * up, llama2.py:242
+                    _Float16 sh, sl;
+                    pc_split(s, sh, sl);
+                    hi[e] = sh; lo[e] = sl;
+                }
+                *(h4*)(p.oh + (int64_t)m * p.ldo + fbase) = hi;
+                if (p.ol) *(h4*)(p.ol + (int64_t)m * p.ldo + fbase) = lo;
+            }
+        }
+        return;
+    }
+    const int n = ni * BN + wn * 64 + (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8 * MT; ++it) {
+        const int row = it * 4 + (lane >> 4), m = mrow0 + row;
+        f4 v = *(const f4*)(st + row * 64 + (lane & 15) * 4);
+        if (m < p.M && n < p.N) {
+            if (p.wscale) {
+                const f4 sv = *(const f4*)(p.wscale + n);
+                v[0] *= sv[0]; v[1] *= sv[1]; v[2] *= sv[2]; v[3] *= sv[3];
+            }
+            if (EPI == EPI_GELU) {
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));   // nn.GELU(), falcon.py:726
+                    _Float16 sh, sl;
+                    pc_split(s, sh, sl);
+                    hi[e] = sh; lo[e] = sl;
+                }
+                *(h4*)(p.oh + (int64_t)m * p.ldo + n) = hi;
+                if (p.ol) *(h4*)(p.ol + (int64_t)m * p.ldo + n) = lo;
+            } else {
+                float* yp = p.y + (int64_t)m * p.ldy + n;
+                if (EPI == EPI_ADD) {
+                    const f4 old = *(const f4*)yp;
+                    v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+                }
+                *(f4*)yp = v;
+            }
+        }
+    }
+}
+
+// 16 bytes of zeros for activation chunks past K (device constant: no allocation, graph-capturable)
+__device__ __attribute__((aligned(16))) _Float16 g_zero_chunk[8];
+
+template <int WM, int EPI>
+int launch_dense(DenseParams& p, hipStream_t s) {
+    constexpr int BN = 64 * (8 / WM);
+    const int units = (EPI == EPI_SILU) ? pc_ceil_div(p.nfeat, BN / 2) : pc_ceil_div(p.N, BN);
+    p.mb = pc_ceil_div(p.M, BM);
+    p.nb = units;
+    const dim3 grid(8 * p.mb * pc_ceil_div(p.nb, 8)), block(512);
+    if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false>), grid, block, 0, s, p);
+    return pc_check_launch("gemm_dense_kernel");
+}
+
+template <int EPI>
+int launch_dense_tile(DenseParams& p, hipStream_t s) {
+    static const int forced = [] { const char* e = getenv("PC_DENSE_BN"); return e ? atoi(e) : 0; }();
+    // 256-wide weight panels unless their grid would leave a good part of the 256 CUs idle
+    const int cols = (EPI == EPI_SILU) ? p.nfeat * 2 : p.N;
+    const int blocks256 = pc_ceil_div(p.M, BM) * pc_ceil_div(cols, 256);
+    const bool narrow = forced ? forced == 128 : blocks256 < 200;
+    return narrow ? launch_dense<4, EPI>(p, s) : launch_dense<2, EPI>(p, s);
+}
+
+}  // namespace
+
+PC_EXPORT int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw,
+                            const float* w_scale, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy,
+                            void* out_hi, void* out_lo, int64_t ldo, void* stream) {
+    PC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0, PC_ERR_ARG, "pc_gemm_dense: need M, N, K > 0, K%%8==0, N%%4==0");
+    PC_REQUIRE(x_hi && w, PC_ERR_ARG, "pc_gemm_dense: null pointer");
+    PC_REQUIRE(ldx >= K && ldw >= K && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w & 15) == 0 &&
+               ((uintptr_t)x_lo & 15) == 0, PC_ERR_ARG, "pc_gemm_dense: operands must be 16-byte aligned with row strides %% 8 == 0");
+    PC_REQUIRE(!w_scale || ((uintptr_t)w_scale & 15) == 0, PC_ERR_ARG, "pc_gemm_dense: w_scale must be 16-byte aligned");
+    DenseParams p;
+    memset(&p, 0, sizeof(p));
+    p.xh = (const _Float16*)x_hi; p.xl = (const _Float16*)x_lo; p.ldx = ldx;
+    p.w = (const _Float16*)w; p.ldw = ldw; p.wscale = w_scale;
+    p.M = M; p.N = N; p.K = K;
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero_chunk)) != hipSuccess || !z) {
+        pc_set_error("pc_gemm_dense: hipGetSymbolAddress failed");
+        return PC_ERR_ARG;
+    }
+    p.zeros = (const _Float16*)z;
+    hipStream_t s = (hipStream_t)stream;
+    if (epilogue == EPI_SILU || epilogue == EPI_GELU) {
+        PC_REQUIRE(out_hi && ldo % 4 == 0 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0, PC_ERR_ARG,
+                   "pc_gemm_dense: activation epilogues need an 8-byte aligned out_hi plane (out_lo optional)");
+        p.oh = (_Float16*)out_hi; p.ol = (_Float16*)out_lo; p.ldo = ldo;
+        if (epilogue == EPI_SILU) {
+            PC_REQUIRE(N % 8 == 0 && ldo >= N / 2, PC_ERR_ARG, "pc_gemm_dense: SiLU epilogue needs N = 2*inter, inter %% 4 == 0, ldo >= inter");
+            p.nfeat = N / 2;
+            return launch_dense_tile<EPI_SILU>(p, s);
+        }
+        PC_REQUIRE(ldo >= N, PC_ERR_ARG, "pc_gemm_dense: GELU epilogue needs ldo >= N");
+        return launch_dense_tile<EPI_GELU>(p, s);
+    }
+    PC_REQUIRE(y && ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0, PC_ERR_ARG, "pc_gemm_dense: bad fp32 output");
+    p.y = y; p.ldy = ldy;
+    if (epilogue == EPI_ADD) return launch_dense_tile<EPI_ADD>(p, s);
+    PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_dense: unknown epilogue %d", epilogue);
+    return launch_dense_tile<EPI_STORE>(p, s);
+}

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
+    "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
 }
 
 
@@ -424,3 +425,19 @@ def embed_gather(table, ids_i64, out, n_tok: int, hidden: int, vocab: int, strea
 def probe_layouts(out_mfma, out_tr, stream: Optional[int] = None) -> None:
     rc = load().pc_probe_layouts(out_mfma.data_ptr(), out_tr.data_ptr(), current_stream() if stream is None else stream)
     check(rc, "pc_probe_layouts")
+
+
+def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out_hi=None, out_lo=None, wscale=None,
+               ldx: Optional[int] = None, ldw: Optional[int] = None, ldy: Optional[int] = None, ldo: Optional[int] = None,
+               stream: Optional[int] = None) -> None:
+    """Many-row projection ``(x_hi + x_lo) @ w^T`` (pc_gemm_dense.hip): fp16 row-major operands, fp32 accumulation,
+    epilogue EPI_STORE (y = .), EPI_ADD (y += .), EPI_SILU (out = silu(gate) * up as hi / lo planes, w = [gate; up]) or
+    EPI_GELU (out = gelu(.) planes).  ``x_lo`` may be None (single-precision-plane activations)."""
+    ld_o = 0
+    if out_hi is not None:
+        ld_o = ldo if ldo is not None else out_hi.stride(-2)
+    rc = load().pc_gemm_dense(x_hi.data_ptr(), _ptr(x_lo), x_hi.stride(-2) if ldx is None else ldx, w.data_ptr(),
+                              w.stride(-2) if ldw is None else ldw, _ptr(wscale), M, N, K, epilogue, _ptr(y),
+                              (0 if y is None else y.stride(-2)) if ldy is None else ldy, _ptr(out_hi), _ptr(out_lo), ld_o,
+                              current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_dense")

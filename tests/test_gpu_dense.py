@@ -1,0 +1,127 @@
+"""pc_gemm_dense (csrc/pc_gemm_dense.hip): the many-row MFMA projection with split-precision activations and fused
+epilogues, against float64 numpy on the same fp16 inputs (the oracle's nn.Linear is ``h @ w.T`` in fp32,
+oracle/llama_oracle.py LlamaOracle.forward; float64 here so the comparison sees only the kernel's rounding)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _n():
+    from promptcache_amd import _native
+    _native.load()
+    return _native
+
+
+def _split(x32):
+    hi = x32.astype(np.float16)
+    lo = (x32 - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def _inputs(M, N, K, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    x = (scale * rng.standard_normal((M, K))).astype(np.float32)
+    w = (0.05 * rng.standard_normal((N, K))).astype(np.float16)
+    return x, w
+
+
+# (M, N, K): ragged M, N not a multiple of the 256/128 panels, K with a partial last 64-step, both tile widths
+SHAPES = [(128, 256, 64), (1, 4, 8), (130, 260, 72), (300, 4096, 4096), (1000, 12288, 4096), (77, 512, 344),
+          (257, 4672, 4544), (640, 4096, 11008), (2050, 1024, 128)]
+
+
+@pytest.mark.parametrize("two", [True, False])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_dense_store_and_add(M, N, K, two):
+    n = _n()
+    x, w = _inputs(M, N, K, seed=M + N + K)
+    hi, lo = _split(x)
+    xs = hi.astype(np.float64) + (lo.astype(np.float64) if two else 0.0)
+    ref = xs @ w.astype(np.float64).T
+    th, tl, tw = torch.from_numpy(hi).to(DEV), torch.from_numpy(lo).to(DEV), torch.from_numpy(w).to(DEV)
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_STORE, y=y)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    tol = 2e-6 * np.sqrt(K) * np.abs(xs).max() * 0.05 * 8 + 1e-6
+    assert np.abs(got - ref).max() < tol, (np.abs(got - ref).max(), tol)
+    # residual epilogue: y += acc on top of existing values, and rows past M / cols past N untouched (canary columns)
+    base = torch.from_numpy(np.random.default_rng(1).standard_normal((M, N + 4)).astype(np.float32)).to(DEV)
+    y2 = base.clone()
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_ADD, y=y2, ldy=N + 4)
+    torch.cuda.synchronize()
+    got2 = y2.cpu().numpy().astype(np.float64)
+    assert np.abs(got2[:, :N] - (base.cpu().numpy()[:, :N].astype(np.float64) + ref)).max() < tol
+    assert np.array_equal(got2[:, N:], base.cpu().numpy()[:, N:].astype(np.float64))
+
+
+@pytest.mark.parametrize("M,inter,K", [(128, 128, 64), (300, 11008, 4096), (45, 344, 128), (1030, 1376, 512), (513, 13824, 5120)])
+def test_dense_silu_epilogue(M, inter, K):
+    n = _n()
+    x, w = _inputs(M, 2 * inter, K, seed=inter)
+    hi, lo = _split(x)
+    xs = hi.astype(np.float64) + lo.astype(np.float64)
+    acc = xs @ w.astype(np.float64).T
+    g, u = acc[:, :inter], acc[:, inter:]
+    ref = g / (1.0 + np.exp(-g)) * u
+    th, tl, tw = torch.from_numpy(hi).to(DEV), torch.from_numpy(lo).to(DEV), torch.from_numpy(w).to(DEV)
+    oh = torch.full((M, inter), float("nan"), dtype=torch.float16, device=DEV)
+    ol = torch.full((M, inter), float("nan"), dtype=torch.float16, device=DEV)
+    n.gemm_dense(th, tl, tw, M, 2 * inter, K, n.EPI_SILU, out_hi=oh, out_lo=ol)
+    torch.cuda.synchronize()
+    got = oh.float().cpu().numpy().astype(np.float64) + ol.float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err < 3e-6 * max(1.0, np.abs(ref).max()) * np.sqrt(K) / 8 + 1e-6, err
+    # the hi plane alone is the fp16 rounding of the value
+    assert np.abs(oh.float().cpu().numpy() - ref.astype(np.float32).astype(np.float16).astype(np.float32)).max() <= \
+        np.abs(ref).max() * 2.0 ** -10
+
+
+def test_dense_gelu_and_wscale():
+    n = _n()
+    M, N, K = 200, 1792, 448
+    x, w = _inputs(M, N, K, seed=9)
+    hi, lo = _split(x)
+    xs = hi.astype(np.float64) + lo.astype(np.float64)
+    sc = (0.5 + np.random.default_rng(2).random(N)).astype(np.float32)
+    acc = (xs @ w.astype(np.float64).T) * sc.astype(np.float64)
+    from math import erf
+    ref = 0.5 * acc * (1.0 + np.vectorize(erf)(acc * 0.7071067811865476))
+    th, tl, tw = torch.from_numpy(hi).to(DEV), torch.from_numpy(lo).to(DEV), torch.from_numpy(w).to(DEV)
+    ts = torch.from_numpy(sc).to(DEV)
+    oh = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    ol = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    n.gemm_dense(th, tl, tw, M, N, K, n.EPI_GELU, out_hi=oh, out_lo=ol, wscale=ts)
+    y = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    n.gemm_dense(th, tl, tw, M, N, K, n.EPI_STORE, y=y, wscale=ts)
+    torch.cuda.synchronize()
+    got = oh.float().cpu().numpy().astype(np.float64) + ol.float().cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref).max() < 5e-6 * max(1.0, np.abs(ref).max())
+    assert np.abs(y.cpu().numpy() - acc).max() < 5e-6 * max(1.0, np.abs(acc).max())
+
+
+def test_dense_strided_views_and_argument_errors():
+    """Operands are views into wider buffers (row strides larger than K / N), as the layer stack hands them over."""
+    n = _n()
+    M, N, K = 150, 384, 192
+    x, w = _inputs(M, N, K, seed=4)
+    hi, lo = _split(x)
+    buf = torch.zeros((2, M, K + 64), dtype=torch.float16, device=DEV)
+    buf[0, :, :K] = torch.from_numpy(hi).to(DEV)
+    buf[1, :, :K] = torch.from_numpy(lo).to(DEV)
+    wb = torch.zeros((N, K + 8), dtype=torch.float16, device=DEV)
+    wb[:, :K] = torch.from_numpy(w).to(DEV)
+    y = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    n.gemm_dense(buf[0, :, :K], buf[1, :, :K], wb[:, :K], M, N, K, n.EPI_STORE, y=y)
+    torch.cuda.synchronize()
+    ref = (hi.astype(np.float64) + lo.astype(np.float64)) @ w.astype(np.float64).T
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-4
+    lib = n.load()
+    assert lib.pc_gemm_dense(None, None, 8, None, 8, None, 1, 4, 8, 0, None, 4, None, None, 0, None) < 0
+    assert lib.pc_gemm_dense(buf.data_ptr(), None, K, wb.data_ptr(), K, None, M, N, 12, 0, y.data_ptr(), N, None, None, 0, None) < 0
+    assert b"K%8" in lib.pc_last_error_string()

@@ -68,55 +68,13 @@ class FalconHIP(LlamaHIP):
 
     # ------------------------------------------------------------------------------------------
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
-        if self.precise_dense:
-            return self._forward_dense_split(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
+        """Many-row path (schema encode / no-cache prefill): the four projections of a Falcon block on pc_gemm_dense
+        (q|k|v store, dense_h_to_4h + GELU, dense + residual, dense_4h_to_h + residual), split-precision activations
+        unless PC_FAST_DENSE=1 (see LlamaHIP._forward_dense)."""
         n = _native
         dev = self.device
         c = self.config
-        H, D, hid = self.H, self.D, c.hidden_size
-        T = B * q_len
-        W = (H + 2) * D
-        eps = c.layer_norm_epsilon
-        f32 = torch.float32
-        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
-        n.rope_table(pos32, self.inv_freq, cs, T, D)
-        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
-        x = h16.float()  # fp32 residual stream
-        attn = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        act = torch.empty((T, 4 * hid), dtype=self.dtype, device=dev)
-        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
-        layers = self.layers if num_layers is None else self.layers[:num_layers]
-        for li, lw in enumerate(layers):
-            n.layernorm(x, lw["ln_w"], lw["ln_b"], h16, T, hid, eps)                              # falcon.py:779
-            qkv = self._mm(h16, lw, "wqkv")                                    # [T, (H+2)*D]
-            kp, vp = arena.k_plane(li), arena.v_plane(li)
-            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
-                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True)
-            if self._kv_only and li == len(layers) - 1:
-                break             # schema encode: the K / V of the last layer are written; nothing after them is used
-            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
-                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws)
-            h4 = self._mm(h16, lw, "w1")                                       # same LayerNorm output (:798)
-            n.gelu(h4, act, T * 4 * hid)
-            x.add_(self._mm(attn, lw, "wo"))
-            x.add_(self._mm(act, lw, "w2"))
-        if self._kv_only:
-            return None
-        if last_token_only:
-            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
-            hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
-            n.layernorm(xl, self.lnf_w, self.lnf_b, hl, B, hid, eps)
-            return torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
-        n.layernorm(x, self.lnf_w, self.lnf_b, h16, T, hid, eps)
-        return torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)
-
-    def _forward_dense_split(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
-        """Many-row path with split-precision activations (see LlamaHIP._forward_dense_split)."""
-        n = _native
-        dev = self.device
-        c = self.config
+        two = self.precise_dense
         H, D, hid = self.H, self.D, c.hidden_size
         T = B * q_len
         W = (H + 2) * D
@@ -126,45 +84,56 @@ class FalconHIP(LlamaHIP):
         n.rope_table(pos32, self.inv_freq, cs, T, D)
         h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)
         n.embed_gather(self.embed, ids, h2[0], T, hid, c.vocab_size)
-        x = h2[0].float()
+        x = h2[0].float()  # fp32 residual stream
         attn2 = torch.empty((2, T, H * D), dtype=self.dtype, device=dev)
         act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        lo_for, full_lo = self._dense_pass_lo(arena, B, 1, q_len, past_len)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev) if two else None
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        lo_for, full_lo = self._dense_pass_lo(arena, B, 1, q_len, past_len) if two else ((lambda li: None), False)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        lo = (lambda t: t[1]) if two else (lambda t: None)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
+
+        def norm(src, gw, gb, rows):
+            if two:
+                n.layernorm_split(src, gw, gb, h2[0], h2[1], rows, hid, eps)
+            else:
+                n.layernorm(src, gw, gb, h2[0], rows, hid, eps)
+
         for li, lw in enumerate(layers):
-            n.layernorm_split(x, lw["ln_w"], lw["ln_b"], h2[0], h2[1], T, hid, eps)
-            qkv = self._mm(h2.view(2 * T, hid), lw, "wqkv")      # rows [0, T): hi part, [T, 2T): lo part
+            norm(x, lw["ln_w"], lw["ln_b"], T)                                                     # falcon.py:779
+            self._proj(h2[0], lo(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)                   # [T, (H+2)*D]
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo, in2_offset=T * W)
+                          q_out_lo=q16l, kv_lo=kv_lo)
             if self._kv_only and li == len(layers) - 1:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
-                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l, out_lo=attn2[1], kv_lo=kv_lo)
-            h4 = self._mm(h2.view(2 * T, hid), lw, "w1")
-            n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
-            o2 = self._mm(attn2.view(2 * T, H * D), lw, "wo")
-            n.add3(x, o2[:T], o2[T:], T * hid)
-            d2 = self._mm(act2.view(2 * T, 4 * hid), lw, "w2")
-            n.add3(x, d2[:T], d2[T:], T * hid)
+                       q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
+                       out_lo=lo(attn2), kv_lo=kv_lo)
+            # parallel attention + MLP on the same LayerNorm output (:798)
+            self._proj(h2[0], lo(h2), lw, "w1", T, 4 * hid, hid, n.EPI_GELU, out_hi=act2[0], out_lo=lo(act2))
+            self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)
+            self._proj(act2[0], lo(act2), lw, "w2", T, hid, 4 * hid, n.EPI_ADD, y=x)
         if full_lo:
             arena.lo_len = past_len + q_len
         if self._kv_only:
             return None
+        head = {"lm_head": self.lm_head}
+        V = c.vocab_size
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
-            hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)
-            n.layernorm_split(xl, self.lnf_w, self.lnf_b, hl[0], hl[1], B, hid, eps)
-            lg = torch.mm(hl.view(2 * B, hid), self.lm_head.t(), out_dtype=f32)
-            return (lg[:B] + lg[B:]).view(B, 1, -1)
-        n.layernorm_split(x, self.lnf_w, self.lnf_b, h2[0], h2[1], T, hid, eps)
-        lg = torch.mm(h2.view(2 * T, hid), self.lm_head.t(), out_dtype=f32)
-        return (lg[:T] + lg[T:]).view(B, q_len, -1)
+            norm(xl, self.lnf_w, self.lnf_b, B)
+            logits = torch.empty((B, V), dtype=f32, device=dev)
+            self._proj(h2[0, :B], h2[1, :B] if two else None, head, "lm_head", B, V, hid, n.EPI_STORE, y=logits)
+            return logits.view(B, 1, V)
+        norm(x, self.lnf_w, self.lnf_b, T)
+        logits = torch.empty((T, V), dtype=f32, device=dev)
+        self._proj(h2[0], lo(h2), head, "lm_head", T, V, hid, n.EPI_STORE, y=logits)
+        return logits.view(B, q_len, V)
 
     def _forward_skinny(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
         """T <= 512 rows: weight-streaming projections (pc_gemm.hip).  The o_proj and dense_4h_to_h launches both leave

@@ -84,7 +84,7 @@ class LlamaHIP:
         """``int8_weights`` (the adapters' ``load_in_8bit=True``): the decoder-layer linears are quantised row-wise to
         int8 (``_native.quantize_rows_int8``); passes of <= 64 rows stream the int8 fragment images (half the bytes, exact
         arithmetic on the dequantised values); longer passes run hipBLASLt on the int8 codes held in fp16 (exact) and
-        scale the product per output feature (``_mm``)."""
+        scale the product per output feature (``_proj``)."""
         self._setup(shape, device, decode_headroom)
         c = shape
         self.H, self.Hkv, self.D, self.L = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.num_hidden_layers
@@ -149,7 +149,7 @@ class LlamaHIP:
             src = wt if perm is None else wt[perm].contiguous()
             return wt, fr(src), (None, None)
         q, sc = _native.quantize_rows_int8(wt)
-        dense = q.to(self.dtype)                      # the int8 codes, exact in fp16; _mm applies the scales (many-row paths)
+        dense = q.to(self.dtype)                      # the int8 codes, exact in fp16; _proj applies the scales (many-row paths)
         dsc = sc
         if perm is not None:
             q, sc = q[perm].contiguous(), sc[perm].contiguous()
@@ -159,17 +159,6 @@ class LlamaHIP:
     def _linear_entries(name: str, prepped) -> dict:
         dense, frag, (sc, dsc) = prepped
         return {name: dense, name + "_f": frag, name + "_s": sc, name + "_ds": dsc}
-
-    @staticmethod
-    def _mm(a: torch.Tensor, lw: dict, key: str) -> torch.Tensor:
-        """``a @ W^T`` in fp32 on hipBLASLt.  int8 mode: ``lw[key]`` holds the int8 codes as fp16 (exact) and the per-output
-        scales are applied to the product -- the many-row paths then compute with exactly the dequantised weights the
-        streaming kernels use, instead of an fp16 rounding of them (2e-2 on 32-layer logits)."""
-        y = torch.mm(a, lw[key].t(), out_dtype=torch.float32)
-        sc = lw.get(key + "_ds")
-        if sc is not None:
-            y.mul_(sc)
-        return y
 
     TAIL_HEADROOM = 256     # decoded rows a generation's residual tail has room for past the prompt's own
 
@@ -308,70 +297,24 @@ class LlamaHIP:
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
     # ------------------------------------------------------------------------------------------
+    def _proj(self, a_hi, a_lo, lw: dict, key: str, M: int, N: int, K: int, epi: int, **out) -> None:
+        """One many-row projection on the hand-written MFMA kernel (pc_gemm_dense.hip): ``(a_hi + a_lo) @ W^T`` with the
+        epilogue fused.  int8 mode: ``lw[key]`` holds the int8 codes as fp16 (exact) and the per-output scales
+        (``key_ds``) are applied to the accumulator tile -- the many-row paths then compute with exactly the dequantised
+        weights the streaming kernels use."""
+        _native.gemm_dense(a_hi, a_lo, lw[key], M, N, K, epi, wscale=lw.get(key + "_ds"), **out)
+
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
-        """Layer stack for many rows (schema encode, no-cache prefill): hipBLASLt projections with fp32 outputs, HIP
-        kernels for everything between them."""
-        if self.precise_dense:
-            return self._forward_dense_split(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
+        """Layer stack for many rows (schema encode, no-cache prefill): every projection is a pc_gemm_dense launch with
+        its residual add / SiLU*up fused; RMSNorm, RoPE + KV append and the attention are HIP kernels between them.
+        precise_dense (default): split-precision activations (hi, lo fp16 planes) -- an fp16 activation costs 2^-12 per
+        projection input and through 32 layers that alone moves 7b-shape logits by 2-3e-2 against the reference's fp32
+        path (the module KV an encode stores drifts the same way).  Both planes meet the same weight fragments inside
+        the GEMM tile; Q, P and the pass's own K / V rows are split-precision in the attention as well.
+        PC_FAST_DENSE=1: the hi plane only (half the MFMA work, fp16-activation accuracy)."""
         n = _native
         dev = self.device
-        H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
-        inter = self.config.intermediate_size
-        T = B * q_len
-        W = (H + 2 * Hkv) * D
-        eps = self.config.rms_norm_eps
-        cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
-        n.rope_table(pos32, self.inv_freq, cs, T, D)
-        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        n.embed_gather(self.embed, ids, h16, T, hid, self.config.vocab_size)
-        x = h16.float()  # fp32 residual stream
-        attn = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        act = torch.empty((T, inter), dtype=self.dtype, device=dev)
-        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
-
-        f32 = torch.float32
-        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        layers = self.layers if num_layers is None else self.layers[:num_layers]   # truncated stacks: parity probes
-        for li, lw in enumerate(layers):
-            n.rmsnorm(x, lw["ln1"], h16, T, hid, eps, True)
-            # projections keep fp32 outputs (fp16 x fp16 -> fp32 accumulate -> fp32 store): one rounding less
-            # per stage against the reference's fp32 CPU path
-            qkv = self._mm(h16, lw, "wqkv")       # [T, (H+2Hkv)*D]
-            k_new = qkv[:, H * D:]
-            v_new = qkv[:, (H + Hkv) * D:]
-            kp, vp = arena.k_plane(li), arena.v_plane(li)
-            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, k_new, v_new, q_len * W, W, kp, vp,
-                          arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True)
-            if self._kv_only and li == len(layers) - 1:
-                break             # schema encode: the K / V of the last layer are written; nothing after them is used
-            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn,
-                       q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws)
-            x.add_(self._mm(attn, lw, "wo"))
-            n.rmsnorm(x, lw["ln2"], h16, T, hid, eps, True)
-            gu = self._mm(h16, lw, "wgu")         # [T, 2*inter]
-            n.silu_mul(gu, act, T, inter, True)
-            x.add_(self._mm(act, lw, "wdown"))
-
-        if self._kv_only:
-            return None
-        if last_token_only:
-            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
-            hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
-            n.rmsnorm(xl, self.norm, hl, B, hid, eps, True)
-            logits = torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
-        else:
-            n.rmsnorm(x, self.norm, h16, T, hid, eps, True)
-            logits = torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)   # llama2.py:1050-1051
-        return logits
-
-    def _forward_dense_split(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
-        """The dense layer stack with split-precision activations.  An fp16 activation costs 2^-11 per projection
-        input; through 32 layers that alone moves 7b-shape logits by 2-3e-2 against the reference's fp32 path (the
-        module KV an encode stores drifts the same way).  Here every projection input is a (hi, lo) fp16 pair stacked
-        along the rows of ONE hipBLASLt GEMM ([hi; lo] @ W^T, fp32 out) whose two halves are added by the consumer:
-        twice the GEMM flops, fp32-level activations."""
-        n = _native
-        dev = self.device
+        two = self.precise_dense
         H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
         inter = self.config.intermediate_size
         T = B * q_len
@@ -380,51 +323,59 @@ class LlamaHIP:
         f32 = torch.float32
         cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
         n.rope_table(pos32, self.inv_freq, cs, T, D)
-        h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)          # [hi; lo] of the normalised stream
+        h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)          # (hi, lo) of the normalised stream
         n.embed_gather(self.embed, ids, h2[0], T, hid, self.config.vocab_size)
         x = h2[0].float()  # fp32 residual stream
         attn2 = torch.empty((2, T, H * D), dtype=self.dtype, device=dev)
         act2 = torch.empty((2, T, inter), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
-        lo_for, full_lo = self._dense_pass_lo(arena, B, Hkv, q_len, past_len)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev) if two else None
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        lo_for, full_lo = self._dense_pass_lo(arena, B, Hkv, q_len, past_len) if two else ((lambda li: None), False)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        lo = (lambda t: t[1]) if two else (lambda t: None)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
+
+        def norm(src, gain, rows):
+            if two:
+                n.rmsnorm_split(src, gain, h2[0], h2[1], rows, hid, eps)
+            else:
+                n.rmsnorm(src, gain, h2[0], rows, hid, eps, True)
+
         for li, lw in enumerate(layers):
-            n.rmsnorm_split(x, lw["ln1"], h2[0], h2[1], T, hid, eps)
-            qkv = self._mm(h2.view(2 * T, hid), lw, "wqkv")      # rows [0, T): hi part, [T, 2T): lo part
+            norm(x, lw["ln1"], T)
+            self._proj(h2[0], lo(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
-            # the two halves are summed inside the RoPE / append kernel (in2_offset)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo, in2_offset=T * W)
+                          q_out_lo=q16l, kv_lo=kv_lo)
             if self._kv_only and li == len(layers) - 1:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
-                       out_lo=attn2[1], kv_lo=kv_lo)
-            o2 = self._mm(attn2.view(2 * T, H * D), lw, "wo")
-            n.add3(x, o2[:T], o2[T:], T * hid)
-            n.rmsnorm_split(x, lw["ln2"], h2[0], h2[1], T, hid, eps)
-            gu2 = self._mm(h2.view(2 * T, hid), lw, "wgu")
-            n.silu_mul_split(gu2[:T], gu2[T:], act2[0], act2[1], T, inter)
-            d2 = self._mm(act2.view(2 * T, inter), lw, "wdown")
-            n.add3(x, d2[:T], d2[T:], T * hid)
+                       out_lo=lo(attn2), kv_lo=kv_lo)
+            self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)                    # x += attn @ Wo^T
+            norm(x, lw["ln2"], T)
+            self._proj(h2[0], lo(h2), lw, "wgu", T, 2 * inter, hid, n.EPI_SILU, out_hi=act2[0], out_lo=lo(act2))
+            self._proj(act2[0], lo(act2), lw, "wdown", T, hid, inter, n.EPI_ADD, y=x)                   # x += act @ Wd^T
         if full_lo:
             arena.lo_len = past_len + q_len
         if self._kv_only:
             return None
+        head = {"lm_head": self.lm_head}
+        V = self.config.vocab_size
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
-            hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)
-            n.rmsnorm_split(xl, self.norm, hl[0], hl[1], B, hid, eps)
-            lg = torch.mm(hl.view(2 * B, hid), self.lm_head.t(), out_dtype=f32)
-            return (lg[:B] + lg[B:]).view(B, 1, -1)
-        n.rmsnorm_split(x, self.norm, h2[0], h2[1], T, hid, eps)
-        lg = torch.mm(h2.view(2 * T, hid), self.lm_head.t(), out_dtype=f32)
-        return (lg[:T] + lg[T:]).view(B, q_len, -1)
+            norm(xl, self.norm, B)
+            logits = torch.empty((B, V), dtype=f32, device=dev)
+            self._proj(h2[0, :B], h2[1, :B] if two else None, head, "lm_head", B, V, hid, n.EPI_STORE, y=logits)
+            return logits.view(B, 1, V)
+        norm(x, self.norm, T)
+        logits = torch.empty((T, V), dtype=f32, device=dev)
+        self._proj(h2[0], lo(h2), head, "lm_head", T, V, hid, n.EPI_STORE, y=logits)   # llama2.py:1050-1051: every row
+        return logits.view(B, q_len, V)
 
     # ------------------------------------------------------------------------------------------
     def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,

@@ -172,56 +172,12 @@ class MptHIP(LlamaHIP):
 
     # ------------------------------------------------------------------------------------------
     def _forward_dense(self, ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers):
-        if self.precise_dense:
-            return self._forward_dense_split(ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers)
+        """Many-row path (schema encode / no-cache prefill): Wqkv, out_proj + residual, up_proj + GELU, down_proj +
+        residual on pc_gemm_dense; split-precision activations unless PC_FAST_DENSE=1 (see LlamaHIP._forward_dense)."""
         n = _native
         dev = self.device
         c = self.config
-        H, D, hid = self.H, self.D, c.hidden_size
-        T = B * q_len
-        W = 3 * hid
-        eps = c.layer_norm_epsilon
-        f32 = torch.float32
-        cs = self._identity_rotation(T)
-        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
-        x = h16.float()
-        attn = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        act = torch.empty((T, 4 * hid), dtype=self.dtype, device=dev)
-        q16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
-        alibi = (kpos, self.slopes_log2)
-        layers = self.layers if num_layers is None else self.layers[:num_layers]
-        for li, lw in enumerate(layers):
-            n.layernorm(x, lw["ln1"], None, h16, T, hid, eps)                                   # mpt.py:240
-            qkv = self._mm(h16, lw, "wqkv")                                  # [T, 3*hid]  :143
-            kp, vp = arena.k_plane(li), arena.v_plane(li)
-            n.rope_append(qkv, q_len * W, W, q16, q_len * hid, hid, qkv[:, hid:], qkv[:, 2 * hid:], q_len * W, W,
-                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, H, D, q_len, past_len, arena.cap, True)
-            if self._kv_only and li == len(layers) - 1:
-                break             # schema encode: the K / V of the last layer are written; nothing after them is used
-            n.attn_fwd(q16, q_len * hid, hid, kp, vp, arena.batch_stride, arena.head_stride, attn,
-                       q_len * hid, hid, B, H, H, D, q_len, past_len, self.softmax_scale, ws, alibi=alibi)
-            x.add_(self._mm(attn, lw, "wo"))                                 # :185, :254
-            n.layernorm(x, lw["ln2"], None, h16, T, hid, eps)                                   # :256
-            h4 = self._mm(h16, lw, "w1")
-            n.gelu(h4, act, T * 4 * hid)
-            x.add_(self._mm(act, lw, "w2"))                                  # :197-201
-        if self._kv_only:
-            return None
-        if last_token_only:
-            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
-            hl = torch.empty((B, hid), dtype=self.dtype, device=dev)
-            n.layernorm(xl, self.lnf, None, hl, B, hid, eps)
-            return torch.mm(hl, self.lm_head.t(), out_dtype=f32).view(B, 1, -1)
-        n.layernorm(x, self.lnf, None, h16, T, hid, eps)
-        return torch.mm(h16, self.lm_head.t(), out_dtype=f32).view(B, q_len, -1)
-
-    def _forward_dense_split(self, ids, kpos, arena, B, q_len, past_len, last_token_only, num_layers):
-        """Many-row path with split-precision activations (see LlamaHIP._forward_dense_split)."""
-        n = _native
-        dev = self.device
-        c = self.config
+        two = self.precise_dense
         H, D, hid = self.H, self.D, c.hidden_size
         T = B * q_len
         W = 3 * hid
@@ -234,44 +190,53 @@ class MptHIP(LlamaHIP):
         attn2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)
         act2 = torch.empty((2, T, 4 * hid), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        q16l = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        lo_for, full_lo = self._dense_pass_lo(arena, B, H, q_len, past_len)
+        q16l = torch.empty((T, hid), dtype=self.dtype, device=dev) if two else None
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        lo_for, full_lo = self._dense_pass_lo(arena, B, H, q_len, past_len) if two else ((lambda li: None), False)
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         alibi = (kpos, self.slopes_log2)
+        lo = (lambda t: t[1]) if two else (lambda t: None)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
+
+        def norm(src, gw, rows):
+            if two:
+                n.layernorm_split(src, gw, None, h2[0], h2[1], rows, hid, eps)
+            else:
+                n.layernorm(src, gw, None, h2[0], rows, hid, eps)
+
         for li, lw in enumerate(layers):
-            n.layernorm_split(x, lw["ln1"], None, h2[0], h2[1], T, hid, eps)
-            qkv = self._mm(h2.view(2 * T, hid), lw, "wqkv")      # rows [0, T): hi part, [T, 2T): lo part
+            norm(x, lw["ln1"], T)                                                               # mpt.py:240
+            self._proj(h2[0], lo(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)                # [T, 3*hid]  :143
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * hid, hid, qkv[:, hid:], qkv[:, 2 * hid:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, H, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo, in2_offset=T * W)
+                          q_out_lo=q16l, kv_lo=kv_lo)
             if self._kv_only and li == len(layers) - 1:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * hid, hid, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * hid, hid, B, H, H, D, q_len, past_len, self.softmax_scale, ws, alibi=alibi, q_lo=q16l,
-                       out_lo=attn2[1], kv_lo=kv_lo)
-            o2 = self._mm(attn2.view(2 * T, hid), lw, "wo")
-            n.add3(x, o2[:T], o2[T:], T * hid)
-            n.layernorm_split(x, lw["ln2"], None, h2[0], h2[1], T, hid, eps)
-            h4 = self._mm(h2.view(2 * T, hid), lw, "w1")
-            n.gelu_split(h4[:T], h4[T:], act2[0], act2[1], T * 4 * hid)
-            d2 = self._mm(act2.view(2 * T, 4 * hid), lw, "w2")
-            n.add3(x, d2[:T], d2[T:], T * hid)
+                       out_lo=lo(attn2), kv_lo=kv_lo)
+            self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, hid, n.EPI_ADD, y=x)               # :185, :254
+            norm(x, lw["ln2"], T)                                                               # :256
+            self._proj(h2[0], lo(h2), lw, "w1", T, 4 * hid, hid, n.EPI_GELU, out_hi=act2[0], out_lo=lo(act2))
+            self._proj(act2[0], lo(act2), lw, "w2", T, hid, 4 * hid, n.EPI_ADD, y=x)            # :197-201
         if full_lo:
             arena.lo_len = past_len + q_len
         if self._kv_only:
             return None
+        head = {"lm_head": self.lm_head}
+        V = c.vocab_size
         if last_token_only:
             xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
-            hl = torch.empty((2, B, hid), dtype=self.dtype, device=dev)
-            n.layernorm_split(xl, self.lnf, None, hl[0], hl[1], B, hid, eps)
-            lg = torch.mm(hl.view(2 * B, hid), self.lm_head.t(), out_dtype=f32)
-            return (lg[:B] + lg[B:]).view(B, 1, -1)
-        n.layernorm_split(x, self.lnf, None, h2[0], h2[1], T, hid, eps)
-        lg = torch.mm(h2.view(2 * T, hid), self.lm_head.t(), out_dtype=f32)
-        return (lg[:T] + lg[T:]).view(B, q_len, -1)
+            norm(xl, self.lnf, B)
+            logits = torch.empty((B, V), dtype=f32, device=dev)
+            self._proj(h2[0, :B], h2[1, :B] if two else None, head, "lm_head", B, V, hid, n.EPI_STORE, y=logits)
+            return logits.view(B, 1, V)
+        norm(x, self.lnf, T)
+        logits = torch.empty((T, V), dtype=f32, device=dev)
+        self._proj(h2[0], lo(h2), head, "lm_head", T, V, hid, n.EPI_STORE, y=logits)
+        return logits.view(B, q_len, V)
 
     def _forward_skinny(self, ids, kpos, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
         n = _native

@@ -148,34 +148,92 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool ktail = (K % BK) != 0;
-    stage(0, lds, ktail && nk == 1);
-    for (int t = 0; t < nk; ++t) {
-        // tile t has landed (this wave's LDS-DMA drained) and is visible to everyone; everyone is also done reading
-        // the other buffer (K-step t-1), which the next stage overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        char* cur = lds + (t & 1) * kStage;
-        if (t + 1 < nk) stage(t + 1, lds + ((t + 1) & 1) * kStage, ktail && t + 2 == nk);
+    // ---- main loop: one barrier per K-step, fragment reads one 16-deep slab ahead of the MFMAs ----
+    // Two fragment register sets alternate over the 4 slabs of a K-step.  The reads of slab s+1 are issued in front of
+    // the MFMAs of slab s, so their LDS latency passes under 4*MT MFMAs of 32 cycles each; the last slab of K-step t is
+    // multiplied AFTER the barrier, next to the first reads of K-step t+1 and the LDS-DMA issue of K-step t+2, so the
+    // matrix pipe has work while the workgroup re-synchronises.
+    struct Frags { h8 ah[MT], al[TWO ? MT : 1], bw[NT]; };
+    auto load_frags = [&](Frags& f, const char* buf, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            h8 ah[MT], al[TWO ? MT : 1], bw[NT];
+        for (int i = 0; i < MT; ++i) {
+            f.ah[i] = *(const h8*)(buf + a_base + i * 32 * 128 + foff[ks]);
+            if (TWO) f.al[i] = *(const h8*)(buf + kXT + a_base + i * 32 * 128 + foff[ks]);
+        }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                ah[i] = *(const h8*)(cur + a_base + i * 32 * 128 + foff[ks]);
-                if (TWO) al[i] = *(const h8*)(cur + kXT + a_base + i * 32 * 128 + foff[ks]);
-            }
+        for (int j = 0; j < NT; ++j) f.bw[j] = *(const h8*)(buf + b_base + j * 32 * 128 + foff[ks]);
+    };
+    auto mfmas = [&](const Frags& f) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bw[j] = *(const h8*)(cur + b_base + j * 32 * 128 + foff[ks]);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bw[j], acc[i][j], 0, 0, 0);
+        if (TWO) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
-                    if (TWO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bw[j], acc[i][j], 0, 0, 0);
         }
+    };
+    // Pin the issue order of one (reads of the next slab, MFMAs of this slab) pair: a read in front of every MFMA until
+    // the reads run out.  Left alone, hipcc sinks the ds_reads next to their first use and waits lgkmcnt(0) right
+    // behind them (seen in the ISA: four exposed LDS round trips per K-step).
+    auto interleave = [&]() {
+        // one MFMA, then two reads, until the reads run out: every read of the next slab is in flight at least three
+        // MFMAs (~100 cycles) before the wait in front of that slab's first MFMA
+        constexpr int R = MT * (TWO ? 2 : 1) + NT, MF = MT * NT * (TWO ? 2 : 1);
+#pragma unroll
+        for (int k = 0; k < MF; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+            if (2 * k + 1 < R) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // two DS reads
+            else if (2 * k < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // (an odd one left)
+        }
+    };
+    const bool ktail = (K % BK) != 0;
+    Frags fa, fb;
+    stage(0, lds, ktail && nk == 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1) stage(1, lds + kStage, ktail && nk == 2);
+    load_frags(fa, lds, 0);
+    for (int t = 0; t + 1 < nk; ++t) {
+        const char* cur = lds + (t & 1) * kStage;
+        load_frags(fb, cur, 1);
+        mfmas(fa);
+        interleave();
+        load_frags(fa, cur, 2);
+        mfmas(fb);
+        interleave();
+        load_frags(fb, cur, 3);
+        mfmas(fa);
+        interleave();
+        // K-step t+1 has landed (this wave's LDS-DMA drained, then everyone's via the barrier), and every wave's reads
+        // of K-step t are complete (__syncthreads waits lgkmcnt(0)): its buffer may be overwritten.  The stage index
+        // is clamped instead of branched on (past the end it re-loads the last K-step into the idle buffer): a branch
+        // here splits the block and hipcc then waits for the fresh reads below before the MFMAs that do not need them.
+        __builtin_amdgcn_sched_barrier(0);      // slab 2's MFMAs stay in front of the barrier: they cover slab 3's reads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tn = t + 2 < nk ? t + 2 : nk - 1;
+        stage(tn, lds + (t & 1) * kStage, ktail && tn == nk - 1);
+        load_frags(fa, lds + ((t + 1) & 1) * kStage, 0);
+        mfmas(fb);
+        interleave();
     }
+    {
+        const char* cur = lds + ((nk - 1) & 1) * kStage;
+        load_frags(fb, cur, 1);
+        mfmas(fa);
+        interleave();
+        load_frags(fa, cur, 2);
+        mfmas(fb);
+        interleave();
+        load_frags(fb, cur, 3);
+        mfmas(fa);
+        interleave();
+        mfmas(fb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the clamped re-load of the last K-step)
 
     // ---- epilogue: accumulators -> wave-private LDS tile [32*MT][64] fp32 -> full-row global stores ----
     __syncthreads();                                       // every wave is done with the staging buffers

@@ -306,6 +306,26 @@ int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const vo
                         int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
                         int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
 
+/* Ragged-prefix batches (schema encode: scaffold suffixes of different unions in one batch, each over its own trunk
+ * prefix -- the batched form of cache_engine.py:217-304's per-scaffold forwards): pc_rope_append_ex / pc_attn_fwd_ex with
+ * ONE PAST LENGTH PER BATCH ROW.  past_lens: device int32[B]; past_len = their maximum (bounds check, KV-split sizing).
+ * Batch row b appends its q_len new rows at arena rows [past_lens[b], past_lens[b] + q_len) and attends to keys
+ * [0, past_lens[b]) plus the new rows up to its own (index-order mask, llama2.py:62-76).  Residual planes, when given,
+ * are arena-shaped (lo_row0 = 0). */
+int pc_rope_append_var(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                       int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new, const void* v_new,
+                       int64_t kv_new_batch_stride, int64_t kv_new_token_stride, void* k_arena, void* v_arena,
+                       int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
+                       int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
+                       const int32_t* past_lens, void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride,
+                       int32_t lo_row0, void* stream);
+int pc_attn_fwd_var(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
+                    const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out, void* out_lo,
+                    int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
+                    int32_t q_len, int32_t past_len, const int32_t* past_lens, float softmax_scale, void* workspace,
+                    int64_t workspace_bytes, const void* k_lo, const void* v_lo, int64_t lo_batch_stride,
+                    int64_t lo_head_stride, void* stream);
+
 /* Many-row projection (schema encode / no-cache prefill / long questions; MFMA-bound), csrc/pc_gemm_dense.hip:
  *     acc[m][n] = sum_k (x_hi[m][k] + x_lo[m][k]) * w[n][k]        fp16 operands, fp32 accumulation
  * x_hi / x_lo: split-precision activation planes [M][K] (row stride ldx halfs; x_lo may be NULL), w: the nn.Linear

@@ -54,6 +54,7 @@ struct AttnParams {
     _Float16* of_hi; _Float16* of_lo;   // optional: fragment-major split-precision output planes (pc_gemm.hip)
     float* part_o; float* part_ml;
     const int32_t* past_len_dev;
+    const int32_t* past_lens;   // optional [B]: one past length per batch row (ragged prefixes); p.past_len = their maximum
     // ALiBi (MPT, promptcache/model/mpt.py:90-110, :160-175): score += slope[h] * key_pos[b][key]; both pre-scaled to
     // the log2 domain by the host (slope * log2 e), key_pos = the POSITION ID of each cached / new key
     const float* key_pos; int64_t kp_bs; const float* slopes;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
-    const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int past_len = p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len);
     int nsp = p.nsplit;
     if constexpr (HP && !KVLO) {
         if (p.tail) {
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
     }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
-    const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int past_len = p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len);
     const int kv_len = past_len + q_len;
     int kps = (kv_len + p.nsplit - 1) / p.nsplit;
     kps = (kps + kTK - 1) / kTK * kTK;
@@ -845,7 +846,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
                   int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
                   const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo,
-                  const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream) {
+                  const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream,
+                  const int32_t* past_lens = nullptr) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -864,12 +866,13 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.out_lo = (_Float16*)out_lo;
     p.of_hi = (_Float16*)out_frag_hi; p.of_lo = (_Float16*)out_frag_lo;
     p.past_len_dev = past_len_dev;
+    p.past_lens = past_lens;
     p.key_pos = key_pos; p.kp_bs = key_pos_batch_stride; p.slopes = slopes;
     p.k_lo = (const _Float16*)k_lo; p.v_lo = (const _Float16*)v_lo; p.lo_bs = lo_bs; p.lo_hs = lo_hs; p.lo_row0 = lo_row0;
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
-    p.tail = (k_lo && lo_row0 == -1 && q_len <= kTailMax) ? 1 : 0;
+    p.tail = (k_lo && lo_row0 == -1 && q_len <= kTailMax && !past_lens) ? 1 : 0;
     if (p.tail) {
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
         // next instantiation of the merge kernel (4 / 8 / 16 / 32 partials per row)
@@ -941,4 +944,23 @@ PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_st
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
                          workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
                          slopes_log2, out_lo, k_lo, v_lo, lo_batch_stride, lo_head_stride, lo_row0, stream);
+}
+
+// pc_attn_fwd_ex with one past length PER BATCH ROW (device int32[B]; `past_len` = their maximum: it sizes the KV splits):
+// batch row b attends to its keys [0, past_lens[b]) plus the new rows it appended behind them.  Residual planes, when
+// given, must be arena-shaped (lo_row0 = 0).  Replaces the same reference ops as pc_attn_fwd (llama2.py:368-398).
+PC_EXPORT int pc_attn_fwd_var(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
+                              const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
+                              void* out_lo, int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H,
+                              int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, const int32_t* past_lens,
+                              float softmax_scale, void* workspace, int64_t workspace_bytes, const void* k_lo,
+                              const void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream) {
+    PC_REQUIRE(past_lens, PC_ERR_ARG, "pc_attn_fwd_var: past_lens is required");
+    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || q_lo), PC_ERR_ARG,
+               "pc_attn_fwd_var: k_lo / v_lo go together and need q_lo (split-precision Q)");
+    PC_REQUIRE(!k_lo || lo_head_stride % 8 == 0, PC_ERR_ARG, "pc_attn_fwd_var: the lo strides must keep 16-byte alignment");
+    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
+                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
+                         workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, nullptr, out_lo, k_lo, v_lo, lo_batch_stride,
+                         lo_head_stride, 0, stream, past_lens);
 }

@@ -58,13 +58,16 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
     _Float16* __restrict__ k_arena, _Float16* __restrict__ v_arena, int64_t a_bs, int64_t a_hs,
     const float2* __restrict__ cs, int H, int Hkv, int D, int q_len, int past_len,
     const int32_t* __restrict__ past_len_dev, _Float16* __restrict__ k_lo, _Float16* __restrict__ v_lo, int64_t lo_bs,
-    int64_t lo_hs, int lo_row0, int64_t in2) {
+    int64_t lo_hs, int lo_row0, int64_t in2, const int32_t* __restrict__ past_lens) {
+    // past_lens (optional, [B]): every batch row appends behind its OWN past length (ragged prefixes: scaffold suffixes
+    // of different unions encoded in one batch over their trunk prefixes, cache_engine.py SchemaCache._process)
     // in2 != 0: every input element is the SUM x[i] + x[i + in2] -- the two row halves a stacked [hi; lo] projection leaves
     // k_lo / v_lo (optional): fp16 residuals of the appended K / V rows, [B][Hkv][rows][D] with strides lo_bs / lo_hs,
     // row = key index - lo_row0 (lo_row0 = past_len: compact, new rows only; 0: arena-shaped) -- the pass's own
     // keys in split precision for the attention of that pass (the arena keeps the fp16 value the reference stages)
     const int t = blockIdx.x, b = blockIdx.y;
     if (past_len_dev) past_len = *past_len_dev;
+    if (past_lens) past_len = past_lens[b];
     const int half = D >> 1;
     const int cph = D >> 4;  // 8-pair chunks per head
     const int nq = H * cph, nk = Hkv * cph, nv = Hkv * (D >> 3);
@@ -156,7 +159,8 @@ int rope_append_impl(const void* q, int64_t q_batch_stride, int64_t q_token_stri
                      void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
                      const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
                      int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev,
-                     void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, int64_t in2, void* stream) {
+                     void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, int64_t in2, void* stream,
+                     const int32_t* past_lens = nullptr) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG, "pc_rope_append: bad sizes");
     PC_REQUIRE(D > 0 && D % 16 == 0, PC_ERR_ARG, "pc_rope_append: head_dim must be a multiple of 16");
     if (q_len == 0) return PC_OK;
@@ -171,14 +175,14 @@ int rope_append_impl(const void* q, int64_t q_batch_stride, int64_t q_token_stri
                            qo_token_stride, (const float*)k_new, (const float*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
                            arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev, (_Float16*)k_lo,
-                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0, in2);
+                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0, in2, past_lens);
     else
         hipLaunchKernelGGL(rope_append_kernel<_Float16>, dim3(q_len, B), dim3(256), 0, (hipStream_t)stream,
                            (const _Float16*)q, q_batch_stride, q_token_stride, (_Float16*)q_out, (_Float16*)q_out_lo, qo_batch_stride,
                            qo_token_stride, (const _Float16*)k_new, (const _Float16*)v_new, kv_new_batch_stride,
                            kv_new_token_stride, (_Float16*)k_arena, (_Float16*)v_arena, arena_batch_stride,
                            arena_head_stride, (const float2*)cs, H, Hkv, D, q_len, past_len, past_len_dev, (_Float16*)k_lo,
-                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0, in2);
+                           (_Float16*)v_lo, lo_bs, lo_hs, lo_row0, in2, past_lens);
     return pc_check_launch("rope_append_kernel");
 }
 }  // namespace
@@ -212,4 +216,24 @@ PC_EXPORT int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q
                             kv_new_batch_stride, kv_new_token_stride, k_arena, v_arena, arena_batch_stride,
                             arena_head_stride, cs, B, H, Hkv, D, q_len, past_len, cap, in_is_f32, past_len_dev, k_lo, v_lo,
                             lo_batch_stride, lo_head_stride, lo_row0, in2_offset, stream);
+}
+
+// pc_rope_append_ex with one past length PER BATCH ROW (device int32[B]; `past_len` is then their maximum, used for the
+// bounds check only): row b appends its q_len new K / V rows at arena rows [past_lens[b], past_lens[b] + q_len).
+PC_EXPORT int pc_rope_append_var(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                                 int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new,
+                                 const void* v_new, int64_t kv_new_batch_stride, int64_t kv_new_token_stride,
+                                 void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
+                                 const float* cs, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                                 int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_lens,
+                                 void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0,
+                                 void* stream) {
+    PC_REQUIRE(past_lens, PC_ERR_ARG, "pc_rope_append_var: past_lens is required");
+    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr), PC_ERR_ARG, "pc_rope_append_var: k_lo and v_lo go together");
+    PC_REQUIRE(!k_lo || (lo_row0 == 0 && lo_head_stride % 8 == 0), PC_ERR_ARG,
+               "pc_rope_append_var: residual planes must be arena-shaped (lo_row0 = 0) with 16-byte aligned strides");
+    return rope_append_impl(q, q_batch_stride, q_token_stride, q_out, q_out_lo, qo_batch_stride, qo_token_stride, k_new, v_new,
+                            kv_new_batch_stride, kv_new_token_stride, k_arena, v_arena, arena_batch_stride,
+                            arena_head_stride, cs, B, H, Hkv, D, q_len, past_len, cap, in_is_f32, nullptr, k_lo, v_lo,
+                            lo_batch_stride, lo_head_stride, lo_row0, 0, stream, past_lens);
 }

@@ -59,6 +59,10 @@ SIGNATURES = {
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
+    "pc_rope_append_var": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
+                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "pc_attn_fwd_var": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
+                                  _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
 }
 
@@ -135,8 +139,19 @@ def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Opt
 
 def rope_append(q, q_bs, q_ts, q_out, qo_bs, qo_ts, k_new, v_new, n_bs, n_ts, k_arena, v_arena, a_bs, a_hs, cs,
                 B, H, Hkv, D, q_len, past_len, cap, in_is_f32: bool, past_len_dev=None, q_out_lo=None,
-                stream: Optional[int] = None, kv_lo=None, in2_offset: int = 0) -> None:
-    """``in2_offset`` (elements, with ``kv_lo``): inputs are ``x[i] + x[i + in2_offset]`` (the halves of a [hi; lo] GEMM)."""
+                stream: Optional[int] = None, kv_lo=None, in2_offset: int = 0, past_lens=None) -> None:
+    """``in2_offset`` (elements, with ``kv_lo``): inputs are ``x[i] + x[i + in2_offset]`` (the halves of a [hi; lo] GEMM).
+    ``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum), pc_rope_append_var."""
+    if past_lens is not None:
+        assert in2_offset == 0 and past_len_dev is None and (kv_lo is None or kv_lo[4] == 0)
+        rc = load().pc_rope_append_var(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
+                                       v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
+                                       cs.data_ptr(), B, H, Hkv, D, q_len, past_len, cap, int(in_is_f32), past_lens.data_ptr(),
+                                       None if kv_lo is None else kv_lo[0].data_ptr(), None if kv_lo is None else kv_lo[1].data_ptr(),
+                                       0 if kv_lo is None else kv_lo[2], 0 if kv_lo is None else kv_lo[3], 0,
+                                       current_stream() if stream is None else stream)
+        check(rc, "pc_rope_append_var")
+        return
     if kv_lo is not None:
         rc = load().pc_rope_append_ex(q.data_ptr(), q_bs, q_ts, q_out.data_ptr(), _ptr(q_out_lo), qo_bs, qo_ts, k_new.data_ptr(),
                                       v_new.data_ptr(), n_bs, n_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
@@ -159,13 +174,23 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None, out_lo=None, kv_lo=None) -> None:
-    """``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
+             alibi=None, out_lo=None, kv_lo=None, past_lens=None) -> None:
+    """``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum), pc_attn_fwd_var.
+    ``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
     ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi).
     ``out_lo``: row-major residual plane of ``out``; ``kv_lo=(k_lo, v_lo, batch_stride, head_stride, row0)``: residuals of K/V rows from key index row0 on
     (written by ``rope_append(..., kv_lo=...)``), both via pc_attn_fwd_ex."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
+    if past_lens is not None:
+        assert alibi is None and out_frag is None and past_len_dev is None and (kv_lo is None or kv_lo[4] == 0)
+        rc = load().pc_attn_fwd_var(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, _ptr(out),
+                                    _ptr(out_lo), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, past_lens.data_ptr(), scale,
+                                    _ptr(workspace), ws_bytes, None if kv_lo is None else kv_lo[0].data_ptr(),
+                                    None if kv_lo is None else kv_lo[1].data_ptr(), 0 if kv_lo is None else kv_lo[2],
+                                    0 if kv_lo is None else kv_lo[3], current_stream() if stream is None else stream)
+        check(rc, "pc_attn_fwd_var")
+        return
     if out_lo is not None or kv_lo is not None:
         kpos, slopes = (None, None) if alibi is None else alibi
         rc = load().pc_attn_fwd_ex(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,

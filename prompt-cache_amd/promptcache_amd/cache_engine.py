@@ -293,37 +293,59 @@ class SchemaCache:
                 store_owned(i, arena, row)
             del out, arena
 
-        # scaffolds sharing the same trunk prefix length (the members of one union) go through one batched forward
-        by_prefix: Dict[int, List[int]] = {}
-        for i in shared:
-            by_prefix.setdefault(prefix[i], []).append(i)
-        for n_pre, members in sorted(by_prefix.items()):
-            suffix_len = [len(jobs[i]["token_ids"]) - n_pre for i in members]
-            for idxs in self._pack(members, [len(j["token_ids"]) - n_pre for j in jobs], batch_size):
-                group = [jobs[i] for i in idxs]
-                width = max(len(j["token_ids"]) for j in group) - n_pre
-                arena = KVArena(len(group), L, Hkv, n_pre + width, D, dev)
-                arena.buf[:, :, :, :, :n_pre].copy_(trunk_arena.buf[:, :, :, :, :n_pre].expand(len(group), -1, -1, -1, -1, -1))
-                if trunk_arena.lo is not None and trunk_arena.lo_len >= n_pre:   # the trunk's keys stay split-precision
-                    arena.with_lo().lo[:, :, :, :, :n_pre].copy_(
-                        trunk_arena.lo[:, :, :, :, :n_pre].expand(len(group), -1, -1, -1, -1, -1))
-                    arena.lo_len = n_pre
-                arena.length = n_pre
-                ids_pad, mask = pad_batch([j["token_ids"][n_pre:] for j in group], lm.eos_token_id)
-                pos_pad, _ = pad_batch([j["position_ids"][n_pre:] for j in group], 0)
-                if full_pos:                                 # ALiBi models take the position id of every key
-                    pos_pad = [list(jobs[0]["position_ids"][:n_pre]) + row for row in pos_pad]
-                out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
-                         position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
-                         attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
-                         past_key_values=arena.views(), use_cache=True, many_rows=True, kv_only=True)
-                arena = out.past_key_values.arena
-                for row, i in enumerate(idxs):
-                    encoded_tokens += len(jobs[i]["token_ids"])
-                    computed_tokens += len(jobs[i]["token_ids"]) - n_pre
-                    store_owned(i, arena, row)
-                del out, arena
-            del suffix_len
+        # Suffix passes.  Where the model takes one past length per batch row (``supports_ragged_past``) ALL of them are
+        # packed together, longest suffix first, whatever union they belong to: a batch row holds its own trunk prefix
+        # [0, n_pre_i) and appends its suffix behind it, so one forward carries thousands of rows and the projections
+        # run in the MFMA-bound regime (members of a single union alone are a few hundred rows: ~65 % of that rate).
+        # Otherwise (ALiBi: one position row per batch row) scaffolds sharing the same prefix length -- the members of
+        # one union -- go through one batched forward.
+        ragged = bool(getattr(getattr(lm, "hf_model", None), "supports_ragged_past", False)) and not full_pos and \
+            self.ragged_suffix_batches
+        suffix_len = [len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)]
+        if ragged:
+            groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size)]
+        else:
+            by_prefix: Dict[int, List[int]] = {}
+            for i in shared:
+                by_prefix.setdefault(prefix[i], []).append(i)
+            groups = [(n_pre, idxs) for n_pre, members in sorted(by_prefix.items())
+                      for idxs in self._pack(members, suffix_len, batch_size)]
+        for n_same, idxs in groups:
+            group = [jobs[i] for i in idxs]
+            pre = [prefix[i] for i in idxs]
+            n_max = max(pre)
+            width = max(suffix_len[i] for i in idxs)
+            arena = KVArena(len(group), L, Hkv, n_max + width, D, dev)
+            has_lo = trunk_arena.lo is not None and trunk_arena.lo_len >= n_max     # the trunk's keys stay split-precision
+            if has_lo:
+                arena.with_lo()
+            if n_same is not None:
+                arena.buf[:, :, :, :, :n_max].copy_(trunk_arena.buf[:, :, :, :, :n_max].expand(len(group), -1, -1, -1, -1, -1))
+                if has_lo:
+                    arena.lo[:, :, :, :, :n_max].copy_(trunk_arena.lo[:, :, :, :, :n_max].expand(len(group), -1, -1, -1, -1, -1))
+            else:
+                for row, n_pre in enumerate(pre):
+                    arena.buf[row, :, :, :, :n_pre].copy_(trunk_arena.buf[0, :, :, :, :n_pre])
+                    if has_lo:
+                        arena.lo[row, :, :, :, :n_pre].copy_(trunk_arena.lo[0, :, :, :, :n_pre])
+            if has_lo:
+                arena.lo_len = n_max
+            arena.length = n_max
+            ids_pad, mask = pad_batch([j["token_ids"][n:] for j, n in zip(group, pre)], lm.eos_token_id)
+            pos_pad, _ = pad_batch([j["position_ids"][n:] for j, n in zip(group, pre)], 0)
+            if full_pos:                                 # ALiBi models take the position id of every key
+                pos_pad = [list(jobs[0]["position_ids"][:n_max]) + row for row in pos_pad]
+            extra = {} if n_same is not None else {"past_lens": torch.tensor(pre, device=dev, dtype=torch.int32)}
+            out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
+                     position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
+                     attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
+                     past_key_values=arena.views(), use_cache=True, many_rows=True, kv_only=True, **extra)
+            arena = out.past_key_values.arena
+            for row, i in enumerate(idxs):
+                encoded_tokens += len(jobs[i]["token_ids"])
+                computed_tokens += suffix_len[i]
+                store_owned(i, arena, row)
+            del out, arena
         del trunk_arena
         # ascending job order == the global segment order restricted to this rank (what the all-gather plan assumes)
         local_segments: List[Tuple[TokenSequence, torch.Tensor]] = [p for i in sorted(per_job) for p in per_job[i]]
@@ -350,6 +372,8 @@ class SchemaCache:
     # encode scaffolds as suffixes over the root scaffold's K/V where they share a prefix with it (see _process)
     share_trunk = os.environ.get("PC_SHARE_TRUNK", "1") != "0"
     share_trunk_min = 32
+    # pack suffix passes of different unions into one batch (per-row past lengths; models with supports_ragged_past)
+    ragged_suffix_batches = os.environ.get("PC_RAGGED_SUFFIX", "1") != "0"
 
     def _pack(self, mine: List[int], lengths: List[int], batch_size: int) -> List[List[int]]:
         """Group this rank's scaffold passes into right-padded batches.  ``batch_size`` is the reference's knob

@@ -108,12 +108,12 @@ class FalconHIP(LlamaHIP):
             kv_lo = lo_for(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + 1) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, 1, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo)
+                          q_out_lo=q16l, kv_lo=kv_lo, past_lens=self._past_lens)
             if self._kv_only and li == len(layers) - 1:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, 1, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
-                       out_lo=lo(attn2), kv_lo=kv_lo)
+                       out_lo=lo(attn2), kv_lo=kv_lo, past_lens=self._past_lens)
             # parallel attention + MLP on the same LayerNorm output (:798)
             self._proj(h2[0], lo(h2), lw, "w1", T, 4 * hid, hid, n.EPI_GELU, out_hi=act2[0], out_lo=lo(act2))
             self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)

@@ -77,6 +77,8 @@ class LlamaHIP:
         # values).  See _tail_mode / _dense_pass_lo.
         self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
         self._kv_only = False      # set per call (see __call__)
+        self._past_lens = None     # set per call: per-row past lengths of a ragged-prefix encode batch
+        self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
@@ -242,8 +244,11 @@ class LlamaHIP:
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                  past_key_values=None, attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True,
                  last_token_only: bool = False, num_layers: Optional[int] = None, many_rows: bool = False,
-                 kv_only: bool = False, **_unused) -> CausalLMOutput:
-        """``kv_only`` (many-row path): stop after the last layer's K / V are in the arena and return no logits -- all a
+                 kv_only: bool = False, past_lens: Optional[torch.Tensor] = None, **_unused) -> CausalLMOutput:
+        """``past_lens`` (int32 [B], many-row path over an encode arena): one past length per batch row -- row b appends
+        behind its own ``past_lens[b]`` rows and attends to those plus its new rows (scaffold suffixes of different
+        unions batched over their trunk prefixes); the arena's ``length`` must be their maximum.
+        ``kv_only`` (many-row path): stop after the last layer's K / V are in the arena and return no logits -- all a
         schema-encode pass is run for (the reference discards the rest, cache_engine.py:243-296).
         ``many_rows``: take the stacked-GEMM path for more than 64 rows even where the row-split kernel would be
         faster -- it alone keeps the pass's own K/V in split precision, which is what a schema encode wants (its K/V
@@ -266,10 +271,16 @@ class LlamaHIP:
 
         T = B * q_len
         self._kv_only = bool(kv_only)
+        self._past_lens = None
+        if past_lens is not None:
+            if not (many_rows and past_key_values is not None):
+                raise ValueError("past_lens goes with many_rows=True over an encode arena")
+            self._past_lens = past_lens.to(device=dev, dtype=torch.int32).contiguous()
         # a schema-encode pass (fresh arena, or a suffix over a trunk arena that carries residuals) always takes the
         # many-row path, however few rows it has: that path alone reads the prefix's residual planes and stops after the
         # last layer's K / V; and a pass that is not the serving prefill / decode must not capture a throwaway hipGraph
-        encode_pass = many_rows and self.precise_dense and (past_key_values is None or arena.lo is not None)
+        encode_pass = many_rows and (self._past_lens is not None or
+                                     self.precise_dense and (past_key_values is None or arena.lo is not None))
         graphed = self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs and not many_rows and not kv_only
         mid = self.skinny and not encode_pass and T <= self.MID_MAX_ROWS and \
             not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS)
@@ -349,13 +360,13 @@ class LlamaHIP:
             kv_lo = lo_for(li)
             n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
                           kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo)
+                          q_out_lo=q16l, kv_lo=kv_lo, past_lens=self._past_lens)
             if self._kv_only and li == len(layers) - 1:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
-                       out_lo=lo(attn2), kv_lo=kv_lo)
+                       out_lo=lo(attn2), kv_lo=kv_lo, past_lens=self._past_lens)
             self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)                    # x += attn @ Wo^T
             norm(x, lw["ln2"], T)
             self._proj(h2[0], lo(h2), lw, "wgu", T, 2 * inter, hid, n.EPI_SILU, out_hi=act2[0], out_lo=lo(act2))

@@ -74,6 +74,7 @@ class MptHIP(LlamaHIP):
         self.inv_freq_cpu = torch.zeros(1)                      # no rotary table (kept for interface symmetry)
         self.softmax_scale = 1.0 / math.sqrt(self.D)            # mpt.py:139-140
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
+        self.supports_ragged_past = False   # ALiBi takes one position row per batch row, laid out for ONE past length
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

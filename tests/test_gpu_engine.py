@@ -568,3 +568,34 @@ def test_checkpoint_directory_path_equals_in_memory_weights(tmp_path):
     assert a.get_cache_shape() == b.get_cache_shape()
     ids = torch.randint(3, shape.vocab_size, (1, 23), generator=torch.Generator().manual_seed(2)).cuda()
     assert torch.equal(a(input_ids=ids, use_cache=True).logits, b(input_ids=ids, use_cache=True).logits)
+
+
+def test_ragged_suffix_batches_store_the_same_module_kv_as_per_union_batches():
+    """Suffix passes of different unions packed into ONE batch with per-row past lengths (pc_rope_append_var /
+    pc_attn_fwd_var) must store the module KV that the per-union batches store (same passes, same trunk rows; only the
+    batch composition -- and with it the tile shapes of the projections -- differs)."""
+    from promptcache_amd import CacheEngine, synth
+    from promptcache_amd.cache_engine import SchemaCache
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 5, 2.0), device="cuda:0")
+    sp, _ = synth.persona_like("p", system_len=70, intro_len=20,
+                               traits=(("age", (30, 26, 33)), ("home", (41, 37, 44, 35)), ("job", (25, 29, 22)), ("pet", (50, 12))), seed=4)
+    text = lm.get_formatter()(sp)
+    stores = {}
+    try:
+        for ragged in (True, False):
+            SchemaCache.ragged_suffix_batches = ragged
+            eng = CacheEngine(1024, lm)
+            eng.add_schema(text)
+            sc = eng.schemas["p"]
+            assert sc.encode_stats["trunk_shared_passes"] >= 6
+            stores[ragged] = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in sc.cache_l1.values()),
+                                    key=lambda t: (t[0], t[1]))
+    finally:
+        SchemaCache.ragged_suffix_batches = True
+    assert [(a, b) for a, b, _ in stores[True]] == [(a, b) for a, b, _ in stores[False]]
+    worst = max(float((x[2] - y[2]).abs().max()) for x, y in zip(stores[True], stores[False]))
+    print(f"ragged vs per-union suffix batches: max |dKV| = {worst:.2e}")
+    assert worst < 4e-3        # an fp16 ulp of O(1) values where fp32 sums in different tile shapes round across a tie

@@ -1179,3 +1179,61 @@ def test_residual_tail_outlives_the_pass_for_decode():
     # the tail holds one residual row per appended key, in key order
     rec = arena[0, 0, :, base:past].double() + tail[0, 0, :, :past - base].double()
     assert (rec - torch.cat(Kd[1:], 1)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("two", [True, False])
+def test_ragged_past_rope_append_and_attention_match_oracle_row_by_row(two):
+    """pc_rope_append_var + pc_attn_fwd_var: one past length per batch row (schema-encode suffix batches over trunk prefixes
+    of different lengths).  Every batch row must equal the single-row call / the oracle at its own past length."""
+    n = _n()
+    rng = np.random.default_rng(21)
+    B, H, Hkv, D, q_len = 3, 4, 2, 128, 70
+    pasts = [5, 130, 64]
+    cap = max(pasts) + q_len + 2
+    W = (H + 2 * Hkv) * D
+    qkv = torch.from_numpy(rng.standard_normal((B, q_len, W), dtype=np.float32)).to(DEV)
+    arena = torch.from_numpy(rng.standard_normal((B, 2, Hkv, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
+    lo = torch.zeros_like(arena)
+    inv = torch.from_numpy(_inv_freq(D, 10000.0)).to(DEV)
+    pos = torch.from_numpy(np.stack([np.arange(p, p + q_len) for p in pasts]).astype(np.int32)).to(DEV)
+    cs = torch.empty((B * q_len, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(pos.reshape(-1), inv, cs, B * q_len, D)
+    pl = torch.tensor(pasts, dtype=torch.int32, device=DEV)
+
+    def run(arena_t, lo_t, rows, past_arg, past_lens):
+        Bn = len(rows)
+        q16 = torch.empty((Bn, q_len, H * D), dtype=torch.float16, device=DEV)
+        q16l = torch.empty_like(q16) if two else None
+        kp, vp = arena_t[:, 0], arena_t[:, 1]
+        bs, hs = 2 * Hkv * cap * D, cap * D
+        kvlo = (lo_t[:, 0], lo_t[:, 1], bs, hs, 0) if two else None
+        x = qkv[rows].contiguous()
+        c = cs.view(B, q_len, D // 2, 2)[rows].contiguous().view(Bn * q_len, D // 2, 2)
+        n.rope_append(x, q_len * W, W, q16, q_len * H * D, H * D, x[:, :, H * D:], x[:, :, (H + Hkv) * D:], q_len * W, W,
+                      kp, vp, bs, hs, c, Bn, H, Hkv, D, q_len, past_arg, cap, True, q_out_lo=q16l, kv_lo=kvlo, past_lens=past_lens)
+        out = torch.full((Bn, q_len, H * D), float("nan"), dtype=torch.float16, device=DEV)
+        out_lo = torch.empty_like(out) if two else None
+        ws = torch.empty(max(n.attn_workspace_bytes(Bn, H, D, q_len, past_arg + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+        n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, bs, hs, out, q_len * H * D, H * D, Bn, H, Hkv, D, q_len, past_arg,
+                   1.0 / np.sqrt(D), ws, q_lo=q16l, out_lo=out_lo, kv_lo=kvlo, past_lens=past_lens)
+        torch.cuda.synchronize()
+        return out.float() + (out_lo.float() if two else 0.0), q16
+
+    a1, l1 = arena.clone(), lo.clone()
+    got, _ = run(a1, l1, [0, 1, 2], max(pasts), pl)
+    assert torch.isfinite(got).all()
+    for b, p in enumerate(pasts):
+        a2, l2 = arena[b:b + 1].clone(), lo[b:b + 1].clone()
+        one, q16 = run(a2, l2, [b], p, None)
+        # same kernels, same data, a scalar past length: identical bits
+        assert torch.equal(a1[b, :, :, :p + q_len], a2[0, :, :, :p + q_len])
+        assert torch.equal(got[b], one[0])
+        # rows past the row's own end were not touched
+        assert torch.equal(a1[b, :, :, p + q_len:], arena[b, :, :, p + q_len:])
+        # and the oracle on that row (K/V as appended, Q as rotated)
+        kk = (a2[0, 0].float() + l2[0, 0].float())[None, :, :p + q_len]
+        vv = (a2[0, 1].float() + l2[0, 1].float())[None, :, :p + q_len]
+        qq = q16.float().view(1, q_len, H, D)
+        ref = orc.attention_core(qq.cpu().numpy().transpose(0, 2, 1, 3), kk.cpu().numpy(), vv.cpu().numpy(), p, H // Hkv)
+        ref = ref.transpose(0, 2, 1, 3).reshape(q_len, H * D)
+        np.testing.assert_allclose(one[0].cpu().numpy(), ref, atol=4e-3 if not two else 2.5e-3, rtol=1e-2)

@@ -1194,7 +1194,7 @@ def test_ragged_past_rope_append_and_attention_match_oracle_row_by_row(two):
     qkv = torch.from_numpy(rng.standard_normal((B, q_len, W), dtype=np.float32)).to(DEV)
     arena = torch.from_numpy(rng.standard_normal((B, 2, Hkv, cap, D), dtype=np.float32).astype(np.float16)).to(DEV)
     lo = torch.zeros_like(arena)
-    inv = torch.from_numpy(_inv_freq(D, 10000.0)).to(DEV)
+    inv = _inv_freq(D, 10000.0).to(DEV)
     pos = torch.from_numpy(np.stack([np.arange(p, p + q_len) for p in pasts]).astype(np.int32)).to(DEV)
     cs = torch.empty((B * q_len, D // 2, 2), dtype=torch.float32, device=DEV)
     n.rope_table(pos.reshape(-1), inv, cs, B * q_len, D)

@@ -43,6 +43,7 @@ constexpr int kTK = 64;        // keys per LDS tile
 constexpr int kThreads = 256;  // 4 waves
 constexpr int kQB = 64;        // query rows per workgroup
 constexpr int kMaxSplit = 32;
+constexpr int kSmallQ = 16;    // most query rows per batch row attn_small_kernel takes
 constexpr float kNegBig = -1.0e30f;  // finite "-inf" for the running max
 
 struct AttnParams {
@@ -66,6 +67,7 @@ struct AttnParams {
     // 0 .. nsplit-2 stream the STAGED keys [0, past_len) only; the workgroup of split nsplit-1 computes the attention over
     // the rows this pass appended in fp32 (attn_tail_block) and leaves it as one more partial for the merge kernel.
     int32_t tail;
+    int32_t small;          // attn_small_kernel launch (host-side dispatch flag)
     int32_t xcd_remap, nqblk, nbatch;
     float scale_log2;
 };
@@ -717,6 +719,205 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// q_len <= 16 over a long staged cache (the cached prefill proper: q ~ 12 new tokens over S ~ 1.7 k staged keys).
+// HBM-bound on the K/V stream, and at this size LATENCY-bound: the 64-rows-per-workgroup kernel above gives one active
+// wave per workgroup a serial chain of 3 tiles behind barriers (12.4 us + a 5 us merge launch for 28.5 MB).  Here every
+// WAVE owns a contiguous slice of the keys -- ceil(kv_len / (4 * nstream)) of them, one 64-key tile for the persona
+// shape -- and runs with no barrier at all:
+//   * K fragments go straight from global memory into the MFMA A operand (a lane's 16 bytes are exactly its fragment:
+//     key row n, head dims 32 ks + 8 g ..; no LDS round trip for K);
+//   * V rows are loaded coalesced, pass through a wave-private LDS tile and come back transposed (ds_read_b64_tr_b16);
+//   * all of a tile's loads (32 KiB per wave, 128 KiB per workgroup) are issued before the first wait, so the whole
+//     K/V stream of the launch is in flight after one round trip;
+//   * the four waves' (m, l, O) partials are merged through LDS and leave as ONE partial per workgroup, so the merge
+//     kernel reads nstream (+1) partials per row instead of one per 3-tile split.
+// Q and P are split-precision pairs (HP).  Tail mode (see attn_tail_block) adds one workgroup per head for the pass's own
+// rows; without it the new rows are part of the stream under the index-order causal mask.
+template <int D, bool ALIBI>
+__global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParams p) {
+    constexpr int KS = D / 32, DB = D / 16, CPR = D / 8;
+    constexpr int LPW = kTK * CPR / 64;              // 16-byte V loads per lane per tile
+    constexpr int kTileHalfs = kTK * D;
+    constexpr int kTailBytes = (2 * 16 * D + 16 * D + 16 * 16) * 4;
+    constexpr int kLdsBytes = 4 * kTileHalfs * 2 > kTailBytes ? 4 * kTileHalfs * 2 : kTailBytes;
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
+    const int hkv = h / (p.H / p.Hkv);
+    const int q_len = p.q_len;
+    const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int nstream = p.tail ? p.nsplit - 1 : p.nsplit;
+    if (p.tail && split == nstream) {                 // workgroup-uniform: the pass's own rows, fp32
+        float* f = (float*)smem;
+        attn_tail_block<D, 16, ALIBI>(p, f, f + 16 * D, f + 2 * 16 * D, f + 3 * 16 * D, b, h, split);
+        return;
+    }
+    const int kv_len = p.tail ? past_len : past_len + q_len;
+    int cpw = (kv_len + nstream * 4 - 1) / (nstream * 4);          // keys per wave
+    cpw = (cpw + 15) & ~15;
+    const int k0 = (split * 4 + wave) * cpw;
+    const int k1 = (k0 + cpw < kv_len) ? k0 + cpw : kv_len;
+    const int qi = n;                                              // this lane's query row
+    const int row_vis_end = qi < q_len ? (p.tail ? past_len : past_len + qi + 1) : 0;
+
+    h8 qf[KS], qfl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[ks] = z; qfl[ks] = z;
+        if (qi < q_len) {
+            const int64_t off = b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 32 + g * 8;
+            qf[ks] = *(const h8*)(p.q + off);
+            if (p.q_lo) qfl[ks] = *(const h8*)(p.q_lo + off);
+        }
+    }
+    f4 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { f4 z = {0.f, 0.f, 0.f, 0.f}; o[db] = z; }
+    float m_run = kNegBig, l_run = 0.f;
+    const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+    const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
+    [[maybe_unused]] const float slope = ALIBI ? p.slopes[h] : 0.f;
+    [[maybe_unused]] const float* kpos = ALIBI ? p.key_pos + b * p.kp_bs : nullptr;
+    _Float16* Vw = (_Float16*)smem + wave * kTileHalfs;            // this wave's V tile
+
+    for (int key0 = k0; key0 < k1; key0 += kTK) {
+        // ---- every load of the tile first: K as MFMA fragments, V as coalesced rows ----
+        u32x4 kr[4][KS], vr[LPW];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int key = key0 + kb * 16 + n;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                kr[kb][ks] = z;
+                if (key < k1) kr[kb][ks] = *(const u32x4*)(kbase + (int64_t)key * D + ks * 32 + g * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int c = lane + i * 64, row = c / CPR, col = c - row * CPR;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            vr[i] = z;                                              // rows past k1: zeros (0 * garbage could be NaN)
+            if (key0 + row < k1) vr[i] = *(const u32x4*)(vbase + (int64_t)(key0 + row) * D + col * 8);
+        }
+        // ---- S^T = K . Q^T ----
+        float sv[4][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const h8 a = __builtin_bit_cast(h8, kr[kb][ks]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qfl[ks], acc, 0, 0, 0);
+            }
+            f4 kb4 = {0.f, 0.f, 0.f, 0.f};
+            if (ALIBI) kb4 = *(const f4*)(kpos + key0 + kb * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + kb * 16 + g * 4 + r;
+                float sc = acc[r] * p.scale_log2;
+                if (ALIBI) sc += slope * kb4[r];
+                const float s = (key < row_vis_end && key < k1) ? sc : -INFINITY;
+                sv[kb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - m_new);
+        float rs = 0.f;
+        h8 pb[2], pbl[2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = fast_exp2(sv[kb][r] - m_new);
+                rs += e;
+                const _Float16 eh = (_Float16)e;
+                pb[kb >> 1][(kb & 1) * 4 + r] = eh;
+                pbl[kb >> 1][(kb & 1) * 4 + r] = (_Float16)(e - (float)eh);
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha; }
+        m_run = m_new;
+        // ---- V through the wave-private LDS tile (rows rotated by 32 B per row, see attn_fwd_kernel), back transposed ----
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int c = lane + i * 64, row = c / CPR, col = c - row * CPR;
+            *(u32x4*)(Vw + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int vrow = t * 32 + g * 4 + (n >> 2);
+                const _Float16* vp = Vw + vrow * D + ((db * 16 + (n & 3) * 4 + 16 * (vrow & 7)) & (D - 1));
+                const h4 lo = lds_tr_read(vp);
+                const h4 hi = lds_tr_read(vp + 16 * D);
+                const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- merge the four waves' partials through LDS: one (m, l, O) partial per workgroup ----
+    __syncthreads();                                     // every wave is done with its V tile
+    float* mo = (float*)smem;                            // [4][DB][64][4]
+    float* mml = mo + 4 * DB * 64 * 4;                   // [4][16][2]
+#pragma unroll
+    for (int db = 0; db < DB; ++db) *(f4*)(mo + ((wave * DB + db) * 64 + lane) * 4) = o[db];
+    if (g == 0) { mml[(wave * 16 + n) * 2] = m_run; mml[(wave * 16 + n) * 2 + 1] = l_run; }
+    __syncthreads();
+    float mw[4], lw[4], mstar = kNegBig;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        mw[w] = mml[(w * 16 + n) * 2]; lw[w] = mml[(w * 16 + n) * 2 + 1];
+        mstar = fmaxf(mstar, mw[w]);
+    }
+    float wt[4], lsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { wt[w] = fast_exp2(mw[w] - mstar); lsum += wt[w] * lw[w]; }
+    if (qi >= q_len) return;
+    const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
+    constexpr int DPW = (DB + 3) / 4;                    // head-dim blocks merged by one wave
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int db = wave * DPW + j;
+        if (db < DB) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f4 x = *(const f4*)(mo + ((w * DB + db) * 64 + lane) * 4);
+                acc[0] += wt[w] * x[0]; acc[1] += wt[w] * x[1]; acc[2] += wt[w] * x[2]; acc[3] += wt[w] * x[3];
+            }
+            *(f4*)(p.part_o + slot * D + db * 16 + g * 4) = acc;
+        }
+    }
+    if (wave == 0 && g == 0) { p.part_ml[slot * 2] = mstar; p.part_ml[slot * 2 + 1] = lsum; }
+}
+
+// workgroups per head of attn_small_kernel: fill the 256 CUs (each workgroup = 4 key slices)
+int small_nstream(int B, int H) {
+    static const int forced = [] { const char* e = getenv("PC_ATTN_SMALL_WG"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced < 15 ? forced : 15;
+    int ns = 256 / (B * H);
+    if (ns < 1) ns = 1;
+    if (ns > 15) ns = 15;
+    return ns;
+}
+
 // Merge split-KV partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i.
 // One workgroup per (query row, head), one thread per head dim.  (A variant with one workgroup per head and
 // float4 items measured 8.0 us vs 6.3 us per launch inside the captured forward: more parallel, shorter chains win.)
@@ -798,10 +999,13 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     const bool rows32 = !p.q_lo && !p.k_lo && use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
     p.nqblk = pc_ceil_div(p.q_len, rows32 ? kQB32 : kQB);
     p.nbatch = B;
-    p.xcd_remap = (p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
+    p.xcd_remap = (!p.small && p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
     if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
-    if (rows32) {
+    if (p.small) {
+        if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_small_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
+    } else if (rows32) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.k_lo && !p.tail) {
@@ -835,6 +1039,8 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     int ns = choose_nsplit(B, H, q_len, kv_len_max);
     // passes of <= kTailMax rows may run in tail mode (pc_attn_fwd_ex with lo_row0 = -1): one more split, always merged
     if (q_len <= kTailMax) ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
+    // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
+    if (q_len <= kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;
     if (ns <= 1) return 0;
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
@@ -873,7 +1079,16 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
     p.tail = (k_lo && lo_row0 == -1 && q_len <= kTailMax && !past_lens) ? 1 : 0;
-    if (p.tail) {
+    // <= 16 rows over a long cache: one key slice per WAVE, partials merged per workgroup (attn_small_kernel).  Not for
+    // launches that carry residual tiles in the stream (decode over a residual tail, lo_row0 != -1).
+    static const bool small_off = [] { const char* e = getenv("PC_ATTN_NO_SMALL"); return e && e[0] == '1'; }();
+    bool small = !small_off && q_len <= kSmallQ && !past_lens && (!k_lo || p.tail) && past_len + q_len >= 256;
+    if (small) {
+        const int ns = small_nstream(B, H) + p.tail;
+        if (ns >= 2) p.nsplit = ns; else small = false;
+    }
+    p.small = small ? 1 : 0;
+    if (p.tail && !small) {
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
         // next instantiation of the merge kernel (4 / 8 / 16 / 32 partials per row)
         int ms = p.nsplit;

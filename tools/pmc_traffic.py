@@ -1,0 +1,55 @@
+"""Collect HBM traffic per launch of the timed step's kernels from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+never combined with trace domains) and write profiles/pmc_traffic.json, which bench.py reads for its `traffic` fields.
+gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> doubled (guide, HBM section); units: KiB.
+
+    python tools/pmc_traffic.py            (on the GPU box; runs bench.py --no-context twice under rocprofv3)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
+os.makedirs(OUT, exist_ok=True)
+env = dict(os.environ, TMPDIR="/tmp")
+vals = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = os.path.join(OUT, ctr)
+    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable,
+                    os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-context", "--no-cpu-baseline",
+                    "--no-library"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    vals[ctr] = {k: v[1] / v[0] for k, v in agg.items()}
+
+
+def pick(sub, *more):
+    out = {}
+    for ctr in vals:
+        ks = [k for k in vals[ctr] if sub in k and all(m in k for m in more)]
+        out[ctr] = vals[ctr][ks[0]] if ks else None
+    if out["FETCH_SIZE"] is None or out["WRITE_SIZE"] is None:
+        return None
+    return int((2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024)
+
+
+src = "tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --no-context; (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch"
+tab = {
+    "kv_copy_kernel": {"signature": "S=1725,L=32,Hkv=32,D=128", "hbm_bytes_per_launch": pick("kv_copy_kernel"), "source": src},
+    "gemm_skinny_add": {"signature": "T=12,hid=4096,inter=11008",
+                        "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 1, 1"), "source": src + " (average of o_proj and down_proj)"},
+    "gemm_skinny_gate_up": {"signature": "T=12,hid=4096,inter=11008", "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 3, 2"), "source": src},
+}
+a, c = pick("attn_small_kernel"), pick("attn_combine_kernel")
+tab["attn_cached"] = {"signature": "H=32,Hkv=32,D=128,q=12,S=1725", "hbm_bytes_per_launch": (a + c) if a and c else None,
+                      "source": src + " (attn_small_kernel + attn_combine_kernel)"}
+json.dump(tab, open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(tab, indent=1))

@@ -1,9 +1,15 @@
-#!/bin/bash
-# rocprofv3 kernel trace of the bench's timed steps; prints the per-kernel summary of the last N ms.
-# usage: tools/prof_bench.sh <outdir-under-gpurun_out> [tail_ms] [extra bench args]
-out=gpurun_out/$1; tail_ms=${2:-30}; shift; shift
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out -o bench -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-context --no-library --no-int8 "$@" > $out.log 2>&1
-grep metric $out.log | cut -c1-160
-python tools/rocpd_stats.py $out/bench_results.db --tail-ms $tail_ms | cut -c1-200 | head -${TOPN:-16}
-rm -f $out/bench_results.db   # keep gpurun_out small; the summary is what gets committed
+# rocprofv3 kernel stats of the timed step only (context legs off): bash tools/prof_bench.sh <outdir-name>
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$1
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o b -f csv -- python $R/bench.py --steps 40 --warmup 5 --no-context --no-cpu-baseline --no-library > $OUT/bench.json 2> $OUT/bench.err
+python3 - <<PY
+import csv,glob
+f=glob.glob("$OUT/prof/**/*kernel_stats.csv", recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+with open("$OUT/kernel_stats.txt","w") as o:
+    for r in rows[:16]:
+        line=f'{r["Name"][:110]:110s} calls={r["Calls"]:>6s} total_ms={float(r["TotalDurationNs"])/1e6:9.2f} avg_us={float(r["AverageNs"])/1e3:9.2f} pct={r["Percentage"]}'
+        print(line); o.write(line+"\n")
+PY

@@ -437,7 +437,13 @@ def main():
     macs_tok = (mcfg.hidden_size * (lm.hf_model.H + 2 * lm.hf_model.Hkv) * lm.hf_model.D + lm.hf_model.H * lm.hf_model.D * mcfg.hidden_size
                 + 3 * mcfg.hidden_size * mcfg.intermediate_size)          # projection MACs per token per layer
     enc_flops = 2.0 * planes * macs_tok * mcfg.num_hidden_layers * int(sc.encode_stats["computed_tokens"])
-    encode = {"roofline": {"bound": "mfma", "achieved": enc_flops / t_enc / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+    enc_per_rank = [int(sc.encode_stats["computed_tokens"])]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device=device)
+        t[rank] = enc_per_rank[0]
+        dist.all_reduce(t)
+        enc_per_rank = [int(v) for v in t.tolist()]
+    encode = {"per_rank_computed_tokens": enc_per_rank, "roofline": {"bound": "mfma", "achieved": enc_flops / t_enc / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                            "frac": enc_flops / t_enc / 1e12 / 2500.0, "traffic": None,
                            "what": f"projection flops executed by pc_gemm_dense ({planes} activation plane(s) x 2 x MACs x layers x "
                                    "computed tokens, padding rows and attention not counted) / wall time of the whole add_schema "
@@ -463,19 +469,27 @@ def main():
                         for i, lens in enumerate([(306, 76, 800, 800, 800), (1500, 1200), (400,) * 6])]
         barrier()
         t0 = time.perf_counter()
-        for text in lib_schemas:
-            eng.add_schema(fmt(text))
+        eng.add_schemas([fmt(text) for text in lib_schemas])       # schema-level sharding + overlapped exchange (N > 1)
         barrier()
         t_lib = time.perf_counter() - t0
         names = [n for n in eng.schemas if n.startswith("lib-")]
         lib_tokens = sum(sum(len(j["token_ids"]) for j in eng.schemas[n]._plan()) for n in names)
         lib_passes = sum(int(eng.schemas[n].encode_stats["total_passes"]) for n in names)
         lib_cached = sum(int(eng.schemas[n].encode_stats["cached_tokens"]) for n in names)
-        library = {"schemas": len(names), "passes": lib_passes, "tokens": int(lib_tokens), "cached_tokens": lib_cached,
+        mine_comp = int(sum(eng.schemas[n].encode_stats["computed_tokens"] for n in names))
+        per_rank = [mine_comp]
+        if world > 1:
+            t = torch.zeros(world, dtype=torch.int64, device=device)
+            t[rank] = mine_comp
+            dist.all_reduce(t)
+            per_rank = [int(v) for v in t.tolist()]
+        library = {"per_rank_computed_tokens": per_rank,
+                   "schemas": len(names), "passes": lib_passes, "tokens": int(lib_tokens), "cached_tokens": lib_cached,
                    "module_kv_bytes": int(lib_cached) * lm.hf_model.config.kv_bytes_per_token, "seconds": t_lib,
                    "tokens_per_s": lib_tokens / t_lib, "sharded_over": world,
-                   "note": "BASELINE config 5 stand-in: synthetic schema library, add_schema per schema, passes sharded "
-                           "over the ranks + one all-gather of module KV per schema"}
+                   "note": "BASELINE config 5 stand-in: synthetic schema library through CacheEngine.add_schemas: whole schemas "
+                           "dealt to the ranks (LPT on the tokens each encode really runs; every trunk computed once), slabs "
+                           "broadcast from their owners at exact size, exchange of schema k overlapped with the encode of k+1"}
         for n in names:
             eng.remove_schema(n)
 

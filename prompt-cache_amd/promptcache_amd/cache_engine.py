@@ -183,12 +183,57 @@ class SchemaCache:
         self.cache_l2: Dict[Tuple[int, int], Tuple[TokenSequenceCache, TokenSequenceCache]] = {}
         self.target_device = lm.device if target_device is None else target_device
         self.encode_stats: Dict[str, float] = {}
+        self._pending: list = []        # exchange work handles not yet waited for (async multi-GPU library encode)
+        self._jobs = None
         if not no_cache:
-            self._process(batch_size)
-            if module_memory == "host":
-                for c in self.cache_l1.values():
-                    c.offload()
-                gc.collect()
+            self.encode(batch_size)
+
+    def encode(self, batch_size: int = 1, owner_rank: Optional[int] = None, async_exchange: bool = False) -> None:
+        """Run the module-KV precompute.  ``owner_rank``: encode the WHOLE schema on that rank (the others only receive:
+        schema-level sharding of a library, ``CacheEngine.add_schemas``); None: shard this schema's passes over the ranks.
+        ``async_exchange``: leave the module-KV exchange in flight (``wait_exchange`` before the segments are read)."""
+        self._process(batch_size, owner_rank, async_exchange)
+        if self.module_memory == "host":
+            self.wait_exchange()
+            for c in self.cache_l1.values():
+                c.offload()
+            gc.collect()
+
+    def wait_exchange(self) -> None:
+        for h in self._pending:
+            h.wait()
+        self._pending = []
+
+    def plan_cost(self) -> int:
+        """Tokens this schema's encode runs through the model (suffixes behind the shared trunk prefix counted once)."""
+        jobs, prefix = self._plan_with_prefix()
+        return sum(len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs))
+
+    def _plan_with_prefix(self):
+        """(jobs, prefix): the plan plus, per job, the number of leading tokens it shares with the root scaffold (job 0)
+        when it is encoded as a suffix over the trunk's K/V (0 = encoded in full).  Cached: tokenising every scaffold of a
+        large schema is the expensive host step, and a library scheduler asks for the cost before it encodes."""
+        if self._jobs is not None:
+            return self._jobs
+        jobs = self._plan()
+        # ---- trunk reuse.  Scaffolds are emitted in position order and differ from the root scaffold (job 0: every
+        # union at its default member) from the first token of their own union member on, so under the causal mask
+        # the K/V of their common prefix is the root pass's K/V.  Such a scaffold is encoded as "suffix over the
+        # trunk's prefix rows" -- the very cached-prefill the engine exists for -- instead of from scratch (the
+        # reference re-encodes every scaffold in full, cache_engine.py:221-248).
+        prefix = [0] * len(jobs)
+        if self.share_trunk and len(jobs) > 1:
+            t_ids, t_pos = jobs[0]["token_ids"], jobs[0]["position_ids"]
+            for i in range(1, len(jobs)):
+                ids, pos = jobs[i]["token_ids"], jobs[i]["position_ids"]
+                n = 0
+                lim = min(len(ids), len(t_ids)) - 1          # at least one token is always run
+                while n < lim and ids[n] == t_ids[n] and pos[n] == t_pos[n]:
+                    n += 1
+                if n >= self.share_trunk_min and n >= len(ids) // 5:
+                    prefix[i] = n
+        self._jobs = (jobs, prefix)
+        return self._jobs
 
     # ------------------------------------------------------------------------------------------
     def _plan(self):
@@ -213,31 +258,29 @@ class SchemaCache:
         return [j for j in jobs if j["owned"]]
 
     @torch.inference_mode()
-    def _process(self, batch_size: int = 1):
+    def _process(self, batch_size: int = 1, owner_rank: Optional[int] = None, async_exchange: bool = False):
         lm = self.lm
         L, Hkv, D = lm.get_cache_shape()
         dev = lm.device
-        jobs = self._plan()
+        jobs, prefix = self._plan_with_prefix()
         rank, world = parallel.rank_world()
-        # ---- trunk reuse.  Scaffolds are emitted in position order and differ from the root scaffold (job 0: every
-        # union at its default member) from the first token of their own union member on, so under the causal mask
-        # the K/V of their common prefix is the root pass's K/V.  Such a scaffold is encoded as "suffix over the
-        # trunk's prefix rows" -- the very cached-prefill the engine exists for -- instead of from scratch (the
-        # reference re-encodes every scaffold in full, cache_engine.py:221-248).
-        prefix = [0] * len(jobs)
-        if self.share_trunk and len(jobs) > 1:
-            t_ids, t_pos = jobs[0]["token_ids"], jobs[0]["position_ids"]
-            for i in range(1, len(jobs)):
-                ids, pos = jobs[i]["token_ids"], jobs[i]["position_ids"]
-                n = 0
-                lim = min(len(ids), len(t_ids)) - 1          # at least one token is always run
-                while n < lim and ids[n] == t_ids[n] and pos[n] == t_pos[n]:
-                    n += 1
-                if n >= self.share_trunk_min and n >= len(ids) // 5:
-                    prefix[i] = n
-        # shard by what a pass actually costs: its suffix behind the trunk prefix (world == 1 -> everything)
-        shards = parallel.shard_jobs([len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)], world)
+        if owner_rank is not None:
+            # schema-level sharding: one rank encodes every pass (and the trunk exactly once), the others receive
+            shards = [list(range(len(jobs))) if r == owner_rank else [] for r in range(world)]
+        else:
+            # shard by what a pass actually costs: its suffix behind the trunk prefix (world == 1 -> everything)
+            shards = parallel.shard_jobs([len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)], world)
         mine = shards[rank]
+        # every rank's segments live back to back in ONE slab per rank (ascending job order, then plan order inside a
+        # job): the encode writes its stores through views of the slab, and the exchange moves whole slabs in place
+        seg_numel = lambda tc: L * 2 * Hkv * len(tc) * D                                        # noqa: E731
+        sizes_by_rank = [[seg_numel(tc) for i in idxs for tc in jobs[i]["owned"]] for idxs in shards]
+        my_slab, my_views = parallel.carve(sizes_by_rank[rank], torch.float16, dev)
+        view_of: Dict[Tuple[int, int], torch.Tensor] = {}
+        it = iter(my_views)
+        for i in mine:
+            for k in range(len(jobs[i]["owned"])):
+                view_of[(i, k)] = next(it)
 
         encoded_tokens = computed_tokens = 0
         per_job: Dict[int, List[Tuple[TokenSequence, torch.Tensor]]] = {}
@@ -251,7 +294,7 @@ class SchemaCache:
             # position ids of a scaffold may be interleaved, but each segment is contiguous (:275-279)
             src_off = [pos.index(tc.offset) for tc in owned]
             lens = [len(tc) for tc in owned]
-            stores = [torch.empty((L, 2, Hkv, n, D), dtype=torch.float16, device=dev) for n in lens]
+            stores = [view_of[(job_idx, k)].view(L, 2, Hkv, n, D) for k, n in enumerate(lens)]
             _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
             if custom_store_hooks:
                 # an adapter that overrides store_k_hook / store_v_hook (reference :284-285) sees the per-layer
@@ -347,23 +390,22 @@ class SchemaCache:
                 store_owned(i, arena, row)
             del out, arena
         del trunk_arena
-        # ascending job order == the global segment order restricted to this rank (what the all-gather plan assumes)
-        local_segments: List[Tuple[TokenSequence, torch.Tensor]] = [p for i in sorted(per_job) for p in per_job[i]]
-
         if world > 1:
-            # one exchange step: every GPU ends with the whole module library
-            order = [(i, tc) for i in range(len(jobs)) for tc in jobs[i]["owned"]]
-            owner_rank = {i: r for r, idxs in enumerate(shards) for i in idxs}
-            seg_table = [(owner_rank[i], L * 2 * Hkv * len(tc) * D) for i, tc in order]
-            local = [s for _, s in local_segments]
-            gathered = parallel.allgather_segments(local, seg_table, rank, world, dev)
-            for (i, tc), flat in zip(order, gathered):
-                self.cache_l1[id(tc)] = TokenSequenceCache(tc, flat.view(L, 2, Hkv, len(tc), D))
+            # one exchange step: every GPU ends with the whole module library (slabs travel as they are: no padding to
+            # the largest shard, no pack copy; see parallel.exchange_slabs)
+            views_by_rank, handles = parallel.exchange_slabs(my_slab, sizes_by_rank, rank, world, dev, async_op=async_exchange)
+            self._pending.extend(handles)
+            for r, idxs in enumerate(shards):
+                vit = iter(views_by_rank[r])
+                for i in idxs:
+                    for tc in jobs[i]["owned"]:
+                        self.cache_l1[id(tc)] = TokenSequenceCache(tc, next(vit).view(L, 2, Hkv, len(tc), D))
         else:
-            for tc, store in local_segments:
-                self.cache_l1[id(tc)] = TokenSequenceCache(tc, store)
+            for i in sorted(per_job):
+                for tc, store in per_job[i]:
+                    self.cache_l1[id(tc)] = TokenSequenceCache(tc, store)
         self.encode_stats = dict(passes=len(mine), total_passes=len(jobs), encoded_tokens=encoded_tokens,
-                                 computed_tokens=computed_tokens, trunk_shared_passes=len(shared),
+                                 computed_tokens=computed_tokens, trunk_shared_passes=len(shared), owner_rank=owner_rank,
                                  cached_tokens=sum(len(c) for c in self.cache_l1.values()))
         gc.collect()
 
@@ -427,6 +469,36 @@ class CacheEngine:
         self.schemas[schema.name] = SchemaCache(schema, self.lm, batch_size, target_device=self.target_device,
                                                 no_cache=no_cache, module_memory=self.module_memory)
 
+    def add_schemas(self, schemas: Sequence[Union[str, Schema]], batch_size: int = 1, max_tokens: Optional[int] = None) -> None:
+        """Encode a whole module LIBRARY (the reference loops ``add_schema`` over its schema files, eval.py:172-181).
+        One GPU: the same loop.  Several GPUs (``torch.distributed`` initialised):
+          * at least as many schemas as ranks: SCHEMA-level sharding -- whole schemas are dealt to the ranks by
+            longest-processing-time-first on ``SchemaCache.plan_cost`` (the tokens a schema's encode really runs), so
+            every trunk is computed exactly once, on the rank that needs it, and no pass of one schema waits for another
+            rank's trunk; every other rank receives the schema's slab from its owner;
+          * fewer schemas than ranks: each schema's passes are sharded over all ranks (``SchemaCache._process``).
+        Either way the exchange of schema k is left in flight while schema k + 1 is encoded (RCCL runs on its own
+        stream), and all of them are waited for at the end."""
+        parsed = [Schema(sc, self.lm, max_tokens=max_tokens) if isinstance(sc, str) else sc for sc in schemas]
+        names = [sc.name for sc in parsed]
+        for nm in names:
+            if nm in self.schemas or names.count(nm) > 1:
+                raise ValueError(f"There is already a schema named {nm} in the cache")
+        rank, world = parallel.rank_world()
+        caches = [SchemaCache(sc, self.lm, batch_size, target_device=self.target_device, no_cache=True,
+                              module_memory=self.module_memory) for sc in parsed]
+        owners: List[Optional[int]] = [None] * len(caches)
+        if world > 1 and len(caches) >= world:
+            shards = parallel.shard_jobs([c.plan_cost() for c in caches], world)
+            for r, idxs in enumerate(shards):
+                for k in idxs:
+                    owners[k] = r
+        for k, c in enumerate(caches):
+            c.encode(batch_size, owner_rank=owners[k], async_exchange=world > 1)
+            self.schemas[c.schema.name] = c
+        for c in caches:
+            c.wait_exchange()
+
     def get_schema(self, name: str) -> Optional[Schema]:
         return self.schemas[name].schema if name in self.schemas else None
 
@@ -459,6 +531,7 @@ class CacheEngine:
         if prompt.schema not in self.schemas:
             raise ValueError(f"There is no such layout named {prompt.schema} in the cache")
         cached = self.schemas[prompt.schema]
+        cached.wait_exchange()
         schema = cached.schema
 
         used: List[TokenSequence] = []

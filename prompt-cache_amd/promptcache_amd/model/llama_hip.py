@@ -51,7 +51,7 @@ class LlamaHIP:
     # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly; above, the stacked
     # [hi; lo] hipBLASLt projections of the many-row path are faster (crossover measured at ~256 rows: q = 130:
     # 9.5 vs 9.8 ms, q = 258: 13.9 vs 13.9 ms, q = 402: 17.8 vs 17.2 ms; the kernel itself takes up to 512)
-    MID_MAX_ROWS = int(os.environ.get("PC_MID_MAX_ROWS", "256"))
+    MID_MAX_ROWS = int(os.environ.get("PC_MID_MAX_ROWS", "512"))
 
     def _setup(self, shape, device, decode_headroom: int) -> None:
         """State every architecture shares: device, KV-arena headroom, workspace and the hipGraph cache."""

@@ -6,12 +6,18 @@ The reference has no distributed code; what shards is its
 ``SchemaCache._process`` loop (``promptcache/cache_engine.py:217-304``): one forward pass per scaffold
 path, no cross-path dependency.  Single-prompt TTFT stays on one GPU (replicas only).
 
-Exchange step: each rank packs the segment stores it owns into ONE flat fp16 buffer; shards are
-padded to the largest and exchanged with a single ``all_gather_into_tensor`` (one large collective
-instead of one per segment: on the fully connected 8-GPU xGMI node each GPU receives (G-1)/G of the
-library over its 7 links concurrently).  Every rank knows every segment's owner and size from the
-(deterministic) plan, so no metadata is exchanged, and the received segments are used in place as views
-of the gathered buffer (``pc_kv_gather`` takes arbitrary source pointers).
+Exchange step (``exchange_slabs``): a rank's encode writes the segment stores it owns straight into ONE
+contiguous slab (``carve``: the stores ARE views of the slab, there is no pack copy); every rank then
+receives every other rank's slab at its exact size -- one broadcast per owner, issued back to back and
+asynchronously (what an uneven all-gather is on RCCL: grouped point-to-point transfers over the fully
+connected xGMI links; no padding to the largest shard travels).  Every rank knows every segment's owner
+and size from the (deterministic) plan, so no metadata is exchanged, and the received segments are used
+in place as views of the received slabs (``pc_kv_gather`` takes arbitrary source pointers).  The handles
+are returned to the caller: a library encode overlaps the exchange of schema k with the encode of
+schema k + 1 (``CacheEngine.add_schemas``).
+
+``allgather_segments`` is the round-1 form (pack + one max-padded ``all_gather_into_tensor``), kept for
+callers that hold loose segment tensors.
 """
 from __future__ import annotations
 
@@ -69,4 +75,52 @@ def allgather_segments(local: Sequence[torch.Tensor], seg_table: Sequence[Tuple[
     for j, (owner, numel) in enumerate(seg_table):
         base = owner * shard + offsets[j]
         out.append(recv[base:base + numel])
+    return out
+
+
+def carve(sizes: Sequence[int], dtype, device, align: int = 8) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """One contiguous slab holding segments of ``sizes`` elements back to back (each start ``align``-element = 16-byte
+    aligned) -> (slab, [flat view per segment]).  The encode writes the stores it owns through these views."""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + align - 1) // align * align
+    slab = torch.empty(total, dtype=dtype, device=device)
+    return slab, [slab[o:o + n] for o, n in zip(offs, sizes)]
+
+
+def exchange_slabs(mine: torch.Tensor, sizes_by_rank: Sequence[Sequence[int]], rank: int, world: int, device, dtype=None,
+                   group=None, async_op: bool = False):
+    """Every rank contributes one slab laid out by ``carve(sizes_by_rank[rank])``; returns ``(views_by_rank, handles)``:
+    ``views_by_rank[r]`` = the flat per-segment views of rank r's slab (this rank's own slab is ``mine`` itself, the
+    others are received at their exact size: nothing is padded, nothing is re-packed).  One broadcast per non-empty
+    owner, in rank order on every rank (collective call order must match).  ``async_op``: return the pending work
+    handles instead of waiting -- the caller keeps computing and waits before the segments are read."""
+    import torch.distributed as dist
+    dtype = dtype or mine.dtype
+    views_by_rank, handles = [], []
+    for r in range(world):
+        if r == rank:
+            slab, views = mine, carve_views(mine, sizes_by_rank[r])
+        else:
+            slab, views = carve(sizes_by_rank[r], dtype, device)
+        views_by_rank.append(views)
+        if slab.numel() > 0:
+            h = dist.broadcast(slab, src=r if group is None else dist.get_global_rank(group, r), group=group, async_op=True)
+            handles.append(h)
+    if not async_op:
+        for h in handles:
+            h.wait()
+        handles = []
+    return views_by_rank, handles
+
+
+def carve_views(slab: torch.Tensor, sizes: Sequence[int], align: int = 8) -> List[torch.Tensor]:
+    """The per-segment views of a slab that ``carve(sizes)`` laid out."""
+    out, off = [], 0
+    for n in sizes:
+        out.append(slab[off:off + n])
+        off += (n + align - 1) // align * align
+    if off != slab.numel():
+        raise ValueError(f"slab of {slab.numel()} elements does not match the plan ({off})")
     return out

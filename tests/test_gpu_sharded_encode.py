@@ -56,9 +56,30 @@ def _worker(rank, world, port, q):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         eng = CacheEngine(1024, lm)
-        eng.add_schema(fmt(sp))                                    # world == 2: sharded passes + all-gather
+        eng.add_schema(fmt(sp))                                    # world == 2: sharded passes + slab exchange
         lib2, st2 = library(eng)
         logits2 = serve(eng)
+        # a LIBRARY of three schemas through add_schemas: schema-level sharding (3 >= world), each schema encoded on one
+        # rank (its trunk exactly once) and broadcast; every rank must hold every schema, equal to the solo encode
+        texts = []
+        for k, nm in enumerate(("libA", "libB", "libC")):
+            t, _ = synth.persona_like(nm, system_len=40 + 10 * k, intro_len=15, traits=(("a", (20, 24)), ("b", (30, 22, 27))), seed=7 + k)
+            texts.append(fmt(t))
+        eng.add_schemas(texts)
+        owners = [eng.schemas[nm].encode_stats["owner_rank"] for nm in ("libA", "libB", "libC")]
+        assert sorted(set(owners)) == [0, 1], owners
+        mine = [nm for nm, o in zip(("libA", "libB", "libC"), owners) if o == rank]
+        for nm in ("libA", "libB", "libC"):
+            st = eng.schemas[nm].encode_stats
+            assert (st["passes"] == st["total_passes"]) == (nm in mine) and (st["computed_tokens"] > 0) == (nm in mine)
+        solo.add_schemas(texts)
+        worst_lib = 0.0
+        for nm in ("libA", "libB", "libC"):
+            a = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in solo.schemas[nm].cache_l1.values()), key=lambda t: t[:2])
+            b = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in eng.schemas[nm].cache_l1.values()), key=lambda t: t[:2])
+            assert [(o, n) for o, n, _ in a] == [(o, n) for o, n, _ in b]
+            worst_lib = max(worst_lib, max(float((x[2] - y[2]).abs().max()) for x, y in zip(a, b)))
+        assert worst_lib == 0.0, worst_lib          # same passes, same batches, same kernels on the owner: bit-identical
         dist.barrier()
         dist.destroy_process_group()
 

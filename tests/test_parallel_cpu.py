@@ -86,3 +86,70 @@ def test_allgather_segments_world2_gloo():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(0, True), (1, True)]
+
+
+def _slab_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        unit = 16
+        # "library" of 3 schemas; per schema the segment sizes per rank (schema 1 is owned by rank 1 alone: the
+        # schema-level sharding of CacheEngine.add_schemas; schemas 0 and 2 are pass-sharded over both ranks)
+        plans = [[[3, 1, 7], [2, 5]], [[], [4, 4, 1]], [[9], [1, 1]]]
+
+        def seg(k, r, j, n):
+            return (torch.arange(n * unit, dtype=torch.float32) * 0.5 + 1000 * k + 100 * r + 10 * j).to(torch.float16)
+
+        results, pending = [], []
+        for k, lens_by_rank in enumerate(plans):
+            sizes = [[n * unit for n in lens] for lens in lens_by_rank]
+            slab, views = parallel.carve(sizes[rank], torch.float16, "cpu")
+            assert all(v.data_ptr() % 16 == 0 for v in views)
+            for j, (v, n) in enumerate(zip(views, lens_by_rank[rank])):
+                v.copy_(seg(k, rank, j, n))                       # the "encode" writes through the views
+            views_by_rank, handles = parallel.exchange_slabs(slab, sizes, rank, world, "cpu", async_op=True)
+            assert views_by_rank[rank][0].data_ptr() == slab.data_ptr() if views else True     # own slab used in place
+            pending.append(handles)
+            results.append(views_by_rank)
+        for hs in pending:                                        # the exchanges overlap the later "encodes"
+            for h in hs:
+                h.wait()
+        ok = True
+        for k, lens_by_rank in enumerate(plans):
+            for r in range(world):
+                assert len(results[k][r]) == len(lens_by_rank[r])
+                for j, n in enumerate(lens_by_rank[r]):
+                    ok = ok and torch.equal(results[k][r][j], seg(k, r, j, n))
+        # a slab that does not match the plan is an error
+        try:
+            parallel.carve_views(torch.empty(5, dtype=torch.float16), [16])
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_slabs_world2_gloo_exact_sizes_async():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, True), (1, True)]
+
+
+def test_carve_lays_segments_out_16_byte_aligned():
+    slab, views = parallel.carve([5, 16, 3], torch.float16, "cpu")
+    assert slab.numel() == 8 + 16 + 8 and [v.numel() for v in views] == [5, 16, 3]
+    assert [(v.data_ptr() - slab.data_ptr()) // 2 for v in views] == [0, 8, 24]
+    assert [v.numel() for v in parallel.carve_views(slab, [5, 16, 3])] == [5, 16, 3]
+    empty, none = parallel.carve([], torch.float16, "cpu")
+    assert empty.numel() == 0 and none == []

@@ -599,7 +599,23 @@ def main():
                 past, tok = o2.past_key_values, int(torch.argmax(o2.logits[0, -1]))
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
         result["decode"] = {"tokens_per_s": nstep / dt, "ms_per_token": dt / nstep * 1e3, "kv_len": S + q + 2 * nstep,
-                            "how": "greedy steps through lm(), hipGraph replay per step (second block of 32 timed)"}
+                            "how": "greedy steps through lm(), hipGraph replay per step + host argmax (second block of 32 timed)"}
+        # the same generation as GenerationEngine runs it: device-side greedy loop (argmax + token feed inside the graph)
+        loop = lm.hf_model.greedy_loop(past, tok, max(pos2) + 2 + 2 * nstep, 4 * nstep)
+        if loop is not None:
+            for _ in range(nstep):
+                loop.enqueue()
+            loop.token(nstep - 1)                                  # warm: graph captured, code loaded
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(2 * nstep):
+                loop.enqueue()
+            last = loop.token(3 * nstep - 1)
+            dtl = time.perf_counter() - t0
+            result["decode_device_loop"] = {"tokens_per_s": 2 * nstep / dtl, "ms_per_token": dtl / (2 * nstep) * 1e3,
+                                            "kv_len": S + q + 5 * nstep, "last_token": last,
+                                            "how": "GreedyLoop: one hipGraph replay per token (forward + pc_greedy_advance), no "
+                                                   "host round trip; what GenerationEngine.generate uses for greedy decoding"}
+            del loop
     if rank == 0 and not args.no_context:
         # context: TTFT of a prompt whose new-token count has not been seen yet (an eager pass + hipGraph capture before
         # the first replay), then the same prompt again (replay): what a serving mix of question lengths pays once per length

@@ -343,6 +343,13 @@ int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w
                   int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
                   int64_t ldo, void* stream);
 
+/* Greedy decode without a host round trip per token (generation_engine.py:123-168, greedy branch :159): the tail of a
+ * captured decode step.  token = argmax(logits[0..vocab)) (lowest index among equal maxima); ids[0] = token, pos[0] += 1,
+ * past_len[0] += 1 -- the device words the NEXT replay of the same hipGraph reads its token id, position id and past
+ * length from -- and ring[counter % ring_cap] = token, counter += 1 for the host to collect tokens when it wants them. */
+int pc_greedy_advance(const float* logits, int32_t vocab, int64_t* ids, int32_t* pos, int32_t* past_len, int32_t* ring,
+                      int32_t* counter, int32_t ring_cap, void* stream);
+
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (probe_kernel in csrc/pc_misc.hip). */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);

@@ -252,6 +252,52 @@ __global__ void probe_kernel(float* out_mfma, float* out_tr) {
     for (int j = 0; j < 4; ++j) out_tr[256 + l * 4 + j] = (float)h1[j];
 }
 
+
+// ---- greedy decode step tail, on the device ------------------------------------------------------------------------
+// token = argmax(logits[0..V)) -- the lowest index among equal maxima, torch.argmax's answer on a contiguous row
+// (generation_engine.py:159: int(torch.argmax(last_token_logits))) -- stored where the NEXT replay of the captured
+// decode graph reads its inputs: ids[0] = token, pos[0] += 1, past[0] += 1; the token also goes to ring[ctr % cap] and
+// ctr is incremented.  One workgroup; the whole step stays on the GPU (no host round trip between decode steps).
+__global__ __launch_bounds__(1024) void greedy_advance_kernel(const float* __restrict__ logits, int V, int64_t* ids,
+                                                              int32_t* pos, int32_t* past, int32_t* ring, int32_t* ctr,
+                                                              int ring_cap) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid * 4; i < V; i += 4096) {
+        if (i + 3 < V) {
+            const f4 x = *(const f4*)(logits + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x[e] > best) { best = x[e]; bi = i + e; }
+        } else {
+            for (int e = 0; i + e < V; ++e)
+                if (logits[i + e] > best) { best = logits[i + e]; bi = i + e; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;                 // all -inf / NaN: torch returns index 0 for an all-equal row
+        ids[0] = bi;
+        pos[0] += 1;
+        past[0] += 1;
+        const int c = ctr[0];
+        ring[c % ring_cap] = bi;
+        ctr[0] = c + 1;
+    }
+}
+
 }  // namespace
 
 PC_EXPORT int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32_t hidden, float eps,
@@ -364,4 +410,14 @@ PC_EXPORT int pc_probe_layouts(float* out_mfma, float* out_tr, void* stream) {
     PC_REQUIRE(out_mfma && out_tr, PC_ERR_ARG, "pc_probe_layouts: null pointer");
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_mfma, out_tr);
     return pc_check_launch("probe_kernel");
+}
+
+PC_EXPORT int pc_greedy_advance(const float* logits, int32_t vocab, int64_t* ids, int32_t* pos, int32_t* past_len, int32_t* ring,
+                                int32_t* counter, int32_t ring_cap, void* stream) {
+    PC_REQUIRE(logits && ids && pos && past_len && ring && counter && vocab > 0 && ring_cap > 0, PC_ERR_ARG,
+               "pc_greedy_advance: null pointer or bad sizes");
+    PC_REQUIRE(((uintptr_t)logits & 15) == 0, PC_ERR_ARG, "pc_greedy_advance: logits must be 16-byte aligned");
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, vocab, ids, pos, past_len,
+                       ring, counter, ring_cap);
+    return pc_check_launch("greedy_advance_kernel");
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_attn_fwd_var": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                   _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
 }
 
@@ -466,3 +467,10 @@ def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out
                               (0 if y is None else y.stride(-2)) if ldy is None else ldy, _ptr(out_hi), _ptr(out_lo), ld_o,
                               current_stream() if stream is None else stream)
     check(rc, "pc_gemm_dense")
+
+
+def greedy_advance(logits, vocab: int, ids, pos, past, ring, counter, stream: Optional[int] = None) -> None:
+    """Tail of a captured greedy decode step (pc_greedy_advance): argmax -> the graph's own input words + the token ring."""
+    rc = load().pc_greedy_advance(logits.data_ptr(), vocab, ids.data_ptr(), pos.data_ptr(), past.data_ptr(), ring.data_ptr(),
+                                  counter.data_ptr(), ring.numel(), current_stream() if stream is None else stream)
+    check(rc, "pc_greedy_advance")

@@ -16,6 +16,7 @@ hipGraph (``model/llama_hip.py``).
 from __future__ import annotations
 
 import gc
+import os
 from dataclasses import dataclass, field
 from typing import Generator, List, Optional, Tuple
 
@@ -86,6 +87,9 @@ class _Timer:
 
 
 class GenerationEngine:
+    # decode greedy generations as a device-side loop when the model offers one (PC_DEVICE_GREEDY=0: step through lm())
+    device_greedy_loop = os.environ.get("PC_DEVICE_GREEDY", "1") != "0"
+
     def __init__(self, lm: LanguageModel, verbose: bool = False):
         self.lm = lm
         self.verbose = verbose
@@ -128,7 +132,32 @@ class GenerationEngine:
         total_ms = ttft_ms = 0.0
         past = None
 
+        # Greedy decoding whose processed argmax is the raw argmax (no repetition penalty: temperature, top-p and top-k
+        # all keep the largest logit largest) runs as a device-side loop when the model offers one: every step is one
+        # hipGraph replay that also picks the token and feeds it to the next replay (model/llama_hip.py GreedyLoop).
+        # The host keeps ONE replay in flight ahead of the token it is looking at, so stop conditions are evaluated
+        # exactly as below while the GPU never waits for the host; a step enqueued past a stop is simply discarded.
+        loop = None
+        want_loop = params.greedy and params.repetition_penalty <= 1.0 and not use_full_position_ids and \
+            hasattr(getattr(self.lm, "hf_model", None), "greedy_loop") and self.device_greedy_loop
+
         for step in range(params.max_new_tokens):
+            if loop is not None:
+                if loop.n <= step and loop.n < params.max_new_tokens - 1:
+                    loop.enqueue()                             # the replay AFTER the one whose token is read below
+                token = loop.token(step - 1)
+                total_ms += loop.elapsed_ms(step - 1)
+                output_ids.append(token)
+                new_ids.append(token)
+                done = token in params.stop_token_ids
+                if step % stream_interval == 0 or step == params.max_new_tokens - 1 or done:
+                    text, new_text, hit, partial = self._render(output_ids, new_ids, params.stop_str)
+                    done = done or hit
+                    if not partial:
+                        yield Output(text, new_text, total_ms, ttft_ms)
+                if done:
+                    break
+                continue
             if step == 0:
                 if cache is not None and not isinstance(cache, StagedKV):
                     # a plain list of [Hkv, S, D] views: add the batch dim like the reference does (:101-102)
@@ -156,6 +185,11 @@ class GenerationEngine:
                     yield Output(text, new_text, total_ms, ttft_ms)
             if done:
                 break
+            if step == 0 and want_loop and params.max_new_tokens > 1:
+                # the first decoded token sits at position first_free + 1 (the reference's loop index starts at 1, :132)
+                loop = self.lm.hf_model.greedy_loop(past, token, first_free + 1, params.max_new_tokens)
+                if loop is not None:
+                    loop.enqueue()
 
-        del past
+        del past, loop
         gc.collect()

@@ -42,6 +42,71 @@ class CausalLMOutput:
     past_key_values: Optional[StagedKV]
 
 
+class GreedyLoop:
+    """Greedy decode steps that never leave the GPU (reference loop: generation_engine.py:123-168, greedy branch).
+
+    Every step is one replay of a captured hipGraph whose last node (``pc_greedy_advance``) takes the argmax of the
+    step's logits and writes it -- with position + 1 and past length + 1 -- into the device words the next replay reads
+    its inputs from.  The host only enqueues replays (as far ahead as it likes) and picks tokens up from a small ring
+    through pinned memory when it needs them for stop conditions; there is no ``int(argmax)`` sync, no H2D fill and no
+    logits copy per token.  ``enqueue()`` -> slot index; ``token(i)`` waits for slot i only."""
+
+    RING = 4096
+
+    def __init__(self, model: "LlamaHIP", arena: KVArena, token: int, position: int, max_new: int):
+        self.m = model
+        past_len = arena.length
+        need = past_len + max_new + 2
+        if need > arena.cap:
+            arena = arena.grown(max(need, 2 * arena.cap))
+        self.arena = arena
+        st = model._loop_state()
+        self.st = st
+        dev = model.device
+        st["ids"].copy_(torch.tensor([token], dtype=torch.int64), non_blocking=True)
+        st["pos"].copy_(torch.tensor([position], dtype=torch.int32), non_blocking=True)
+        st["ctr"].zero_()
+        self.len0 = past_len
+        self.n = 0                       # replays enqueued
+        self._last_ent = None
+        self.events = []                 # (start, end) per slot
+        self.host = torch.empty(self.RING, dtype=torch.int32, pin_memory=True)
+
+    def enqueue(self) -> int:
+        m, a, st = self.m, self.arena, self.st
+        past_len = self.len0 + self.n
+        m._lo_mode = m._tail_mode(a, 1, past_len)
+        ent = m._loop_graph(a, past_len)
+        # host-known words of the step (the kernels read past_len / tail base from the device)
+        if self.n == 0 or ent is not self._last_ent:
+            st["past"][0:1].fill_(past_len)
+            if m._lo_mode == 2:
+                st["past"][1:2].fill_(a.tail_base)
+        self._last_ent = ent
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ent[0].replay()
+        e1.record()
+        i = self.n
+        self.host[i % self.RING: i % self.RING + 1].copy_(st["ring"][i % self.RING: i % self.RING + 1], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self.events.append((e0, e1, done))
+        a.length = past_len + 1
+        m._tail_done(a, m._lo_mode, 1, past_len)
+        self.n += 1
+        return i
+
+    def token(self, i: int) -> int:
+        self.events[i][2].synchronize()
+        return int(self.host[i % self.RING])
+
+    def elapsed_ms(self, i: int) -> float:
+        e0, e1, done = self.events[i]
+        done.synchronize()
+        return e0.elapsed_time(e1)
+
+
 class LlamaHIP:
     """Weights live on one MI355X in fp16; ``wqkv`` and ``wgu`` are the row-concatenated q|k|v and
     gate|up projections so each is one GEMM."""
@@ -79,6 +144,7 @@ class LlamaHIP:
         self._kv_only = False      # set per call (see __call__)
         self._past_lens = None     # set per call: per-row past lengths of a ragged-prefix encode batch
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
+        self.supports_greedy_loop = True    # decode steps can run as a device-side loop (GreedyLoop)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
@@ -456,6 +522,61 @@ class LlamaHIP:
             st_past[1:2].fill_(arena.tail_base)
         g.replay()
         return out.clone()
+
+    def _loop_state(self) -> dict:
+        """Device words shared by every captured decode-loop graph of this model: token id, position id, {past length,
+        residual-tail base}, the token ring and its counter (see GreedyLoop)."""
+        st = getattr(self, "_loop_st", None)
+        if st is None:
+            dev = self.device
+            st = dict(ids=torch.zeros(1, dtype=torch.int64, device=dev), pos=torch.zeros(1, dtype=torch.int32, device=dev),
+                      past=torch.zeros(2, dtype=torch.int32, device=dev), ring=torch.zeros(GreedyLoop.RING, dtype=torch.int32, device=dev),
+                      ctr=torch.zeros(1, dtype=torch.int32, device=dev))
+            self._loop_st = st
+        return st
+
+    def _loop_graph(self, arena: KVArena, past_len: int):
+        """The captured graph of ONE greedy decode step over ``arena`` (forward of the token in the loop state + argmax +
+        state advance), keyed like ``_graphed_skinny``."""
+        n = _native
+        nsplit_key = n.attn_workspace_bytes(1, self.H, self.D, 1, past_len + 1)
+        mode = self._lo_mode
+        key = ("loop", arena.buf.data_ptr(), arena.cap, nsplit_key, self.fuse_norm, mode,
+               arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0)
+        ent = self._graphs.pop(key, None)
+        if ent is not None:
+            self._graphs[key] = ent
+            return ent
+        if len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
+        st = self._loop_state()
+        st["past"][0:1].fill_(past_len)
+        if mode == 2:
+            st["past"][1:2].fill_(arena.tail_base)
+        V = self.config.vocab_size
+        # one eager pass first (loads code objects / sizes the allocator): it rewrites the K / V row the first replay
+        # writes again and does not touch the loop state
+        self._forward_skinny(st["ids"], st["pos"], st["past"], arena, 1, 1, past_len, False, None)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._forward_skinny(st["ids"], st["pos"], st["past"], arena, 1, 1, past_len, False, None)
+            n.greedy_advance(out, V, st["ids"], st["pos"], st["past"], st["ring"], st["ctr"])
+        ent = (g, out)
+        self._graphs[key] = ent
+        return ent
+
+    def greedy_loop(self, past, token: int, position: int, max_new: int) -> Optional["GreedyLoop"]:
+        """A device-side greedy decode loop over the arena behind ``past`` (None when this model / cache cannot host one:
+        the caller then steps through ``__call__``)."""
+        if not (self.skinny and self.use_graphs and self.supports_greedy_loop):
+            return None
+        found = arena_from_past(past, self.L, self.Hkv, self.D)
+        if found is None or found[0].B != 1:
+            return None
+        arena, S = found
+        arena.length = S
+        return GreedyLoop(self, arena, token, position, max_new)
 
     def _tail_for(self, arena, past_dev):
         """Per-layer ``((k_lo, v_lo, batch_stride, head_stride, lo_row0) | None, lo_base)`` for the current tail mode."""

@@ -75,6 +75,7 @@ class MptHIP(LlamaHIP):
         self.softmax_scale = 1.0 / math.sqrt(self.D)            # mpt.py:139-140
         self.fuse_norm = False       # LayerNorm is not a per-row scale: no norm folding into the projections
         self.supports_ragged_past = False   # ALiBi takes one position row per batch row, laid out for ONE past length
+        self.supports_greedy_loop = False   # every step re-bases the per-key position row on the host (see __call__)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

@@ -599,3 +599,64 @@ def test_ragged_suffix_batches_store_the_same_module_kv_as_per_union_batches():
     worst = max(float((x[2] - y[2]).abs().max()) for x, y in zip(stores[True], stores[False]))
     print(f"ragged vs per-union suffix batches: max |dKV| = {worst:.2e}")
     assert worst < 4e-3        # an fp16 ulp of O(1) values where fp32 sums in different tile shapes round across a tie
+
+
+@pytest.mark.parametrize("family", ["llama", "falcon"])
+def test_device_greedy_loop_equals_stepping_through_the_model(family):
+    """GenerationEngine's device-side greedy loop (one hipGraph replay per token: forward + argmax + state advance, no host
+    round trip) must emit exactly the tokens of the per-step path (lm() call + host argmax), including across an arena
+    growth, with a stop token ending the generation at the same place."""
+    from promptcache_amd import CacheEngine, GenerationEngine, GenerationParameters, Prompt, synth
+    from promptcache_amd.model import Falcon, Llama2
+    from promptcache_amd.model.config import FALCON_SHAPES, SHAPES
+    from promptcache_amd.model.weights import make_falcon_weights_np, make_weights_np
+    if family == "falcon":
+        lm = Falcon(name="x", shape=FALCON_SHAPES["falcon-mid"], weights=make_falcon_weights_np(FALCON_SHAPES["falcon-mid"], 4, 3.0), device="cuda:0")
+    else:
+        lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 4, 3.0), device="cuda:0")
+    sp, pp = synth.flat_docs("gl", 12, (40, 33), 9, seed=6)
+    fmt = lm.get_formatter()
+    eng = CacheEngine(160, lm)                     # S + q + 100 new tokens > 160: the loop must grow the arena up front
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+
+    def run(device_loop, stop_ids, n_new):
+        GenerationEngine.device_greedy_loop = device_loop
+        ids, pos, _, cache = eng.process(prompt)
+        params = GenerationParameters(temperature=0.0, max_new_tokens=n_new, stop_token_ids=stop_ids, stop_str=[])
+        outs = list(GenerationEngine(lm).generate(ids, pos, params, cache, stream_interval=3))
+        return outs
+
+    try:
+        a = run(True, [], 100)
+        b = run(False, [], 100)
+        assert a[-1].new_text == b[-1].new_text and len(a) == len(b)
+        assert [o.new_text for o in a] == [o.new_text for o in b]
+        assert a[-1].elapsed_time > 0 and a[-1].response_time > a[-1].elapsed_time
+        toks = lm.encode(b[-1].new_text)
+        # stop at a token that shows up mid-way: same truncation on both paths
+        from collections import Counter
+        ref_ids = None
+        GenerationEngine.device_greedy_loop = False
+        ids, pos, _, cache = eng.process(prompt)
+        full = list(GenerationEngine(lm).generate(ids, pos, GenerationParameters(temperature=0.0, max_new_tokens=40, stop_token_ids=[],
+                                                                                 stop_str=[]), cache, stream_interval=1))
+        texts = [o.new_text for o in full]
+        assert len(texts) == 40
+        # find the generated token at step 17 by decoding differences is tokenizer-dependent; use the model directly
+        ids, pos, _, cache = eng.process(prompt)
+        out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"), past_key_values=cache, use_cache=True)
+        seq, past, p0 = [], out.past_key_values, max(pos) + 1
+        tok = int(torch.argmax(out.logits[0, -1]))
+        for i in range(20):
+            seq.append(tok)
+            o = lm(input_ids=torch.tensor([[tok]], device="cuda"), position_ids=torch.tensor([[p0 + 1 + i]], device="cuda"),
+                   past_key_values=past, use_cache=True)
+            past, tok = o.past_key_values, int(torch.argmax(o.logits[0, -1]))
+        stop = seq[12]
+        first = seq.index(stop)
+        s1 = run(True, [stop], 60)
+        s2 = run(False, [stop], 60)
+        assert s1[-1].new_text == s2[-1].new_text == lm.decode(seq[:first + 1])
+    finally:
+        GenerationEngine.device_greedy_loop = True

@@ -1237,3 +1237,30 @@ def test_ragged_past_rope_append_and_attention_match_oracle_row_by_row(two):
         ref = orc.attention_core(qq.cpu().numpy().transpose(0, 2, 1, 3), kk.cpu().numpy(), vv.cpu().numpy(), p, H // Hkv)
         ref = ref.transpose(0, 2, 1, 3).reshape(q_len, H * D)
         np.testing.assert_allclose(one[0].cpu().numpy(), ref, atol=4e-3 if not two else 2.5e-3, rtol=1e-2)
+
+
+def test_greedy_advance_argmax_ties_and_state_words():
+    """pc_greedy_advance: argmax with the lowest index among equal maxima (torch.argmax on a contiguous row), written to
+    the loop's device words; position and past length advance by one; the ring records the tokens in order."""
+    n = _n()
+    rng = np.random.default_rng(3)
+    ids = torch.zeros(1, dtype=torch.int64, device=DEV)
+    pos = torch.tensor([41], dtype=torch.int32, device=DEV)
+    past = torch.tensor([1700, 7], dtype=torch.int32, device=DEV)
+    ring = torch.full((8,), -1, dtype=torch.int32, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    want = []
+    for V in (32000, 32016, 50432, 1027, 5):
+        x = rng.standard_normal(V).astype(np.float32)
+        if V > 100:
+            top = x.max() + 1.0
+            where = sorted(rng.choice(V, size=3, replace=False).tolist())
+            x[where] = top                                     # three equal maxima: the first one wins
+        t = torch.zeros(V + 4, dtype=torch.float32, device=DEV)[:V]
+        t.copy_(torch.from_numpy(x))
+        n.greedy_advance(t, V, ids, pos, past, ring, ctr)
+        torch.cuda.synchronize()
+        want.append(int(np.argmax(x)))
+        assert int(ids[0]) == want[-1] == int(torch.argmax(t))
+    assert int(pos[0]) == 41 + 5 and past.tolist() == [1705, 7] and int(ctr[0]) == 5
+    assert ring[:5].tolist() == want and ring[5:].tolist() == [-1, -1, -1]

@@ -53,6 +53,7 @@ class GreedyLoop:
 
     RING = 4096
 
+    @torch.inference_mode()
     def __init__(self, model: "LlamaHIP", arena: KVArena, token: int, position: int, max_new: int):
         self.m = model
         past_len = arena.length
@@ -72,6 +73,7 @@ class GreedyLoop:
         self.events = []                 # (start, end) per slot
         self.host = torch.empty(self.RING, dtype=torch.int32, pin_memory=True)
 
+    @torch.inference_mode()
     def enqueue(self) -> int:
         m, a, st = self.m, self.arena, self.st
         past_len = self.len0 + self.n
@@ -523,6 +525,7 @@ class LlamaHIP:
         g.replay()
         return out.clone()
 
+    @torch.inference_mode()
     def _loop_state(self) -> dict:
         """Device words shared by every captured decode-loop graph of this model: token id, position id, {past length,
         residual-tail base}, the token ring and its counter (see GreedyLoop)."""

@@ -630,6 +630,16 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
         if (forced == 4) { PC_GO(4); return pc_check_launch("gemm_skinny_kernel"); }
     }
     if (forced == 2) { PC_GO(2); return pc_check_launch("gemm_skinny_kernel"); }
+    if constexpr (MT * TT <= 2) {
+        // one or two tiles per workgroup (the N = hidden projections): measured in-graph on the 7b shapes
+        // (tools/gemm_n4096_sweep.py), k-steps per block 4 / 8 / 16: o_proj 9.3 / 9.8 / 9.5 us at 12 rows, 8.0 / 8.9 / 8.9 at
+        // one row; down_proj 24.3 / 24.7 / 23.2 at 12 rows, 19.1 / 20.9 / 21.8 at one row -- shallow blocks win except for
+        // the long-K launch with its activation loads (more than 4 rows), which wants the deep one
+        if (!forced) {
+            if (p.M > 4 && p.KS >= 256) { PC_GO(16); } else { PC_GO(4); }
+            return pc_check_launch("gemm_skinny_kernel");
+        }
+    }
     PC_GO(UD);
 #undef PC_GO
     return pc_check_launch("gemm_skinny_kernel");

@@ -143,6 +143,10 @@ class LlamaHIP:
         # fp32 for the whole generation, llama2.py:361-388, generation_engine.py:123-147; the arena still holds the fp16
         # values).  See _tail_mode / _dense_pass_lo.
         self.new_kv_lo = os.environ.get("PC_NEW_KV_LO", "1") != "0"
+        # ... and keep doing so through the DECODE steps of a generation (every decoded row gets a residual, every step's
+        # attention reads residual tiles): decode logits 5e-5 from the oracle instead of 2-4e-3 -- both far inside the
+        # 1e-2 bar -- for ~5 % of the decode rate.  Opt-in (PC_DECODE_TAIL=1 or model.decode_tail = True).
+        self.decode_tail = os.environ.get("PC_DECODE_TAIL", "0") == "1"
         self._kv_only = False      # set per call (see __call__)
         self._past_lens = None     # set per call: per-row past lengths of a ragged-prefix encode batch
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
@@ -244,6 +248,8 @@ class LlamaHIP:
             arena.ensure_tail(q_len + self.TAIL_HEADROOM)
             return 1
         t = arena.tail_lo
+        if not self.decode_tail:
+            return 0
         # (a caller may rewind the arena by a few rows: the tail then still covers [tail_base, past_len))
         if t is not None and 0 <= arena.tail_base <= past_len <= arena.tail_base + arena.tail_len and \
                 past_len - arena.tail_base + 1 <= t.shape[4]:

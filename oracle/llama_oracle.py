@@ -163,6 +163,11 @@ class LlamaOracle:
         self.cfg = cfg
         self.w = {k: np.asarray(v, dtype=F32) for k, v in weights.items()}
 
+    def _lin(self, x: np.ndarray, key: str) -> np.ndarray:
+        """``nn.Linear`` without bias: ``x @ W^T`` in fp32.  (One overridable place: ``oracle/llmint8_oracle.py`` swaps in
+        the LLM.int8 linear for the decoder-layer projections.)"""
+        return x @ self.w[key].T
+
     def forward(self, input_ids: np.ndarray, position_ids: np.ndarray,
                 past: Optional[Sequence[Tuple[np.ndarray, np.ndarray]]] = None,
                 n_layers: Optional[int] = None, want_attn0: bool = False):
@@ -184,9 +189,9 @@ class LlamaOracle:
         for i in range(L):
             res = x
             h = rmsnorm(x, w[f"l{i}.ln1"], c.rms_norm_eps)
-            q = (h @ w[f"l{i}.wq"].T).reshape(B, ql, H, D).transpose(0, 2, 1, 3)
-            k = (h @ w[f"l{i}.wk"].T).reshape(B, ql, Hkv, D).transpose(0, 2, 1, 3)
-            v = (h @ w[f"l{i}.wv"].T).reshape(B, ql, Hkv, D).transpose(0, 2, 1, 3)
+            q = self._lin(h, f"l{i}.wq").reshape(B, ql, H, D).transpose(0, 2, 1, 3)
+            k = self._lin(h, f"l{i}.wk").reshape(B, ql, Hkv, D).transpose(0, 2, 1, 3)
+            v = self._lin(h, f"l{i}.wv").reshape(B, ql, Hkv, D).transpose(0, 2, 1, 3)
             q = apply_rope(q, cos, sin)
             k = apply_rope(k, cos, sin)
             if past is not None:  # llama2.py:361-364
@@ -197,10 +202,10 @@ class LlamaOracle:
             a = a.transpose(0, 2, 1, 3).reshape(B, ql, H * D)
             if i == 0:
                 attn0 = a
-            x = res + a @ w[f"l{i}.wo"].T
+            x = res + self._lin(a, f"l{i}.wo")
             res = x
             h = rmsnorm(x, w[f"l{i}.ln2"], c.rms_norm_eps)
-            x = res + (silu(h @ w[f"l{i}.gate"].T) * (h @ w[f"l{i}.up"].T)) @ w[f"l{i}.down"].T
+            x = res + self._lin(silu(self._lin(h, f"l{i}.gate")) * self._lin(h, f"l{i}.up"), f"l{i}.down")
         x = rmsnorm(x, w["norm"], c.rms_norm_eps)
         logits = (x @ w["lm_head"].T).astype(F32)  # llama2.py:1050-1051, all q rows
         if want_attn0:

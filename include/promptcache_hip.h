@@ -343,6 +343,40 @@ int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w
                   int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
                   int64_t ldo, void* stream);
 
+/* ---- LLM.int8(): int8 weights AND int8 activations with the fp16 outlier decomposition -------------------------------
+ * What load_in_8bit=True means in the reference's GPU runs (demo.py:27-29, eval.py:36-42, config/llm_config_*.json:5 ->
+ * transformers -> bitsandbytes.nn.Linear8bitLt(threshold = 6.0)).  bitsandbytes is not part of the reference tree: these
+ * entry points implement its published algorithm (Dettmers et al., NeurIPS 2022, section 3; csrc/pc_int8.hip; CPU
+ * restatement oracle/llmint8_oracle.py) and replace, per decoder-layer nn.Linear, the call Linear8bitLt.forward makes.
+ *
+ * pc_quant_act_i8: x = fp16 activations, row-major [T][ldx] (frag = 0) or a fragment-major plane [T/16][K/32][64][8]
+ *   (frag = 1; pc_gemm.hip).  Per row: entries |x| >= threshold are outliers (their column gets flags_set[k] = 1), the
+ *   rest is quantised vector-wise: codes = round_half_even(x * 127 / absmax_row) as fp16 values in the layout of x,
+ *   x_scale[t] = absmax_row / 127.  flags_clear (optional, K bytes): zeroed for the next activation slot.
+ * pc_outlier_corr: corr[t][n] = sum over flagged columns k of x[t][k] * fp16(w_codes[r][k] * w_scale[r])
+ *   - codes[t][k] * w_codes[r][k] * x_scale[t] * w_scale[r],  r = row_perm ? row_perm[n] : n  (w_codes: the weight codes
+ *   held in fp16, row-major [N][ldw]); *has = 1 when any column is flagged, else 0 and corr is left untouched.
+ * pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 / pc_gemm_dense_a8: the projections over the codes,
+ *   y = (sum_k w_code[n][k] * x_code[m][k]) * w_scale[n] * x_scale[m] + (*corr_has ? corr[m][n] : 0), then the epilogue of
+ *   pc_gemm_skinny / pc_gemm_qkv_rope_ex / pc_gemm_dense (same epilogue codes and outputs). */
+int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale, void* flags_set,
+                    void* flags_clear, float threshold, void* stream);
+int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
+                    const float* x_scale, const void* w_codes, int64_t ldw, const float* w_scale, const int32_t* row_perm,
+                    int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream);
+int pc_gemm_skinny_a8(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
+                      const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K,
+                      int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
+int pc_gemm_qkv_rope_a8(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
+                        const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t K,
+                        const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
+                        int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
+                        int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
+                        int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
+int pc_gemm_dense_a8(const void* xq, int64_t ldx, const void* w_codes, int64_t ldw, const float* w_scale, const float* x_scale,
+                     const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                     float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream);
+
 /* Greedy decode without a host round trip per token (generation_engine.py:123-168, greedy branch :159): the tail of a
  * captured decode step.  token = argmax(logits[0..vocab)) (lowest index among equal maxima); ids[0] = token, pos[0] += 1,
  * past_len[0] += 1 -- the device words the NEXT replay of the same hipGraph reads its token id, position id and past

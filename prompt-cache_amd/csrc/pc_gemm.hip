@@ -77,6 +77,10 @@ struct GemmParams {
     // int8 weights (W8 kernels, M <= 64): wf is the fragment image of OFFSET-BINARY bytes (q + 128), 8 B per lane per
     // k-step, wscale[n] the fp32 scale of output feature n (row order of the image); y = scale * sum_k q[n][k] x[k]
     const float* wscale; int32_t w8;
+    // LLM.int8 activations (pc_int8.hip): the activation planes hold int8 CODES, xscale[m] = SCA[m] / 127 rescales row m, and
+    // corr[m][n] (row stride ldc, output-feature index in the image's row order) is added before the epilogue's
+    // nonlinearity when *corr_has != 0 (the fp16 outlier part of the decomposition)
+    const float* xscale; const float* corr; int64_t ldc; const int32_t* corr_has;
     RopeEpi rope;
 };
 
@@ -260,6 +264,19 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
         if (EPI == EPI_SILU) {
             const f4 su = *(const f4*)(p.wscale + (p.npairs + unit) * 16 + g * 4);
             u[0] *= su[0]; u[1] *= su[1]; u[2] *= su[2]; u[3] *= su[3];
+        }
+    }
+    if (p.xscale && unit < nunits && row < p.M) {
+        const float xs = p.xscale[row];
+        v[0] *= xs; v[1] *= xs; v[2] *= xs; v[3] *= xs;
+        if (EPI == EPI_SILU) { u[0] *= xs; u[1] *= xs; u[2] *= xs; u[3] *= xs; }
+        if (*p.corr_has) {
+            const f4 cv = *(const f4*)(p.corr + (int64_t)row * p.ldc + unit * 16 + g * 4);
+            v[0] += cv[0]; v[1] += cv[1]; v[2] += cv[2]; v[3] += cv[3];
+            if (EPI == EPI_SILU) {
+                const f4 cu = *(const f4*)(p.corr + (int64_t)row * p.ldc + (p.npairs + unit) * 16 + g * 4);
+                u[0] += cu[0]; u[1] += cu[1]; u[2] += cu[2]; u[3] += cu[3];
+            }
         }
     }
     if (unit < nunits && row < p.M) {
@@ -898,8 +915,11 @@ int choose_T(int units) {
 namespace {
 int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma, float eps,
                      int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
-                     int32_t kslices, void* stream, const float* wscale = nullptr) {
+                     int32_t kslices, void* stream, const float* wscale = nullptr, const float* xscale = nullptr,
+                     const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr) {
     PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
+    PC_REQUIRE(!xscale || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0 && kslices == 1),
+               PC_ERR_ARG, "pc_gemm_skinny_a8: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N), corr_has, no K-slices");
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
     PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && (epilogue == EPI_STORE || epilogue == EPI_SILU)), PC_ERR_ARG,
@@ -911,6 +931,7 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
     PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
                "pc_gemm_skinny_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
     p.wscale = wscale; p.w8 = wscale ? 1 : 0;
+    p.xscale = xscale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
     p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
     PC_REQUIRE(kslices >= 1 && kslices <= 16 && (kslices == 1 || epilogue == EPI_STORE), PC_ERR_ARG,
@@ -940,7 +961,8 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                        const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
-                       const float* wscale = nullptr, int32_t lo_base = -1);
+                       const float* wscale = nullptr, int32_t lo_base = -1, const float* xscale = nullptr,
+                       const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr);
 }  // namespace
 
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
@@ -987,7 +1009,8 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                        const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
-                       const float* wscale, int32_t lo_base) {
+                       const float* wscale, int32_t lo_base, const float* xscale, const float* corr, int64_t ldc,
+                       const int32_t* corr_has) {
     const int N = (H + 2 * Hkv) * D;
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
@@ -1002,6 +1025,9 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
     PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
                "pc_gemm_qkv_rope_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
     p.wscale = wscale; p.w8 = wscale ? 1 : 0;
+    PC_REQUIRE(!xscale || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0), PC_ERR_ARG,
+               "pc_gemm_qkv_rope_a8: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N) and corr_has");
+    p.xscale = xscale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
     p.y = nullptr; p.ldy = 0; p.of_hi = nullptr; p.of_lo = nullptr; p.KSo = 0;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.kslices = 1; p.slab_stride = 0;
     p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
@@ -1100,4 +1126,30 @@ PC_EXPORT int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm
     return gemm_qkv_rope_impl(wf_perm, xf_hi, xf_lo, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
                               v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
                               past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base);
+}
+
+// ---- LLM.int8 (int8 weights AND int8 activations, pc_int8.hip) -------------------------------------------------------
+// xq_hi holds the activation CODES of pc_quant_act_i8 as an fp16 fragment plane (|code| <= 127: exact), xq_lo a plane of zeros;
+// y = (sum_k code_w[n][k] * code_x[m][k]) * w_scale[n] * x_scale[m]  (+ corr[m][n] when *corr_has) through the epilogue.
+// The integer dot product is accumulated in fp32 by the fp16 MFMAs: exact below 2^24 per accumulator.
+PC_EXPORT int pc_gemm_skinny_a8(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
+                                const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K,
+                                int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream) {
+    PC_REQUIRE(xq_hi && xq_lo && w_scale && x_scale, PC_ERR_ARG, "pc_gemm_skinny_a8: null pointer");
+    return gemm_skinny_impl(wf8, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream, w_scale,
+                            x_scale, corr, ldc, corr_has);
+}
+
+PC_EXPORT int pc_gemm_qkv_rope_a8(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
+                                  const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M,
+                                  int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena,
+                                  void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H,
+                                  int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
+                                  const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
+                                  int64_t lo_head_stride, int32_t lo_base, void* stream) {
+    PC_REQUIRE(xq_hi && xq_lo && w_scale_perm && x_scale, PC_ERR_ARG, "pc_gemm_qkv_rope_a8: null pointer");
+    return gemm_qkv_rope_impl(wf8_perm, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
+                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
+                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base,
+                              x_scale, corr, ldc, corr_has);
 }

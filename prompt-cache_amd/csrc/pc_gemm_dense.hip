@@ -54,6 +54,9 @@ struct DenseParams {
     const _Float16* xh; const _Float16* xl; int64_t ldx;   // [M][K] planes (xl may be null), row stride in halfs
     const _Float16* w; int64_t ldw;                        // [N][K]
     const float* wscale;                                   // optional per-output-row scale (int8 codes held in fp16)
+    // LLM.int8 (pc_int8.hip): xh holds activation CODES, xscale[m] = SCA[m] / 127; corr[m][n] (global weight-row index n) is
+    // added before the epilogue's nonlinearity when *corr_has != 0
+    const float* xscale; const float* corr; int64_t ldc; const int32_t* corr_has;
     const _Float16* zeros;                                 // >= 16 B of zeros: source of activation chunks past K
     float* y; int64_t ldy;                                 // EPI_STORE / EPI_ADD
     _Float16* oh; _Float16* ol; int64_t ldo;               // EPI_SILU / EPI_GELU output planes
@@ -260,6 +263,17 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
                     g[0] *= sg[0]; g[1] *= sg[1]; g[2] *= sg[2]; g[3] *= sg[3];
                     u[0] *= su[0]; u[1] *= su[1]; u[2] *= su[2]; u[3] *= su[3];
                 }
+                if (p.xscale) {
+                    const float xs = p.xscale[m];
+                    g[0] *= xs; g[1] *= xs; g[2] *= xs; g[3] *= xs;
+                    u[0] *= xs; u[1] *= xs; u[2] *= xs; u[3] *= xs;
+                    if (*p.corr_has) {
+                        const f4 cg = *(const f4*)(p.corr + (int64_t)m * p.ldc + fbase);
+                        const f4 cu = *(const f4*)(p.corr + (int64_t)m * p.ldc + p.nfeat + fbase);
+                        g[0] += cg[0]; g[1] += cg[1]; g[2] += cg[2]; g[3] += cg[3];
+                        u[0] += cu[0]; u[1] += cu[1]; u[2] += cu[2]; u[3] += cu[3];
+                    }
+                }
                 h4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -283,6 +297,14 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
             if (p.wscale) {
                 const f4 sv = *(const f4*)(p.wscale + n);
                 v[0] *= sv[0]; v[1] *= sv[1]; v[2] *= sv[2]; v[3] *= sv[3];
+            }
+            if (p.xscale) {
+                const float xs = p.xscale[m];
+                v[0] *= xs; v[1] *= xs; v[2] *= xs; v[3] *= xs;
+                if (*p.corr_has) {
+                    const f4 cv = *(const f4*)(p.corr + (int64_t)m * p.ldc + n);
+                    v[0] += cv[0]; v[1] += cv[1]; v[2] += cv[2]; v[3] += cv[3];
+                }
             }
             if (EPI == EPI_GELU) {
                 h4 hi, lo;
@@ -334,9 +356,10 @@ int launch_dense_tile(DenseParams& p, hipStream_t s) {
 
 }  // namespace
 
-PC_EXPORT int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw,
-                            const float* w_scale, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy,
-                            void* out_hi, void* out_lo, int64_t ldo, void* stream) {
+namespace {
+int gemm_dense_impl(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw, const float* w_scale,
+                    const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N,
+                    int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream) {
     PC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0, PC_ERR_ARG, "pc_gemm_dense: need M, N, K > 0, K%%8==0, N%%4==0");
     PC_REQUIRE(x_hi && w, PC_ERR_ARG, "pc_gemm_dense: null pointer");
     PC_REQUIRE(ldx >= K && ldw >= K && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w & 15) == 0 &&
@@ -346,6 +369,9 @@ PC_EXPORT int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, con
     memset(&p, 0, sizeof(p));
     p.xh = (const _Float16*)x_hi; p.xl = (const _Float16*)x_lo; p.ldx = ldx;
     p.w = (const _Float16*)w; p.ldw = ldw; p.wscale = w_scale;
+    PC_REQUIRE(!x_scale || (w_scale && !x_lo && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0), PC_ERR_ARG,
+               "pc_gemm_dense_a8: int8 activations need w_scale, no lo plane, corr (16-byte aligned, ldc >= N) and corr_has");
+    p.xscale = x_scale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
     p.M = M; p.N = N; p.K = K;
     void* z = nullptr;
     if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero_chunk)) != hipSuccess || !z) {
@@ -371,4 +397,24 @@ PC_EXPORT int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, con
     if (epilogue == EPI_ADD) return launch_dense_tile<EPI_ADD>(p, s);
     PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_dense: unknown epilogue %d", epilogue);
     return launch_dense_tile<EPI_STORE>(p, s);
+}
+}  // namespace
+
+PC_EXPORT int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw,
+                            const float* w_scale, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy,
+                            void* out_hi, void* out_lo, int64_t ldo, void* stream) {
+    return gemm_dense_impl(x_hi, x_lo, ldx, w, ldw, w_scale, nullptr, nullptr, 0, nullptr, M, N, K, epilogue, y, ldy, out_hi,
+                           out_lo, ldo, stream);
+}
+
+// LLM.int8 form of pc_gemm_dense (pc_int8.hip): xq = activation CODES of pc_quant_act_i8 held in fp16 (row-major [M][K]), w =
+// weight codes held in fp16, y = (sum_k w[n][k] * xq[m][k]) * w_scale[n] * x_scale[m] (+ corr[m][n] when *corr_has), then
+// the epilogue.  The integer dot product is accumulated in fp32 by the fp16 MFMAs: exact below 2^24 per accumulator.
+PC_EXPORT int pc_gemm_dense_a8(const void* xq, int64_t ldx, const void* w_codes, int64_t ldw, const float* w_scale,
+                               const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M,
+                               int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
+                               int64_t ldo, void* stream) {
+    PC_REQUIRE(w_scale && x_scale, PC_ERR_ARG, "pc_gemm_dense_a8: null pointer");
+    return gemm_dense_impl(xq, nullptr, ldx, w_codes, ldw, w_scale, x_scale, corr, ldc, corr_has, M, N, K, epilogue, y, ldy,
+                           out_hi, out_lo, ldo, stream);
 }

@@ -1,0 +1,185 @@
+// LLM.int8() activation side (the reference's GPU configs load every model with load_in_8bit=True: demo.py:27-29,
+// eval.py:36-42, config/llm_config_*.json:5 -> transformers -> bitsandbytes.nn.Linear8bitLt(threshold = 6.0)).
+// bitsandbytes is a third-party dependency that is not in the reference tree; what is implemented is its published
+// algorithm (Dettmers et al., "LLM.int8()", NeurIPS 2022, section 3; restated on the CPU in oracle/llmint8_oracle.py):
+//
+//   X  = fp16(input)                                   [T][K]
+//   O  = {k : |X[t][k]| >= threshold for some t}       outlier columns
+//   X0 = X with every entry |x| >= threshold zeroed;   SCA[t] = max_k |X0[t][k]|
+//   CA = round_half_even(X0 * 127 / SCA), columns in O zeroed
+//   Y  = (CA . CB^T) * SCA[t] * SCB[n] / 127^2  +  X[:, O] . fp16(CB[:, O] * SCB / 127)^T
+//
+// Two kernels around the projection launch (pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 below 65 rows, pc_gemm_dense above):
+//   quant_act_kernel     one workgroup per row: outlier test, row absmax without the outliers, codes (held in fp16: |code|
+//                        <= 127 is exact, the projection kernels run their fp16 MFMAs on them with fp32 accumulation --
+//                        exact integers below 2^24 per accumulator), x_scale[t] = SCA[t] / 127, and one flag byte per
+//                        outlier column.  Only the outlier ENTRIES are zeroed here.
+//   outlier_corr_kernel  compacts the flagged columns (deterministic order) and writes
+//                            corr[t][n] = sum_{k in O} ( X[t][k] * fp16(CB[n][k] * scale[n])  -  CA[t][k] * CB[n][k] * x_scale[t] * scale[n] )
+//                        i.e. the fp16 part of the decomposition MINUS what the int8 product still carries in those columns
+//                        for rows whose own entry is not an outlier -- algebraically the "zero the whole column" of the
+//                        published form, without a second pass over CA.  The projection's epilogue adds corr before its
+//                        nonlinearity when *has != 0.  With no outlier (the usual case behind a norm) the kernel ends after
+//                        the flag scan.
+// Layouts: activations either row-major [T][ld] or the fragment-major planes of pc_gemm.hip ([M/16][K/32][64][8]).
+#include <hip/hip_fp16.h>
+
+#include "pc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
+    return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
+}
+
+template <int G, bool FRAG>
+__global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restrict__ x, int64_t ld, int K, _Float16* __restrict__ codes,
+                                                        float* __restrict__ x_scale, unsigned char* __restrict__ flags_set,
+                                                        unsigned char* __restrict__ flags_clear, float threshold) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, nchunk = K >> 3, KS = K >> 5;
+    // the flag bytes of the NEXT activation slot are cleared here (its quantiser runs after this launch, its last reader ran
+    // long before): no memset node, no race with this slot's own flags
+    if (flags_clear)
+        for (int k = row * 256 + tid; k < K; k += gridDim.x * 256) flags_clear[k] = 0;
+    float a[G][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int c = tid + i * 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[i][e] = 0.f;
+        if (c < nchunk) {
+            const int64_t off = FRAG ? frag_off(row, c * 8, KS) : (int64_t)row * ld + c * 8;
+            const h8 v = *(const h8*)(x + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                const bool outl = threshold > 0.f && fabsf(f) >= threshold;
+                if (outl) flags_set[c * 8 + e] = 1;
+                a[i][e] = outl ? 0.f : f;
+                mx = fmaxf(mx, fabsf(a[i][e]));
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    const float sca = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float inv = sca > 0.f ? 127.0f / sca : 0.f;
+    if (tid == 0) x_scale[row] = sca / 127.0f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int c = tid + i * 256;
+        if (c < nchunk) {
+            h8 q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r = rintf(a[i][e] * inv);
+                r = fminf(fmaxf(r, -127.f), 127.f);
+                q[e] = (_Float16)r;
+            }
+            const int64_t off = FRAG ? frag_off(row, c * 8, KS) : (int64_t)row * ld + c * 8;
+            *(h8*)(codes + off) = q;
+        }
+    }
+}
+
+constexpr int kMaxCols = 1024;      // outlier columns handled per batch of the correction kernel
+
+template <bool FRAG>
+__global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* __restrict__ flags, int K, const _Float16* __restrict__ x,
+                                                           const _Float16* __restrict__ codes, int64_t ldx, const float* __restrict__ x_scale,
+                                                           const _Float16* __restrict__ cb, int64_t ldw, const float* __restrict__ w_scale,
+                                                           const int32_t* __restrict__ row_perm, int T, int N, float* __restrict__ corr,
+                                                           int64_t ldc, int32_t* __restrict__ has) {
+    __shared__ int cols[kMaxCols];
+    __shared__ int cnt[257];
+    const int tid = threadIdx.x, KS = K >> 5;
+    // ---- deterministic compaction of the flagged columns: thread i owns the contiguous range [i*per, (i+1)*per) ----
+    const int per = (K + 255) / 256;
+    int mine = 0;
+    for (int k = tid * per; k < (tid + 1) * per && k < K; ++k) mine += flags[k] ? 1 : 0;
+    cnt[tid + 1] = mine;
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int i = 1; i <= 256; ++i) cnt[i] += cnt[i - 1];
+    __syncthreads();
+    const int total = cnt[256];
+    if (total == 0) {
+        if (blockIdx.x == 0 && tid == 0) has[0] = 0;
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) has[0] = 1;
+    const int nl = tid & 63, tg = tid >> 6;                   // 64 output columns x 4 row groups per workgroup
+    const int n = blockIdx.x * 64 + nl;
+    const int nrow = n < N ? (row_perm ? row_perm[n] : n) : 0;
+    const float ws = n < N ? w_scale[nrow] : 0.f;
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        const int t = t0 + tg;
+        float acc = 0.f;
+        for (int base = 0; base < total; base += kMaxCols) {
+            __syncthreads();
+            {   // this batch of the column list (in column order)
+                int w = cnt[tid] - base;
+                for (int k = tid * per; k < (tid + 1) * per && k < K; ++k)
+                    if (flags[k]) { if (w >= 0 && w < kMaxCols) cols[w] = k; ++w; }
+            }
+            __syncthreads();
+            const int nb = total - base < kMaxCols ? total - base : kMaxCols;
+            if (t < T && n < N) {
+                const float xs = x_scale[t] * ws;
+                for (int j = 0; j < nb; ++j) {
+                    const int k = cols[j];
+                    const int64_t xo = FRAG ? frag_off(t, k, KS) : (int64_t)t * ldx + k;
+                    const float xv = (float)x[xo], ca = (float)codes[xo];
+                    const float wq = (float)cb[(int64_t)nrow * ldw + k];
+                    const float wd = (float)(_Float16)(wq * ws);            // fp16(CB * SCB / 127): the fp16 weight column
+                    acc += xv * wd - ca * wq * xs;
+                }
+            }
+        }
+        if (t < T && n < N) corr[(int64_t)t * ldc + n] = acc;
+    }
+}
+
+}  // namespace
+
+PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale,
+                              void* flags_set, void* flags_clear, float threshold, void* stream) {
+    PC_REQUIRE(T > 0 && K > 0 && K % 32 == 0 && K <= 16384, PC_ERR_ARG, "pc_quant_act_i8: need T > 0, K %% 32 == 0, K <= 16384");
+    PC_REQUIRE(x && codes && x_scale && flags_set, PC_ERR_ARG, "pc_quant_act_i8: null pointer");
+    PC_REQUIRE(frag || (ldx >= K && ldx % 8 == 0), PC_ERR_ARG, "pc_quant_act_i8: row-major planes need ldx >= K, ldx %% 8 == 0");
+    const int groups = pc_ceil_div(K / 8, 256);
+    hipStream_t s = (hipStream_t)stream;
+#define PC_Q(GV)                                                                                                          \
+    do {                                                                                                                  \
+        if (frag) hipLaunchKernelGGL((quant_act_kernel<GV, true>), dim3(T), dim3(256), 0, s, (const _Float16*)x, ldx, K,  \
+                                     (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, threshold); \
+        else hipLaunchKernelGGL((quant_act_kernel<GV, false>), dim3(T), dim3(256), 0, s, (const _Float16*)x, ldx, K,       \
+                                (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, threshold); \
+    } while (0)
+    if (groups <= 1) PC_Q(1); else if (groups <= 2) PC_Q(2); else if (groups <= 4) PC_Q(4); else PC_Q(8);
+#undef PC_Q
+    return pc_check_launch("quant_act_kernel");
+}
+
+PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
+                              const float* x_scale, const void* w_codes, int64_t ldw, const float* w_scale, const int32_t* row_perm,
+                              int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream) {
+    PC_REQUIRE(T > 0 && N > 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_outlier_corr: bad sizes");
+    PC_REQUIRE(flags && x && codes && x_scale && w_codes && w_scale && corr && has && ldc >= N, PC_ERR_ARG, "pc_outlier_corr: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(pc_ceil_div(N, 64));
+    if (frag)
+        hipLaunchKernelGGL((outlier_corr_kernel<true>), grid, dim3(256), 0, s, (const unsigned char*)flags, K, (const _Float16*)x,
+                           (const _Float16*)codes, ldx, x_scale, (const _Float16*)w_codes, ldw, w_scale, row_perm, T, N, corr, ldc, has);
+    else
+        hipLaunchKernelGGL((outlier_corr_kernel<false>), grid, dim3(256), 0, s, (const unsigned char*)flags, K, (const _Float16*)x,
+                           (const _Float16*)codes, ldx, x_scale, (const _Float16*)w_codes, ldw, w_scale, row_perm, T, N, corr, ldc, has);
+    return pc_check_launch("outlier_corr_kernel");
+}

@@ -64,6 +64,12 @@ SIGNATURES = {
     "pc_attn_fwd_var": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                   _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp]),
+    "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "pc_gemm_skinny_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "pc_gemm_qkv_rope_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
+                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "pc_gemm_dense_a8": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
 }
 
@@ -474,3 +480,55 @@ def greedy_advance(logits, vocab: int, ids, pos, past, ring, counter, stream: Op
     rc = load().pc_greedy_advance(logits.data_ptr(), vocab, ids.data_ptr(), pos.data_ptr(), past.data_ptr(), ring.data_ptr(),
                                   counter.data_ptr(), ring.numel(), current_stream() if stream is None else stream)
     check(rc, "pc_greedy_advance")
+
+
+# ---- LLM.int8 (pc_int8.hip) -------------------------------------------------------------------------------------------
+LLM_INT8_THRESHOLD = 6.0        # transformers' llm_int8_threshold default, what load_in_8bit=True runs with
+
+
+def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags_clear=None, threshold: float = LLM_INT8_THRESHOLD,
+                 ldx: Optional[int] = None, stream: Optional[int] = None) -> None:
+    """LLM.int8 activation quantiser: fp16 ``x`` (row-major [T, ld] or a fragment plane) -> ``codes`` (fp16, same layout),
+    ``x_scale`` [T] fp32, outlier-column flag bytes."""
+    rc = load().pc_quant_act_i8(x.data_ptr(), (0 if frag else x.stride(-2)) if ldx is None else ldx, int(frag), T, K, codes.data_ptr(),
+                                x_scale.data_ptr(), flags_set.data_ptr(), _ptr(flags_clear), threshold,
+                                current_stream() if stream is None else stream)
+    check(rc, "pc_quant_act_i8")
+
+
+def outlier_corr(flags, K: int, x, codes, frag: bool, x_scale, w_codes, w_scale, row_perm, T: int, N: int, corr, has,
+                 ldx: Optional[int] = None, stream: Optional[int] = None) -> None:
+    rc = load().pc_outlier_corr(flags.data_ptr(), K, x.data_ptr(), codes.data_ptr(), (0 if frag else x.stride(-2)) if ldx is None else ldx,
+                                int(frag), x_scale.data_ptr(), w_codes.data_ptr(), w_codes.stride(-2), w_scale.data_ptr(),
+                                _ptr(row_perm), T, N, corr.data_ptr(), corr.stride(-2), has.data_ptr(),
+                                current_stream() if stream is None else stream)
+    check(rc, "pc_outlier_corr")
+
+
+def gemm_skinny_a8(wf8, w_scale, xq, zeros, x_scale, corr, has, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,
+                   of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
+    rc = load().pc_gemm_skinny_a8(wf8.data_ptr(), w_scale.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
+                                  corr.data_ptr(), corr.stride(-2), has.data_ptr(), M, N, K, epilogue, _ptr(y), ldy, _ptr(of_hi),
+                                  _ptr(of_lo), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_skinny_a8")
+
+
+def gemm_qkv_rope_a8(wf8, w_scale, xq, zeros, x_scale, corr, has, M: int, K: int, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs,
+                     B, H, Hkv, D, q_len, past_len, cap, past_len_dev=None, kv_lo=None, lo_base: int = -1,
+                     stream: Optional[int] = None) -> None:
+    rc = load().pc_gemm_qkv_rope_a8(wf8.data_ptr(), w_scale.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
+                                    corr.data_ptr(), corr.stride(-2), has.data_ptr(), M, K, cs.data_ptr(), q_hi.data_ptr(),
+                                    q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len,
+                                    past_len, cap, _ptr(past_len_dev), None if not kv_lo else kv_lo[0].data_ptr(),
+                                    None if not kv_lo else kv_lo[1].data_ptr(), 0 if not kv_lo else kv_lo[2],
+                                    0 if not kv_lo else kv_lo[3], lo_base, current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_qkv_rope_a8")
+
+
+def gemm_dense_a8(xq, w_codes, w_scale, x_scale, corr, has, M: int, N: int, K: int, epilogue: int, y=None, out_hi=None, out_lo=None,
+                  stream: Optional[int] = None) -> None:
+    rc = load().pc_gemm_dense_a8(xq.data_ptr(), xq.stride(-2), w_codes.data_ptr(), w_codes.stride(-2), w_scale.data_ptr(),
+                                 x_scale.data_ptr(), corr.data_ptr(), corr.stride(-2), has.data_ptr(), M, N, K, epilogue, _ptr(y),
+                                 0 if y is None else y.stride(-2), _ptr(out_hi), _ptr(out_lo),
+                                 0 if out_hi is None else out_hi.stride(-2), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_dense_a8")

@@ -151,6 +151,7 @@ class LlamaHIP:
         self._past_lens = None     # set per call: per-row past lengths of a ragged-prefix encode batch
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
         self.supports_greedy_loop = True    # decode steps can run as a device-side loop (GreedyLoop)
+        self.llm_int8 = False
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
@@ -185,8 +186,18 @@ class LlamaHIP:
         # (the int8 images are cut on pairs of 32-feature k-steps: every GEMM K must be a multiple of 64)
         self.int8_weights = bool(int8_weights) and self.skinny and c.hidden_size % 64 == 0 and \
             c.intermediate_size % 64 == 0 and (self.H * self.D) % 64 == 0
+        # load_in_8bit on the Llama family = LLM.int8() as published (int8 weights AND vector-wise int8 activations with the
+        # fp16 outlier decomposition, threshold 6.0: what the reference's GPU runs execute through bitsandbytes;
+        # csrc/pc_int8.hip, oracle/llmint8_oracle.py).  PC_INT8_WEIGHT_ONLY=1 keeps round 1's weight-only mode instead
+        # (split-precision fp16 activations over the int8 weights) -- the mode the Falcon / MPT adapters still run.
+        self.llm_int8 = self.int8_weights and os.environ.get("PC_INT8_WEIGHT_ONLY", "0") != "1"
         if self.int8_weights:
             self.MID_MAX_ROWS = self.SKINNY_MAX_ROWS      # the row-split kernel has no int8 variant: 65+ rows go dense
+        if self.llm_int8:
+            kmax = max(c.hidden_size, c.intermediate_size, self.H * self.D)
+            self._i8_flags = torch.zeros((4, kmax), dtype=torch.uint8, device=dev)       # outlier-column flags, one per slot
+            self._i8_zero = torch.zeros(((self.SKINNY_MAX_ROWS + 15) // 16) * 16 * kmax, dtype=self.dtype, device=dev)
+            self.fuse_norm = False                        # activations are quantised between the norm and the projection
 
         prep = self._prep_linear
 
@@ -209,7 +220,9 @@ class LlamaHIP:
         self.inv_freq_cpu = 1.0 / (c.rope_theta ** (torch.arange(0, self.D, 2).float() / self.D))
         self.inv_freq = self.inv_freq_cpu.to(dev)
         self.softmax_scale = 1.0 / math.sqrt(self.D)
-        self.fuse_norm = os.environ.get("PC_FUSE_NORM", "1") != "0"
+        self.fuse_norm = os.environ.get("PC_FUSE_NORM", "1") != "0" and not getattr(self, "llm_int8", False)
+        if self.skinny:
+            self._qkv_perm_i32 = self._qkv_perm.to(torch.int32).contiguous()
 
     # ------------------------------------------------------------------------------------------
     def new_arena(self, batch: int, cap: int) -> KVArena:
@@ -397,6 +410,8 @@ class LlamaHIP:
         path (the module KV an encode stores drifts the same way).  Both planes meet the same weight fragments inside
         the GEMM tile; Q, P and the pass's own K / V rows are split-precision in the attention as well.
         PC_FAST_DENSE=1: the hi plane only (half the MFMA work, fp16-activation accuracy)."""
+        if self.llm_int8:
+            return self._forward_dense_int8(ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers)
         n = _native
         dev = self.device
         two = self.precise_dense
@@ -460,6 +475,157 @@ class LlamaHIP:
         norm(x, self.norm, T)
         logits = torch.empty((T, V), dtype=f32, device=dev)
         self._proj(h2[0], lo(h2), head, "lm_head", T, V, hid, n.EPI_STORE, y=logits)   # llama2.py:1050-1051: every row
+        return logits.view(B, q_len, V)
+
+    # ------------------------------------------------------------------------------------------
+    # LLM.int8 layer stacks (load_in_8bit=True): every decoder-layer projection input is quantised vector-wise to int8 codes
+    # (pc_quant_act_i8), the projection runs over weight codes x activation codes and is rescaled by w_scale[n] * x_scale[m]
+    # in its epilogue, and columns holding an activation >= 6 are carried in fp16 (pc_outlier_corr) -- Dettmers et al. 2022 as
+    # bitsandbytes' Linear8bitLt applies it.  Norms, RoPE, attention, residual stream and lm_head are the fp16-mode kernels.
+    def _i8_lin_frag(self, slot, act_hi, K, lw, key, perm, T, N, bufs):
+        """Quantise a fragment-plane activation (its hi plane is the fp16 value bitsandbytes would see) and prepare the outlier
+        correction for projection ``key``: -> (codes, x_scale, corr, has)."""
+        n = _native
+        codes, xs, corr, has = bufs
+        n.quant_act_i8(act_hi, True, T, K, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
+        n.outlier_corr(self._i8_flags[slot], K, act_hi, codes, True, xs, lw[key], lw[key + "_ds"], perm, T, N, corr, has)
+        return codes, xs, corr, has
+
+    def _forward_skinny_int8(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
+        n = _native
+        dev = self.device
+        c = self.config
+        H, Hkv, D, hid, inter = self.H, self.Hkv, self.D, c.hidden_size, c.intermediate_size
+        T = B * q_len
+        W = (H + 2 * Hkv) * D
+        eps = c.rms_norm_eps
+        mt = (T + 15) // 16
+        f32 = torch.float32
+        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
+        x = h16.float()
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len), 4) // 4, dtype=f32, device=dev)
+        tail = self._tail_for(arena, past_dev)
+
+        def planes(k, cnt=2):
+            return tuple(torch.empty((mt, k // 32, 64, 8), dtype=self.dtype, device=dev) for _ in range(cnt))
+
+        xh, xl, xq = planes(hid, 3)
+        ah, al, aq = planes(H * D, 3)
+        ch, cl, cq = planes(inter, 3)
+        zero = self._i8_zero
+        has = torch.zeros(4, dtype=torch.int32, device=dev)
+        bufs = [(xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, W), dtype=f32, device=dev), has[0:1]),
+                (aq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[1:2]),
+                (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3]),
+                (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4])]
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        for li, lw in enumerate(layers):
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kvlo, lo_base = tail(li)
+            n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps)
+            cd, xs, corr, hs = self._i8_lin_frag(0, xh, hid, lw, "wqkv", self._qkv_perm_i32, T, W, bufs[0])
+            n.gemm_qkv_rope_a8(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, corr, hs, T, hid, cs, q16, q16l, H * D, kp, vp,
+                               arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
+                               kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                       B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                       q_lo=q16l, kv_lo=kvlo)
+            cd, xs, corr, hs = self._i8_lin_frag(1, ah, H * D, lw, "wo", None, T, hid, bufs[1])
+            n.gemm_skinny_a8(lw["wo_f"], lw["wo_s"], cd, zero, xs, corr, hs, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
+            n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps)
+            cd, xs, corr, hs = self._i8_lin_frag(2, xh, hid, lw, "wgu", None, T, 2 * inter, bufs[2])
+            n.gemm_skinny_a8(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, corr, hs, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)
+            cd, xs, corr, hs = self._i8_lin_frag(3, ch, inter, lw, "wdown", None, T, hid, bufs[3])
+            n.gemm_skinny_a8(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, corr, hs, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)
+        V = c.vocab_size
+        if last_token_only:
+            xlast = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            lh, ll = planes(hid)
+            n.rmsnorm_frag(xlast, self.norm, lh, ll, B, hid, eps)
+            logits = torch.empty((B, V), dtype=f32, device=dev)
+            n.gemm_skinny(self.lm_head_f, lh, ll, B, V, hid, n.EPI_STORE, y=logits, ldy=V)
+            return logits.view(B, 1, V)
+        n.rmsnorm_frag(x, self.norm, xh, xl, T, hid, eps)
+        logits = torch.empty((T, V), dtype=f32, device=dev)
+        n.gemm_skinny(self.lm_head_f, xh, xl, T, V, hid, n.EPI_STORE, y=logits, ldy=V)
+        return logits.view(B, q_len, V)
+
+    def _forward_dense_int8(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Many-row LLM.int8 stack: row-major activations, pc_gemm_dense_a8 over the codes.  Q, P and the pass's own K / V rows
+        stay split-precision in the attention, as in the fp16 mode."""
+        n = _native
+        dev = self.device
+        H, Hkv, D, hid = self.H, self.Hkv, self.D, self.config.hidden_size
+        inter = self.config.intermediate_size
+        T = B * q_len
+        W = (H + 2 * Hkv) * D
+        eps = self.config.rms_norm_eps
+        f32 = torch.float32
+        cs = torch.empty((T, D // 2, 2), dtype=f32, device=dev)
+        n.rope_table(pos32, self.inv_freq, cs, T, D)
+        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        n.embed_gather(self.embed, ids, h16, T, hid, self.config.vocab_size)
+        x = h16.float()
+        hq = torch.empty((T, hid), dtype=self.dtype, device=dev)
+        attn2 = torch.empty((2, T, H * D), dtype=self.dtype, device=dev)
+        aq = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        act = torch.empty((T, inter), dtype=self.dtype, device=dev)
+        cq = torch.empty((T, inter), dtype=self.dtype, device=dev)
+        q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)
+        qkv = torch.empty((T, W), dtype=f32, device=dev)
+        xs = torch.empty(T, dtype=f32, device=dev)
+        corr = torch.empty(T * max(W, 2 * inter), dtype=f32, device=dev)
+        has = torch.zeros(4, dtype=torch.int32, device=dev)
+        lo_for, full_lo = self._dense_pass_lo(arena, B, Hkv, q_len, past_len)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        layers = self.layers if num_layers is None else self.layers[:num_layers]
+        fl = self._i8_flags
+
+        def lin(slot, a16, codes, K, lw, key, N, epi, **out):
+            n.quant_act_i8(a16, False, T, K, codes, xs, fl[slot], fl[(slot + 1) % 4])
+            cv = corr[:T * N].view(T, N)
+            n.outlier_corr(fl[slot], K, a16, codes, False, xs, lw[key], lw[key + "_ds"], None, T, N, cv, has[slot:slot + 1])
+            n.gemm_dense_a8(codes, lw[key], lw[key + "_ds"], xs, cv, has[slot:slot + 1], T, N, K, epi, **out)
+
+        for li, lw in enumerate(layers):
+            n.rmsnorm(x, lw["ln1"], h16, T, hid, eps, True)
+            lin(0, h16, hq, hid, lw, "wqkv", W, n.EPI_STORE, y=qkv)
+            kp, vp = arena.k_plane(li), arena.v_plane(li)
+            kv_lo = lo_for(li)
+            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
+                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
+                          q_out_lo=q16l, kv_lo=kv_lo, past_lens=self._past_lens)
+            if self._kv_only and li == len(layers) - 1:
+                break
+            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
+                       q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
+                       out_lo=attn2[1], kv_lo=kv_lo, past_lens=self._past_lens)
+            lin(1, attn2[0], aq, H * D, lw, "wo", hid, n.EPI_ADD, y=x)
+            n.rmsnorm(x, lw["ln2"], h16, T, hid, eps, True)
+            lin(2, h16, hq, hid, lw, "wgu", 2 * inter, n.EPI_SILU, out_hi=act)
+            lin(3, act, cq, inter, lw, "wdown", hid, n.EPI_ADD, y=x)
+        if full_lo:
+            arena.lo_len = past_len + q_len
+        if self._kv_only:
+            return None
+        V = self.config.vocab_size
+        head = {"lm_head": self.lm_head}
+        h2 = torch.empty((2, T, hid), dtype=self.dtype, device=dev)
+        if last_token_only:
+            xl = x.view(B, q_len, hid)[:, -1, :].contiguous()
+            n.rmsnorm_split(xl, self.norm, h2[0], h2[1], B, hid, eps)
+            logits = torch.empty((B, V), dtype=f32, device=dev)
+            self._proj(h2[0, :B], h2[1, :B], head, "lm_head", B, V, hid, n.EPI_STORE, y=logits)
+            return logits.view(B, 1, V)
+        n.rmsnorm_split(x, self.norm, h2[0], h2[1], T, hid, eps)
+        logits = torch.empty((T, V), dtype=f32, device=dev)
+        self._proj(h2[0], h2[1], head, "lm_head", T, V, hid, n.EPI_STORE, y=logits)
         return logits.view(B, q_len, V)
 
     # ------------------------------------------------------------------------------------------
@@ -600,6 +766,8 @@ class LlamaHIP:
         launch over fragment-major weights with split-precision (hi/lo fp16) activations; residual adds and
         SiLU*up are fused into GEMM epilogues; RMSNorm and attention emit the fragment planes directly.
         ``past_dev`` (device int32[1]) makes the pass graph-capturable: the kernels read past_len from it."""
+        if self.llm_int8:
+            return self._forward_skinny_int8(ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers)
         n = _native
         dev = self.device
         c = self.config

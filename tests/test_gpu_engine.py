@@ -368,11 +368,15 @@ def test_host_memory_tier_stages_the_same_bytes_and_logits():
         CacheEngine(64, lm, module_memory="disk")
 
 
+@pytest.mark.parametrize("mode", ["llm_int8", "weight_only"])
 @pytest.mark.parametrize("shape_name,seed", [("mid64", 21), ("mid64_gqa", 22)])
-def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed):
-    """``load_in_8bit=True`` (the reference's GPU configs): weight-only int8 for the decoder linears.  The oracle runs the
-    ordinary fp32 path over the DEQUANTISED weights (oracle/int8_oracle.py); cached prefill and greedy decode stream the
-    int8 fragment images, the schema encode runs hipBLASLt on the dequantised weights rounded to fp16."""
+def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed, mode, monkeypatch):
+    """``load_in_8bit=True`` (the reference's GPU configs).  Default on the Llama family: LLM.int8() as published -- int8
+    weights, vector-wise int8 activations, fp16 outlier columns (threshold 6.0) -- against oracle/llmint8_oracle.py through
+    schema encode (many-row path), cached prefill and greedy decode (weight-streaming path).  ``PC_INT8_WEIGHT_ONLY=1``:
+    round 1's weight-only mode against the ordinary fp32 oracle over the DEQUANTISED weights (oracle/int8_oracle.py)."""
+    if mode == "weight_only":
+        monkeypatch.setenv("PC_INT8_WEIGHT_ONLY", "1")
     from promptcache_amd import CacheEngine, Prompt
     from promptcache_amd.model import Llama2
     from promptcache_amd.model.config import SHAPES
@@ -384,6 +388,7 @@ def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed
     w16 = make_weights_np(shape, seed, 2.0)
     lm = Llama2(name="x", shape=shape, weights=w16, device="cuda:0", load_in_8bit=True)
     assert lm.hf_model.int8_weights and lm.hf_model.layers[0]["wqkv_s"] is not None
+    assert lm.hf_model.llm_int8 == (mode == "llm_int8")
     eng = CacheEngine(256, lm)
     eng.add_schema(lm.get_formatter()(str(g["schema_text"])))
     prompt = Prompt(str(g["prompt_text"]), [lm.get_formatter()])
@@ -397,6 +402,9 @@ def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed
     wd = io.dequantized_llama_weights({k: v.astype(np.float32) for k, v in w16.items()})
     assert not np.array_equal(wd["l0.wq"], w16["l0.wq"].astype(np.float32)) and np.array_equal(wd["lm_head"], w16["lm_head"].astype(np.float32))
     model = LlamaOracle(cfg, wd)
+    if mode == "llm_int8":
+        from oracle.llmint8_oracle import LlamaInt8Oracle
+        model = LlamaInt8Oracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
     sc = eng.get_schema("trip")
     jobs = []
     for p in sc.encode_paths():
@@ -419,9 +427,11 @@ def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed
     ref16 = LlamaOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()})
     lib16 = eo.encode_schema(ref16, jobs)
     _, _, (logits16, _) = eo.cached_prefill(ref16, lib16, used, ids, pos, 256)
-    print(f"[int8 {shape_name}] end to end {err:.2e}; on oracle-staged KV {err2:.2e}; int8 vs fp16 weights (oracle) "
+    print(f"[int8 {mode} {shape_name}] end to end {err:.2e}; on oracle-staged KV {err2:.2e}; int8 vs fp16 weights (oracle) "
           f"{np.abs(logits16 - logits).max():.2e}")
-    assert err < LOGIT_TOL and err2 < 2e-3
+    # (LLM.int8: an activation within an fp32 ulp of a quantisation tie may land on the neighbouring code on the two sides;
+    # one code is 1/127 of the row's largest activation times one weight)
+    assert err < LOGIT_TOL and err2 < (5e-3 if mode == "llm_int8" else 2e-3)
     # four decode steps, teacher-forced with the oracle's greedy tokens (hipGraph replay, int8 images, M = 1)
     past, olog = out2.past_key_values, logits
     for i in range(4):

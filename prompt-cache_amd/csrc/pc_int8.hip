@@ -37,13 +37,13 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
 template <int G, bool FRAG>
 __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restrict__ x, int64_t ld, int K, _Float16* __restrict__ codes,
                                                         float* __restrict__ x_scale, unsigned char* __restrict__ flags_set,
-                                                        unsigned char* __restrict__ flags_clear, float threshold) {
+                                                        unsigned char* __restrict__ flags_clear, int clear_len, float threshold) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x, nchunk = K >> 3, KS = K >> 5;
     // the flag bytes of the NEXT activation slot are cleared here (its quantiser runs after this launch, its last reader ran
     // long before): no memset node, no race with this slot's own flags
     if (flags_clear)
-        for (int k = row * 256 + tid; k < K; k += gridDim.x * 256) flags_clear[k] = 0;
+        for (int k = row * 256 + tid; k < clear_len; k += gridDim.x * 256) flags_clear[k] = 0;
     float a[G][8];
     float mx = 0.f;
 #pragma unroll
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
 }  // namespace
 
 PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale,
-                              void* flags_set, void* flags_clear, float threshold, void* stream) {
+                              void* flags_set, void* flags_clear, int32_t clear_len, float threshold, void* stream) {
     PC_REQUIRE(T > 0 && K > 0 && K % 32 == 0 && K <= 16384, PC_ERR_ARG, "pc_quant_act_i8: need T > 0, K %% 32 == 0, K <= 16384");
     PC_REQUIRE(x && codes && x_scale && flags_set, PC_ERR_ARG, "pc_quant_act_i8: null pointer");
     PC_REQUIRE(frag || (ldx >= K && ldx % 8 == 0), PC_ERR_ARG, "pc_quant_act_i8: row-major planes need ldx >= K, ldx %% 8 == 0");
@@ -159,9 +159,9 @@ PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t 
 #define PC_Q(GV)                                                                                                          \
     do {                                                                                                                  \
         if (frag) hipLaunchKernelGGL((quant_act_kernel<GV, true>), dim3(T), dim3(256), 0, s, (const _Float16*)x, ldx, K,  \
-                                     (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, threshold); \
+                                     (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold); \
         else hipLaunchKernelGGL((quant_act_kernel<GV, false>), dim3(T), dim3(256), 0, s, (const _Float16*)x, ldx, K,       \
-                                (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, threshold); \
+                                (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold); \
     } while (0)
     if (groups <= 1) PC_Q(1); else if (groups <= 2) PC_Q(2); else if (groups <= 4) PC_Q(4); else PC_Q(8);
 #undef PC_Q

@@ -64,7 +64,7 @@ SIGNATURES = {
     "pc_attn_fwd_var": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                   _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp]),
+    "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_skinny_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "pc_gemm_qkv_rope_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
@@ -491,7 +491,8 @@ def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags
     """LLM.int8 activation quantiser: fp16 ``x`` (row-major [T, ld] or a fragment plane) -> ``codes`` (fp16, same layout),
     ``x_scale`` [T] fp32, outlier-column flag bytes."""
     rc = load().pc_quant_act_i8(x.data_ptr(), (0 if frag else x.stride(-2)) if ldx is None else ldx, int(frag), T, K, codes.data_ptr(),
-                                x_scale.data_ptr(), flags_set.data_ptr(), _ptr(flags_clear), threshold,
+                                x_scale.data_ptr(), flags_set.data_ptr(), _ptr(flags_clear),
+                                0 if flags_clear is None else flags_clear.numel(), threshold,
                                 current_stream() if stream is None else stream)
     check(rc, "pc_quant_act_i8")
 

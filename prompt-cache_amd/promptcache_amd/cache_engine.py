@@ -222,7 +222,7 @@ class SchemaCache:
         # trunk's prefix rows" -- the very cached-prefill the engine exists for -- instead of from scratch (the
         # reference re-encodes every scaffold in full, cache_engine.py:221-248).
         prefix = [0] * len(jobs)
-        if self.share_trunk and len(jobs) > 1:
+        if self.share_trunk and len(jobs) > 1 and self._batch_invariant():
             t_ids, t_pos = jobs[0]["token_ids"], jobs[0]["position_ids"]
             for i in range(1, len(jobs)):
                 ids, pos = jobs[i]["token_ids"], jobs[i]["position_ids"]
@@ -417,6 +417,12 @@ class SchemaCache:
     # pack suffix passes of different unions into one batch (per-row past lengths; models with supports_ragged_past)
     ragged_suffix_batches = os.environ.get("PC_RAGGED_SUFFIX", "1") != "0"
 
+    def _batch_invariant(self) -> bool:
+        """False when a row's result depends on which other rows travel in the same forward -- LLM.int8 picks its fp16
+        outlier COLUMNS over all rows of a call (model/llama_hip.py ``llm_int8``).  The reference encodes one whole scaffold
+        per call (``batch_size`` 1, cache_engine.py:232-248), so such a model gets exactly that: no trunk reuse, no packing."""
+        return bool(getattr(getattr(self.lm, "hf_model", None), "batch_invariant", True))
+
     def _pack(self, mine: List[int], lengths: List[int], batch_size: int) -> List[List[int]]:
         """Group this rank's scaffold passes into right-padded batches.  ``batch_size`` is the reference's knob
         (``cache_engine.py:232``: consecutive passes, in order); with the default of 1 the engine packs on its own:
@@ -424,6 +430,8 @@ class SchemaCache:
         rows run at ~75 % of their M ~ 5000 rate on MI355X, and padded rows never influence real ones."""
         if batch_size > 1:
             return [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
+        if not self._batch_invariant():
+            return [[i] for i in mine]
         order = sorted(mine, key=lambda i: (-lengths[i], i))
         groups, cur = [], []
         for i in order:

@@ -152,6 +152,7 @@ class LlamaHIP:
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
         self.supports_greedy_loop = True    # decode steps can run as a device-side loop (GreedyLoop)
         self.llm_int8 = False
+        self.batch_invariant = True         # a row's result does not depend on the other rows of the forward (see llm_int8)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
@@ -198,6 +199,7 @@ class LlamaHIP:
             self._i8_flags = torch.zeros((4, kmax), dtype=torch.uint8, device=dev)       # outlier-column flags, one per slot
             self._i8_zero = torch.zeros(((self.SKINNY_MAX_ROWS + 15) // 16) * 16 * kmax, dtype=self.dtype, device=dev)
             self.fuse_norm = False                        # activations are quantised between the norm and the projection
+            self.batch_invariant = False                  # the fp16 outlier columns are chosen over ALL rows of a call
 
         prep = self._prep_linear
 

@@ -106,9 +106,9 @@ def test_llm_int8_linear_matches_the_oracle(path, with_outliers):
     n = _n()
     T, K, N = (12, 4096, 512) if path == "skinny" else (300, 4096, 768)
     outl = [(0, 5, 8.5), (3, 5, -7.25), (T - 1, 4000, 6.0), (1, 77, 30.0)] if with_outliers else []
-    x = _acts(T, K, seed=9, outliers=outl)
-    if with_outliers:
-        x[:, 77] *= 1.0                                       # column 77: one outlier entry, ordinary entries in the other rows
+    x = _acts(T, K, seed=9, outliers=outl)                    # (column 77: one outlier entry, ordinary entries in the other rows)
+    if not with_outliers:
+        x = np.clip(x, -5.9, 5.9)
     rng = np.random.default_rng(1)
     w = (0.03 * rng.standard_normal((N, K))).astype(np.float32)
     y, has, q, sc = (_linear_skinny if path == "skinny" else _linear_dense)(n, x, w)

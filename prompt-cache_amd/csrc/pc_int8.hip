@@ -98,11 +98,24 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
                                                            int64_t ldc, int32_t* __restrict__ has) {
     __shared__ int cols[kMaxCols];
     __shared__ int cnt[257];
+    __shared__ __attribute__((aligned(16))) unsigned char lf[16384];       // the flag bytes (K <= 16384)
     const int tid = threadIdx.x, KS = K >> 5;
+    // ---- flags into LDS with coalesced 16-byte loads; the usual case (no outlier anywhere) ends right here ----
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    int any = 0;
+    for (int c = tid; c < (K >> 4); c += 256) {
+        const u4v v = ((const u4v*)flags)[c];
+        ((u4v*)lf)[c] = v;
+        any |= (v[0] | v[1] | v[2] | v[3]) != 0;
+    }
+    if (!__syncthreads_or(any)) {
+        if (blockIdx.x == 0 && tid == 0) has[0] = 0;
+        return;
+    }
     // ---- deterministic compaction of the flagged columns: thread i owns the contiguous range [i*per, (i+1)*per) ----
     const int per = (K + 255) / 256;
     int mine = 0;
-    for (int k = tid * per; k < (tid + 1) * per && k < K; ++k) mine += flags[k] ? 1 : 0;
+    for (int k = tid * per; k < (tid + 1) * per && k < K; ++k) mine += lf[k] ? 1 : 0;
     cnt[tid + 1] = mine;
     if (tid == 0) cnt[0] = 0;
     __syncthreads();
@@ -110,10 +123,6 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
         for (int i = 1; i <= 256; ++i) cnt[i] += cnt[i - 1];
     __syncthreads();
     const int total = cnt[256];
-    if (total == 0) {
-        if (blockIdx.x == 0 && tid == 0) has[0] = 0;
-        return;
-    }
     if (blockIdx.x == 0 && tid == 0) has[0] = 1;
     const int nl = tid & 63, tg = tid >> 6;                   // 64 output columns x 4 row groups per workgroup
     const int n = blockIdx.x * 64 + nl;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
             {   // this batch of the column list (in column order)
                 int w = cnt[tid] - base;
                 for (int k = tid * per; k < (tid + 1) * per && k < K; ++k)
-                    if (flags[k]) { if (w >= 0 && w < kMaxCols) cols[w] = k; ++w; }
+                    if (lf[k]) { if (w >= 0 && w < kMaxCols) cols[w] = k; ++w; }
             }
             __syncthreads();
             const int nb = total - base < kMaxCols ? total - base : kMaxCols;
@@ -171,7 +180,8 @@ PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t 
 PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
                               const float* x_scale, const void* w_codes, int64_t ldw, const float* w_scale, const int32_t* row_perm,
                               int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream) {
-    PC_REQUIRE(T > 0 && N > 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_outlier_corr: bad sizes");
+    PC_REQUIRE(T > 0 && N > 0 && K > 0 && K % 32 == 0 && K <= 16384 && ((uintptr_t)flags & 15) == 0, PC_ERR_ARG,
+               "pc_outlier_corr: bad sizes (K %% 32 == 0, K <= 16384, flags 16-byte aligned)");
     PC_REQUIRE(flags && x && codes && x_scale && w_codes && w_scale && corr && has && ldc >= N, PC_ERR_ARG, "pc_outlier_corr: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pc_ceil_div(N, 64));

@@ -657,9 +657,10 @@ def main():
             m.upload(device)
         torch.cuda.synchronize()
     if rank == 0 and not args.no_context and not args.no_int8:
-        # context: the reference's GPU configs load the model with load_in_8bit=True (config/llm_config_llama2_7b.json:5).
-        # Weight-only int8 here: same prompt, same staged module KV (bit-identical gather), the
-        # decoder linears streamed as int8 fragment images.  A different numeric mode: never `value`.
+        # context: the reference's GPU configs load the model with load_in_8bit=True (config/llm_config_llama2_7b.json:5) =
+        # LLM.int8() through bitsandbytes.  Here: the published algorithm (int8 weights, vector-wise
+        # int8 activations, fp16 outlier columns at threshold 6.0), same prompt, same staged module KV (bit-identical
+        # gather).  A different numeric mode: never `value`.
         lm8 = Llama2(args.model, device=device, random_init=True, seed=0, load_in_8bit=True)
         ids8, pos8, _, cache8 = eng.process(prompt)
         i8_t = torch.tensor([ids8], device=device, dtype=torch.long)
@@ -681,8 +682,10 @@ def main():
                 past8, tok8 = o8.past_key_values, int(torch.argmax(o8.logits[0, -1]))
             torch.cuda.synchronize(); dt8 = time.perf_counter() - t0
         result["int8_weights"] = {"ttft_ms": sorted(ts8[2:])[len(ts8[2:]) // 2], "decode_tokens_per_s": 32 / dt8,
-                                  "what": "load_in_8bit=True: row-wise absmax int8 decoder linears (weight-only, exact "
-                                          "arithmetic on the dequantised values), lm_head fp16; module KV from the fp16 engine"}
+                                  "mode": "llm_int8" if lm8.hf_model.llm_int8 else "weight_only",
+                                  "what": "load_in_8bit=True: LLM.int8() as published (row-wise absmax int8 weights, vector-wise "
+                                          "int8 activations, fp16 outlier columns at |x| >= 6), lm_head fp16; module KV from the "
+                                          "fp16 engine; PC_INT8_WEIGHT_ONLY=1 selects round 1's weight-only mode"}
         del lm8, o8, past8, cache8
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

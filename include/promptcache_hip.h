@@ -354,15 +354,16 @@ int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w
  *   rest is quantised vector-wise: codes = round_half_even(x * 127 / absmax_row) as fp16 values in the layout of x,
  *   x_scale[t] = absmax_row / 127.  flags_clear (optional, clear_len bytes): zeroed for the next activation slot.
  * pc_outlier_corr: corr[t][n] = sum over flagged columns k of x[t][k] * fp16(w_codes[r][k] * w_scale[r])
- *   - codes[t][k] * w_codes[r][k] * x_scale[t] * w_scale[r],  r = row_perm ? row_perm[n] : n  (w_codes: the weight codes
- *   held in fp16, row-major [N][ldw]); *has = 1 when any column is flagged, else 0 and corr is left untouched.
+ *   - codes[t][k] * w_codes[r][k] * x_scale[t] * w_scale[r],  r = row_perm ? row_perm[n] : n  (w_codes_t: the int8 weight
+ *   codes TRANSPOSED, [K][ldt], so that a weight column is contiguous); *has = 1 when any column is flagged, else 0 and
+ *   corr is left untouched.
  * pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 / pc_gemm_dense_a8: the projections over the codes,
  *   y = (sum_k w_code[n][k] * x_code[m][k]) * w_scale[n] * x_scale[m] + (*corr_has ? corr[m][n] : 0), then the epilogue of
  *   pc_gemm_skinny / pc_gemm_qkv_rope_ex / pc_gemm_dense (same epilogue codes and outputs). */
 int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale, void* flags_set,
                     void* flags_clear, int32_t clear_len, float threshold, void* stream);
 int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
-                    const float* x_scale, const void* w_codes, int64_t ldw, const float* w_scale, const int32_t* row_perm,
+                    const float* x_scale, const void* w_codes_t, int64_t ldt, const float* w_scale, const int32_t* row_perm,
                     int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream);
 int pc_gemm_skinny_a8(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
                       const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K,

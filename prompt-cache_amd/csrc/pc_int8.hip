@@ -16,6 +16,7 @@
 //                        outlier column.  Only the outlier ENTRIES are zeroed here.
 //   outlier_corr_kernel  compacts the flagged columns (deterministic order) and writes
 //                            corr[t][n] = sum_{k in O} ( X[t][k] * fp16(CB[n][k] * scale[n])  -  CA[t][k] * CB[n][k] * x_scale[t] * scale[n] )
+//                        (CB read from a transposed int8 image [K][N]: a column of W is contiguous there)
 //                        i.e. the fp16 part of the decomposition MINUS what the int8 product still carries in those columns
 //                        for rows whose own entry is not an outlier -- algebraically the "zero the whole column" of the
 //                        published form, without a second pass over CA.  The projection's epilogue adds corr before its
@@ -88,12 +89,13 @@ __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restri
     }
 }
 
-constexpr int kMaxCols = 1024;      // outlier columns handled per batch of the correction kernel
+constexpr int kMaxCols = 128;       // outlier columns handled per batch of the correction kernel
+constexpr int kCorrRows = 64;       // activation rows staged per pass
 
 template <bool FRAG>
 __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* __restrict__ flags, int K, const _Float16* __restrict__ x,
                                                            const _Float16* __restrict__ codes, int64_t ldx, const float* __restrict__ x_scale,
-                                                           const _Float16* __restrict__ cb, int64_t ldw, const float* __restrict__ w_scale,
+                                                           const signed char* __restrict__ cbt, int64_t ldt, const float* __restrict__ w_scale,
                                                            const int32_t* __restrict__ row_perm, int T, int N, float* __restrict__ corr,
                                                            int64_t ldc, int32_t* __restrict__ has) {
     __shared__ int cols[kMaxCols];
@@ -128,31 +130,53 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
     const int n = blockIdx.x * 64 + nl;
     const int nrow = n < N ? (row_perm ? row_perm[n] : n) : 0;
     const float ws = n < N ? w_scale[nrow] : 0.f;
-    for (int t0 = 0; t0 < T; t0 += 4) {
-        const int t = t0 + tg;
-        float acc = 0.f;
-        for (int base = 0; base < total; base += kMaxCols) {
+    __shared__ _Float16 wl[kMaxCols][64];                     // this workgroup's weight codes of the batch's columns
+    __shared__ _Float16 xl[kCorrRows][kMaxCols];              // fp16 activations / their codes at the batch's columns
+    __shared__ _Float16 cl[kCorrRows][kMaxCols];
+    for (int base = 0; base < total; base += kMaxCols) {
+        __syncthreads();
+        {   // this batch of the column list (in column order)
+            int w = cnt[tid] - base;
+            for (int k = tid * per; k < (tid + 1) * per && k < K; ++k)
+                if (lf[k]) { if (w >= 0 && w < kMaxCols) cols[w] = k; ++w; }
+        }
+        __syncthreads();
+        const int nb = total - base < kMaxCols ? total - base : kMaxCols;
+        // the weight codes of the batch's columns, from the TRANSPOSED int8 image [K][N] (a column of W is a contiguous row
+        // there: gathering 600 columns of down_proj from the row-major image cost 400 us per launch), once per workgroup
+        // and batch, then reused by every activation row
+        for (int e = tid; e < nb * 64; e += 256) {
+            const int j = e >> 6, l = e & 63;
+            const int nn = blockIdx.x * 64 + l;
+            const int nr = nn < N ? (row_perm ? row_perm[nn] : nn) : 0;
+            wl[j][l] = (_Float16)(float)cbt[(int64_t)cols[j] * ldt + nr];
+        }
+        for (int t0 = 0; t0 < T; t0 += kCorrRows) {
             __syncthreads();
-            {   // this batch of the column list (in column order)
-                int w = cnt[tid] - base;
-                for (int k = tid * per; k < (tid + 1) * per && k < K; ++k)
-                    if (lf[k]) { if (w >= 0 && w < kMaxCols) cols[w] = k; ++w; }
+            const int nt = T - t0 < kCorrRows ? T - t0 : kCorrRows;
+            // activations and codes at the flagged columns into LDS (independent loads), so that the sum below runs
+            // out of LDS: with the loads inside the column loop a 600-column batch took 400 us
+            for (int e = tid; e < nt * nb; e += 256) {
+                const int tt = e / nb, j = e - tt * nb;
+                const int64_t xo = FRAG ? frag_off(t0 + tt, cols[j], KS) : (int64_t)(t0 + tt) * ldx + cols[j];
+                xl[tt][j] = x[xo];
+                cl[tt][j] = codes[xo];
             }
             __syncthreads();
-            const int nb = total - base < kMaxCols ? total - base : kMaxCols;
-            if (t < T && n < N) {
-                const float xs = x_scale[t] * ws;
+            for (int tt = tg; tt < nt; tt += 4) {
+                float acc = 0.f;
+                const float xs = x_scale[t0 + tt] * ws;
                 for (int j = 0; j < nb; ++j) {
-                    const int k = cols[j];
-                    const int64_t xo = FRAG ? frag_off(t, k, KS) : (int64_t)t * ldx + k;
-                    const float xv = (float)x[xo], ca = (float)codes[xo];
-                    const float wq = (float)cb[(int64_t)nrow * ldw + k];
-                    const float wd = (float)(_Float16)(wq * ws);            // fp16(CB * SCB / 127): the fp16 weight column
-                    acc += xv * wd - ca * wq * xs;
+                    const float wq = (float)wl[j][nl];
+                    const float wd = (float)(_Float16)(wq * ws);        // fp16(CB * SCB / 127): the fp16 weight column
+                    acc += (float)xl[tt][j] * wd - (float)cl[tt][j] * wq * xs;
+                }
+                if (n < N) {
+                    float* cp = corr + (int64_t)(t0 + tt) * ldc + n;
+                    *cp = base == 0 ? acc : *cp + acc;
                 }
             }
         }
-        if (t < T && n < N) corr[(int64_t)t * ldc + n] = acc;
     }
 }
 
@@ -178,18 +202,19 @@ PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t 
 }
 
 PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
-                              const float* x_scale, const void* w_codes, int64_t ldw, const float* w_scale, const int32_t* row_perm,
+                              const float* x_scale, const void* w_codes_t, int64_t ldt, const float* w_scale, const int32_t* row_perm,
                               int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream) {
     PC_REQUIRE(T > 0 && N > 0 && K > 0 && K % 32 == 0 && K <= 16384 && ((uintptr_t)flags & 15) == 0, PC_ERR_ARG,
                "pc_outlier_corr: bad sizes (K %% 32 == 0, K <= 16384, flags 16-byte aligned)");
-    PC_REQUIRE(flags && x && codes && x_scale && w_codes && w_scale && corr && has && ldc >= N, PC_ERR_ARG, "pc_outlier_corr: null pointer");
+    PC_REQUIRE(flags && x && codes && x_scale && w_codes_t && w_scale && corr && has && ldc >= N && ldt >= N, PC_ERR_ARG,
+               "pc_outlier_corr: null pointer or short strides");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pc_ceil_div(N, 64));
     if (frag)
         hipLaunchKernelGGL((outlier_corr_kernel<true>), grid, dim3(256), 0, s, (const unsigned char*)flags, K, (const _Float16*)x,
-                           (const _Float16*)codes, ldx, x_scale, (const _Float16*)w_codes, ldw, w_scale, row_perm, T, N, corr, ldc, has);
+                           (const _Float16*)codes, ldx, x_scale, (const signed char*)w_codes_t, ldt, w_scale, row_perm, T, N, corr, ldc, has);
     else
         hipLaunchKernelGGL((outlier_corr_kernel<false>), grid, dim3(256), 0, s, (const unsigned char*)flags, K, (const _Float16*)x,
-                           (const _Float16*)codes, ldx, x_scale, (const _Float16*)w_codes, ldw, w_scale, row_perm, T, N, corr, ldc, has);
+                           (const _Float16*)codes, ldx, x_scale, (const signed char*)w_codes_t, ldt, w_scale, row_perm, T, N, corr, ldc, has);
     return pc_check_launch("outlier_corr_kernel");
 }

@@ -497,10 +497,11 @@ def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags
     check(rc, "pc_quant_act_i8")
 
 
-def outlier_corr(flags, K: int, x, codes, frag: bool, x_scale, w_codes, w_scale, row_perm, T: int, N: int, corr, has,
+def outlier_corr(flags, K: int, x, codes, frag: bool, x_scale, w_codes_t, w_scale, row_perm, T: int, N: int, corr, has,
                  ldx: Optional[int] = None, stream: Optional[int] = None) -> None:
+    """``w_codes_t``: the int8 weight codes transposed, [K, N] (``q.t().contiguous()``)."""
     rc = load().pc_outlier_corr(flags.data_ptr(), K, x.data_ptr(), codes.data_ptr(), (0 if frag else x.stride(-2)) if ldx is None else ldx,
-                                int(frag), x_scale.data_ptr(), w_codes.data_ptr(), w_codes.stride(-2), w_scale.data_ptr(),
+                                int(frag), x_scale.data_ptr(), w_codes_t.data_ptr(), w_codes_t.stride(-2), w_scale.data_ptr(),
                                 _ptr(row_perm), T, N, corr.data_ptr(), corr.stride(-2), has.data_ptr(),
                                 current_stream() if stream is None else stream)
     check(rc, "pc_outlier_corr")

@@ -152,6 +152,7 @@ class LlamaHIP:
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
         self.supports_greedy_loop = True    # decode steps can run as a device-side loop (GreedyLoop)
         self.llm_int8 = False
+        self._last_qt = None
         self.batch_invariant = True         # a row's result does not depend on the other rows of the forward (see llm_int8)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
 
@@ -210,11 +211,12 @@ class LlamaHIP:
             if self.skinny and i == 0:
                 self._qkv_perm = _native.qkv_rope_row_perm(self.H + 2 * self.Hkv, self.D).to(dev)
             # q|k|v fragment image: rotary pairs share a 16-row tile (pc_gemm_qkv_rope)
-            wqkv, wqkv_f, wqkv_s = prep(wqkv, self._qkv_perm if self.skinny else None)
-            wo, wo_f, wo_s = prep(wo)
-            wgu, wgu_f, wgu_s = prep(wgu)
-            wdown, wdown_f, wdown_s = prep(wdown)
+            wqkv, wqkv_f, wqkv_s = prep(wqkv, self._qkv_perm if self.skinny else None); t_qkv = self._last_qt
+            wo, wo_f, wo_s = prep(wo); t_o = self._last_qt
+            wgu, wgu_f, wgu_s = prep(wgu); t_gu = self._last_qt
+            wdown, wdown_f, wdown_s = prep(wdown); t_d = self._last_qt
             self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown,
+                                    wqkv_t8=t_qkv, wo_t8=t_o, wgu_t8=t_gu, wdown_t8=t_d,
                                     wqkv_f=wqkv_f, wo_f=wo_f, wgu_f=wgu_f, wdown_f=wdown_f,
                                     wqkv_s=wqkv_s[0], wo_s=wo_s[0], wgu_s=wgu_s[0], wdown_s=wdown_s[0],
                                     wqkv_ds=wqkv_s[1], wo_ds=wo_s[1], wgu_ds=wgu_s[1], wdown_ds=wdown_s[1]))
@@ -240,14 +242,14 @@ class LlamaHIP:
         q, sc = _native.quantize_rows_int8(wt)
         dense = q.to(self.dtype)                      # the int8 codes, exact in fp16; _proj applies the scales (many-row paths)
         dsc = sc
+        self._last_qt = q.t().contiguous() if getattr(self, "llm_int8", False) else None   # [K][N] int8: columns for pc_outlier_corr
         if perm is not None:
             q, sc = q[perm].contiguous(), sc[perm].contiguous()
         return dense, _native.to_weight_frags_i8(q), (sc, dsc)
 
-    @staticmethod
-    def _linear_entries(name: str, prepped) -> dict:
+    def _linear_entries(self, name: str, prepped) -> dict:
         dense, frag, (sc, dsc) = prepped
-        return {name: dense, name + "_f": frag, name + "_s": sc, name + "_ds": dsc}
+        return {name: dense, name + "_f": frag, name + "_s": sc, name + "_ds": dsc, name + "_t8": getattr(self, "_last_qt", None)}
 
     TAIL_HEADROOM = 256     # decoded rows a generation's residual tail has room for past the prompt's own
 
@@ -490,7 +492,7 @@ class LlamaHIP:
         n = _native
         codes, xs, corr, has = bufs
         n.quant_act_i8(act_hi, True, T, K, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
-        n.outlier_corr(self._i8_flags[slot], K, act_hi, codes, True, xs, lw[key], lw[key + "_ds"], perm, T, N, corr, has)
+        n.outlier_corr(self._i8_flags[slot], K, act_hi, codes, True, xs, lw[key + "_t8"], lw[key + "_ds"], perm, T, N, corr, has)
         return codes, xs, corr, has
 
     def _forward_skinny_int8(self, ids, pos32, past_dev, arena, B, q_len, past_len, last_token_only, num_layers):
@@ -592,7 +594,7 @@ class LlamaHIP:
         def lin(slot, a16, codes, K, lw, key, N, epi, **out):
             n.quant_act_i8(a16, False, T, K, codes, xs, fl[slot], fl[(slot + 1) % 4])
             cv = corr[:T * N].view(T, N)
-            n.outlier_corr(fl[slot], K, a16, codes, False, xs, lw[key], lw[key + "_ds"], None, T, N, cv, has[slot:slot + 1])
+            n.outlier_corr(fl[slot], K, a16, codes, False, xs, lw[key + "_t8"], lw[key + "_ds"], None, T, N, cv, has[slot:slot + 1])
             n.gemm_dense_a8(codes, lw[key], lw[key + "_ds"], xs, cv, has[slot:slot + 1], T, N, K, epi, **out)
 
         for li, lw in enumerate(layers):

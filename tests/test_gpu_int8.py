@@ -74,7 +74,7 @@ def _linear_skinny(n, x, w, perm=None):
     has = torch.full((1,), -1, dtype=torch.int32, device=DEV)
     zero = torch.zeros_like(hi)
     n.quant_act_i8(hi, True, T, K, codes, xs, flags, None)
-    n.outlier_corr(flags, K, hi, codes, True, xs, wcodes, sc, None, T, N, corr, has)
+    n.outlier_corr(flags, K, hi, codes, True, xs, q.t().contiguous(), sc, None, T, N, corr, has)
     y = torch.full((T, N), float("nan"), dtype=torch.float32, device=DEV)
     n.gemm_skinny_a8(wf8, sc, codes, zero, xs, corr, has, T, N, K, n.EPI_STORE, y=y, ldy=N)
     torch.cuda.synchronize()
@@ -93,7 +93,7 @@ def _linear_dense(n, x, w):
     corr = torch.full((T, N), float("nan"), dtype=torch.float32, device=DEV)
     has = torch.full((1,), -1, dtype=torch.int32, device=DEV)
     n.quant_act_i8(x16, False, T, K, codes, xs, flags, None)
-    n.outlier_corr(flags, K, x16, codes, False, xs, wcodes, sc, None, T, N, corr, has)
+    n.outlier_corr(flags, K, x16, codes, False, xs, q.t().contiguous(), sc, None, T, N, corr, has)
     y = torch.full((T, N), float("nan"), dtype=torch.float32, device=DEV)
     n.gemm_dense_a8(codes, wcodes, sc, xs, corr, has, T, N, K, n.EPI_STORE, y=y)
     torch.cuda.synchronize()

@@ -343,6 +343,15 @@ int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w
                   int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
                   int64_t ldo, void* stream);
 
+/* pc_gemm_dense with a caller-owned scratch buffer (16-byte aligned, workspace_bytes long).  A plain-store / residual-add
+ * launch whose tile grid would leave most of the 256 CUs idle -- the N = hidden projections (llama2.py:405 o_proj, :242
+ * down_proj) at a few hundred rows -- cuts K into up to 8 slices: partial slabs [slices][M][N] fp32 in the workspace, added
+ * in slice order by a second launch (deterministic).  When the slabs do not fit, or the grid is large enough, the call is
+ * exactly pc_gemm_dense. */
+int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw, const float* w_scale,
+                     int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
+                     int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- LLM.int8(): int8 weights AND int8 activations with the fp16 outlier decomposition -------------------------------
  * What load_in_8bit=True means in the reference's GPU runs (demo.py:27-29, eval.py:36-42, config/llm_config_*.json:5 ->
  * transformers -> bitsandbytes.nn.Linear8bitLt(threshold = 6.0)).  bitsandbytes is not part of the reference tree: these

@@ -61,6 +61,9 @@ struct DenseParams {
     float* y; int64_t ldy;                                 // EPI_STORE / EPI_ADD
     _Float16* oh; _Float16* ol; int64_t ldo;               // EPI_SILU / EPI_GELU output planes
     int32_t M, N, K, mb, nb, nfeat;                        // nfeat: SiLU features (= N / 2)
+    // split-K (EPI_STORE instantiation only): grid.y slices of `kper` K-steps, slice z stores its partial sums to
+    // y + z * slab_stride; dense_reduce_kernel then adds the slabs in fixed order (launch_dense_splitk)
+    int32_t kper; int64_t slab_stride;
 };
 
 __device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
@@ -84,7 +87,9 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
     const int nloc = slot / p.mb, mi = slot - nloc * p.mb, ni = nloc * 8 + xcd;
     if (ni >= p.nb) return;
     const int m0 = mi * BM;
-    const int K = p.K, nk = (K + BK - 1) / BK;
+    const int K = p.K, nkt = (K + BK - 1) / BK;          // K-steps of the whole product
+    const int t0 = blockIdx.y * p.kper;                  // this slice's first K-step (kper = nkt without split-K)
+    const int nk = (p.kper < nkt - t0) ? p.kper : nkt - t0;
 
     // global weight row of LDS weight-tile row r; -1 = past the end (clamped source, never stored)
     auto wrow = [&](int r) -> int {
@@ -117,7 +122,10 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         cw[j] = scp ^ ((r >> 1) & 7);
         gw[j] = p.w + (int64_t)gr * p.ldw + cw[j] * 8;
     }
-    auto stage = [&](int t, char* buf, bool tail) {
+    const bool ktail = (K % BK) != 0;
+    auto stage = [&](int tl, char* buf) {
+        const int t = t0 + tl;
+        const bool tail = ktail && t == nkt - 1;
         const int64_t ko = (int64_t)t * BK;
         const int kchunks = tail ? (K - t * BK) / 8 : 8;          // valid 16-byte chunks in this K-step
 #pragma unroll
@@ -192,12 +200,11 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
             else if (2 * k < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // (an odd one left)
         }
     };
-    const bool ktail = (K % BK) != 0;
     Frags fa, fb;
-    stage(0, lds, ktail && nk == 1);
+    stage(0, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (nk > 1) stage(1, lds + kStage, ktail && nk == 2);
+    if (nk > 1) stage(1, lds + kStage);
     load_frags(fa, lds, 0);
     for (int t = 0; t + 1 < nk; ++t) {
         const char* cur = lds + (t & 1) * kStage;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tn = t + 2 < nk ? t + 2 : nk - 1;
-        stage(tn, lds + (t & 1) * kStage, ktail && tn == nk - 1);
+        stage(tn, lds + (t & 1) * kStage);
         load_frags(fa, lds + ((t + 1) & 1) * kStage, 0);
         mfmas(fb);
         interleave();
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
                 *(h4*)(p.oh + (int64_t)m * p.ldo + n) = hi;
                 if (p.ol) *(h4*)(p.ol + (int64_t)m * p.ldo + n) = lo;
             } else {
-                float* yp = p.y + (int64_t)m * p.ldy + n;
+                float* yp = p.y + (int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldy + n;
                 if (EPI == EPI_ADD) {
                     const f4 old = *(const f4*)yp;
                     v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
@@ -329,28 +336,87 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
     }
 }
 
+// Split-K tail: y[m][n] (+)= sum_z slab[z][m][n], slabs added in slice order (deterministic), 16 B per lane.
+template <bool ADD>
+__global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restrict__ slab, int64_t slab_stride, int ks,
+                                                           float* __restrict__ y, int64_t ldy, int M, int N) {
+    const int n4 = N >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+    const float* sp = slab + (int64_t)m * N + n;
+    f4 v = *(const f4*)sp;
+    for (int z = 1; z < ks; ++z) {
+        const f4 x = *(const f4*)(sp + z * slab_stride);
+        v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+    }
+    float* yp = y + (int64_t)m * ldy + n;
+    if (ADD) {
+        const f4 old = *(const f4*)yp;
+        v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+    }
+    *(f4*)yp = v;
+}
+
 // 16 bytes of zeros for activation chunks past K (device constant: no allocation, graph-capturable)
 __device__ __attribute__((aligned(16))) _Float16 g_zero_chunk[8];
 
 template <int WM, int EPI>
-int launch_dense(DenseParams& p, hipStream_t s) {
+int launch_dense(DenseParams& p, hipStream_t s, int kslices = 1) {
     constexpr int BN = 64 * (8 / WM);
     const int units = (EPI == EPI_SILU) ? pc_ceil_div(p.nfeat, BN / 2) : pc_ceil_div(p.N, BN);
     p.mb = pc_ceil_div(p.M, BM);
     p.nb = units;
-    const dim3 grid(8 * p.mb * pc_ceil_div(p.nb, 8)), block(512);
+    const int nkt = pc_ceil_div(p.K, BK);
+    p.kper = pc_ceil_div(nkt, kslices);
+    const dim3 grid(8 * p.mb * pc_ceil_div(p.nb, 8), pc_ceil_div(nkt, p.kper)), block(512);
     if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false>), grid, block, 0, s, p);
     return pc_check_launch("gemm_dense_kernel");
 }
 
+// Few-row launches of the N = hidden projections (o_proj, down_proj at a few hundred rows: 64-128 tiles of 128 x 256 for
+// 256 CUs): the K range is cut into slices that run as separate workgroups and meet in a fixed-order reduction.
+// Returns 0 when split-K does not apply (the caller then launches the plain form).
+template <int EPI>
+int launch_dense_splitk(DenseParams& p, hipStream_t s, float* ws, int64_t ws_bytes, int* launched) {
+    static const int forced_ks = [] { const char* e = getenv("PC_DENSE_KS"); return e ? atoi(e) : 0; }();
+    static const int forced_bn = [] { const char* e = getenv("PC_DENSE_BN"); return e ? atoi(e) : 0; }();
+    *launched = 0;
+    if (!ws || p.xscale || (EPI != EPI_ADD && EPI != EPI_STORE)) return 0;
+    const int nkt = pc_ceil_div(p.K, BK), mb = pc_ceil_div(p.M, BM);
+    // widest panel whose slices still fill the chip: 256-wide tiles do twice the MFMAs per LDS byte of 128-wide ones
+    const int b256 = mb * pc_ceil_div(p.N, 256), b128 = mb * pc_ceil_div(p.N, 128);
+    bool narrow = forced_bn ? forced_bn == 128 : false;
+    int ks = forced_ks ? forced_ks : 256 / b256;
+    if (!forced_ks && !forced_bn && ks < 2 && 256 / b128 >= 2) { narrow = true; ks = 256 / b128; }
+    if (ks > 8) ks = 8;
+    while (ks > 1 && nkt / ks < 8) --ks;                     // keep >= 8 K-steps per slice
+    if (ks < 2 || (int64_t)ks * p.M * p.N * 4 > ws_bytes) return 0;
+    float* y = p.y; const int64_t ldy = p.ldy;
+    p.y = ws; p.ldy = p.N; p.slab_stride = (int64_t)p.M * p.N;
+    const int rc = narrow ? launch_dense<4, EPI_STORE>(p, s, ks) : launch_dense<2, EPI_STORE>(p, s, ks);
+    if (rc) return rc;
+    const int nslab = pc_ceil_div(pc_ceil_div(p.K, BK), p.kper);
+    const int64_t items = (int64_t)p.M * (p.N >> 2);
+    const dim3 grid((unsigned)((items + 255) / 256)), block(256);
+    if (EPI == EPI_ADD) hipLaunchKernelGGL((dense_reduce_kernel<true>), grid, block, 0, s, ws, p.slab_stride, nslab, y, ldy, p.M, p.N);
+    else hipLaunchKernelGGL((dense_reduce_kernel<false>), grid, block, 0, s, ws, p.slab_stride, nslab, y, ldy, p.M, p.N);
+    *launched = 1;
+    return pc_check_launch("dense_reduce_kernel");
+}
+
 template <int EPI>
 int launch_dense_tile(DenseParams& p, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("PC_DENSE_BN"); return e ? atoi(e) : 0; }();
-    // 256-wide weight panels unless their grid would leave a good part of the 256 CUs idle
+    // 256-wide weight panels (twice the MFMAs per LDS byte) unless the 128-wide grid needs fewer tile-rounds of the 256
+    // CUs: a 128-wide tile pass takes 0.62 of a 256-wide one (measured at K = 4096 and 11008,
+    // profiles/r02_dense_splitk.txt), e.g. 1000 x 4096: 128 wide tiles = one round of half the chip, 256 narrow tiles =
+    // one round of all of it
     const int cols = (EPI == EPI_SILU) ? p.nfeat * 2 : p.N;
-    const int blocks256 = pc_ceil_div(p.M, BM) * pc_ceil_div(cols, 256);
-    const bool narrow = forced ? forced == 128 : blocks256 < 200;
+    const int mb = pc_ceil_div(p.M, BM);
+    const int b256 = mb * pc_ceil_div(cols, 256), b128 = mb * pc_ceil_div(cols, 128);
+    const bool narrow = forced ? forced == 128 : (b256 <= 512 && 0.62f * pc_ceil_div(b128, 256) < 1.0f * pc_ceil_div(b256, 256));
     return narrow ? launch_dense<4, EPI>(p, s) : launch_dense<2, EPI>(p, s);
 }
 
@@ -359,7 +425,8 @@ int launch_dense_tile(DenseParams& p, hipStream_t s) {
 namespace {
 int gemm_dense_impl(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw, const float* w_scale,
                     const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N,
-                    int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream) {
+                    int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream,
+                    void* workspace = nullptr, int64_t ws_bytes = 0) {
     PC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0, PC_ERR_ARG, "pc_gemm_dense: need M, N, K > 0, K%%8==0, N%%4==0");
     PC_REQUIRE(x_hi && w, PC_ERR_ARG, "pc_gemm_dense: null pointer");
     PC_REQUIRE(ldx >= K && ldw >= K && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w & 15) == 0 &&
@@ -394,8 +461,14 @@ int gemm_dense_impl(const void* x_hi, const void* x_lo, int64_t ldx, const void*
     }
     PC_REQUIRE(y && ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0, PC_ERR_ARG, "pc_gemm_dense: bad fp32 output");
     p.y = y; p.ldy = ldy;
+    PC_REQUIRE(epilogue == EPI_ADD || epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_dense: unknown epilogue %d", epilogue);
+    PC_REQUIRE(!workspace || ((uintptr_t)workspace & 15) == 0, PC_ERR_ARG, "pc_gemm_dense_ws: workspace must be 16-byte aligned");
+    int launched = 0;
+    const int rc = epilogue == EPI_ADD ? launch_dense_splitk<EPI_ADD>(p, s, (float*)workspace, ws_bytes, &launched)
+                                       : launch_dense_splitk<EPI_STORE>(p, s, (float*)workspace, ws_bytes, &launched);
+    if (rc || launched) return rc;
+    p.y = y; p.ldy = ldy; p.slab_stride = 0;
     if (epilogue == EPI_ADD) return launch_dense_tile<EPI_ADD>(p, s);
-    PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_dense: unknown epilogue %d", epilogue);
     return launch_dense_tile<EPI_STORE>(p, s);
 }
 }  // namespace
@@ -405,6 +478,16 @@ PC_EXPORT int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, con
                             void* out_hi, void* out_lo, int64_t ldo, void* stream) {
     return gemm_dense_impl(x_hi, x_lo, ldx, w, ldw, w_scale, nullptr, nullptr, 0, nullptr, M, N, K, epilogue, y, ldy, out_hi,
                            out_lo, ldo, stream);
+}
+
+// pc_gemm_dense with a caller-owned scratch buffer: plain-store / residual-add launches whose tile grid would leave most
+// of the 256 CUs idle (a few hundred rows against N = hidden) cut K into slices -- partial slabs [slices][M][N] fp32 in
+// `workspace`, added in slice order by a second launch.  Without room for the slabs the call is pc_gemm_dense.
+PC_EXPORT int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw,
+                               const float* w_scale, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy,
+                               void* out_hi, void* out_lo, int64_t ldo, void* workspace, int64_t ws_bytes, void* stream) {
+    return gemm_dense_impl(x_hi, x_lo, ldx, w, ldw, w_scale, nullptr, nullptr, 0, nullptr, M, N, K, epilogue, y, ldy, out_hi,
+                           out_lo, ldo, stream, workspace, ws_bytes);
 }
 
 // LLM.int8 form of pc_gemm_dense (pc_int8.hip): xq = activation CODES of pc_quant_act_i8 held in fp16 (row-major [M][K]), w =

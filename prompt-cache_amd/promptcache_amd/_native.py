@@ -71,6 +71,7 @@ SIGNATURES = {
                                       _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_gemm_dense_a8": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "pc_gemm_dense_ws": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
 
@@ -461,13 +462,22 @@ def probe_layouts(out_mfma, out_tr, stream: Optional[int] = None) -> None:
 
 def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out_hi=None, out_lo=None, wscale=None,
                ldx: Optional[int] = None, ldw: Optional[int] = None, ldy: Optional[int] = None, ldo: Optional[int] = None,
-               stream: Optional[int] = None) -> None:
+               stream: Optional[int] = None, workspace=None) -> None:
     """Many-row projection ``(x_hi + x_lo) @ w^T`` (pc_gemm_dense.hip): fp16 row-major operands, fp32 accumulation,
     epilogue EPI_STORE (y = .), EPI_ADD (y += .), EPI_SILU (out = silu(gate) * up as hi / lo planes, w = [gate; up]) or
-    EPI_GELU (out = gelu(.) planes).  ``x_lo`` may be None (single-precision-plane activations)."""
+    EPI_GELU (out = gelu(.) planes).  ``x_lo`` may be None (single-precision-plane activations).
+    ``workspace`` (any device tensor): scratch for the split-K form of few-row launches (pc_gemm_dense_ws)."""
     ld_o = 0
     if out_hi is not None:
         ld_o = ldo if ldo is not None else out_hi.stride(-2)
+    if workspace is not None:
+        rc = load().pc_gemm_dense_ws(x_hi.data_ptr(), _ptr(x_lo), x_hi.stride(-2) if ldx is None else ldx, w.data_ptr(),
+                                     w.stride(-2) if ldw is None else ldw, _ptr(wscale), M, N, K, epilogue, _ptr(y),
+                                     (0 if y is None else y.stride(-2)) if ldy is None else ldy, _ptr(out_hi), _ptr(out_lo),
+                                     ld_o, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                     current_stream() if stream is None else stream)
+        check(rc, "pc_gemm_dense_ws")
+        return
     rc = load().pc_gemm_dense(x_hi.data_ptr(), _ptr(x_lo), x_hi.stride(-2) if ldx is None else ldx, w.data_ptr(),
                               w.stride(-2) if ldw is None else ldw, _ptr(wscale), M, N, K, epilogue, _ptr(y),
                               (0 if y is None else y.stride(-2)) if ldy is None else ldy, _ptr(out_hi), _ptr(out_lo), ld_o,

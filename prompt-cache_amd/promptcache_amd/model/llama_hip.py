@@ -404,7 +404,14 @@ class LlamaHIP:
         epilogue fused.  int8 mode: ``lw[key]`` holds the int8 codes as fp16 (exact) and the per-output scales
         (``key_ds``) are applied to the accumulator tile -- the many-row paths then compute with exactly the dequantised
         weights the streaming kernels use."""
-        _native.gemm_dense(a_hi, a_lo, lw[key], M, N, K, epi, wscale=lw.get(key + "_ds"), **out)
+        ws = None
+        if epi in (_native.EPI_ADD, _native.EPI_STORE) and M <= 2048:
+            # few-row launches of the N = hidden projections cut K into slices (pc_gemm_dense_ws): the slabs of the widest
+            # split it ever takes are 256 tiles x 128 x 256 x 4 B
+            ws = getattr(self, "_dense_ws", None)
+            if ws is None:
+                ws = self._dense_ws = torch.empty(34 << 20, dtype=torch.uint8, device=self.device)
+        _native.gemm_dense(a_hi, a_lo, lw[key], M, N, K, epi, wscale=lw.get(key + "_ds"), workspace=ws, **out)
 
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
         """Layer stack for many rows (schema encode, no-cache prefill): every projection is a pc_gemm_dense launch with

@@ -59,6 +59,47 @@ def test_dense_store_and_add(M, N, K, two):
     assert np.array_equal(got2[:, N:], base.cpu().numpy()[:, N:].astype(np.float64))
 
 
+# few-row launches of the N = hidden projections take the split-K form when a workspace is supplied (pc_gemm_dense_ws);
+# (1000, 12288, 4096) and (77, 512, 8) do not split (large grid / too few K-steps) and must equal pc_gemm_dense bit for bit
+@pytest.mark.parametrize("two", [True, False])
+@pytest.mark.parametrize("M,N,K", [(300, 4096, 4096), (512, 4096, 11008), (130, 260, 1096), (800, 5120, 13824),
+                                   (1000, 12288, 4096), (77, 512, 8), (1, 4096, 4096)])
+def test_dense_split_k_with_workspace(M, N, K, two):
+    n = _n()
+    x, w = _inputs(M, N, K, seed=7 * M + N + K)
+    hi, lo = _split(x)
+    xs = hi.astype(np.float64) + (lo.astype(np.float64) if two else 0.0)
+    ref = xs @ w.astype(np.float64).T
+    th, tl, tw = torch.from_numpy(hi).to(DEV), torch.from_numpy(lo).to(DEV), torch.from_numpy(w).to(DEV)
+    ws = torch.full((34 << 20,), 0xFF, dtype=torch.uint8, device=DEV)          # NaN-filled scratch
+    tol = 2e-6 * np.sqrt(K) * np.abs(xs).max() * 0.05 * 8 + 1e-6
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_STORE, y=y, workspace=ws)
+    base = torch.from_numpy(np.random.default_rng(1).standard_normal((M, N + 4)).astype(np.float32)).to(DEV)
+    y2 = base.clone()
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_ADD, y=y2, ldy=N + 4, workspace=ws)
+    y3 = torch.empty_like(y)
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_STORE, y=y3)
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_STORE, y=y, workspace=ws[:1024])   # no room: the plain form
+    torch.cuda.synchronize()
+    assert torch.equal(y, y3)
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_STORE, y=y, workspace=ws)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < tol, (np.abs(got - ref).max(), tol)
+    got2 = y2.cpu().numpy().astype(np.float64)
+    assert np.abs(got2[:, :N] - (base.cpu().numpy()[:, :N].astype(np.float64) + ref)).max() < tol
+    assert np.array_equal(got2[:, N:], base.cpu().numpy()[:, N:].astype(np.float64))
+    if (M, N, K) in ((1000, 12288, 4096), (77, 512, 8)):
+        assert torch.equal(y, y3)
+    # deterministic: the slabs are added in slice order
+    y4 = torch.empty_like(y)
+    n.gemm_dense(th, tl if two else None, tw, M, N, K, n.EPI_STORE, y=y4, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y4)
+
+
 @pytest.mark.parametrize("M,inter,K", [(128, 128, 64), (300, 11008, 4096), (45, 344, 128), (1030, 1376, 512), (513, 13824, 5120)])
 def test_dense_silu_epilogue(M, inter, K):
     n = _n()

@@ -352,6 +352,33 @@ int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, const void
                      int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
                      int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- pc_gemm_chain: the projections between two attention calls of a <= 16-row forward as ONE persistent launch --------
+ *   phase 0  x += attn @ Wo^T                                   o_proj + residual        llama2.py:405, :638
+ *   phase 1  act = silu(gate(n2(x))) * up(n2(x))                post_attention_layernorm + gate / up + SiLU  llama2.py:640-643, :242
+ *   phase 2  x += act @ Wdown^T                                 down_proj + residual     llama2.py:242, :644
+ *   phase 3  (wqkv_f_next != NULL) the NEXT layer's input_layernorm + q|k|v + RoPE + in-place KV append  llama2.py:628, :345-364
+ * i.e. pc_gemm_skinny(epilogue 1), pc_gemm_skinny_norm(epilogue 2), pc_gemm_skinny(epilogue 1), pc_gemm_qkv_rope_ex(norm
+ * source) with the same operands, tiles, K split and reduction order: the results are bit-identical to those four launches.
+ * One workgroup per CU stays resident across the phases and meets the others at grid barriers; every wave fetches the first
+ * weight block of the next phase before it waits, so the HBM stream does not stop at the seams.
+ * attn_hi / attn_lo: fragment planes [1][attn_width/32][64][8] (pc_attn_fwd* out_frag_*), act_hi / act_lo: scratch planes
+ * [1][inter/32][64][8]; x: fp32 residual stream [M][hidden], updated in place; weights: fragment images (fp16).
+ * sync_state: pc_chain_sync_words() uint32 words of device memory, zeroed ONCE by the caller and then owned by these calls
+ * (monotonic counters: no reset between launches or graph replays; launches sharing a state must be stream-ordered).  Every
+ * in-kernel wait is bounded: on a timeout word pc_chain_sync_err_word() of the state becomes non-zero, the launch still
+ * terminates, its results are invalid and the state must be zeroed again.
+ * M <= 16.  Shapes without an instantiation (tile widths other than the 7b / 13b ones) return PC_ERR_ARG: the caller then
+ * issues the separate launches. */
+int32_t pc_chain_sync_words(void);
+int32_t pc_chain_sync_err_word(void);
+int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* attn_lo, int32_t attn_width, float* x, int32_t M,
+                  int32_t hidden, const void* wgu_f, const void* ln2_weight, float eps, int32_t inter, void* act_hi,
+                  void* act_lo, const void* wdown_f, const void* wqkv_f_next, const void* ln1_weight_next, const float* cs,
+                  void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
+                  int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
+                  int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
+                  int64_t lo_head_stride, int32_t lo_base, void* sync_state, void* stream);
+
 /* ---- LLM.int8(): int8 weights AND int8 activations with the fp16 outlier decomposition -------------------------------
  * What load_in_8bit=True means in the reference's GPU runs (demo.py:27-29, eval.py:36-42, config/llm_config_*.json:5 ->
  * transformers -> bitsandbytes.nn.Linear8bitLt(threshold = 6.0)).  bitsandbytes is not part of the reference tree: these

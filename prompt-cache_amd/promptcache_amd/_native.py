@@ -71,6 +71,11 @@ SIGNATURES = {
                                       _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_gemm_dense_a8": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "pc_chain_sync_words": (C.c_int32, []),
+    "pc_chain_sync_err_word": (C.c_int32, []),
+    "pc_gemm_chain": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64,
+                                _i32, _vp, _vp]),
     "pc_gemm_dense_ws": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
@@ -483,6 +488,35 @@ def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out
                               (0 if y is None else y.stride(-2)) if ldy is None else ldy, _ptr(out_hi), _ptr(out_lo), ld_o,
                               current_stream() if stream is None else stream)
     check(rc, "pc_gemm_dense")
+
+
+def chain_sync_state(device) -> "torch.Tensor":
+    """Zeroed sync state of pc_gemm_chain (owned by the launches afterwards; one per stream of chained launches)."""
+    import torch
+    return torch.zeros(load().pc_chain_sync_words(), dtype=torch.int32, device=device)
+
+
+def chain_sync_error(state) -> int:
+    """Non-zero: an in-kernel wait of pc_gemm_chain timed out (synchronises)."""
+    return int(state[load().pc_chain_sync_err_word()].item())
+
+
+def gemm_chain(wo_f, attn_hi, attn_lo, attn_width: int, x, M: int, hidden: int, wgu_f, ln2, eps: float, inter: int, act_hi, act_lo,
+               wdown_f, sync_state, qkv=None, stream: Optional[int] = None) -> None:
+    """o_proj -> gate|up -> down_proj (-> the next layer's q|k|v) as one persistent launch (pc_gemm_chain).
+    ``qkv`` = dict(wqkv_f, ln1, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap,
+    past_len_dev=None, kv_lo=None (k_lo, v_lo, bs, hs), lo_base=-1) or None."""
+    q = qkv or {}
+    lo = q.get("kv_lo") or (None, None, 0, 0)
+    rc = load().pc_gemm_chain(wo_f.data_ptr(), attn_hi.data_ptr(), attn_lo.data_ptr(), attn_width, x.data_ptr(), M, hidden,
+                              wgu_f.data_ptr(), ln2.data_ptr(), eps, inter, act_hi.data_ptr(), act_lo.data_ptr(),
+                              wdown_f.data_ptr(), _ptr(q.get("wqkv_f")), _ptr(q.get("ln1")), _ptr(q.get("cs")),
+                              _ptr(q.get("q_hi")), _ptr(q.get("q_lo")), q.get("q_ts", 0), _ptr(q.get("k_arena")),
+                              _ptr(q.get("v_arena")), q.get("a_bs", 0), q.get("a_hs", 0), q.get("B", 0), q.get("H", 0),
+                              q.get("Hkv", 0), q.get("D", 0), q.get("q_len", 0), q.get("past_len", 0), q.get("cap", 0),
+                              _ptr(q.get("past_len_dev")), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], q.get("lo_base", -1),
+                              sync_state.data_ptr(), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_chain")
 
 
 def greedy_advance(logits, vocab: int, ids, pos, past, ring, counter, stream: Optional[int] = None) -> None:

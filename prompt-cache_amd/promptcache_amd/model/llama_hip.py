@@ -135,6 +135,10 @@ class LlamaHIP:
         self._graphs = {}
         self.max_graphs = 256   # one per (q_len, split count, mode): a serving mix of prompt lengths stays resident
         self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
+        # pc_gemm_chain (one persistent launch for o_proj -> gate|up -> down -> next q|k|v): correct and bit-identical, but
+        # measured SLOWER than the four launches on MI355X (106-121 vs 88 us per layer, profiles/r02_chain_trace.txt): opt-in
+        self.use_chain = os.environ.get("PC_CHAIN", "0") == "1"
+        self._chain_sync = None
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops
         self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
@@ -649,15 +653,40 @@ class LlamaHIP:
         c = self.config
         H, Hkv, D, hid, inter = self.H, self.Hkv, self.D, c.hidden_size, c.intermediate_size
         T, eps, V = B * q_len, c.rms_norm_eps, c.vocab_size
+        # fp16 weights: everything between two attention calls -- o_proj, gate|up, down_proj and the NEXT layer's q|k|v -- is
+        # one persistent launch (pc_gemm_chain: the same four bodies, bit-identical, but the weight stream runs through
+        # the seams); three launches per layer instead of six.  Shapes without an instantiation fall back here.
+        chain = self.use_chain and layers and layers[0]["wqkv_s"] is None
+        if chain and self._chain_sync is None:
+            self._chain_sync = n.chain_sync_state(self.device)
+        qkv_done = False
         for li, lw in enumerate(layers):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kvlo, lo_base = tail(li) if tail is not None else (None, -1)
-            n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
-                                 arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
-                                 kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"], lo_base=lo_base)
+            if not qkv_done:
+                n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                                     arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
+                                     kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"], lo_base=lo_base)
+            qkv_done = False
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo)
+            if chain:
+                nxt = None
+                if li + 1 < len(layers):
+                    nl = layers[li + 1]
+                    nkv, nbase = tail(li + 1) if tail is not None else (None, -1)
+                    nxt = dict(wqkv_f=nl["wqkv_f"], ln1=nl["ln1"], cs=cs, q_hi=q16, q_lo=q16l, q_ts=H * D,
+                               k_arena=arena.k_plane(li + 1), v_arena=arena.v_plane(li + 1), a_bs=arena.batch_stride,
+                               a_hs=arena.head_stride, B=B, H=H, Hkv=Hkv, D=D, q_len=q_len, past_len=past_len, cap=arena.cap,
+                               past_len_dev=past_dev, kv_lo=nkv and nkv[:4], lo_base=nbase)
+                try:
+                    n.gemm_chain(lw["wo_f"], ah, al, H * D, x, T, hid, lw["wgu_f"], lw["ln2"], eps, inter, ch, cl, lw["wdown_f"],
+                                 self._chain_sync, qkv=nxt)
+                    qkv_done = nxt is not None
+                    continue
+                except RuntimeError:
+                    chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"])  # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
                                wscale=lw["wgu_s"])
@@ -676,7 +705,7 @@ class LlamaHIP:
         n = _native
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
         mode = self._lo_mode
-        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm,
+        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm, self.use_chain,
                mode, arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0)
         ent = self._graphs.pop(key, None)
         if ent is not None:
@@ -727,7 +756,7 @@ class LlamaHIP:
         n = _native
         nsplit_key = n.attn_workspace_bytes(1, self.H, self.D, 1, past_len + 1)
         mode = self._lo_mode
-        key = ("loop", arena.buf.data_ptr(), arena.cap, nsplit_key, self.fuse_norm, mode,
+        key = ("loop", arena.buf.data_ptr(), arena.cap, nsplit_key, self.fuse_norm, self.use_chain, mode,
                arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0)
         ent = self._graphs.pop(key, None)
         if ent is not None:

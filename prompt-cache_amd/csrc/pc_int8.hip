@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restri
 
 constexpr int kMaxCols = 128;       // outlier columns handled per batch of the correction kernel
 constexpr int kCorrRows = 64;       // activation rows staged per pass
+constexpr int kCorrCols = 16;       // output columns per workgroup of the correction kernel
 
 template <bool FRAG>
 __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* __restrict__ flags, int K, const _Float16* __restrict__ x,
@@ -126,11 +127,13 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
     __syncthreads();
     const int total = cnt[256];
     if (blockIdx.x == 0 && tid == 0) has[0] = 1;
-    const int nl = tid & 63, tg = tid >> 6;                   // 64 output columns x 4 row groups per workgroup
-    const int n = blockIdx.x * 64 + nl;
+    // 16 output columns x 16 row slots per workgroup: four times the workgroups of a 64-column split (N = 4096 gave 64
+    // workgroups on 256 CUs) and a 12-row step keeps 12 of the 16 slots busy instead of 3 of 4 at three rows each
+    const int nl = tid & (kCorrCols - 1), tg = tid / kCorrCols;
+    const int n = blockIdx.x * kCorrCols + nl;
     const int nrow = n < N ? (row_perm ? row_perm[n] : n) : 0;
     const float ws = n < N ? w_scale[nrow] : 0.f;
-    __shared__ _Float16 wl[kMaxCols][64];                     // this workgroup's weight codes of the batch's columns
+    __shared__ _Float16 wl[kMaxCols][kCorrCols];              // this workgroup's weight codes of the batch's columns
     __shared__ _Float16 xl[kCorrRows][kMaxCols];              // fp16 activations / their codes at the batch's columns
     __shared__ _Float16 cl[kCorrRows][kMaxCols];
     for (int base = 0; base < total; base += kMaxCols) {
@@ -145,9 +148,9 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
         // the weight codes of the batch's columns, from the TRANSPOSED int8 image [K][N] (a column of W is a contiguous row
         // there: gathering 600 columns of down_proj from the row-major image cost 400 us per launch), once per workgroup
         // and batch, then reused by every activation row
-        for (int e = tid; e < nb * 64; e += 256) {
-            const int j = e >> 6, l = e & 63;
-            const int nn = blockIdx.x * 64 + l;
+        for (int e = tid; e < nb * kCorrCols; e += 256) {
+            const int j = e / kCorrCols, l = e & (kCorrCols - 1);
+            const int nn = blockIdx.x * kCorrCols + l;
             const int nr = nn < N ? (row_perm ? row_perm[nn] : nn) : 0;
             wl[j][l] = (_Float16)(float)cbt[(int64_t)cols[j] * ldt + nr];
         }
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
                 cl[tt][j] = codes[xo];
             }
             __syncthreads();
-            for (int tt = tg; tt < nt; tt += 4) {
+            for (int tt = tg; tt < nt; tt += 256 / kCorrCols) {
                 float acc = 0.f;
                 const float xs = x_scale[t0 + tt] * ws;
                 for (int j = 0; j < nb; ++j) {
@@ -209,7 +212,7 @@ PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const
     PC_REQUIRE(flags && x && codes && x_scale && w_codes_t && w_scale && corr && has && ldc >= N && ldt >= N, PC_ERR_ARG,
                "pc_outlier_corr: null pointer or short strides");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(pc_ceil_div(N, 64));
+    const dim3 grid(pc_ceil_div(N, kCorrCols));
     if (frag)
         hipLaunchKernelGGL((outlier_corr_kernel<true>), grid, dim3(256), 0, s, (const unsigned char*)flags, K, (const _Float16*)x,
                            (const _Float16*)codes, ldx, x_scale, (const signed char*)w_codes_t, ldt, w_scale, row_perm, T, N, corr, ldc, has);

@@ -269,7 +269,7 @@ class SchemaCache:
             shards = [list(range(len(jobs))) if r == owner_rank else [] for r in range(world)]
         else:
             # shard by what a pass actually costs: its suffix behind the trunk prefix (world == 1 -> everything)
-            shards = parallel.shard_jobs([len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)], world)
+            shards = parallel.shard_jobs([len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)], world)   # (plan_cost's measure)
         mine = shards[rank]
         # every rank's segments live back to back in ONE slab per rank (ascending job order, then plan order inside a
         # job): the encode writes its stores through views of the slab, and the exchange moves whole slabs in place
@@ -282,6 +282,17 @@ class SchemaCache:
             for k in range(len(jobs[i]["owned"])):
                 view_of[(i, k)] = next(it)
 
+        # Rows a pass has to run: up to its last owned token.  Under the causal mask the K/V of a token depend on nothing behind
+        # it, so the tail of a scaffold that this pass does not own (the reference runs it and throws it away,
+        # cache_engine.py:243-296) is cut off -- and the root pass also covers the longest prefix a suffix pass builds on.
+        truncate = self.truncate_scaffolds and self._batch_invariant()      # (LLM.int8: a call's rows choose its outlier columns)
+        need = []
+        for i, j in enumerate(jobs):
+            pos = j["position_ids"]
+            end = max(pos.index(tc.offset) + len(tc) for tc in j["owned"])
+            if i == 0:
+                end = max([end] + [prefix[k] for k in range(len(jobs))])
+            need.append(end if truncate else len(j["token_ids"]))
         encoded_tokens = computed_tokens = 0
         per_job: Dict[int, List[Tuple[TokenSequence, torch.Tensor]]] = {}
         full_pos = bool(getattr(lm, "use_full_position_ids", False))
@@ -310,21 +321,20 @@ class SchemaCache:
         trunk_arena: Optional[KVArena] = None
         if shared:
             job = jobs[0]
-            out = lm(input_ids=torch.tensor([job["token_ids"]], device=dev, dtype=torch.long),
-                     position_ids=torch.tensor([job["position_ids"]], device=dev, dtype=torch.long), use_cache=True,
+            out = lm(input_ids=torch.tensor([job["token_ids"][:need[0]]], device=dev, dtype=torch.long),
+                     position_ids=torch.tensor([job["position_ids"][:need[0]]], device=dev, dtype=torch.long), use_cache=True,
                      many_rows=True, kv_only=True)
             trunk_arena = out.past_key_values.arena
-            computed_tokens += len(job["token_ids"])
+            computed_tokens += need[0]
             if 0 in whole:                                   # this rank also owns the root pass: store from the same run
                 whole.remove(0)
                 encoded_tokens += len(job["token_ids"])
                 store_owned(0, trunk_arena, 0)
             del out
 
-        for idxs in self._pack(whole, [len(j["token_ids"]) for j in jobs], batch_size):
-            group = [jobs[i] for i in idxs]
-            ids_pad, mask = pad_batch([j["token_ids"] for j in group], lm.eos_token_id)
-            pos_pad, _ = pad_batch([j["position_ids"] for j in group], 0)
+        for idxs in self._pack(whole, need, batch_size):
+            ids_pad, mask = pad_batch([jobs[i]["token_ids"][:need[i]] for i in idxs], lm.eos_token_id)
+            pos_pad, _ = pad_batch([jobs[i]["position_ids"][:need[i]] for i in idxs], 0)
             out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                      position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
                      attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
@@ -332,7 +342,7 @@ class SchemaCache:
             arena: KVArena = out.past_key_values.arena
             for row, i in enumerate(idxs):
                 encoded_tokens += len(jobs[i]["token_ids"])
-                computed_tokens += len(jobs[i]["token_ids"])
+                computed_tokens += need[i]
                 store_owned(i, arena, row)
             del out, arena
 
@@ -344,7 +354,7 @@ class SchemaCache:
         # one union -- go through one batched forward.
         ragged = bool(getattr(getattr(lm, "hf_model", None), "supports_ragged_past", False)) and not full_pos and \
             self.ragged_suffix_batches
-        suffix_len = [len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)]
+        suffix_len = [need[i] - prefix[i] for i in range(len(jobs))]
         if ragged:
             groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size)]
         else:
@@ -374,8 +384,8 @@ class SchemaCache:
             if has_lo:
                 arena.lo_len = n_max
             arena.length = n_max
-            ids_pad, mask = pad_batch([j["token_ids"][n:] for j, n in zip(group, pre)], lm.eos_token_id)
-            pos_pad, _ = pad_batch([j["position_ids"][n:] for j, n in zip(group, pre)], 0)
+            ids_pad, mask = pad_batch([jobs[i]["token_ids"][prefix[i]:need[i]] for i in idxs], lm.eos_token_id)
+            pos_pad, _ = pad_batch([jobs[i]["position_ids"][prefix[i]:need[i]] for i in idxs], 0)
             if full_pos:                                 # ALiBi models take the position id of every key
                 pos_pad = [list(jobs[0]["position_ids"][:n_max]) + row for row in pos_pad]
             extra = {} if n_same is not None else {"past_lens": torch.tensor(pre, device=dev, dtype=torch.int32)}
@@ -411,6 +421,10 @@ class SchemaCache:
 
     # tokens (padding included) one encode forward may carry when scaffolds are packed into a batch
     encode_token_budget = 8192
+    encode_rows_max = 32                    # passes per forward (each holds its own arena row: prefix + suffix K/V)
+    encode_forward_cost = int(os.environ.get("PC_ENC_FWD_COST", "150"))   # fixed cost of one more forward, in token rows (_pack)
+    # run a scaffold only up to its last owned token (exact under the causal mask; see _process)
+    truncate_scaffolds = os.environ.get("PC_TRUNCATE_SCAFFOLDS", "1") != "0"
     # encode scaffolds as suffixes over the root scaffold's K/V where they share a prefix with it (see _process)
     share_trunk = os.environ.get("PC_SHARE_TRUNK", "1") != "0"
     share_trunk_min = 32
@@ -432,17 +446,32 @@ class SchemaCache:
             return [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
         if not self._batch_invariant():
             return [[i] for i in mine]
+        # Longest first, cut into consecutive groups so that the padded rows (rows x width of the group's longest pass)
+        # plus a fixed cost per forward are minimal: passes of similar length travel together.  (Greedy filling to the
+        # budget padded the persona schema's 149..282-token suffixes to 282 and 258: 17 % of the rows were padding; the
+        # optimal cut pads 6 %.)  The many-row GEMM runs at its full rate from ~500 rows up (profiles/r02_dense_splitk.txt),
+        # so smaller groups cost only the per-forward launches: ~2 ms, ~150 rows' worth.
         order = sorted(mine, key=lambda i: (-lengths[i], i))
-        groups, cur = [], []
-        for i in order:
-            width = lengths[cur[0]] if cur else lengths[i]
-            if cur and ((len(cur) + 1) * width > self.encode_token_budget or len(cur) >= 16):
-                groups.append(cur)
-                cur = []
-            cur.append(i)
-        if cur:
-            groups.append(cur)
-        return groups
+        n = len(order)
+        if n == 0:
+            return []
+        INF = float("inf")
+        best = [INF] * (n + 1)
+        cut = [0] * (n + 1)
+        best[0] = 0
+        for j in range(1, n + 1):
+            for i in range(max(0, j - self.encode_rows_max), j):
+                rows = (j - i) * lengths[order[i]]
+                if rows > self.encode_token_budget and j - i > 1:
+                    continue
+                c = best[i] + rows + self.encode_forward_cost
+                if c < best[j]:
+                    best[j], cut[j] = c, i
+        groups, j = [], n
+        while j > 0:
+            groups.append(order[cut[j]:j])
+            j = cut[j]
+        return groups[::-1]
 
     def get_cache_l1(self, seq: TokenSequence) -> Optional[TokenSequenceCache]:
         return self.cache_l1.get(id(seq))

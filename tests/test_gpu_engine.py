@@ -237,7 +237,9 @@ def test_trunk_reuse_encode_equals_full_encode(family):
     stores = {}
     try:
         for share in (True, False):
-            SchemaCache.share_trunk = share
+            # False = the reference's encode: every scaffold from its first to its last token (no trunk reuse, no cut behind
+            # the last owned token)
+            SchemaCache.share_trunk = SchemaCache.truncate_scaffolds = share
             eng = CacheEngine(1024, lm)
             eng.add_schema(text)
             sc = eng.schemas["p"]
@@ -249,7 +251,7 @@ def test_trunk_reuse_encode_equals_full_encode(family):
             stores[share] = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in sc.cache_l1.values()),
                                    key=lambda t: (t[0], t[1]))
     finally:
-        SchemaCache.share_trunk = True
+        SchemaCache.share_trunk = SchemaCache.truncate_scaffolds = True
     assert [(a, b) for a, b, _ in stores[True]] == [(a, b) for a, b, _ in stores[False]]
     worst = max(float((x[2] - y[2]).abs().max()) for x, y in zip(stores[True], stores[False]))
     print(f"[{family}] trunk reuse vs full encode: max |dKV| = {worst:.2e}")

@@ -976,14 +976,31 @@ bool use_rows32(int B, int H, int q_len, int kv_len) {
     return B * H * pc_ceil_div(q_len, kQB32) >= 256 || kv_len >= 8 * q_len;
 }
 
-int choose_nsplit(int B, int H, int q_len, int kv_len) {
+// hp: the launch carries split-precision Q (the 64-rows-per-workgroup kernel whatever the size)
+int choose_nsplit(int B, int H, int q_len, int kv_len, bool hp) {
     static const int forced = [] { const char* e = getenv("PC_ATTN_NSPLIT"); return e ? atoi(e) : 0; }();
-    const int nqblk = pc_ceil_div(q_len, use_rows32(B, H, q_len, kv_len) ? kQB32 : kQB);
+    const int nqblk = pc_ceil_div(q_len, (!hp && use_rows32(B, H, q_len, kv_len)) ? kQB32 : kQB);
     const int base = B * H * nqblk;
     // ~1.25 workgroups per CU: fewer, longer KV streams per workgroup beat many short ones (measured on the
     // persona shape: 10 splits x 32 heads = 18.7 us vs 13 splits 20.3 us vs 4 splits 23.8 us per layer)
     int ns = forced > 0 ? forced : (320 + base / 2) / (base > 0 ? base : 1);
     const int max_by_len = kv_len / (2 * kTK);                   // keep >= 2 tiles per split
+    if (forced <= 0 && q_len > kSmallQ && base > 0) {
+        // Many query rows over a long cache (a long question in front of staged modules: 259 rows over 8.3 k keys at the 13b
+        // shape): a workgroup walks kv_len / (64 ns) key tiles and two workgroups share a CU, so what counts is how evenly
+        // base * ns workgroups fill rounds of 512 slots.  Cost in key-tile units: rounds x (tiles per split + 1) + the merge.
+        // Measured (tools/attn_mid.py, 40 heads, q = 259, 8.3 k keys): 2 splits 252 us, 3: 276, 4: 247, 5: 218, 10: 231;
+        // (32 heads, q = 100, 1.7 k keys) 2: 52, 4: 34.5, 5: 33, 8: 31 -- the rule below picks 5 and 8.
+        const int T = pc_ceil_div(kv_len, kTK);
+        int best = 1;
+        float best_cost = 1e30f;
+        const int lim = max_by_len < kMaxSplit ? (max_by_len < 1 ? 1 : max_by_len) : kMaxSplit;
+        for (int c = 1; c <= lim; ++c) {
+            const float cost = (float)pc_ceil_div(base * c, 512) * (float)(pc_ceil_div(T, c) + 1) + (c > 1 ? 3.f + 0.5f * c : 0.f);
+            if (cost < best_cost) { best_cost = cost; best = c; }
+        }
+        ns = best;
+    }
     if (ns > max_by_len) ns = max_by_len;
     if (ns > kMaxSplit) ns = kMaxSplit;
     if (ns < 1) ns = 1;
@@ -1036,7 +1053,9 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
 
 PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max) {
     if (B <= 0 || H <= 0 || D <= 0 || q_len <= 0) return 0;
-    int ns = choose_nsplit(B, H, q_len, kv_len_max);
+    // (the launch may or may not carry split-precision Q: room for the larger split count)
+    const int ns_a = choose_nsplit(B, H, q_len, kv_len_max, false), ns_b = choose_nsplit(B, H, q_len, kv_len_max, true);
+    int ns = ns_a > ns_b ? ns_a : ns_b;
     // passes of <= kTailMax rows may run in tail mode (pc_attn_fwd_ex with lo_row0 = -1): one more split, always merged
     if (q_len <= kTailMax) ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
     // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
@@ -1077,7 +1096,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.k_lo = (const _Float16*)k_lo; p.v_lo = (const _Float16*)v_lo; p.lo_bs = lo_bs; p.lo_hs = lo_hs; p.lo_row0 = lo_row0;
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len);
+    p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len, q_len <= kQB || q_lo != nullptr);
     p.tail = (k_lo && lo_row0 == -1 && q_len <= kTailMax && !past_lens) ? 1 : 0;
     // <= 16 rows over a long cache: one key slice per WAVE, partials merged per workgroup (attn_small_kernel).  Not for
     // launches that carry residual tiles in the stream (decode over a residual tail, lo_row0 != -1).

@@ -985,9 +985,9 @@ int choose_nsplit(int B, int H, int q_len, int kv_len, bool hp) {
     // persona shape: 10 splits x 32 heads = 18.7 us vs 13 splits 20.3 us vs 4 splits 23.8 us per layer)
     int ns = forced > 0 ? forced : (320 + base / 2) / (base > 0 ? base : 1);
     const int max_by_len = kv_len / (2 * kTK);                   // keep >= 2 tiles per split
-    if (forced <= 0 && q_len > kSmallQ && base > 0) {
-        // Many query rows over a long cache (a long question in front of staged modules: 259 rows over 8.3 k keys at the 13b
-        // shape): a workgroup walks kv_len / (64 ns) key tiles and two workgroups share a CU, so what counts is how evenly
+    if (forced <= 0 && q_len > kSmallQ && base > 0 && kv_len >= 4 * q_len) {
+        // Many query rows over a much longer cache (a long question in front of staged modules: 259 rows over 8.3 k keys at the
+        // 13b shape; not the causal q ~ kv regime of an encode, whose key ranges differ per query block): a workgroup walks kv_len / (64 ns) key tiles and two workgroups share a CU, so what counts is how evenly
         // base * ns workgroups fill rounds of 512 slots.  Cost in key-tile units: rounds x (tiles per split + 1) + the merge.
         // Measured (tools/attn_mid.py, 40 heads, q = 259, 8.3 k keys): 2 splits 252 us, 3: 276, 4: 247, 5: 218, 10: 231;
         // (32 heads, q = 100, 1.7 k keys) 2: 52, 4: 34.5, 5: 33, 8: 31 -- the rule below picks 5 and 8.

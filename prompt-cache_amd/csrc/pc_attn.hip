@@ -336,6 +336,9 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     if (ks0 < kend) issue_loads(ks0);
 
     for (int key0 = ks0; key0 < kend; key0 += kTK) {
+        // (workgroup-uniform) does this tile hold any key with a residual?  Most tiles of a long staged cache do not: their
+        // residual tiles are neither written nor read (a question of 259 rows over 8.3 k staged keys: 129 of 134 tiles)
+        [[maybe_unused]] const bool tile_lo = KVLO && key0 + kTK > lo_row0;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int c = tid + i * kThreads;
@@ -346,12 +349,13 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             // unrotated tile measured SQ_LDS_BANK_CONFLICT = 68 % of SQ_LDS_IDX_ACTIVE: an 8-way conflict)
             *(u32x4*)(Vl + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
             if (KVLO) {
-                *(u32x4*)(Kll + row * D + ((col ^ (row & (CPR - 1))) << 3)) = krl[i];
-                *(u32x4*)(Vll + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vrl[i];
+                if (tile_lo) {
+                    *(u32x4*)(Kll + row * D + ((col ^ (row & (CPR - 1))) << 3)) = krl[i];
+                    *(u32x4*)(Vll + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vrl[i];
+                }
             }
         }
         __syncthreads();
-        [[maybe_unused]] const bool tile_lo = KVLO && key0 + kTK > lo_row0;       // any key with a residual in the tile
         if (key0 + kTK < kend) issue_loads(key0 + kTK);
 
         if (wave_active && key0 < wave_vis_end) {

@@ -23,7 +23,7 @@ ah = torch.empty((mt, H * D // 32, 64, 8), dtype=torch.float16, device=dev)
 al = torch.empty_like(ah)
 ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q, S + q), 4) // 4 * 4, dtype=torch.float32, device=dev)
 past_dev = torch.tensor([S, 0], dtype=torch.int32, device=dev)
-kvlo = (lo[0], lo[1], Hkv * 320 * D, 320 * D, -1)
+kvlo = None if os.environ.get("NO_KVLO") else (lo[0], lo[1], Hkv * 320 * D, 320 * D, -1)
 
 
 def run(i):

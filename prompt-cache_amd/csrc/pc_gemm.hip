@@ -1024,6 +1024,8 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
         mt = mt < mt_last ? mt : mt_last;
         xa[a] = p.xf_hi + (((int64_t)mt * KS + kq0) * 64 + lane) * 8;
     }
+    // row tiles this wave really owns (wave-uniform, >= 1): the MFMAs of the clamped duplicates behind the last tile are skipped
+    const int nva = __builtin_amdgcn_readfirstlane((mt_last + 1 - MTW * wave) < MTW ? (mt_last + 1 - MTW * wave) : MTW);
     const int klast = kq1 - 1 - kq0;                     // last valid k-step, relative to kq0
     // k-step (relative to kq0) loaded for sequence position i; positions past the end repeat the last one
     auto kseq = [&](int i) { return i < klast ? i : klast; };
@@ -1056,12 +1058,15 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
 #pragma unroll
             for (int t = 0; t < TT; ++t) w[t] = *(const h8*)(wst + (j * TT + t) * 512);
 #pragma unroll
-            for (int t = 0; t < TT; ++t)
+            for (int a = 0; a < MTW; ++a) {
+                if (a < nva) {
 #pragma unroll
-                for (int a = 0; a < MTW; ++a) {
-                    acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xs[j % NX][a], acc[a][t], 0, 0, 0);
-                    if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xsl[j % NX][a], acc[a][t], 0, 0, 0);
+                    for (int t = 0; t < TT; ++t) {
+                        acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xs[j % NX][a], acc[a][t], 0, 0, 0);
+                        if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xsl[j % NX][a], acc[a][t], 0, 0, 0);
+                    }
                 }
+            }
         }
     }
 #pragma unroll

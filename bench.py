@@ -673,6 +673,10 @@ def main():
             o8 = lm8(input_ids=i8_t, position_ids=p8_t, past_key_values=cache8, use_cache=True)
             torch.cuda.synchronize(); ts8.append((time.perf_counter() - t0) * 1e3)
         past8, tok8 = o8.past_key_values, int(torch.argmax(o8.logits[0, -1]))
+        # how many fp16 outlier columns the step's last layer split off (the flags of q|k|v's input were cleared by the
+        # down_proj quantiser): the cost of the correction scales with them, and a random-init model has far more than an LLM
+        fl8 = getattr(lm8.hf_model, "_i8_flags", None)
+        outl = None if fl8 is None else {k: int(fl8[i].ne(0).sum()) for i, k in ((1, "o_proj_in"), (2, "gate_up_in"), (3, "down_proj_in"))}
         for phase in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for i in range(32):
@@ -683,6 +687,7 @@ def main():
             torch.cuda.synchronize(); dt8 = time.perf_counter() - t0
         result["int8_weights"] = {"ttft_ms": sorted(ts8[2:])[len(ts8[2:]) // 2], "decode_tokens_per_s": 32 / dt8,
                                   "mode": "llm_int8" if lm8.hf_model.llm_int8 else "weight_only",
+                                  "outlier_columns_last_layer": outl,
                                   "what": "load_in_8bit=True: LLM.int8() as published (row-wise absmax int8 weights, vector-wise "
                                           "int8 activations, fp16 outlier columns at |x| >= 6), lm_head fp16; module KV from the "
                                           "fp16 engine; PC_INT8_WEIGHT_ONLY=1 selects round 1's weight-only mode"}

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restri
     }
 }
 
-constexpr int kMaxCols = 128;       // outlier columns handled per batch of the correction kernel
-constexpr int kCorrRows = 64;       // activation rows staged per pass
+constexpr int kMaxCols = 512;       // outlier columns handled per batch of the correction kernel (each batch costs ~4 us of
+                                    // dependent staging phases: 460 columns took 56 us in four batches of 128)
+constexpr int kCorrRows = 16;       // activation rows staged per pass (one per row slot of the workgroup)
 constexpr int kCorrCols = 16;       // output columns per workgroup of the correction kernel
 
 template <bool FRAG>
@@ -119,11 +120,25 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
     const int per = (K + 255) / 256;
     int mine = 0;
     for (int k = tid * per; k < (tid + 1) * per && k < K; ++k) mine += lf[k] ? 1 : 0;
-    cnt[tid + 1] = mine;
-    if (tid == 0) cnt[0] = 0;
-    __syncthreads();
-    if (tid == 0)
-        for (int i = 1; i <= 256; ++i) cnt[i] += cnt[i - 1];
+    // exclusive prefix sum of the 256 per-thread counts: shuffles inside a wave, the four wave totals through LDS (a
+    // single thread walking cnt[] cost ~12 us of serial LDS round trips in every call that had any outlier column)
+    {
+        __shared__ int wtot[4];
+        const int lane = tid & 63, wv = tid >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) woff += (w < wv) ? wtot[w] : 0;
+        cnt[tid + 1] = woff + incl;                      // inclusive: cnt[i] = flagged columns owned by threads < i
+        if (tid == 0) cnt[0] = 0;
+    }
     __syncthreads();
     const int total = cnt[256];
     if (blockIdx.x == 0 && tid == 0) has[0] = 1;
@@ -169,7 +184,8 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
             for (int tt = tg; tt < nt; tt += 256 / kCorrCols) {
                 float acc = 0.f;
                 const float xs = x_scale[t0 + tt] * ws;
-                for (int j = 0; j < nb; ++j) {
+#pragma unroll 8
+                for (int j = 0; j < nb; ++j) {       // (unrolled: eight columns' LDS reads in flight instead of one round trip each)
                     const float wq = (float)wl[j][nl];
                     const float wd = (float)(_Float16)(wq * ws);        // fp16(CB * SCB / 127): the fp16 weight column
                     acc += (float)xl[tt][j] * wd - (float)cl[tt][j] * wq * xs;

@@ -398,6 +398,12 @@ int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* attn_lo, in
  *   pc_gemm_skinny / pc_gemm_qkv_rope_ex / pc_gemm_dense (same epilogue codes and outputs). */
 int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale, void* flags_set,
                     void* flags_clear, int32_t clear_len, float threshold, void* stream);
+/* pc_rmsnorm_frag + pc_quant_act_i8 in one launch (T <= 64 rows, fragment planes), for the two projection inputs that come out of
+ * an RMSNorm (input_layernorm -> q|k|v, post_attention_layernorm -> gate|up; llama2.py:628, :640): bit-identical to the pair.
+ * x: fp32 residual stream [T][hidden]; x_hi: the normalised fp16 activations (read by pc_outlier_corr), codes / x_scale / flags as
+ * pc_quant_act_i8. */
+int pc_rmsnorm_quant_i8(const float* x, const void* norm_weight, float eps, int32_t T, int32_t hidden, void* x_hi, void* codes,
+                        float* x_scale, void* flags_set, void* flags_clear, int32_t clear_len, float threshold, void* stream);
 int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
                     const float* x_scale, const void* w_codes_t, int64_t ldt, const float* w_scale, const int32_t* row_perm,
                     int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream);

@@ -89,6 +89,93 @@ __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restri
     }
 }
 
+// RMSNorm + quantiser in one launch for the two projection inputs that come out of a norm (q|k|v, gate|up; <= 64-row path):
+// exactly rmsnorm_frag_kernel's arithmetic (pc_gemm.hip: same per-thread partial sums, same reduction order, v = g * (x * rs),
+// hi = fp16(v)) followed by quant_act_kernel's on the hi values, so the pair of launches and this one are bit-identical.
+// Writes the hi plane (the fp16 activations the outlier correction reads), the codes plane, x_scale and the outlier flags.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int G>
+__global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float* __restrict__ x, const _Float16* __restrict__ w,
+                                                            _Float16* __restrict__ of_hi, _Float16* __restrict__ codes,
+                                                            float* __restrict__ x_scale, unsigned char* __restrict__ flags_set,
+                                                            unsigned char* __restrict__ flags_clear, int clear_len, float threshold,
+                                                            int hidden, float eps) {
+    __shared__ float red[4];
+    __shared__ float redq[4];
+    const int row = blockIdx.x, tid = threadIdx.x, nv = hidden >> 3, KS = hidden >> 5;
+    if (flags_clear)
+        for (int k = row * 256 + tid; k < clear_len; k += gridDim.x * 256) flags_clear[k] = 0;
+    const float* xr = x + (int64_t)row * hidden;
+    f4 va[G], vb[G];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int i = tid + k * 256;
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        va[k] = z; vb[k] = z;
+        if (i < nv) {
+            va[k] = *(const f4*)(xr + i * 8);
+            vb[k] = *(const f4*)(xr + i * 8 + 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+        ss += va[k][0] * va[k][0] + va[k][1] * va[k][1] + va[k][2] * va[k][2] + va[k][3] * va[k][3] +
+              vb[k][0] * vb[k][0] + vb[k][1] * vb[k][1] + vb[k][2] * vb[k][2] + vb[k][3] * vb[k][3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
+    float a[G][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int i = tid + k * 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[k][e] = 0.f;
+        if (i < nv) {
+            const h8 gw = *(const h8*)(w + i * 8);
+            h8 hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (float)gw[e] * ((e < 4 ? va[k][e] : vb[k][e - 4]) * rs);
+                _Float16 vh, vl;
+                pc_split(v, vh, vl);
+                hi[e] = vh;
+                const float f = (float)vh;
+                const bool outl = threshold > 0.f && fabsf(f) >= threshold;
+                if (outl) flags_set[i * 8 + e] = 1;
+                a[k][e] = outl ? 0.f : f;
+                mx = fmaxf(mx, fabsf(a[k][e]));
+            }
+            *(h8*)(of_hi + frag_off(row, i * 8, KS)) = hi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) redq[tid >> 6] = mx;
+    __syncthreads();
+    const float sca = fmaxf(fmaxf(redq[0], redq[1]), fmaxf(redq[2], redq[3]));
+    const float inv = sca > 0.f ? 127.0f / sca : 0.f;
+    if (tid == 0) x_scale[row] = sca / 127.0f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int i = tid + k * 256;
+        if (i < nv) {
+            h8 q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r = rintf(a[k][e] * inv);
+                r = fminf(fmaxf(r, -127.f), 127.f);
+                q[e] = (_Float16)r;
+            }
+            *(h8*)(codes + frag_off(row, i * 8, KS)) = q;
+        }
+    }
+}
+
 constexpr int kMaxCols = 512;       // outlier columns handled per batch of the correction kernel (each batch costs ~4 us of
                                     // dependent staging phases: 460 columns took 56 us in four batches of 128)
 constexpr int kCorrRows = 16;       // activation rows staged per pass (one per row slot of the workgroup)
@@ -218,6 +305,23 @@ PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t 
     if (groups <= 1) PC_Q(1); else if (groups <= 2) PC_Q(2); else if (groups <= 4) PC_Q(4); else PC_Q(8);
 #undef PC_Q
     return pc_check_launch("quant_act_kernel");
+}
+
+PC_EXPORT int pc_rmsnorm_quant_i8(const float* x, const void* norm_weight, float eps, int32_t T, int32_t hidden, void* x_hi,
+                                  void* codes, float* x_scale, void* flags_set, void* flags_clear, int32_t clear_len,
+                                  float threshold, void* stream) {
+    PC_REQUIRE(T > 0 && T <= 64 && hidden > 0 && hidden % 32 == 0 && hidden <= 16384, PC_ERR_ARG,
+               "pc_rmsnorm_quant_i8: need 1 <= T <= 64, hidden %% 32 == 0, hidden <= 16384");
+    PC_REQUIRE(x && norm_weight && x_hi && codes && x_scale && flags_set, PC_ERR_ARG, "pc_rmsnorm_quant_i8: null pointer");
+    const int groups = pc_ceil_div(hidden / 8, 256);
+    hipStream_t s = (hipStream_t)stream;
+#define PC_RQ(GV)                                                                                                          \
+    hipLaunchKernelGGL(rmsnorm_quant_kernel<GV>, dim3(T), dim3(256), 0, s, x, (const _Float16*)norm_weight, (_Float16*)x_hi,  \
+                       (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold, \
+                       hidden, eps)
+    if (groups <= 1) PC_RQ(1); else if (groups <= 2) PC_RQ(2); else if (groups <= 4) PC_RQ(4); else PC_RQ(8);
+#undef PC_RQ
+    return pc_check_launch("rmsnorm_quant_kernel");
 }
 
 PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,

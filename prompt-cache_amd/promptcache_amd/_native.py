@@ -65,6 +65,7 @@ SIGNATURES = {
                                   _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
+    "pc_rmsnorm_quant_i8": (C.c_int, [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_skinny_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "pc_gemm_qkv_rope_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
@@ -539,6 +540,16 @@ def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags
                                 0 if flags_clear is None else flags_clear.numel(), threshold,
                                 current_stream() if stream is None else stream)
     check(rc, "pc_quant_act_i8")
+
+
+def rmsnorm_quant_i8(x, norm_weight, eps: float, T: int, hidden: int, x_hi, codes, x_scale, flags_set, flags_clear=None,
+                     threshold: float = LLM_INT8_THRESHOLD, stream: Optional[int] = None) -> None:
+    """RMSNorm + LLM.int8 activation quantiser in one launch (fragment planes, T <= 64): pc_rmsnorm_frag + pc_quant_act_i8."""
+    rc = load().pc_rmsnorm_quant_i8(x.data_ptr(), norm_weight.data_ptr(), eps, T, hidden, x_hi.data_ptr(), codes.data_ptr(),
+                                    x_scale.data_ptr(), flags_set.data_ptr(), _ptr(flags_clear),
+                                    0 if flags_clear is None else flags_clear.numel(), threshold,
+                                    current_stream() if stream is None else stream)
+    check(rc, "pc_rmsnorm_quant_i8")
 
 
 def outlier_corr(flags, K: int, x, codes, frag: bool, x_scale, w_codes_t, w_scale, row_perm, T: int, N: int, corr, has,

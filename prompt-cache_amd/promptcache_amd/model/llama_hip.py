@@ -497,12 +497,16 @@ class LlamaHIP:
     # (pc_quant_act_i8), the projection runs over weight codes x activation codes and is rescaled by w_scale[n] * x_scale[m]
     # in its epilogue, and columns holding an activation >= 6 are carried in fp16 (pc_outlier_corr) -- Dettmers et al. 2022 as
     # bitsandbytes' Linear8bitLt applies it.  Norms, RoPE, attention, residual stream and lm_head are the fp16-mode kernels.
-    def _i8_lin_frag(self, slot, act_hi, K, lw, key, perm, T, N, bufs):
+    def _i8_lin_frag(self, slot, act_hi, K, lw, key, perm, T, N, bufs, norm=None):
         """Quantise a fragment-plane activation (its hi plane is the fp16 value bitsandbytes would see) and prepare the outlier
-        correction for projection ``key``: -> (codes, x_scale, corr, has)."""
+        correction for projection ``key``: -> (codes, x_scale, corr, has).  ``norm=(x_f32, gain, eps)``: the activation is
+        RMSNorm(x) -- normalised, written to ``act_hi`` and quantised in ONE launch (pc_rmsnorm_quant_i8)."""
         n = _native
         codes, xs, corr, has = bufs
-        n.quant_act_i8(act_hi, True, T, K, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
+        if norm is not None:
+            n.rmsnorm_quant_i8(norm[0], norm[1], norm[2], T, K, act_hi, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
+        else:
+            n.quant_act_i8(act_hi, True, T, K, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
         n.outlier_corr(self._i8_flags[slot], K, act_hi, codes, True, xs, lw[key + "_t8"], lw[key + "_ds"], perm, T, N, corr, has)
         return codes, xs, corr, has
 
@@ -542,8 +546,7 @@ class LlamaHIP:
         for li, lw in enumerate(layers):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kvlo, lo_base = tail(li)
-            n.rmsnorm_frag(x, lw["ln1"], xh, xl, T, hid, eps)
-            cd, xs, corr, hs = self._i8_lin_frag(0, xh, hid, lw, "wqkv", self._qkv_perm_i32, T, W, bufs[0])
+            cd, xs, corr, hs = self._i8_lin_frag(0, xh, hid, lw, "wqkv", self._qkv_perm_i32, T, W, bufs[0], norm=(x, lw["ln1"], eps))
             n.gemm_qkv_rope_a8(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, corr, hs, T, hid, cs, q16, q16l, H * D, kp, vp,
                                arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
                                kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
@@ -552,8 +555,7 @@ class LlamaHIP:
                        q_lo=q16l, kv_lo=kvlo)
             cd, xs, corr, hs = self._i8_lin_frag(1, ah, H * D, lw, "wo", None, T, hid, bufs[1])
             n.gemm_skinny_a8(lw["wo_f"], lw["wo_s"], cd, zero, xs, corr, hs, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
-            n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps)
-            cd, xs, corr, hs = self._i8_lin_frag(2, xh, hid, lw, "wgu", None, T, 2 * inter, bufs[2])
+            cd, xs, corr, hs = self._i8_lin_frag(2, xh, hid, lw, "wgu", None, T, 2 * inter, bufs[2], norm=(x, lw["ln2"], eps))
             n.gemm_skinny_a8(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, corr, hs, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)
             cd, xs, corr, hs = self._i8_lin_frag(3, ch, inter, lw, "wdown", None, T, hid, bufs[3])
             n.gemm_skinny_a8(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, corr, hs, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)

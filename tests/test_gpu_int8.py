@@ -123,3 +123,27 @@ def test_llm_int8_linear_matches_the_oracle(path, with_outliers):
         # the decomposition matters: plain vector-wise int8 of the same input is far from it
         y0 = lo.linear(x, qo, so, threshold=0.0)
         assert np.abs(y0 - ref).max() > 50 * np.abs(y - ref).max()
+
+
+@pytest.mark.parametrize("T,hid", [(12, 4096), (1, 5120), (40, 256), (64, 11008)])
+def test_rmsnorm_quant_fused_equals_the_two_launches(T, hid):
+    """pc_rmsnorm_quant_i8 == pc_rmsnorm_frag followed by pc_quant_act_i8, bit for bit (hi plane, codes, scales, flags)."""
+    n = _n()
+    g = torch.Generator().manual_seed(T + hid)
+    x = (2.5 * torch.randn((T, hid), generator=g)).to(DEV)
+    x[0, 3] = 40.0                                              # an outlier behind the norm as well
+    gam = (1.0 + 0.3 * torch.randn(hid, generator=g)).half().to(DEV)
+    mt = (T + 15) // 16
+    shape = (mt, hid // 32, 64, 8)
+    hi_a, lo_a, cd_a = (torch.zeros(shape, dtype=torch.float16, device=DEV) for _ in range(3))
+    hi_b, cd_b = (torch.zeros(shape, dtype=torch.float16, device=DEV) for _ in range(2))
+    xs_a, xs_b = torch.zeros(T, device=DEV), torch.zeros(T, device=DEV)
+    fl_a = torch.zeros((2, 16384), dtype=torch.uint8, device=DEV)
+    fl_b = torch.zeros((2, 16384), dtype=torch.uint8, device=DEV)
+    fl_a[1].fill_(7); fl_b[1].fill_(7)                          # the "next slot" row must come back cleared
+    n.rmsnorm_frag(x.clone(), gam, hi_a, lo_a, T, hid, 1e-5)
+    n.quant_act_i8(hi_a, True, T, hid, cd_a, xs_a, fl_a[0], fl_a[1])
+    n.rmsnorm_quant_i8(x, gam, 1e-5, T, hid, hi_b, cd_b, xs_b, fl_b[0], fl_b[1])
+    torch.cuda.synchronize()
+    assert torch.equal(hi_a, hi_b) and torch.equal(cd_a, cd_b) and torch.equal(xs_a, xs_b) and torch.equal(fl_a, fl_b)
+    assert int(fl_b[0].sum()) >= 1 and int(fl_b[1].sum()) == 0

@@ -398,6 +398,22 @@ int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* attn_lo, in
  *   pc_gemm_skinny / pc_gemm_qkv_rope_ex / pc_gemm_dense (same epilogue codes and outputs). */
 int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale, void* flags_set,
                     void* flags_clear, int32_t clear_len, float threshold, void* stream);
+/* pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 with the outlier correction computed INSIDE the launch (M <= 64): instead of corr /
+ * corr_has the call takes what pc_outlier_corr would have read -- the flag bytes of pc_quant_act_i8 (a 16-byte aligned buffer of
+ * >= 16384 bytes, zero behind K), the fp16 activations x_raw (fragment plane), the transposed int8 weight codes [K][ldt]
+ * (original row order) and, for q|k|v, the image-row -> original-row permutation.  Every workgroup compacts the flags and its
+ * eight waves share the outlier columns; the result equals pc_outlier_corr + pc_gemm_*_a8 up to the fp32 summation order over the
+ * outlier columns.  Saves one launch per projection (~4 us even when no column is flagged). */
+int pc_gemm_skinny_a8c(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
+                       const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt, int32_t M, int32_t N, int32_t K,
+                       int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
+int pc_gemm_qkv_rope_a8c(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
+                         const float* x_scale, const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt,
+                         const int32_t* row_perm, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo,
+                         int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
+                         int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                         int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
+                         int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
 /* pc_rmsnorm_frag + pc_quant_act_i8 in one launch (T <= 64 rows, fragment planes), for the two projection inputs that come out of
  * an RMSNorm (input_layernorm -> q|k|v, post_attention_layernorm -> gate|up; llama2.py:628, :640): bit-identical to the pair.
  * x: fp32 residual stream [T][hidden]; x_hi: the normalised fp16 activations (read by pc_outlier_corr), codes / x_scale / flags as

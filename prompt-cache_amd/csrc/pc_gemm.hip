@@ -81,6 +81,11 @@ struct GemmParams {
     // corr[m][n] (row stride ldc, output-feature index in the image's row order) is added before the epilogue's
     // nonlinearity when *corr_has != 0 (the fp16 outlier part of the decomposition)
     const float* xscale; const float* corr; int64_t ldc; const int32_t* corr_has;
+    // ... or the correction is computed INSIDE the launch (pc_gemm_*_a8c): oflags = the K outlier-column flag bytes of
+    // pc_quant_act_i8 (buffer of >= 16384 bytes, zero behind K), xraw = the fp16 activations (fragment plane, same layout as the
+    // code plane xf_hi), cbt = the int8 weight codes transposed [K][ldt] in ORIGINAL row order, row_perm = image row -> original
+    // row (q|k|v's rotary permutation) or null
+    const unsigned char* oflags; const _Float16* xraw; const signed char* cbt; int64_t ldt; const int32_t* row_perm;
     RopeEpi rope;
 };
 
@@ -269,7 +274,9 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
 // holds output row `row` (token) and features unit*16 + 4*g .. +3.  Must be called by all 64 lanes of a wave
 // (EPI_ROPE exchanges rotary partners across lanes).
 template <int EPI>
-__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, int row, int unit, int g, int slice) {
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, int row, int unit, int g, int slice,
+                                              bool fused_corr = false, f4 fused_cv = f4{0.f, 0.f, 0.f, 0.f},
+                                              f4 fused_cu = f4{0.f, 0.f, 0.f, 0.f}) {
     const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
     if (p.wscale && unit < nunits) {        // int8 weights: per-output-feature scale (linear, so K-sliced partials scale too)
         const f4 sv = *(const f4*)(p.wscale + unit * 16 + g * 4);
@@ -283,7 +290,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
         const float xs = p.xscale[row];
         v[0] *= xs; v[1] *= xs; v[2] *= xs; v[3] *= xs;
         if (EPI == EPI_SILU) { u[0] *= xs; u[1] *= xs; u[2] *= xs; u[3] *= xs; }
-        if (*p.corr_has) {
+        if (fused_corr) {                   // the correction was accumulated inside this launch
+            v[0] += fused_cv[0]; v[1] += fused_cv[1]; v[2] += fused_cv[2]; v[3] += fused_cv[3];
+            if (EPI == EPI_SILU) { u[0] += fused_cu[0]; u[1] += fused_cu[1]; u[2] += fused_cu[2]; u[3] += fused_cu[3]; }
+        } else if (*p.corr_has) {
             const f4 cv = *(const f4*)(p.corr + (int64_t)row * p.ldc + unit * 16 + g * 4);
             v[0] += cv[0]; v[1] += cv[1]; v[2] += cv[2]; v[3] += cv[3];
             if (EPI == EPI_SILU) {
@@ -502,6 +512,93 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
     }
     after_k();
 
+    // ---- LLM.int8 outlier correction inside the launch (pc_gemm_*_a8c) ----
+    // corr[t][n] = sum over the outlier columns k of  X[t][k] * fp16(CB[n][k] * s[n])  -  CA[t][k] * CB[n][k] * xs[t] * s[n]
+    // (pc_int8.hip).  Every workgroup compacts the flag bytes into a column list in the (still idle) reduction buffer -- 32
+    // bytes per thread, ascending, prefix sums by shuffles -- and its eight waves deal the columns among themselves, each
+    // accumulating its share for the workgroup's tiles in the MFMA C layout; the shares meet in the split-K reduction below.
+    // A stand-alone correction launch costs ~4 us even when there is nothing to correct (the usual case behind a norm).
+    [[maybe_unused]] f4 cacc[MT][TT];
+    [[maybe_unused]] bool fused = false;
+    if constexpr (W8) {
+        fused = p.oflags != nullptr;
+        if (fused) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; cacc[a][t] = z; }
+            unsigned short* cols = (unsigned short*)red_raw;
+            constexpr int kColsCap = kWaves * kRT * 64 * 4 * 4 / 2;         // u16 entries that fit the reduction buffer
+            int* wtot = (int*)&ssl[0][0];
+            const u32x4 f0 = *(const u32x4*)(p.oflags + tid * 32), f1 = *(const u32x4*)(p.oflags + tid * 32 + 16);
+            auto nz4 = [](uint32_t w) { return ((w & 0xffu) ? 1 : 0) + ((w & 0xff00u) ? 1 : 0) + ((w & 0xff0000u) ? 1 : 0) + ((w >> 24) ? 1 : 0); };
+            const int mine = nz4(f0[0]) + nz4(f0[1]) + nz4(f0[2]) + nz4(f0[3]) + nz4(f1[0]) + nz4(f1[1]) + nz4(f1[2]) + nz4(f1[3]);
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (lane == 63) wtot[wave] = incl;
+            lds_barrier();
+            int off = incl - mine, total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) { off += (w < wave) ? wtot[w] : 0; total += wtot[w]; }
+            if (mine) {
+                auto put4 = [&](uint32_t w, int base) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if ((w >> (8 * b)) & 0xffu) { if (off < kColsCap) cols[off] = (unsigned short)(base + b); ++off; }
+                };
+                const int c0 = tid * 32;
+                put4(f0[0], c0); put4(f0[1], c0 + 4); put4(f0[2], c0 + 8); put4(f0[3], c0 + 12);
+                put4(f1[0], c0 + 16); put4(f1[1], c0 + 20); put4(f1[2], c0 + 24); put4(f1[3], c0 + 28);
+            }
+            lds_barrier();
+            if (total > kColsCap) total = kColsCap;
+            if (total > 0) {
+                float wsc[TT][4], xsr[MT];
+                int nrow[TT][4];
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = tile[t] * 16 + g * 4 + r;          // image row (tile ids are clamped: always valid)
+                        wsc[t][r] = p.wscale[n];
+                        nrow[t][r] = p.row_perm ? p.row_perm[n] : n;
+                    }
+#pragma unroll
+                for (int a = 0; a < MT; ++a) xsr[a] = row_ok[a] ? p.xscale[a * 16 + m] : 0.f;
+                for (int j = wave; j < total; j += kWaves) {
+                    const int cj = cols[j];
+                    const signed char* wcol = p.cbt + (int64_t)cj * p.ldt;
+                    float wq[TT][4];
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) wq[t][r] = (float)wcol[nrow[t][r]];
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        float xv = 0.f, cv = 0.f;
+                        if (row_ok[a]) {
+                            const int64_t xo = frag_off(a * 16 + m, cj, KS);
+                            xv = (float)p.xraw[xo];
+                            cv = (float)p.xf_hi[xo];
+                        }
+#pragma unroll
+                        for (int t = 0; t < TT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float wd = (float)(_Float16)(wq[t][r] * wsc[t][r]);      // fp16(CB * SCB / 127)
+                                cacc[a][t][r] += xv * wd - cv * wq[t][r] * (xsr[a] * wsc[t][r]);
+                            }
+                    }
+                }
+            }
+            lds_barrier();                                   // the column list is dead: the buffer goes to the reduction
+        }
+    }
+
     // ---- split-K reduction through LDS, fixed order ----
     // An output item is one reduced tile (a gate/up pair of tiles for the SiLU epilogue).  Up to kRT tiles per
     // wave fit the LDS buffer, so the items go through it in rounds of IPR, one item per wave per round; the
@@ -512,6 +609,33 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
     if (r > 0) lds_barrier();                        // the previous round's readers are done with the buffer
+    [[maybe_unused]] f4 csv = {0.f, 0.f, 0.f, 0.f}, csu = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (W8) {
+        if (fused) {                                 // the waves' correction shares first (same slots, same order)
+#pragma unroll
+            for (int i = 0; i < IPR; ++i) {
+                const int item = r * IPR + i;
+                if (item < NOUT) {
+                    const int a = item / TE, t = item - a * TE;
+                    *(f4*)red[wave][i * TPI][lane] = cacc[a][t];
+                    if (EPI == EPI_SILU) *(f4*)red[wave][i * TPI + 1][lane] = cacc[a][T + t];
+                }
+            }
+            lds_barrier();
+            if (wave < IPR && r * IPR + wave < NOUT) {
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) {
+                    const f4 x = *(const f4*)red[w][wave * TPI][lane];
+                    csv[0] += x[0]; csv[1] += x[1]; csv[2] += x[2]; csv[3] += x[3];
+                    if (EPI == EPI_SILU) {
+                        const f4 y = *(const f4*)red[w][wave * TPI + 1][lane];
+                        csu[0] += y[0]; csu[1] += y[1]; csu[2] += y[2]; csu[3] += y[3];
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    }
 #pragma unroll
     for (int i = 0; i < IPR; ++i) {
         const int item = r * IPR + i;
@@ -545,7 +669,8 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
             v[0] *= rs; v[1] *= rs; v[2] *= rs; v[3] *= rs;
             u[0] *= rs; u[1] *= rs; u[2] *= rs; u[3] *= rs;
         }
-        tile_epilogue<EPI>(p, v, u, a * 16 + m, bx * T + t, g, by);
+        if constexpr (W8) tile_epilogue<EPI>(p, v, u, a * 16 + m, bx * T + t, g, by, fused, csv, csu);
+        else tile_epilogue<EPI>(p, v, u, a * 16 + m, bx * T + t, g, by);
     }
     }   // rounds
 }
@@ -1144,13 +1269,22 @@ int choose_T(int units) {
 }  // namespace
 
 namespace {
+// operands of the in-launch LLM.int8 outlier correction (pc_gemm_*_a8c)
+struct A8Fused {
+    const void* flags; const void* xraw; const void* cbt; int64_t ldt; const int32_t* row_perm;
+};
+
 int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma, float eps,
                      int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
                      int32_t kslices, void* stream, const float* wscale = nullptr, const float* xscale = nullptr,
-                     const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr) {
+                     const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr,
+                     const A8Fused* fz = nullptr) {
     PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
-    PC_REQUIRE(!xscale || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0 && kslices == 1),
+    PC_REQUIRE(!xscale || fz || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0 && kslices == 1),
                PC_ERR_ARG, "pc_gemm_skinny_a8: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N), corr_has, no K-slices");
+    PC_REQUIRE(!fz || (xscale && wscale && kslices == 1 && fz->flags && fz->xraw && fz->cbt && fz->ldt >= N && K <= 16384 &&
+                       ((uintptr_t)fz->flags & 15) == 0), PC_ERR_ARG,
+               "pc_gemm_skinny_a8c: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t (ldt >= N), K <= 16384");
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
     PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && (epilogue == EPI_STORE || epilogue == EPI_SILU)), PC_ERR_ARG,
@@ -1163,6 +1297,10 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
                "pc_gemm_skinny_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
     p.wscale = wscale; p.w8 = wscale ? 1 : 0;
     p.xscale = xscale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
+    if (fz) {
+        p.oflags = (const unsigned char*)fz->flags; p.xraw = (const _Float16*)fz->xraw; p.cbt = (const signed char*)fz->cbt;
+        p.ldt = fz->ldt; p.row_perm = fz->row_perm;
+    }
     p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
     PC_REQUIRE(kslices >= 1 && kslices <= 16 && (kslices == 1 || epilogue == EPI_STORE), PC_ERR_ARG,
@@ -1193,7 +1331,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                        const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
                        const float* wscale = nullptr, int32_t lo_base = -1, const float* xscale = nullptr,
-                       const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr);
+                       const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr, const A8Fused* fz = nullptr);
 }  // namespace
 
 PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
@@ -1241,7 +1379,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                        int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
                        const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
                        const float* wscale, int32_t lo_base, const float* xscale, const float* corr, int64_t ldc,
-                       const int32_t* corr_has) {
+                       const int32_t* corr_has, const A8Fused* fz) {
     const int N = (H + 2 * Hkv) * D;
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
@@ -1256,9 +1394,15 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
     PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
                "pc_gemm_qkv_rope_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
     p.wscale = wscale; p.w8 = wscale ? 1 : 0;
-    PC_REQUIRE(!xscale || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0), PC_ERR_ARG,
+    PC_REQUIRE(!xscale || fz || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0), PC_ERR_ARG,
                "pc_gemm_qkv_rope_a8: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N) and corr_has");
+    PC_REQUIRE(!fz || (xscale && wscale && fz->flags && fz->xraw && fz->cbt && fz->ldt >= N && K <= 16384 && ((uintptr_t)fz->flags & 15) == 0),
+               PC_ERR_ARG, "pc_gemm_qkv_rope_a8c: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t (ldt >= N), K <= 16384");
     p.xscale = xscale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
+    if (fz) {
+        p.oflags = (const unsigned char*)fz->flags; p.xraw = (const _Float16*)fz->xraw; p.cbt = (const signed char*)fz->cbt;
+        p.ldt = fz->ldt; p.row_perm = fz->row_perm;
+    }
     p.y = nullptr; p.ldy = 0; p.of_hi = nullptr; p.of_lo = nullptr; p.KSo = 0;
     p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.kslices = 1; p.slab_stride = 0;
     p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
@@ -1480,4 +1624,32 @@ PC_EXPORT int pc_gemm_qkv_rope_a8(const void* wf8_perm, const float* w_scale_per
                               v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
                               past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base,
                               x_scale, corr, ldc, corr_has);
+}
+
+// pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 with the outlier correction computed INSIDE the launch (M <= 64): instead of corr /
+// corr_has the call takes what pc_outlier_corr would have read -- the flag bytes of pc_quant_act_i8 (a buffer of >= 16384 bytes,
+// zero behind K), the fp16 activations x_raw (fragment plane), the transposed int8 weight codes [K][ldt] (original row order) and,
+// for q|k|v, the image-row -> original-row permutation.  Same result up to the fp32 summation order over the outlier columns.
+PC_EXPORT int pc_gemm_skinny_a8c(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
+                                 const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt, int32_t M, int32_t N,
+                                 int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream) {
+    PC_REQUIRE(xq_hi && xq_lo && w_scale && x_scale, PC_ERR_ARG, "pc_gemm_skinny_a8c: null pointer");
+    const A8Fused fz = {flags, x_raw, w_codes_t, ldt, nullptr};
+    return gemm_skinny_impl(wf8, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream, w_scale,
+                            x_scale, nullptr, 0, nullptr, &fz);
+}
+
+PC_EXPORT int pc_gemm_qkv_rope_a8c(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
+                                   const float* x_scale, const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt,
+                                   const int32_t* row_perm, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo,
+                                   int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
+                                   int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
+                                   int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
+                                   int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream) {
+    PC_REQUIRE(xq_hi && xq_lo && w_scale_perm && x_scale && row_perm, PC_ERR_ARG, "pc_gemm_qkv_rope_a8c: null pointer");
+    const A8Fused fz = {flags, x_raw, w_codes_t, ldt, row_perm};
+    return gemm_qkv_rope_impl(wf8_perm, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
+                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
+                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base,
+                              x_scale, nullptr, 0, nullptr, &fz);
 }

@@ -65,6 +65,9 @@ SIGNATURES = {
                                   _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
+    "pc_gemm_skinny_a8c": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "pc_gemm_qkv_rope_a8c": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64,
+                                       _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_rmsnorm_quant_i8": (C.c_int, [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_skinny_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
@@ -540,6 +543,28 @@ def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags
                                 0 if flags_clear is None else flags_clear.numel(), threshold,
                                 current_stream() if stream is None else stream)
     check(rc, "pc_quant_act_i8")
+
+
+def gemm_skinny_a8c(wf8, w_scale, xq, zeros, x_scale, flags, x_raw, w_codes_t, M: int, N: int, K: int, epilogue: int, y=None,
+                    ldy: int = 0, of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
+    """pc_gemm_skinny_a8 with the LLM.int8 outlier correction inside the launch (``flags``: >= 16384 bytes)."""
+    rc = load().pc_gemm_skinny_a8c(wf8.data_ptr(), w_scale.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
+                                   flags.data_ptr(), x_raw.data_ptr(), w_codes_t.data_ptr(), w_codes_t.stride(-2), M, N, K, epilogue,
+                                   _ptr(y), ldy, _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_skinny_a8c")
+
+
+def gemm_qkv_rope_a8c(wf8_perm, w_scale_perm, xq, zeros, x_scale, flags, x_raw, w_codes_t, row_perm, M, K, cs, q_hi, q_lo, q_ts,
+                      k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev=None, kv_lo=None,
+                      lo_base: int = -1, stream: Optional[int] = None) -> None:
+    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
+    rc = load().pc_gemm_qkv_rope_a8c(wf8_perm.data_ptr(), w_scale_perm.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
+                                     flags.data_ptr(), x_raw.data_ptr(), w_codes_t.data_ptr(), w_codes_t.stride(-2),
+                                     row_perm.data_ptr(), M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts,
+                                     k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap,
+                                     _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo_base,
+                                     current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_qkv_rope_a8c")
 
 
 def rmsnorm_quant_i8(x, norm_weight, eps: float, T: int, hidden: int, x_hi, codes, x_scale, flags_set, flags_clear=None,

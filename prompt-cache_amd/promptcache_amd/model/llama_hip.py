@@ -201,7 +201,10 @@ class LlamaHIP:
             self.MID_MAX_ROWS = self.SKINNY_MAX_ROWS      # the row-split kernel has no int8 variant: 65+ rows go dense
         if self.llm_int8:
             kmax = max(c.hidden_size, c.intermediate_size, self.H * self.D)
-            self._i8_flags = torch.zeros((4, kmax), dtype=torch.uint8, device=dev)       # outlier-column flags, one per slot
+            # outlier-column flags, one row per activation slot; 16384 bytes each: the in-launch correction (pc_gemm_*_a8c)
+            # scans a whole row, 32 bytes per thread
+            self._i8_flags = torch.zeros((4, max(kmax, 16384)), dtype=torch.uint8, device=dev)
+            self.i8_fused_corr = os.environ.get("PC_INT8_FUSED_CORR", "1") != "0"
             self._i8_zero = torch.zeros(((self.SKINNY_MAX_ROWS + 15) // 16) * 16 * kmax, dtype=self.dtype, device=dev)
             self.fuse_norm = False                        # activations are quantised between the norm and the projection
             self.batch_invariant = False                  # the fp16 outlier columns are chosen over ALL rows of a call
@@ -543,6 +546,37 @@ class LlamaHIP:
                 (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3]),
                 (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4])]
         layers = self.layers if num_layers is None else self.layers[:num_layers]
+        if self.i8_fused_corr:
+            # the outlier correction runs INSIDE the projection launches (pc_gemm_*_a8c): 10 launches per layer instead of 14
+            fl = self._i8_flags
+
+            def quant(slot, act_hi, K, buf, norm=None):
+                codes, xs = buf[0], buf[1]
+                if norm is not None:
+                    n.rmsnorm_quant_i8(norm[0], norm[1], eps, T, K, act_hi, codes, xs, fl[slot], fl[(slot + 1) % 4])
+                else:
+                    n.quant_act_i8(act_hi, True, T, K, codes, xs, fl[slot], fl[(slot + 1) % 4])
+                return codes, xs
+
+            for li, lw in enumerate(layers):
+                kp, vp = arena.k_plane(li), arena.v_plane(li)
+                kvlo, lo_base = tail(li)
+                cd, xs = quant(0, xh, hid, bufs[0], norm=(x, lw["ln1"]))
+                n.gemm_qkv_rope_a8c(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, fl[0], xh, lw["wqkv_t8"], self._qkv_perm_i32, T, hid, cs,
+                                    q16, q16l, H * D, kp, vp, arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len,
+                                    arena.cap, past_dev, kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
+                n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                           B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                           q_lo=q16l, kv_lo=kvlo)
+                cd, xs = quant(1, ah, H * D, bufs[1])
+                n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
+                cd, xs = quant(2, xh, hid, bufs[2], norm=(x, lw["ln2"]))
+                n.gemm_skinny_a8c(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, fl[2], xh, lw["wgu_t8"], T, 2 * inter, hid, n.EPI_SILU,
+                                  of_hi=ch, of_lo=cl)
+                cd, xs = quant(3, ch, inter, bufs[3])
+                n.gemm_skinny_a8c(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, fl[3], ch, lw["wdown_t8"], T, hid, inter, n.EPI_ADD,
+                                  y=x, ldy=hid)
+            layers = []
         for li, lw in enumerate(layers):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kvlo, lo_base = tail(li)

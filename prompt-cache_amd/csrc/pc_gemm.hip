@@ -557,43 +557,70 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
             lds_barrier();
             if (total > kColsCap) total = kColsCap;
             if (total > 0) {
-                float wsc[TT][4], xsr[MT];
-                int nrow[TT][4];
+                // MFMA form: 32 compacted columns are one k-step.  A lane gathers the operands of its fragment slots -- weight
+                // lane (n, g): codes CB[n][cols[32 s + 8 g + e]] (-> the fp16 dequantised weights and the codes themselves),
+                // activation lane (m, g): X and CA at the same columns -- for two MFMAs per tile: sum X * fp16(CB * s) and the
+                // integer sum CA * CB (exact in fp32), which leaves as  - sum * xs[m] * s[n]  in the C layout.  Slots behind
+                // the last column hold zeros.  (A scalar loop over the columns cost 33 us at 460 columns.)
+                float wsc[TT][4], xsr[MT], wsa[TT];
+                int nra[TT];
 #pragma unroll
-                for (int t = 0; t < TT; ++t)
+                for (int t = 0; t < TT; ++t) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = tile[t] * 16 + g * 4 + r;          // image row (tile ids are clamped: always valid)
-                        wsc[t][r] = p.wscale[n];
-                        nrow[t][r] = p.row_perm ? p.row_perm[n] : n;
-                    }
+                    for (int r = 0; r < 4; ++r) wsc[t][r] = p.wscale[tile[t] * 16 + g * 4 + r];   // (tile ids are clamped: valid)
+                    const int na = tile[t] * 16 + m;                     // the weight row of this lane's A-operand slot
+                    wsa[t] = p.wscale[na];
+                    nra[t] = p.row_perm ? p.row_perm[na] : na;
+                }
 #pragma unroll
                 for (int a = 0; a < MT; ++a) xsr[a] = row_ok[a] ? p.xscale[a * 16 + m] : 0.f;
-                for (int j = wave; j < total; j += kWaves) {
-                    const int cj = cols[j];
-                    const signed char* wcol = p.cbt + (int64_t)cj * p.ldt;
-                    float wq[TT][4];
+                f4 iacc[MT][TT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; iacc[a][t] = z; }
+                const int nks = (total + 31) >> 5;
+                for (int sblk = wave; sblk < nks; sblk += kWaves) {
+                    int cj[8];
+                    bool okc[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = sblk * 32 + g * 8 + e;
+                        okc[e] = j < total;
+                        cj[e] = cols[okc[e] ? j : 0];
+                    }
+                    h8 xb[MT], cb[MT];
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const bool ok = okc[e] && row_ok[a];
+                            const int64_t xo = frag_off(a * 16 + m, cj[e], KS);
+                            xb[a][e] = ok ? p.xraw[xo] : (_Float16)0;
+                            cb[a][e] = ok ? p.xf_hi[xo] : (_Float16)0;
+                        }
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        h8 wa, qa;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float q = okc[e] ? (float)p.cbt[(int64_t)cj[e] * p.ldt + nra[t]] : 0.f;
+                            qa[e] = (_Float16)q;
+                            wa[e] = (_Float16)(q * wsa[t]);              // fp16(CB * SCB / 127)
+                        }
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) {
+                            cacc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[a], cacc[a][t], 0, 0, 0);
+                            iacc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, cb[a], iacc[a][t], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int t = 0; t < TT; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) wq[t][r] = (float)wcol[nrow[t][r]];
-#pragma unroll
-                    for (int a = 0; a < MT; ++a) {
-                        float xv = 0.f, cv = 0.f;
-                        if (row_ok[a]) {
-                            const int64_t xo = frag_off(a * 16 + m, cj, KS);
-                            xv = (float)p.xraw[xo];
-                            cv = (float)p.xf_hi[xo];
-                        }
-#pragma unroll
-                        for (int t = 0; t < TT; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float wd = (float)(_Float16)(wq[t][r] * wsc[t][r]);      // fp16(CB * SCB / 127)
-                                cacc[a][t][r] += xv * wd - cv * wq[t][r] * (xsr[a] * wsc[t][r]);
-                            }
-                    }
-                }
+                        for (int r = 0; r < 4; ++r) cacc[a][t][r] -= iacc[a][t][r] * (xsr[a] * wsc[t][r]);
             }
             lds_barrier();                                   // the column list is dead: the buffer goes to the reduction
         }

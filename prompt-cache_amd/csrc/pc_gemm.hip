@@ -1006,6 +1006,10 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
                     break;                                                                            \
                 }                                                                                     \
             }                                                                                         \
+            if (p.xscale) {   /* LLM.int8 codes: ONE activation plane (the "lo" plane of the a8 calls is all zeros) */ \
+                hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UW, false, true>), grid, block, 0, s, p); \
+                break;                                                                                \
+            }                                                                                         \
             hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, false, true>), grid, block, 0, s, p); \
             break;                                                                                    \
         }                                                                                             \

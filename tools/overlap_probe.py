@@ -43,11 +43,18 @@ def ovl():
     main.wait_stream(side)
 
 
+def ovl_rev():
+    side.wait_stream(main)
+    lm(input_ids=it, position_ids=pt, past_key_values=cache, use_cache=True)       # the graph replay first ...
+    _native.kv_gather(ptrs, lens, offs, a.buf, a.L, a.Hkv, a.D, a.cap, stream=side.cuda_stream)   # ... then the gather beside it
+    main.wait_stream(side)
+
+
 def only():
     lm(input_ids=it, position_ids=pt, past_key_values=cache, use_cache=True)
 
 
-for name, fn in (("forward only", only), ("gather then forward", seq), ("gather || forward", ovl), ("gather then forward", seq)):
+for name, fn in (("forward only", only), ("gather then forward", seq), ("gather || forward", ovl), ("forward || gather", ovl_rev), ("gather then forward", seq)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

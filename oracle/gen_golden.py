@@ -444,7 +444,22 @@ def main():
     model_golden(pc, "tiny_personalike", "tiny", seed=3, scale=4.0, schema_text=sp, prompt_text=pp, max_ctx=400)
     falcon_goldens(pc)
     mpt_goldens(pc)
+    sampling_goldens(pc)
+    write_manifest()
 
+
+def write_manifest():
+    """tests/golden/manifest.json: the key set of every .npz fixture as THIS script writes it.  tests/test_oracle_golden.py
+    fails when a committed fixture and the manifest disagree -- a fixture written by an older revision of this script
+    (a missing or surplus array) cannot pass for a changed reference."""
+    import glob
+    man = {}
+    for fn in sorted(glob.glob(os.path.join(GOLD, "*.npz"))):
+        with np.load(fn, allow_pickle=False) as z:
+            man[os.path.basename(fn)] = sorted(z.files)
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+    print(f"[golden] manifest: {len(man)} fixtures")
 
 
 SAMPLING_CASES = [
@@ -498,5 +513,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--falcon-only" in sys.argv:      # add the Falcon fixtures without regenerating the others
         falcon_goldens(ref_shim.import_reference())
+        sys.exit(0)
+    if "--manifest-only" in sys.argv:
+        write_manifest()
         sys.exit(0)
     main()

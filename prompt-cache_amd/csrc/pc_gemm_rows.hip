@@ -1,0 +1,232 @@
+// 65..512-row weight-streaming projections (gemm_rows_kernel): long questions in front of a staged cache
+// (replaces the nn.Linear calls of promptcache/model/llama2.py:345-347, :405, :242 at q = 65..512; see pc_gemm_skinny.h).
+#include "pc_gemm_skinny.h"
+
+namespace pcg {
+
+
+// ---------------------------------------------------------------------------------------------------
+// 65..512 rows ("mid M": long questions in front of a staged cache).  Still weight streaming -- the weights are
+// read once -- but a workgroup can no longer afford to split K across its waves: every workgroup would re-read
+// all the activation planes and hold MT*TT accumulators per wave.  Here the waves split the ROWS instead:
+//   * compute wave w (w < ceil(M/64)) owns rows [64w, 64w+64) x all TT weight tiles of the workgroup
+//     (4 x TT accumulators), reads its own activation fragments straight from L2 (prefetched one k-step ahead)
+//     and the weight fragments from LDS;
+//   * kStageWaves extra waves do nothing but stream the workgroup's weight tiles HBM -> registers -> LDS, three
+//     stages (24-32 KiB each) deep.  Their load queues hold only weight loads, the compute waves' queues only
+//     activation loads: a wave's loads complete in order, so one wave issuing both would make every L2-hit
+//     activation load wait behind ~2 us HBM weight loads.
+// One raw s_barrier per stage (LDS-only wait: `__syncthreads()` would drain the prefetch queues).
+// Activations: hi and lo planes when the caller passes both (two MFMAs per weight fragment), the hi plane only when
+// xf_lo is NULL.
+constexpr int kStageWaves = 4;
+
+
+template <int TT, int EPI, int MTW, bool TWO>
+__global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const GemmParams p) {
+    constexpr int T = (EPI == EPI_SILU) ? TT / 2 : TT;   // output units (tiles, or gate/up pairs) per workgroup
+    constexpr int KC = (TT <= 4) ? 8 : 4;                // k-steps per stage
+    constexpr int F = TT * KC;                           // 1-KiB fragments per stage
+    constexpr int FPW = F / kStageWaves;
+    constexpr int PD = (MTW == 2) ? 3 : 1, NX = PD + 1;  // activation prefetch distance (k-steps) / register sets
+    static_assert(F % kStageWaves == 0 && KC % NX == 0, "stage must split evenly over the staging waves");
+    __shared__ __attribute__((aligned(16))) _Float16 wbuf[2][F][64][8];
+
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RW = (p.M + 16 * MTW - 1) / (16 * MTW);
+    const int KS = p.KS;
+    const int ksq = (KS + p.kslices - 1) / p.kslices;
+    const int kq0 = blockIdx.y * ksq;
+    const int kq1 = (kq0 + ksq < KS) ? kq0 + ksq : KS;
+    const int nst = (kq1 - kq0 + KC - 1) / KC;
+    const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
+    // (Rotating the K walk per workgroup, so that workgroups do not read the same activation fragments from L2 in
+    // lockstep, measured no gain: L2 channel conflicts are not what bounds this kernel.)
+
+    if (wave >= RW) {
+        // ---------------- staging wave ----------------
+        if (nst <= 0) return;                            // empty K slice (kslices > k-steps): nothing to stream
+        const int sidx = wave - RW;
+        const _Float16* src[FPW];
+        int kst[FPW];
+#pragma unroll
+        for (int i = 0; i < FPW; ++i) {
+            const int f = sidx + kStageWaves * i;        // fragment of the stage: k-step-major, tile-minor
+            const int kk = f / TT, tt = f - kk * TT;
+            int unit = blockIdx.x * T + (EPI == EPI_SILU ? (tt < T ? tt : tt - T) : tt);
+            if (unit >= nunits) unit = nunits - 1;       // clamped duplicates are computed and never stored
+            const int tile = (EPI == EPI_SILU && tt >= T) ? p.npairs + unit : unit;
+            kst[i] = kk;
+            src[i] = p.wf + (((int64_t)tile * KS + kq0 + kk) * 64 + lane) * 8;
+        }
+        h8 r0[FPW], r1[FPW], r2[FPW];
+        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        // loads of stage st into a register set; k-steps past the end of the K range re-read the last valid
+        // one (never out of bounds) and are zeroed when they are written to LDS
+#define PC_STAGE_LOAD(R, ST)                                                                  \
+        {                                                                                     \
+            const int se = (ST) < nst ? (ST) : nst - 1;   /* stages past the end: the last one */ \
+            _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
+                const int kabs = kq0 + se * KC + kst[i];                                      \
+                const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);                           \
+                R[i] = ldg_h8_nt(src[i] + ((int64_t)se * KC - back) * 512);                   \
+            }                                                                                 \
+        }
+#define PC_STAGE_WRITE(R, ST)                                                                 \
+        {                                                                                     \
+            const int se = (ST);                                                              \
+            _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
+                const bool ok = kq0 + se * KC + kst[i] < kq1;                                 \
+                *(h8*)wbuf[(ST) & 1][sidx + kStageWaves * i][lane] = ok ? R[i] : zero;        \
+            }                                                                                 \
+        }
+        // Loads are issued unconditionally (stages past the end re-read the last valid k-step): a load under a
+        // branch makes hipcc's vmcnt bookkeeping assume the not-taken path and wait for the NEWEST loads
+        // before each LDS write, which would drain the three-stage prefetch every stage.
+        PC_STAGE_LOAD(r0, 0)
+        PC_STAGE_LOAD(r1, 1)
+        for (int st = 0; st < nst; st += 3) {
+            PC_STAGE_LOAD(r2, st + 2)
+            PC_STAGE_WRITE(r0, st)
+            lds_barrier();
+            PC_STAGE_LOAD(r0, st + 3)
+            if (st + 1 < nst) {
+                PC_STAGE_WRITE(r1, st + 1)
+                lds_barrier();
+            }
+            PC_STAGE_LOAD(r1, st + 4)
+            if (st + 2 < nst) {
+                PC_STAGE_WRITE(r2, st + 2)
+                lds_barrier();
+            }
+        }
+#undef PC_STAGE_LOAD
+#undef PC_STAGE_WRITE
+        return;
+    }
+
+    // ---------------- compute wave ----------------
+    f4 acc[MTW][TT];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[a][t] = z; }
+    // Activation loads are unconditional as well (same vmcnt reason): row tiles past the end of the planes are
+    // clamped to the last one, pad rows inside it are read as they are -- output column m depends on
+    // activation row m only, and rows >= M are never stored.
+    const _Float16* xa[MTW];
+    const int64_t lo_delta = TWO ? (p.xf_lo - p.xf_hi) : 0;          // lo plane = hi plane + lo_delta (same layout)
+    const int mt_last = ((p.M + 15) >> 4) - 1;
+#pragma unroll
+    for (int a = 0; a < MTW; ++a) {
+        int mt = MTW * wave + a;
+        mt = mt < mt_last ? mt : mt_last;
+        xa[a] = p.xf_hi + (((int64_t)mt * KS + kq0) * 64 + lane) * 8;
+    }
+    // row tiles this wave really owns (wave-uniform, >= 1): the MFMAs of the clamped duplicates behind the last tile are skipped
+    const int nva = __builtin_amdgcn_readfirstlane((mt_last + 1 - MTW * wave) < MTW ? (mt_last + 1 - MTW * wave) : MTW);
+    const int klast = kq1 - 1 - kq0;                     // last valid k-step, relative to kq0
+    // k-step (relative to kq0) loaded for sequence position i; positions past the end repeat the last one
+    auto kseq = [&](int i) { return i < klast ? i : klast; };
+    h8 xs[NX][MTW], xsl[TWO ? NX : 1][MTW];
+    if (nst > 0) {                                       // (an empty K slice stores zeros below)
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int kn = kseq(d);
+#pragma unroll
+            for (int a = 0; a < MTW; ++a) {
+                xs[d][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+                if (TWO) xsl[d][a] = ldg_h8(xa[a] + lo_delta + (int64_t)kn * 512);
+            }
+        }
+    }
+    for (int st = 0; st < nst; ++st) {
+        lds_barrier();                                   // stage st is in wbuf[st & 1]
+        const _Float16* wst = &wbuf[st & 1][0][lane][0];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            // prefetch the activation fragments PD k-steps ahead (clamped at the end of the K range)
+            const int kn = kseq(st * KC + j + PD);
+#pragma unroll
+            for (int a = 0; a < MTW; ++a) {
+                xs[(j + PD) % NX][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
+                if (TWO) xsl[(j + PD) % NX][a] = ldg_h8(xa[a] + lo_delta + (int64_t)kn * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead of this k-step's MFMAs (see k_block)
+            h8 w[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) w[t] = *(const h8*)(wst + (j * TT + t) * 512);
+#pragma unroll
+            for (int a = 0; a < MTW; ++a) {
+                if (a < nva) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xs[j % NX][a], acc[a][t], 0, 0, 0);
+                        if (TWO) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xsl[j % NX][a], acc[a][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f4 u = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_SILU) u = acc[a][T + t];
+            tile_epilogue<EPI>(p, acc[a][t], u, (MTW * wave + a) * 16 + m, (int)blockIdx.x * T + t, g, (int)blockIdx.y);
+        }
+}
+
+// (Tried and dropped: also splitting the rows of a column group over 2-4 workgroups placed on one XCD, with the shape
+// chosen by bytes-per-workgroup: 10-15 % faster on a few isolated shapes (7b q|k|v at 259 / 512 rows), but the forward
+// as a whole did not gain -- q = 98: 5.8 -> 6.2 ms, config 4: 19.4 -> 20.1 ms.)
+// Launch shape of the rows kernel.  Rows per compute wave: 32 while that needs <= 12 compute waves (M <= 384; more,
+// narrower waves hide the L2 latency of the activation loads and spread evenly over the four SIMDs), else 64.
+// Weight tiles per workgroup: the smallest of {3,4,6,8} ({2,3,4} gate/up pairs) that fits the grid into one round.
+template <int EPI>
+int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
+    static const int forced = [] { const char* e = getenv("PC_GEMM_ROWS_TT"); return e ? atoi(e) : 0; }();
+    const GemmParams& p = p_in;
+    const bool narrow = pc_ceil_div(p.M, 32) <= 12;
+    const bool two = p.xf_lo != nullptr;                 // split-precision activations: <= 4 tiles per workgroup (registers)
+    const int RW = narrow ? pc_ceil_div(p.M, 32) : pc_ceil_div(p.M, 64);
+    const dim3 block((RW + kStageWaves) * 64);
+#define PC_ROWS(TTV)                                                                                       \
+    do {                                                                                                   \
+        constexpr int TV = (EPI == EPI_SILU) ? (TTV) / 2 : (TTV);                                          \
+        const dim3 grid(pc_ceil_div(units, TV), p.kslices);                                                \
+        if (two) {                                                                                         \
+            if constexpr ((TTV) <= 4) {                                                                    \
+                if (narrow) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 2, true>), grid, block, 0, s, p); \
+                else hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4, true>), grid, block, 0, s, p);      \
+            }                                                                                              \
+        } else if (narrow) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 2, false>), grid, block, 0, s, p); \
+        else if constexpr ((TTV) <= 6) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4, false>), grid, block, 0, s, p); \
+        return pc_check_launch("gemm_rows_kernel");                                                        \
+    } while (0)
+    const int work = units * p.kslices;
+    if constexpr (EPI == EPI_SILU) {
+        if (forced == 4 || two || (!forced && pc_ceil_div(work, 2) <= 256)) PC_ROWS(4);
+        if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(6);
+        PC_ROWS(8);
+    } else {
+        if (forced == 3 || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(3);
+        if (forced == 4 || two || (!forced && pc_ceil_div(work, 4) <= 256)) PC_ROWS(4);
+        if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 6) <= 256)) PC_ROWS(6);
+        PC_ROWS(8);
+    }
+#undef PC_ROWS
+}
+int launch_rows_epi(int epi, const GemmParams& p, int units, hipStream_t s) {
+    switch (epi) {
+        case EPI_STORE: return launch_rows<EPI_STORE>(p, units, s);
+        case EPI_ADD: return launch_rows<EPI_ADD>(p, units, s);
+        case EPI_SILU: return launch_rows<EPI_SILU>(p, units, s);
+        case EPI_ROPE: return launch_rows<EPI_ROPE>(p, units, s);
+        default: return launch_rows<EPI_GELU>(p, units, s);
+    }
+}
+
+}  // namespace pcg

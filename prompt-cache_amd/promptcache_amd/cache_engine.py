@@ -205,9 +205,33 @@ class SchemaCache:
         self._pending = []
 
     def plan_cost(self) -> int:
-        """Tokens this schema's encode runs through the model (suffixes behind the shared trunk prefix counted once)."""
+        """Tokens this schema's encode runs through the model (suffixes behind the shared trunk prefix counted once, every
+        pass cut behind its last owned token: exactly ``encode_stats["computed_tokens"]`` of a one-rank encode)."""
+        return sum(self.pass_costs())
+
+    def pass_costs(self) -> List[int]:
+        """Rows each pass of the plan runs through the model (job order of ``_plan_with_prefix``)."""
         jobs, prefix = self._plan_with_prefix()
-        return sum(len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs))
+        need = self._need(jobs, prefix)
+        return [need[i] - prefix[i] for i in range(len(jobs))]
+
+    def _need(self, jobs, prefix) -> List[int]:
+        """Rows a pass has to run: up to its last owned token.  Under the causal mask the K/V of a token depend on nothing
+        behind it, so the tail of a scaffold that this pass does not own (the reference runs it and throws it away,
+        cache_engine.py:243-296) is cut off -- and the root pass also covers the longest prefix a suffix pass builds on."""
+        truncate = self.truncate_scaffolds and self._batch_invariant()      # (LLM.int8: a call's rows choose its outlier columns)
+        need = []
+        for i, j in enumerate(jobs):
+            end = self._owned_end(j)
+            if i == 0:
+                end = max([end] + list(prefix))
+            need.append(end if truncate else len(j["token_ids"]))
+        return need
+
+    @staticmethod
+    def _owned_end(job) -> int:
+        pos = job["position_ids"]
+        return max(pos.index(tc.offset) + len(tc) for tc in job["owned"])
 
     def _plan_with_prefix(self):
         """(jobs, prefix): the plan plus, per job, the number of leading tokens it shares with the root scaffold (job 0)
@@ -230,6 +254,11 @@ class SchemaCache:
                 lim = min(len(ids), len(t_ids)) - 1          # at least one token is always run
                 while n < lim and ids[n] == t_ids[n] and pos[n] == t_pos[n]:
                     n += 1
+                # A pass is cut behind its last owned token (``_need``), and at least one row must run through the model:
+                # a union member whose tokens equal, or are a prefix of, the default member's (duplicate documents, members
+                # cut to the same ``max_tokens``) shares MORE than it has to run -- the prefix stops one row short of the cut.
+                if self.truncate_scaffolds:
+                    n = min(n, self._owned_end(jobs[i]) - 1)
                 if n >= self.share_trunk_min and n >= len(ids) // 5:
                     prefix[i] = n
         self._jobs = (jobs, prefix)
@@ -269,7 +298,7 @@ class SchemaCache:
             shards = [list(range(len(jobs))) if r == owner_rank else [] for r in range(world)]
         else:
             # shard by what a pass actually costs: its suffix behind the trunk prefix (world == 1 -> everything)
-            shards = parallel.shard_jobs([len(j["token_ids"]) - prefix[i] for i, j in enumerate(jobs)], world)   # (plan_cost's measure)
+            shards = parallel.shard_jobs([need_i - prefix[i] for i, need_i in enumerate(self._need(jobs, prefix))], world)   # (plan_cost's measure)
         mine = shards[rank]
         # every rank's segments live back to back in ONE slab per rank (ascending job order, then plan order inside a
         # job): the encode writes its stores through views of the slab, and the exchange moves whole slabs in place
@@ -282,17 +311,7 @@ class SchemaCache:
             for k in range(len(jobs[i]["owned"])):
                 view_of[(i, k)] = next(it)
 
-        # Rows a pass has to run: up to its last owned token.  Under the causal mask the K/V of a token depend on nothing behind
-        # it, so the tail of a scaffold that this pass does not own (the reference runs it and throws it away,
-        # cache_engine.py:243-296) is cut off -- and the root pass also covers the longest prefix a suffix pass builds on.
-        truncate = self.truncate_scaffolds and self._batch_invariant()      # (LLM.int8: a call's rows choose its outlier columns)
-        need = []
-        for i, j in enumerate(jobs):
-            pos = j["position_ids"]
-            end = max(pos.index(tc.offset) + len(tc) for tc in j["owned"])
-            if i == 0:
-                end = max([end] + [prefix[k] for k in range(len(jobs))])
-            need.append(end if truncate else len(j["token_ids"]))
+        need = self._need(jobs, prefix)          # rows each pass runs: up to its last owned token
         encoded_tokens = computed_tokens = 0
         per_job: Dict[int, List[Tuple[TokenSequence, torch.Tensor]]] = {}
         full_pos = bool(getattr(lm, "use_full_position_ids", False))
@@ -355,14 +374,15 @@ class SchemaCache:
         ragged = bool(getattr(getattr(lm, "hf_model", None), "supports_ragged_past", False)) and not full_pos and \
             self.ragged_suffix_batches
         suffix_len = [need[i] - prefix[i] for i in range(len(jobs))]
+        row_bytes = L * 2 * Hkv * D * 2 * 2                  # K and V, fp16, + the residual planes of the encode arenas
         if ragged:
-            groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size)]
+            groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size, prefix, row_bytes)]
         else:
             by_prefix: Dict[int, List[int]] = {}
             for i in shared:
                 by_prefix.setdefault(prefix[i], []).append(i)
             groups = [(n_pre, idxs) for n_pre, members in sorted(by_prefix.items())
-                      for idxs in self._pack(members, suffix_len, batch_size)]
+                      for idxs in self._pack(members, suffix_len, batch_size, prefix, row_bytes)]
         for n_same, idxs in groups:
             group = [jobs[i] for i in idxs]
             pre = [prefix[i] for i in idxs]
@@ -437,7 +457,11 @@ class SchemaCache:
         per call (``batch_size`` 1, cache_engine.py:232-248), so such a model gets exactly that: no trunk reuse, no packing."""
         return bool(getattr(getattr(self.lm, "hf_model", None), "batch_invariant", True))
 
-    def _pack(self, mine: List[int], lengths: List[int], batch_size: int) -> List[List[int]]:
+    # bytes one encode forward's group arena (rows x (trunk prefix + suffix width) x K/V + residual planes) may take
+    encode_arena_bytes = int(float(os.environ.get("PC_ENC_ARENA_GB", "48")) * 2 ** 30)
+
+    def _pack(self, mine: List[int], lengths: List[int], batch_size: int, prefix: Optional[List[int]] = None,
+              bytes_per_row_token: int = 0) -> List[List[int]]:
         """Group this rank's scaffold passes into right-padded batches.  ``batch_size`` is the reference's knob
         (``cache_engine.py:232``: consecutive passes, in order); with the default of 1 the engine packs on its own:
         longest first, as many passes per forward as fit ``encode_token_budget`` rows -- dense GEMMs at M ~ 600
@@ -464,6 +488,11 @@ class SchemaCache:
                 rows = (j - i) * lengths[order[i]]
                 if rows > self.encode_token_budget and j - i > 1:
                     continue
+                if prefix is not None and bytes_per_row_token and j - i > 1:
+                    # every row of the group's arena also holds its trunk prefix (sized to the longest one of the group)
+                    n_max = max(prefix[order[k]] for k in range(i, j))
+                    if (j - i) * (n_max + lengths[order[i]]) * bytes_per_row_token > self.encode_arena_bytes:
+                        continue
                 c = best[i] + rows + self.encode_forward_cost
                 if c < best[j]:
                     best[j], cut[j] = c, i

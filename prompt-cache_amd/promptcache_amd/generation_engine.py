@@ -191,5 +191,7 @@ class GenerationEngine:
                 if loop is not None:
                     loop.enqueue()
 
+        if loop is not None:
+            loop.close(len(new_ids) - 1)                     # steps of the loop that produced a token (the first came from the prefill)
         del past, loop
         gc.collect()

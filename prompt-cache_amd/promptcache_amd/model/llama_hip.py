@@ -63,6 +63,10 @@ class GreedyLoop:
         self.arena = arena
         st = model._loop_state()
         self.st = st
+        # The loop state (token / position / past words, ring, counter) is ONE set of device words per model: the newest
+        # loop owns it.  A loop that was superseded (two generate() generators advanced alternately on one model) must
+        # not keep replaying over the other's words -- enqueue() refuses instead of corrupting both sequences.
+        model._live_loop = self
         dev = model.device
         st["ids"].copy_(torch.tensor([token], dtype=torch.int64), non_blocking=True)
         st["pos"].copy_(torch.tensor([position], dtype=torch.int32), non_blocking=True)
@@ -76,6 +80,10 @@ class GreedyLoop:
     @torch.inference_mode()
     def enqueue(self) -> int:
         m, a, st = self.m, self.arena, self.st
+        if getattr(m, "_live_loop", None) is not self:
+            raise RuntimeError("GreedyLoop: another greedy loop on this model took over the device loop state "
+                               "(one device-side greedy generation per model at a time; set "
+                               "GenerationEngine.device_greedy_loop = False to interleave generations)")
         past_len = self.len0 + self.n
         m._lo_mode = m._tail_mode(a, 1, past_len)
         ent = m._loop_graph(a, past_len)
@@ -103,6 +111,16 @@ class GreedyLoop:
         self.events[i][2].synchronize()
         return int(self.host[i % self.RING])
 
+    def close(self, consumed: int) -> None:
+        """The generation ended after ``consumed`` of the enqueued steps were used: a look-ahead replay enqueued past the
+        stop wrote one row too many -- the arena's length goes back to the real sequence, and the loop state is released."""
+        if consumed < self.n:
+            self.arena.length = self.len0 + consumed
+            if self.arena.tail_base >= 0:            # (the residual tail is valid while tail_base + tail_len == length)
+                self.arena.tail_len = max(0, self.arena.length - self.arena.tail_base)
+        if getattr(self.m, "_live_loop", None) is self:
+            self.m._live_loop = None
+
     def elapsed_ms(self, i: int) -> float:
         e0, e1, done = self.events[i]
         done.synchronize()
@@ -115,9 +133,11 @@ class LlamaHIP:
 
     SKINNY_MAX_ROWS = 64   # B*q_len at or below this: split-precision weight-streaming kernels inside one hipGraph
     NORM_FUSED_MAX_ROWS = 16   # ... and at or below this the RMSNorms are folded into the projections
-    # ... and up to here: the row-split weight-streaming kernel (pc_gemm.hip), launched eagerly; above, the stacked
-    # [hi; lo] hipBLASLt projections of the many-row path are faster (crossover measured at ~256 rows: q = 130:
-    # 9.5 vs 9.8 ms, q = 258: 13.9 vs 13.9 ms, q = 402: 17.8 vs 17.2 ms; the kernel itself takes up to 512)
+    # ... and up to here: the row-split weight-streaming kernel (gemm_rows_kernel, pc_gemm.hip), launched eagerly; above,
+    # pc_gemm_dense.  Crossover against pc_gemm_dense_ws (tools/dense_vs_rows.py, profiles/r02_dense_splitk.txt, 7b layer,
+    # split-precision planes on both sides): 259 rows 322 vs 402 us per layer, 512 rows 455 vs 441 us -- the streaming
+    # kernel holds up to its own limit of 512 rows (round 1's 256 was measured against the vendor GEMM this tree no
+    # longer carries)
     MID_MAX_ROWS = int(os.environ.get("PC_MID_MAX_ROWS", "512"))
 
     def _setup(self, shape, device, decode_headroom: int) -> None:
@@ -380,8 +400,8 @@ class LlamaHIP:
         encode_pass = many_rows and (self._past_lens is not None or
                                      self.precise_dense and (past_key_values is None or arena.lo is not None))
         graphed = self.skinny and T <= self.SKINNY_MAX_ROWS and self.use_graphs and not many_rows and not kv_only
-        mid = self.skinny and not encode_pass and T <= self.MID_MAX_ROWS and \
-            not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS)
+        mid = self.skinny and not encode_pass and not kv_only and T <= self.MID_MAX_ROWS and \
+            not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS)   # (the streaming stacks have no kv_only exit)
         streaming = graphed or mid
         self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
         if graphed:
@@ -546,6 +566,10 @@ class LlamaHIP:
                 (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3]),
                 (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4])]
         layers = self.layers if num_layers is None else self.layers[:num_layers]
+        # Outlier flags are set-only and slot s is cleared by the quantiser of slot s - 1: a pass that stopped behind a
+        # layer's q|k|v (kv_only encodes) left slot 0 set, and this pass's first quantiser would OR onto it -- results would
+        # depend on the call history.  One memset node (graph-capturable) makes every forward start clean.
+        self._i8_flags[0].zero_()
         if self.i8_fused_corr:
             # the outlier correction runs INSIDE the projection launches (pc_gemm_*_a8c): 10 launches per layer instead of 14
             fl = self._i8_flags
@@ -637,6 +661,7 @@ class LlamaHIP:
         ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         fl = self._i8_flags
+        fl[0].zero_()                            # (see _forward_skinny_int8: a kv_only pass leaves slot 0 set)
 
         def lin(slot, a16, codes, K, lw, key, N, epi, **out):
             n.quant_act_i8(a16, False, T, K, codes, xs, fl[slot], fl[(slot + 1) % 4])

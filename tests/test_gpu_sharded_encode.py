@@ -1,6 +1,6 @@
 """The N > 1 path of the cache engine END TO END on one GPU box: two processes (both on cuda:0, ``gloo`` for the exchange
 because RCCL wants one device per rank) shard a schema's scaffold passes, run their share through the HIP forward, and
-all-gather the module KV (``SchemaCache._process`` with ``world == 2``, ``parallel.allgather_segments`` on device
+all-gather the module KV (``SchemaCache._process`` with ``world == 2``, ``parallel.exchange_slabs`` on device
 tensors).  Every rank must end with the whole library, equal to the single-process library, and a prompt served from it
 must give the single-process logits."""
 import os

@@ -1,5 +1,9 @@
 """Pins the CPU oracle (numpy restatement) against outputs of the REFERENCE implementation captured by
 oracle/gen_golden.py.  fp32 vs fp32: tolerances are fp32 round-off of different summation orders."""
+import glob
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -65,3 +69,17 @@ def test_union_free_schema_cached_equals_nocache_up_to_kv_rounding():
     equals the no-cache path up to the fp16 rounding of staged KV."""
     g = H.load_case("mid_mha_doc")
     assert np.abs(g["logits_cached"][-1] - g["logits_nocache_last"]).max() < 5e-3
+
+
+def test_fixture_key_sets_match_the_generator_manifest():
+    """Every committed .npz holds exactly the arrays the committed oracle/gen_golden.py writes (tests/golden/manifest.json
+    is written by the same run): a stale fixture fails here instead of looking like a changed reference."""
+    with open(os.path.join(H.GOLD, "manifest.json")) as f:
+        man = json.load(f)
+    files = sorted(os.path.basename(p) for p in glob.glob(os.path.join(H.GOLD, "*.npz")))
+    assert files == sorted(man)
+    for fn in files:
+        with np.load(os.path.join(H.GOLD, fn), allow_pickle=False) as z:
+            assert sorted(z.files) == man[fn], fn
+    model_keys = {tuple(v) for k, v in man.items() if k.startswith("model_")}
+    assert len(model_keys) == 1, "every model fixture carries the same arrays"

@@ -47,3 +47,54 @@ def test_pack_edge_cases():
     same = sc._pack(list(range(40)), [100] * 40, 1)
     assert sorted(i for g in same for i in g) == list(range(40)) and all(len(g) <= sc.encode_rows_max for g in same)
     assert _sc(batch_invariant=False)._pack([0, 1, 2], [7, 9, 8], 1) == [[0], [1], [2]]   # LLM.int8: one scaffold per call
+
+
+def test_pack_counts_the_trunk_prefix_rows_against_the_arena_byte_budget():
+    # 32 short union members behind a long trunk: every row of the group arena also holds its trunk prefix, so the rows
+    # x suffix-width budget alone would put all of them into one forward (32 x 8 k x 1.6 MB/token at 13b = 400 GB)
+    sc = _sc()
+    lengths = [0] + [40] * 32
+    prefix = [0] + [8000] * 32
+    mine = list(range(1, 33))
+    row_bytes = 40 * 2 * 40 * 128 * 2 * 2                    # 13b: L * 2 * Hkv * D * fp16, + residual planes
+    free = sc._pack(mine, lengths, 1)
+    assert max(len(g) for g in free) == 32
+    sc.encode_arena_bytes = 48 * 2 ** 30
+    capped = sc._pack(mine, lengths, 1, prefix, row_bytes)
+    assert sorted(i for g in capped for i in g) == mine
+    for g in capped:
+        assert len(g) == 1 or len(g) * (8000 + 40) * row_bytes <= sc.encode_arena_bytes
+    assert max(len(g) for g in capped) < 32
+
+
+def _plan_of(schema_xml):
+    from tests import helpers as H
+    from promptcache_amd.pml import Schema
+    lm = H.TokOnlyLM()
+    lm.hf_model = types.SimpleNamespace(batch_invariant=True)
+    sc = SchemaCache.__new__(SchemaCache)
+    sc.lm, sc._jobs = lm, None
+    sc.schema = Schema(H.llama_formatter()(schema_xml), lm)
+    return sc
+
+
+def test_union_member_equal_to_or_prefixing_the_default_member_still_runs_one_row():
+    #  the scaffold cut behind the last owned token removed the "at least one token runs" invariant: a member
+    # whose tokens equal / prefix the default member's shared its whole kept range with the trunk -> zero-width passes
+    body = " ".join(f"word{i} of the shared system text" for i in range(12))
+    doc = " ".join(f"fact{i} about the document" for i in range(14))
+    xml = (f'<schema name="dup"><system>{body}</system><user><union scaffold="a">'
+           f'<module name="a">{doc} and a tail that only the first member has</module>'
+           f'<module name="b">{doc}</module><module name="c">{doc} and a tail that only the first member has</module>'
+           f'</union></user><assistant>ok</assistant></schema>')
+    sc = _plan_of(xml)
+    jobs, prefix = sc._plan_with_prefix()
+    need = sc._need(jobs, prefix)
+    assert len(jobs) >= 3 and any(p > 0 for p in prefix)
+    for i in range(len(jobs)):
+        assert need[i] - prefix[i] >= 1, (i, need[i], prefix[i])
+    costs = sc.pass_costs()
+    assert costs == [need[i] - prefix[i] for i in range(len(jobs))] and sc.plan_cost() == sum(costs)
+    # the packer never sees a non-positive width
+    groups = sc._pack([i for i in range(len(jobs)) if prefix[i] > 0], costs, 1)
+    assert all(costs[i] > 0 for g in groups for i in g)

@@ -33,61 +33,6 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        assert parallel.rank_world() == (rank, world)
-        # 7 "scaffold passes" with ragged numbers of owned segments; a pass's KV is a pure function of
-        # (job, segment) so every rank can check what it receives
-        costs = [30, 10, 25, 5, 40, 12, 18]
-        seg_lens = [[3, 1], [1], [7, 2, 1], [], [4], [1, 1, 1], [9]]
-        unit = 16                                     # elements per token (stands for L*2*Hkv*D)
-        shards = parallel.shard_jobs(costs, world)
-        owner = {i: r for r, idxs in enumerate(shards) for i in idxs}
-
-        def kv(job, j, n):
-            base = 1000 * job + 100 * j
-            return (torch.arange(n * unit, dtype=torch.float32) * 0.25 + base).to(torch.float16)
-
-        order = [(i, j, n) for i in range(len(costs)) for j, n in enumerate(seg_lens[i])]
-        table = [(owner[i], n * unit) for i, _, n in order]
-        local = [kv(i, j, n) for i, j, n in order if owner[i] == rank]
-        got = parallel.allgather_segments(local, table, rank, world, "cpu")
-        assert len(got) == len(order)
-        for (i, j, n), t in zip(order, got):
-            assert torch.equal(t, kv(i, j, n)), (i, j)
-        # every segment is a 16-byte-aligned view of ONE gathered buffer
-        base = min(t.data_ptr() for t in got)
-        assert all((t.data_ptr() - base) % 16 == 0 for t in got)
-        assert len({t.untyped_storage().data_ptr() for t in got}) == 1
-        # mismatch between the plan and what a rank holds is an error, not silent corruption
-        try:
-            parallel.allgather_segments(local[:-1], table, rank, world, "cpu")
-            ok = len(local) == 0
-        except ValueError:
-            ok = True
-        q.put((rank, ok))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_allgather_segments_world2_gloo():
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    res = sorted(q.get(timeout=5) for _ in range(world))
-    assert res == [(0, True), (1, True)]
-
-
 def _slab_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -96,7 +41,8 @@ def _slab_worker(rank, world, port, q):
         unit = 16
         # "library" of 3 schemas; per schema the segment sizes per rank (schema 1 is owned by rank 1 alone: the
         # schema-level sharding of CacheEngine.add_schemas; schemas 0 and 2 are pass-sharded over both ranks)
-        plans = [[[3, 1, 7], [2, 5]], [[], [4, 4, 1]], [[9], [1, 1]]]
+        plans = [[[3, 1, 7], [2, 5], [6]], [[], [4, 4, 1], []], [[9], [1, 1], [2, 2, 2, 2]]]
+        plans = [p[:world] for p in plans]
 
         def seg(k, r, j, n):
             return (torch.arange(n * unit, dtype=torch.float32) * 0.5 + 1000 * k + 100 * r + 10 * j).to(torch.float16)
@@ -110,6 +56,8 @@ def _slab_worker(rank, world, port, q):
                 v.copy_(seg(k, rank, j, n))                       # the "encode" writes through the views
             views_by_rank, handles = parallel.exchange_slabs(slab, sizes, rank, world, "cpu", async_op=True)
             assert views_by_rank[rank][0].data_ptr() == slab.data_ptr() if views else True     # own slab used in place
+            rx = parallel.exchange_bytes(sizes)
+            assert rx[rank] == sum(sum((n + 7) // 8 * 8 for n in sz) * 2 for r, sz in enumerate(sizes) if r != rank)
             pending.append(handles)
             results.append(views_by_rank)
         for hs in pending:                                        # the exchanges overlap the later "encodes"
@@ -132,8 +80,8 @@ def _slab_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_exchange_slabs_world2_gloo_exact_sizes_async():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_slabs_gloo_exact_sizes_async(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -143,7 +91,7 @@ def test_exchange_slabs_world2_gloo_exact_sizes_async():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, True), (1, True)]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, True) for r in range(world)]
 
 
 def test_carve_lays_segments_out_16_byte_aligned():

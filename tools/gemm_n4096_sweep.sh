@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+# needs a build with the sweep instantiations: PC_BUILD_FLAGS=-DPC_DEV_SWEEPS python __graft_entry__.py --force
 for M in 1 12; do
   timeout 120 python tools/gemm_n4096_sweep.py $M 1 1
   PC_GEMM_U=16 timeout 120 python tools/gemm_n4096_sweep.py $M 1 1

@@ -345,6 +345,81 @@ def run_config(args, device, world, rank, barrier):
         print(json.dumps(result))
 
 
+def plan_only(args):
+    """``--plan-only`` (CPU, no GPU, no torch.cuda): the schedule of the schema-library encode (BASELINE config 5) for 1 / 2 / 4 /
+    8 ranks from the token layout alone -- rows every rank runs through the model, bytes it receives in the module-KV exchange,
+    and the speed-ups they predict at a given 1-GPU encode rate and xGMI link rate.  One JSON object on stdout."""
+    import types
+    from promptcache_amd import pml, synth
+    from promptcache_amd.cache_engine import CacheEngine, SchemaCache
+    from promptcache_amd.model import _llama_formatter
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.tokenizer import StandInTokenizer
+    shape = SHAPES[args.model]
+    tok = StandInTokenizer(shape.vocab_size)
+    lm = types.SimpleNamespace(hf_tokenizer=tok, unk_token_id=0, eos_token_id=2, encode=tok.encode,
+                               hf_model=types.SimpleNamespace(batch_invariant=True))
+    fmt = _llama_formatter()
+    texts = [synth.persona_like(name=f"lib-persona-{i}", system_len=200 + 40 * i, seed=20 + i)[0] for i in range(5)]
+    texts += [synth.flat_docs(f"lib-docs-{i}", 30, lens, 8, seed=30 + i)[0]
+              for i, lens in enumerate([(306, 76, 800, 800, 800), (1500, 1200), (400,) * 6])]
+
+    def caches_of(texts):
+        out = []
+        for t in texts:
+            sc = SchemaCache.__new__(SchemaCache)
+            sc.lm, sc._jobs = lm, None
+            sc.schema = pml.Schema(fmt(t), lm)
+            out.append(sc)
+        return out
+
+    kvb = shape.kv_bytes_per_token
+    rate, link = args.plan_rate, args.plan_link_gbs * 1e9
+    out = {"what": "predicted multi-GPU schema-encode schedule (CacheEngine.library_schedule / parallel.plan_library), host arithmetic only",
+           "model": args.model, "kv_bytes_per_token": kvb, "assumed_1gpu_tokens_per_s": rate, "assumed_link_GBps": args.plan_link_gbs,
+           "workloads": {}}
+    for name, caches in (("library (config 5 stand-in: 5 persona-structured + 3 document schemas)", caches_of(texts)),
+                         ("persona schema alone (the headline schema)", caches_of([synth.persona_like()[0]]))):
+        items = [c.plan_items() for c in caches]
+        scaffold_tokens = sum(len(j["token_ids"]) for c in caches for j in c._plan())
+        one = sum(t + sum(cs) for t, cs in items)
+        rows = []
+        for world in (1, 2, 4, 8):
+            order, shards = CacheEngine.library_schedule(caches, world)
+            loads, rx, rx_last = [0] * world, [0] * world, [0] * world
+            for k in order:
+                trunk, costs = items[k]
+                jobs = caches[k]._plan_with_prefix()[0]
+                own = [0] * world
+                for r in range(world):
+                    mine = list(range(len(costs))) if world == 1 else shards[k][r]
+                    if mine:
+                        loads[r] += trunk + sum(costs[i] for i in mine)
+                    own[r] = sum(len(tc) for i in mine for tc in jobs[i]["owned"]) * kvb
+                for r in range(world):
+                    rx[r] += sum(own) - own[r]
+                    if k == order[-1]:
+                        rx_last[r] = sum(own) - own[r]
+            row_rate = rate * one / scaffold_tokens          # computed rows per second at the assumed scaffold-token rate
+            t_comp = max(loads) / row_rate
+            links = max(world - 1, 1) * link
+            t_rx_all, t_rx_last = max(rx) / links, max(rx_last) / links
+            rows.append({"ranks": world, "per_rank_computed_rows": loads, "compute_speedup": round(one / max(loads), 2),
+                         "exchange_rx_bytes_per_rank_max": int(max(rx)),
+                         "seconds_compute": round(t_comp, 4), "seconds_exchange_if_fully_exposed": round(t_rx_all, 4),
+                         "seconds_exchange_last_schema": round(t_rx_last, 4),
+                         "predicted_speedup_overlapped": round((one / row_rate) / (t_comp + t_rx_last), 2),
+                         "predicted_speedup_exchange_exposed": round((one / row_rate) / (t_comp + t_rx_all), 2)})
+        out["workloads"][name] = {"schemas": len(caches), "scaffold_tokens": scaffold_tokens, "computed_rows_one_rank": one,
+                                  "by_ranks": rows}
+    out["note"] = ("compute_speedup = rows of a one-rank encode / rows of the most loaded rank (a rank that takes passes of a schema "
+                   "re-runs its trunk); seconds_* price rows at the assumed scaffold-token rate (computed rows cost "
+                   "scaffold_tokens / computed_rows of a scaffold token each) and the exchange at (ranks - 1) links of the "
+                   "assumed rate (one grouped point-to-point step: an owner's slab leaves over ranks - 1 links at once); "
+                   "'overlapped' leaves only the LAST schema's exchange exposed (every earlier one runs under later encodes)")
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,7 +437,14 @@ def main():
     ap.add_argument("--no-library", action="store_true", help="skip the schema-library encode leg (BASELINE config 5)")
     ap.add_argument("--no-int8", action="store_true", help="skip the int8-weight context leg (builds a second model)")
     ap.add_argument("--no-context", action="store_true", help="skip the extra (untimed) no-cache / decode / GEMM-roofline runs")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="CPU only: print the predicted 1/2/4/8-GPU schedule of the schema-library encode and exit")
+    ap.add_argument("--plan-rate", type=float, default=72000.0, help="--plan-only: 1-GPU library encode rate, scaffold tokens/s")
+    ap.add_argument("--plan-link-gbs", type=float, default=153.0, help="--plan-only: one xGMI link, GB/s per direction")
     args = ap.parse_args()
+    if args.plan_only:
+        plan_only(args)
+        return
 
     import torch
     import torch.distributed as dist

@@ -326,6 +326,47 @@ int pc_attn_fwd_var(const void* q, const void* q_lo, int64_t q_batch_stride, int
                     int64_t workspace_bytes, const void* k_lo, const void* v_lo, int64_t lo_batch_stride,
                     int64_t lo_head_stride, void* stream);
 
+/* pc_gemm_skinny_ks -- the N = hidden projections of a <= 16-row forward with their residual add (o_proj llama2.py:405 + :638,
+ * down_proj :242 + :644):  y[m][n] += sum_k x[m][k] W[n][k],  K cut into `kslices` (1..8) slices that run as separate
+ * workgroups of `tiles_per_wg` (1, 2, 4, 8) output tiles each, the slices' partial tiles added INSIDE the launch: every
+ * workgroup writes its partial through to `scratch`, arrives at its tile group's counter, and the last arriver adds the
+ * partials in slice order (deterministic), adds y and stores.  wf / xf_hi / xf_lo as in pc_gemm_skinny.
+ *   scratch   >= pc_gemm_skinny_ks_scratch_bytes(N, kslices) bytes, 16-byte aligned
+ *   counters  ceil(N / 16 / tiles_per_wg) uint32 words, ZERO before the first launch; every launch leaves them zero.
+ *             One launch at a time may use a given scratch / counter pair. */
+int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
+int pc_gemm_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K, float* y,
+                      int64_t ldy, int32_t kslices, int32_t tiles_per_wg, void* scratch, int64_t scratch_bytes,
+                      void* counters, void* stream);
+
+/* pc_attn -- the struct-taking entry of the attention family (replaces llama2.py:368-398 + the implicit mask :62-76,
+ * :798-819 like pc_attn_fwd; pc_attn_fwd / _alibi / _ex / _var fill a subset of this struct and stay as wrappers).
+ * Every field means what the same-named argument of those entry points means; optional pointers are NULL when unused.
+ *   struct_bytes  sizeof(pc_attn_args) of the caller's header (ABI check)
+ *   counters      optional: B * H uint32 words, ZERO before the first launch that sees them; every launch leaves them
+ *                 zero.  With them a pass of <= 16 query rows over a long staged cache (the cached prefill proper and every
+ *                 decode step) is ONE launch: each workgroup writes its split-KV partial through to memory, arrives at its
+ *                 head's counter, and the last arriver merges the partials in split order (the result does not depend on
+ *                 the arrival order).  Without them the partials are merged by a second launch.  One launch at a time
+ *                 may use a given workspace / counter pair. */
+typedef struct pc_attn_args {
+    uint32_t struct_bytes;
+    const void* q; const void* q_lo; int64_t q_batch_stride, q_token_stride;
+    const void* k; const void* v; int64_t kv_batch_stride, kv_head_stride;
+    void* out; void* out_lo; int64_t out_batch_stride, out_token_stride;
+    void* out_frag_hi; void* out_frag_lo;
+    int32_t B, H, Hkv, D, q_len, past_len;
+    float softmax_scale;
+    void* workspace; int64_t workspace_bytes;
+    const int32_t* past_len_dev;
+    const int32_t* past_lens;
+    const float* key_pos; int64_t key_pos_batch_stride; const float* slopes_log2;
+    const void* k_lo; const void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_row0;
+    uint32_t* counters;
+} pc_attn_args;
+int pc_attn(const pc_attn_args* args, void* stream);
+
+
 /* Many-row projection (schema encode / no-cache prefill / long questions; MFMA-bound), csrc/pc_gemm_dense.hip:
  *     acc[m][n] = sum_k (x_hi[m][k] + x_lo[m][k]) * w[n][k]        fp16 operands, fp32 accumulation
  * x_hi / x_lo: split-precision activation planes [M][K] (row stride ldx halfs; x_lo may be NULL), w: the nn.Linear
@@ -445,6 +486,10 @@ int pc_greedy_advance(const float* logits, int32_t vocab, int64_t* ids, int32_t*
 
 /* Diagnostics used by the GPU test-suite: dumps the MFMA C/D lane map and the LDS transpose-read
  * map the attention kernel relies on (probe_kernel in csrc/pc_misc.hip). */
+/* dev hook (tools/gemm_trace.py): weight-streaming launches issued by this thread stamp per-wave wall-clock times
+ * (entry, K loop done, reduced, done) into buf [workgroups][8][4] uint64; NULL switches it off.  No reference counterpart. */
+int pc_dev_gemm_trace(void* buf);
+int pc_dev_attn_trace(void* buf);   /* the same for attn_small_kernel: [workgroups][4][4] (entry, first tile scored, slice done, done) */
 int pc_probe_layouts(float* out_mfma /*[16*16]*/, float* out_tr /*[512]*/, void* stream);
 
 #ifdef __cplusplus

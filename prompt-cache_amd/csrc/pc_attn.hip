@@ -54,6 +54,10 @@ struct AttnParams {
     _Float16* out_lo;       // optional: fp16 residual of `out` (same strides): split-precision row-major output
     _Float16* of_hi; _Float16* of_lo;   // optional: fragment-major split-precision output planes (pc_gemm.hip)
     float* part_o; float* part_ml;
+    // fused split-KV merge (attn_small_kernel): one arrival counter per (batch row, head), zero before the first launch; every
+    // launch leaves them zero.  NULL: the partials are merged by attn_combine_kernel in a second launch.
+    uint32_t* counters;
+    unsigned long long* trace;   // dev (pc_dev_attn_trace): per-wave wall-clock stamps [workgroup][4 waves][4]
     const int32_t* past_len_dev;
     const int32_t* past_lens;   // optional [B]: one past length per batch row (ragged prefixes); p.past_len = their maximum
     // ALiBi (MPT, promptcache/model/mpt.py:90-110, :160-175): score += slope[h] * key_pos[b][key]; both pre-scaled to
@@ -81,6 +85,19 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
 // around the instruction (v_cmp + v_cndmask + v_ldexp per call) buys nothing.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Inter-workgroup hand-off inside one launch (fused split-KV merge): 8-byte agent-scope relaxed atomics on BOTH sides --
+// the stores go through to the coherence point (no release fence), the loads bypass this CU's L1 (no acquire fence).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+__device__ __forceinline__ void st_wt2(float* p, float a, float b) {
+    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+    __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_wt2(const float* p) {
+    const unsigned long long x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32)));
+}
+
 __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     // ds_read_b64_tr_b16: within a 16-lane group, lane i receives sub-element (i%4) of the 8 bytes
     // addressed by lanes {i/4, 4+i/4, 8+i/4, 12+i/4} (verified by pc_probe_layouts on hardware).
@@ -103,7 +120,7 @@ constexpr int kTailMax = PC_TAIL_MAX;   // most rows of one prefill pass the tai
 // 256 threads = NT rows x LPR lanes; a lane owns JPT = NT / LPR keys in the score phase and D / LPR output dims after it.
 // LDS: qs / ks / vs are [NT][D] fp32 (qs, ks with the float4 column XOR-swizzled by the row: the lanes of a row group
 // read different rows of one column; unswizzled they share a bank), ps is [NT][NT].
-template <int D, int NT, bool ALIBI>
+template <int D, int NT, bool ALIBI, bool WT = false>   // WT: the partial leaves through write-through stores (fused merge)
 __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __restrict__ qs, float* __restrict__ ks,
                                                 float* __restrict__ vs, float* __restrict__ ps, int b, int h, int split) {
     constexpr int CPR = D / 8;             // 16-byte fp16 chunks per row
@@ -183,7 +200,10 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) l += __shfl_xor(l, off);
     const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
-    if (jl == 0 && qi < q_len) { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
+    if (jl == 0 && qi < q_len) {
+        if (WT) st_wt2(p.part_ml + slot * 2, m, l);
+        else { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
+    }
     __syncthreads();
     float o[DPT];
 #pragma unroll
@@ -195,8 +215,13 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
         for (int e = 0; e < DPT; ++e) o[e] += w * vs[jj * D + jl * DPT + e];
     }
     if (qi < q_len) {
+        if (WT) {
 #pragma unroll
-        for (int e = 0; e < DPT; ++e) p.part_o[slot * D + jl * DPT + e] = o[e];
+            for (int e = 0; e < DPT; e += 2) st_wt2(p.part_o + slot * D + jl * DPT + e, o[e], o[e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < DPT; ++e) p.part_o[slot * D + jl * DPT + e] = o[e];
+        }
     }
 }
 
@@ -738,14 +763,98 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
 //     kernel reads nstream (+1) partials per row instead of one per 3-tile split.
 // Q and P are split-precision pairs (HP).  Tail mode (see attn_tail_block) adds one workgroup per head for the pass's own
 // rows; without it the new rows are part of the stream under the index-order causal mask.
-template <int D, bool ALIBI>
+__device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
+    // LDS-DMA: each lane's 16 bytes at `g` land at lds_wave_base + 16 * lane (no VGPR round trip; completion = vmcnt)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Fused split-KV merge: the workgroup has written its (m, l, O) partial through to memory; it arrives at the (batch row,
+// head) counter and the LAST arriver merges all nsplit partials in split order (the result does not depend on who is last):
+//     out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i           (what attn_combine_kernel does in a second launch)
+// Hand-off: write-through payload stores, every storing wave drains (vmcnt 0), workgroup barrier, ONE relaxed agent-scope
+// fetch-add; the last arriver reads the partials with agent-scope loads (they bypass its L1): no fence on either side, no
+// spin anywhere.  The last arriver leaves the counter at zero for the next launch.
+template <int D, int NS>
+__device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, int h, int* s_last) {
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        gu32* c = (gu32*)(p.counters + b * p.H + h);
+        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old + 1u == (uint32_t)p.nsplit) ? 1 : 0;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    constexpr int DPT = D / 16;                          // head dims per thread: 16 threads per query row
+    const int qi = tid >> 4, c = tid & 15, q_len = p.q_len, nsplit = p.nsplit;
+    if (qi >= q_len) return;
+    const int64_t base = ((int64_t)b * p.H + h) * nsplit;
+    float mv[NS], lv[NS], ov[NS][DPT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {                       // one batch of independent loads (clamped re-reads behind nsplit)
+        const int sc = s < nsplit ? s : nsplit - 1;
+        const int64_t slot = (base + sc) * q_len + qi;
+        const float2 ml = ld_wt2(p.part_ml + slot * 2);
+        mv[s] = s < nsplit ? ml.x : kNegBig;
+        lv[s] = ml.y;
+#pragma unroll
+        for (int e = 0; e < DPT; e += 2) {
+            const float2 t = ld_wt2(p.part_o + slot * D + c * DPT + e);
+            ov[s][e] = t.x; ov[s][e + 1] = t.y;
+        }
+    }
+    float mstar = kNegBig;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mstar = fmaxf(mstar, mv[s]);
+    float num[DPT], den = 0.f;
+#pragma unroll
+    for (int e = 0; e < DPT; ++e) num[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float w = s < nsplit ? exp2f(mv[s] - mstar) : 0.f;
+        den += w * lv[s];
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) num[e] += w * ov[s][e];
+    }
+    _Float16 hi[DPT], lo[DPT];
+#pragma unroll
+    for (int e = 0; e < DPT; ++e) pc_split(num[e] / den, hi[e], lo[e]);
+    _Float16 *dh, *dl;
+    if (p.of_hi) {
+        const int64_t off = frag_off(b * q_len + qi, h * D + c * DPT, p.H * D / 32);   // DPT consecutive halfs of one fragment
+        dh = p.of_hi + off; dl = p.of_lo + off;
+    } else {
+        const int64_t off = b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + c * DPT;
+        dh = p.out + off; dl = p.out_lo ? p.out_lo + off : nullptr;
+    }
+    if constexpr (DPT == 8) {
+        *(h8*)dh = h8{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        if (dl) *(h8*)dl = h8{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+    } else if constexpr (DPT == 4) {
+        *(h4*)dh = h4{hi[0], hi[1], hi[2], hi[3]};
+        if (dl) *(h4*)dl = h4{lo[0], lo[1], lo[2], lo[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) { dh[e] = hi[e]; if (dl) dl[e] = lo[e]; }
+    }
+}
+
+// NS > 0: ONE launch -- the split-KV partials are merged by the last-arriving workgroup of each head (small_arrive_merge,
+// at most NS partials per row); NS = 0: the partials are left for attn_combine_kernel.
+template <int D, bool ALIBI, int NS>
 __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParams p) {
+    constexpr bool FUSE = NS > 0;
     constexpr int KS = D / 32, DB = D / 16, CPR = D / 8;
-    constexpr int LPW = kTK * CPR / 64;              // 16-byte V loads per lane per tile
+    constexpr int LPW = kTK * CPR / 64;              // 16-byte V chunks per lane per tile
     constexpr int kTileHalfs = kTK * D;
     constexpr int kTailBytes = (2 * 16 * D + 16 * D + 16 * 16) * 4;
     constexpr int kLdsBytes = 4 * kTileHalfs * 2 > kTailBytes ? 4 * kTileHalfs * 2 : kTailBytes;
-    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes + 16];
+    int* s_last = (int*)(smem + kLdsBytes);
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -755,9 +864,15 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
     const int q_len = p.q_len;
     const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
     const int nstream = p.tail ? p.nsplit - 1 : p.nsplit;
+    auto stamp = [&](int slot) {
+        if (p.trace && lane == 0)
+            p.trace[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * 4 + wave) * 4) + slot] = wall_clock64();
+    };
+    stamp(0);
     if (p.tail && split == nstream) {                 // workgroup-uniform: the pass's own rows, fp32
         float* f = (float*)smem;
-        attn_tail_block<D, 16, ALIBI>(p, f, f + 16 * D, f + 2 * 16 * D, f + 3 * 16 * D, b, h, split);
+        attn_tail_block<D, 16, ALIBI, FUSE>(p, f, f + 16 * D, f + 2 * 16 * D, f + 3 * 16 * D, b, h, split);
+        if constexpr (FUSE) small_arrive_merge<D, NS>(p, b, h, s_last);
         return;
     }
     const int kv_len = p.tail ? past_len : past_len + q_len;
@@ -768,15 +883,22 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
     const int qi = n;                                              // this lane's query row
     const int row_vis_end = qi < q_len ? (p.tail ? past_len : past_len + qi + 1) : 0;
 
+    // Every load below is unconditional (rows / keys past the end are clamped to the last valid one and masked later): a load
+    // under a branch makes hipcc's vmcnt bookkeeping wait for the NEWEST loads at the first use, which would put the whole
+    // V stream behind the K round trip.
     h8 qf[KS], qfl[KS];
+    {
+        const int qc = qi < q_len ? qi : q_len - 1;
+        const _Float16* qlo = p.q_lo ? p.q_lo : p.q;          // (no lo plane: a finite stand-in, multiplied by zero below)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        qf[ks] = z; qfl[ks] = z;
-        if (qi < q_len) {
-            const int64_t off = b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 32 + g * 8;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int64_t off = b * p.q_bs + (int64_t)qc * p.q_ts + (int64_t)h * D + ks * 32 + g * 8;
             qf[ks] = *(const h8*)(p.q + off);
-            if (p.q_lo) qfl[ks] = *(const h8*)(p.q_lo + off);
+            qfl[ks] = *(const h8*)(qlo + off);
+        }
+        if (!p.q_lo) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { h8 z = {0, 0, 0, 0, 0, 0, 0, 0}; qfl[ks] = z; }
         }
     }
     f4 o[DB];
@@ -788,27 +910,29 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
     [[maybe_unused]] const float slope = ALIBI ? p.slopes[h] : 0.f;
     [[maybe_unused]] const float* kpos = ALIBI ? p.key_pos + b * p.kp_bs : nullptr;
     _Float16* Vw = (_Float16*)smem + wave * kTileHalfs;            // this wave's V tile
+    char* Vwb = smem + wave * kTileHalfs * 2;                      // (the same, as the wave-uniform LDS-DMA base)
 
     for (int key0 = k0; key0 < k1; key0 += kTK) {
-        // ---- every load of the tile first: K as MFMA fragments, V as coalesced rows ----
-        u32x4 kr[4][KS], vr[LPW];
+        // ---- every load of the tile first: K as MFMA fragments (registers), V by LDS-DMA into the wave's tile ----
+        u32x4 kr[4][KS];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const int key = key0 + kb * 16 + n;
+            const int key = key0 + kb * 16 + n < k1 ? key0 + kb * 16 + n : k1 - 1;     // (keys past k1 are masked below)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                u32x4 z = {0u, 0u, 0u, 0u};
-                kr[kb][ks] = z;
-                if (key < k1) kr[kb][ks] = *(const u32x4*)(kbase + (int64_t)key * D + ks * 32 + g * 8);
-            }
+            for (int ks = 0; ks < KS; ++ks) kr[kb][ks] = *(const u32x4*)(kbase + (int64_t)key * D + ks * 32 + g * 8);
         }
+        // V rows go straight to LDS, rotated by 32 B per row (see attn_fwd_kernel) -- the permutation sits on the per-lane
+        // SOURCE address, LDS-DMA writes lane-linearly: chunk c = 64 i + lane of the tile = (row c / CPR, position c % CPR)
+        // holds source column (position - 2 (row & 7)) mod CPR.  Rows past k1 re-read the last valid row (their P is 0; a
+        // finite value times 0, where uninitialised arena rows could hold NaNs).
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int c = lane + i * 64, row = c / CPR, col = c - row * CPR;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            vr[i] = z;                                              // rows past k1: zeros (0 * garbage could be NaN)
-            if (key0 + row < k1) vr[i] = *(const u32x4*)(vbase + (int64_t)(key0 + row) * D + col * 8);
+            const int c = lane + i * 64, row = c / CPR, pos = c - row * CPR;
+            const int col = (pos - 2 * (row & 7)) & (CPR - 1);
+            const int rr = key0 + row < k1 ? key0 + row : k1 - 1;
+            glds16(vbase + (int64_t)rr * D + col * 8, Vwb + i * 1024);
         }
+        __builtin_amdgcn_sched_barrier(0);               // the whole tile is in flight before the first wait
         // ---- S^T = K . Q^T ----
         float sv[4][4];
         float mx = -INFINITY;
@@ -851,16 +975,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
             }
         rs += __shfl_xor(rs, 16);
         rs += __shfl_xor(rs, 32);
+        if (key0 == k0) stamp(1);                        // K arrived, scores + softmax of the first tile done
         l_run = l_run * alpha + rs;
 #pragma unroll
         for (int db = 0; db < DB; ++db) { o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha; }
         m_run = m_new;
-        // ---- V through the wave-private LDS tile (rows rotated by 32 B per row, see attn_fwd_kernel), back transposed ----
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int c = lane + i * 64, row = c / CPR, col = c - row * CPR;
-            *(u32x4*)(Vw + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
-        }
+        // ---- the V tile has landed (this wave's own DMA: vmcnt covers it, no barrier), back transposed ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
 #pragma unroll
@@ -876,6 +997,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
         }
     }
 
+    stamp(2);                                            // the wave's key slice is done
     // ---- merge the four waves' partials through LDS: one (m, l, O) partial per workgroup ----
     __syncthreads();                                     // every wave is done with its V tile
     float* mo = (float*)smem;                            // [4][DB][64][4]
@@ -893,30 +1015,40 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
     float wt[4], lsum = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { wt[w] = fast_exp2(mw[w] - mstar); lsum += wt[w] * lw[w]; }
-    if (qi >= q_len) return;
-    const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
-    constexpr int DPW = (DB + 3) / 4;                    // head-dim blocks merged by one wave
+    if (qi < q_len) {
+        const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
+        constexpr int DPW = (DB + 3) / 4;                // head-dim blocks merged by one wave
 #pragma unroll
-    for (int j = 0; j < DPW; ++j) {
-        const int db = wave * DPW + j;
-        if (db < DB) {
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < DPW; ++j) {
+            const int db = wave * DPW + j;
+            if (db < DB) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f4 x = *(const f4*)(mo + ((w * DB + db) * 64 + lane) * 4);
-                acc[0] += wt[w] * x[0]; acc[1] += wt[w] * x[1]; acc[2] += wt[w] * x[2]; acc[3] += wt[w] * x[3];
+                for (int w = 0; w < 4; ++w) {
+                    const f4 x = *(const f4*)(mo + ((w * DB + db) * 64 + lane) * 4);
+                    acc[0] += wt[w] * x[0]; acc[1] += wt[w] * x[1]; acc[2] += wt[w] * x[2]; acc[3] += wt[w] * x[3];
+                }
+                float* dst = p.part_o + slot * D + db * 16 + g * 4;
+                if constexpr (FUSE) { st_wt2(dst, acc[0], acc[1]); st_wt2(dst + 2, acc[2], acc[3]); }
+                else *(f4*)dst = acc;
             }
-            *(f4*)(p.part_o + slot * D + db * 16 + g * 4) = acc;
+        }
+        if (wave == 0 && g == 0) {
+            if constexpr (FUSE) st_wt2(p.part_ml + slot * 2, mstar, lsum);
+            else { p.part_ml[slot * 2] = mstar; p.part_ml[slot * 2 + 1] = lsum; }
         }
     }
-    if (wave == 0 && g == 0) { p.part_ml[slot * 2] = mstar; p.part_ml[slot * 2 + 1] = lsum; }
+    if (p.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+    if constexpr (FUSE) small_arrive_merge<D, NS>(p, b, h, s_last);
 }
 
-// workgroups per head of attn_small_kernel: fill the 256 CUs (each workgroup = 4 key slices)
-int small_nstream(int B, int H) {
+// Streaming workgroups per head of attn_small_kernel (each = 4 key slices): ONE workgroup per CU in total, the tail workgroup
+// of each head included -- 8 + 1 splits x 32 heads = 288 workgroups put a second workgroup on 32 of the 256 CUs and the launch
+// waits for those: 7 + 1 (exactly 256) runs the persona step 1.7 % faster end to end (3.908 -> 3.844 ms, profiles/r03_*).
+int small_nstream(int B, int H, int tail = 0) {
     static const int forced = [] { const char* e = getenv("PC_ATTN_SMALL_WG"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced < 15 ? forced : 15;
-    int ns = 256 / (B * H);
+    int ns = 256 / (B * H) - tail;
     if (ns < 1) ns = 1;
     if (ns > 15) ns = 15;
     return ns;
@@ -1023,9 +1155,20 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     p.xcd_remap = (!p.small && p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
     if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
+    if (p.small && p.counters) {
+        // one launch: the last-arriving workgroup of each head merges the partials (no attn_combine_kernel)
+#define PC_SMALL_FUSED(NSV)                                                                                          \
+        do {                                                                                                       \
+            if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, NSV>), grid, dim3(kThreads), 0, stream, p);  \
+            else hipLaunchKernelGGL((attn_small_kernel<D, false, NSV>), grid, dim3(kThreads), 0, stream, p);          \
+        } while (0)
+        if (p.nsplit <= 4) PC_SMALL_FUSED(4); else if (p.nsplit <= 8) PC_SMALL_FUSED(8); else PC_SMALL_FUSED(16);
+#undef PC_SMALL_FUSED
+        return pc_check_launch("attn_small_kernel");
+    }
     if (p.small) {
-        if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
-        else hipLaunchKernelGGL((attn_small_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
+        if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_small_kernel<D, false, 0>), grid, dim3(kThreads), 0, stream, p);
     } else if (rows32) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
@@ -1068,6 +1211,10 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
 
+// dev hook: the next attention launches of this thread stamp per-wave wall-clock times into `buf` (NULL: off)
+static thread_local unsigned long long* g_attn_trace = nullptr;
+PC_EXPORT int pc_dev_attn_trace(void* buf) { g_attn_trace = (unsigned long long*)buf; return PC_OK; }
+
 namespace {
 int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
                   const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
@@ -1076,7 +1223,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
                   const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo,
                   const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream,
-                  const int32_t* past_lens = nullptr) {
+                  const int32_t* past_lens = nullptr, uint32_t* counters = nullptr) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -1096,6 +1243,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.of_hi = (_Float16*)out_frag_hi; p.of_lo = (_Float16*)out_frag_lo;
     p.past_len_dev = past_len_dev;
     p.past_lens = past_lens;
+    p.counters = counters;
+    p.trace = g_attn_trace;
     p.key_pos = key_pos; p.kp_bs = key_pos_batch_stride; p.slopes = slopes;
     p.k_lo = (const _Float16*)k_lo; p.v_lo = (const _Float16*)v_lo; p.lo_bs = lo_bs; p.lo_hs = lo_hs; p.lo_row0 = lo_row0;
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
@@ -1107,7 +1256,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     static const bool small_off = [] { const char* e = getenv("PC_ATTN_NO_SMALL"); return e && e[0] == '1'; }();
     bool small = !small_off && q_len <= kSmallQ && !past_lens && (!k_lo || p.tail) && past_len + q_len >= 256;
     if (small) {
-        const int ns = small_nstream(B, H) + p.tail;
+        const int ns = small_nstream(B, H, p.tail) + p.tail;
         if (ns >= 2) p.nsplit = ns; else small = false;
     }
     p.small = small ? 1 : 0;
@@ -1201,4 +1350,32 @@ PC_EXPORT int pc_attn_fwd_var(const void* q, const void* q_lo, int64_t q_batch_s
                          out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
                          workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, nullptr, out_lo, k_lo, v_lo, lo_batch_stride,
                          lo_head_stride, 0, stream, past_lens);
+}
+
+// pc_attn: the one struct-taking entry of the attention family (the entry points above are wrappers that fill a subset of it).
+// `counters` (optional, B*H zeroed uint32 words, left zero by every launch): launches of <= 16 query rows over a long staged
+// cache then merge their split-KV partials INSIDE the launch (last-arriving workgroup per head) instead of through a second one.
+PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {
+    PC_REQUIRE(a && a->struct_bytes == (uint32_t)sizeof(pc_attn_args), PC_ERR_ARG,
+               "pc_attn: args is NULL or struct_bytes != sizeof(pc_attn_args) (ABI mismatch)");
+    PC_REQUIRE((a->k_lo == nullptr) == (a->v_lo == nullptr) && (!a->k_lo || a->q_lo), PC_ERR_ARG,
+               "pc_attn: k_lo / v_lo go together and need q_lo (split-precision Q)");
+    PC_REQUIRE(!a->k_lo || a->lo_head_stride % 8 == 0, PC_ERR_ARG, "pc_attn: the lo strides must keep 16-byte alignment");
+    PC_REQUIRE((a->key_pos == nullptr) == (a->slopes_log2 == nullptr), PC_ERR_ARG, "pc_attn: key_pos and slopes go together");
+    PC_REQUIRE(!a->key_pos || (a->key_pos_batch_stride % 4 == 0 && ((uintptr_t)a->key_pos & 15) == 0), PC_ERR_ARG,
+               "pc_attn: key_pos rows not 16-byte aligned");
+    if (a->past_lens) {
+        PC_REQUIRE(!a->past_len_dev && !a->key_pos && !a->out_frag_hi && (!a->k_lo || a->lo_row0 == 0), PC_ERR_ARG,
+                   "pc_attn: per-row past lengths exclude past_len_dev, ALiBi and fragment output; residual planes must be arena-shaped");
+    } else {
+        PC_REQUIRE(!a->k_lo || a->lo_row0 == -1 || (a->lo_row0 == -2 && a->past_len_dev) ||
+                   (a->lo_row0 >= 0 && a->lo_row0 <= a->past_len && !a->past_len_dev), PC_ERR_ARG,
+                   "pc_attn: lo_row0 must be -1 (= past_len), -2 (= past_len_dev[1]) or lie in [0, past_len] of a host past_len");
+    }
+    PC_REQUIRE(!a->counters || ((uintptr_t)a->counters & 3) == 0, PC_ERR_ARG, "pc_attn: counters not 4-byte aligned");
+    return attn_fwd_impl(a->q, a->q_lo, a->q_batch_stride, a->q_token_stride, a->k, a->v, a->kv_batch_stride, a->kv_head_stride,
+                         a->out, a->out_batch_stride, a->out_token_stride, a->B, a->H, a->Hkv, a->D, a->q_len, a->past_len,
+                         a->softmax_scale, a->workspace, a->workspace_bytes, a->past_len_dev, a->out_frag_hi, a->out_frag_lo,
+                         a->key_pos, a->key_pos_batch_stride, a->slopes_log2, a->out_lo, a->k_lo, a->v_lo, a->lo_batch_stride,
+                         a->lo_head_stride, a->lo_row0, stream, a->past_lens, a->counters);
 }

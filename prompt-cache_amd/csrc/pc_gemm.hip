@@ -29,7 +29,23 @@ int choose_T(int units) {
 
 using namespace pcg;
 
+// dev hook: the next weight-streaming launches of this thread stamp per-wave wall-clock times into `buf` (NULL: off)
+static thread_local unsigned long long* g_gemm_trace = nullptr;
+PC_EXPORT int pc_dev_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return PC_OK; }
+
 namespace {
+
+// intra-workgroup K skew / priority alternation of the <= 64-row launches (GemmParams::kskew, prio_alt); dev overrides
+void set_k_balance(GemmParams& p, int K) {
+    static const int skew = [] { const char* e = getenv("PC_GEMM_KSKEW"); return e ? atoi(e) : 0; }();
+    static const int alt = [] { const char* e = getenv("PC_GEMM_PRIO_ALT"); return e ? atoi(e) : 0; }();
+    p.prio_alt = alt;
+    p.kskew = skew;
+    // the fused-RMSNorm source stages a wave's gain slice in LDS: at most kGamSteps k-steps per wave
+    const int n = pc_ceil_div(K / 32, p.kslices > 0 ? p.kslices : 1);
+    if (p.xn && (n * (64 + p.kskew) + 8 * 64 - 1) / (8 * 64) > kGamSteps) p.kskew = 0;
+    if (p.M > 64) p.kskew = 0;                               // (the row-split kernel has no K split inside a workgroup)
+}
 
 int launch_MT(int epi, const GemmParams& p, int T, int units, hipStream_t s) {
     const int mt = pc_ceil_div(p.M, 16);
@@ -181,8 +197,8 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
                "pc_gemm_skinny_a8c: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t (ldt >= N), K <= 16384");
     PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
     PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
-    PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && (epilogue == EPI_STORE || epilogue == EPI_SILU)), PC_ERR_ARG,
-               "pc_gemm_skinny_norm: the fused-RMSNorm source needs M <= 16, no K-slicing, epilogue 0 or 2");
+    PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && (epilogue == EPI_STORE || epilogue == EPI_SILU) && K <= 32 * kGamSteps * kWaves),
+               PC_ERR_ARG, "pc_gemm_skinny_norm: the fused-RMSNorm source needs M <= 16, K <= 16384, no K-slicing, epilogue 0 or 2");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
@@ -200,6 +216,8 @@ int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const
     PC_REQUIRE(kslices >= 1 && kslices <= 16 && (kslices == 1 || epilogue == EPI_STORE), PC_ERR_ARG,
                "pc_gemm_skinny: K-slicing (kslices=%d) is available for the plain-store epilogue only", kslices);
     p.kslices = kslices; p.slab_stride = (int64_t)M * ldy;
+    p.trace = g_gemm_trace;
+    set_k_balance(p, K);
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == EPI_SILU) {
         PC_REQUIRE(N % 64 == 0, PC_ERR_ARG, "pc_gemm_skinny: SiLU epilogue needs N = 2*inter with inter%%32==0");
@@ -278,6 +296,7 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
     PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
     PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
     PC_REQUIRE(wf_perm && (xf_hi || xn) && cs && q_hi && q_lo && k_arena && v_arena, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
+    PC_REQUIRE(!xn || K <= 32 * kGamSteps * kWaves, PC_ERR_ARG, "pc_gemm_qkv_rope_norm: the fused-RMSNorm source needs K <= 16384");
     PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
                "pc_gemm_qkv_rope: past_len %d + q_len %d exceeds arena rows %d", past_len, q_len, cap);
     PC_REQUIRE(q_token_stride % 4 == 0 && arena_head_stride % 4 == 0, PC_ERR_ARG, "pc_gemm_qkv_rope: strides must keep 8-byte alignment");
@@ -309,6 +328,8 @@ int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo
                "pc_gemm_qkv_rope: lo_base must be -1 (pass-relative rows), -2 (past_len_dev[1]) or lie in [0, past_len]");
     p.rope.lo_base = lo_base;
     p.rope.H = H; p.rope.Hkv = Hkv; p.rope.D = D; p.rope.q_len = q_len; p.rope.past_len = past_len;
+    p.trace = g_gemm_trace;
+    set_k_balance(p, K);
     return launch_MT(EPI_ROPE, p, choose_T(p.ntiles), p.ntiles, (hipStream_t)stream);
 }
 }  // namespace

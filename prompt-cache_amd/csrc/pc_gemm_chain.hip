@@ -93,7 +93,7 @@ constexpr int kSyncWave = kWaves - 1;          // the wave that arrives / polls 
 template <int T, int EPI, int U, bool NORM, bool HAVE_PRE, class PF>
 __device__ __forceinline__ void chain_phase(const GemmParams& p, int nblk, const GridSync& gs, uint32_t seam, bool last_seam,
                                             const h8 (*pre)[(EPI == EPI_SILU) ? 2 * T : T], PF prefetch_next,
-                                            float* red, float (*ssl)[16]) {
+                                            float* red, float (*ssl)[16], _Float16* gam_lds) {
     static_assert(T <= 4, "one reduction round, and the sync wave never stores");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool storing = wave < T;                        // single-round launches (MT = 1): output item w is wave w's
@@ -106,14 +106,14 @@ __device__ __forceinline__ void chain_phase(const GemmParams& p, int nblk, const
         {
             const bool lastb = wg + nwg >= nblk;
             auto early = [&]() { if (lastb && early_wave) prefetch_next(); };
-            if constexpr (HAVE_PRE) gemm_skinny_body<1, T, EPI, true, U, NORM, false, true>(p, wg, 0, red, ssl, pre, early);
-            else gemm_skinny_body<1, T, EPI, true, U, NORM, false, false>(p, wg, 0, red, ssl, nullptr, early);
+            if constexpr (HAVE_PRE) gemm_skinny_body<1, T, EPI, true, U, NORM, false, true>(p, wg, 0, red, ssl, pre, early, gam_lds);
+            else gemm_skinny_body<1, T, EPI, true, U, NORM, false, false>(p, wg, 0, red, ssl, nullptr, early, gam_lds);
         }
         for (int bx = wg + nwg; bx < nblk; bx += nwg) {
             const bool lastb = bx + nwg >= nblk;
             auto early = [&]() { if (lastb && early_wave) prefetch_next(); };
             lds_barrier();                                // the reduction buffer of the previous block is free
-            gemm_skinny_body<1, T, EPI, true, U, NORM, false, false>(p, bx, 0, red, ssl, nullptr, early);
+            gemm_skinny_body<1, T, EPI, true, U, NORM, false, false>(p, bx, 0, red, ssl, nullptr, early, gam_lds);
         }
     } else if (early_wave) {
         prefetch_next();                                  // no block in this phase: still prefetch the next one
@@ -142,6 +142,7 @@ template <int TO, int TG, int TD, int TQ, int UO, int UG, int UD, int UQ>
 __global__ __launch_bounds__(kThreads) void gemm_chain_kernel(const ChainParams c) {
     __shared__ __attribute__((aligned(16))) float red[kWaves * 8 * 64 * 4];      // 64 KiB: the widest phase's reduction buffer
     __shared__ float ssl[kWaves][16];
+    __shared__ __attribute__((aligned(16))) _Float16 gam_lds[kWaves * kGamHalfs];
     GridSync gs;
     gs.init(c.sync);
     gs.tr = c.trace;
@@ -153,13 +154,13 @@ __global__ __launch_bounds__(kThreads) void gemm_chain_kernel(const ChainParams 
     auto pf_d = [&]() { if (wg < c.nblk[2]) prefetch_first_block<TD, EPI_ADD, UD>(c.ph[2], wg, pre_d); };
     auto pf_q = [&]() { if (qkv && wg < c.nblk[3]) prefetch_first_block<TQ, EPI_ROPE, UQ>(c.ph[3], wg, pre_q); };
     auto pf_none = [&]() {};
-    chain_phase<TO, EPI_ADD, UO, false, false>(c.ph[0], c.nblk[0], gs, 1, false, nullptr, pf_g, red, ssl);
-    chain_phase<TG, EPI_SILU, UG, true, true>(c.ph[1], c.nblk[1], gs, 2, !qkv, pre_g, pf_d, red, ssl);
+    chain_phase<TO, EPI_ADD, UO, false, false>(c.ph[0], c.nblk[0], gs, 1, false, nullptr, pf_g, red, ssl, gam_lds);
+    chain_phase<TG, EPI_SILU, UG, true, true>(c.ph[1], c.nblk[1], gs, 2, !qkv, pre_g, pf_d, red, ssl, gam_lds);
     if (qkv) {
-        chain_phase<TD, EPI_ADD, UD, false, true>(c.ph[2], c.nblk[2], gs, 3, true, pre_d, pf_q, red, ssl);
-        chain_phase<TQ, EPI_ROPE, UQ, true, true>(c.ph[3], c.nblk[3], gs, 0, false, pre_q, pf_none, red, ssl);
+        chain_phase<TD, EPI_ADD, UD, false, true>(c.ph[2], c.nblk[2], gs, 3, true, pre_d, pf_q, red, ssl, gam_lds);
+        chain_phase<TQ, EPI_ROPE, UQ, true, true>(c.ph[3], c.nblk[3], gs, 0, false, pre_q, pf_none, red, ssl, gam_lds);
     } else {
-        chain_phase<TD, EPI_ADD, UD, false, true>(c.ph[2], c.nblk[2], gs, 0, false, pre_d, pf_none, red, ssl);
+        chain_phase<TD, EPI_ADD, UD, false, true>(c.ph[2], c.nblk[2], gs, 0, false, pre_d, pf_none, red, ssl, gam_lds);
     }
 }
 
@@ -196,6 +197,7 @@ PC_EXPORT int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* a
     PC_REQUIRE(wo_f && attn_hi && attn_lo && x && wgu_f && ln2_weight && act_hi && act_lo && wdown_f && sync_state, PC_ERR_ARG,
                "pc_gemm_chain: null pointer");
     PC_REQUIRE(M > 0 && M <= 16, PC_ERR_ARG, "pc_gemm_chain: M=%d outside 1..16", M);
+    PC_REQUIRE(hidden <= 32 * kGamSteps * kWaves, PC_ERR_ARG, "pc_gemm_chain: hidden %d > 16384", hidden);
     PC_REQUIRE(hidden > 0 && hidden % 32 == 0 && inter > 0 && inter % 32 == 0 && attn_width > 0 && attn_width % 32 == 0, PC_ERR_ARG,
                "pc_gemm_chain: hidden, inter and the attention width must be multiples of 32");
     ChainParams c;

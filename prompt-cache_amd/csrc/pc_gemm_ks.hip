@@ -1,0 +1,165 @@
+// N = hidden projections of a <= 16-row forward (o_proj, down_proj: llama2.py:405 + :638, :242 + :644) with K split ACROSS
+// workgroups and the reduction INSIDE the launch.
+//
+// Why.  These launches have only N / 16 = 256 output tiles.  With one tile per workgroup (gemm_skinny_kernel<1, 1, EPI_ADD>)
+// every workgroup walks all of K, and per k-step a wave issues one 1-KiB weight load next to TWO 1-KiB activation loads (hi and
+// lo plane, L2 hits): two thirds of what the CU's vector memory pipe carries is activations that every one of the 256 CUs
+// re-reads -- 0.41 / 0.49 of the HBM roof for o_proj / down_proj.  Giving a workgroup T tiles and 1 / S of K keeps S * 256 / T
+// workgroups in flight while a k-step's activation loads serve T weight fragments (round 2 measured the stream alone at 18.2 us
+// instead of 23.2 us for down_proj at T = 8, S = 8, profiles/r02_gemm_n4096_sweep.txt).  The S partial tiles must then be added:
+//   * every workgroup writes its reduced partial tile(s) THROUGH to memory (8-byte agent-scope stores, lane-linear: 1 KiB per
+//     tile), drains them, and one lane adds 1 to the arrival counter of its tile group;
+//   * the LAST arriver of a group reads all S partials back (agent-scope loads: they bypass its L1), adds them in slice order
+//     0 .. S-1 -- the result does not depend on who arrived last -- adds the residual stream and stores y; it leaves the counter
+//     at zero for the next launch.  No spin, no fence, no second launch.
+#include "pc_gemm_skinny.h"
+
+using namespace pcg;
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+__device__ __forceinline__ void st_wt2(float* p, float a, float b) {
+    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+    __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_wt2(const float* p) {
+    const unsigned long long x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32)));
+}
+
+constexpr int kMaxSlices = 8;
+
+struct KsParams {
+    GemmParams g;            // wf, xf_hi, xf_lo, y, ldy, M, ntiles, KS, kslices
+    float* slabs;            // [kslices][ntiles][64][4] fp32 partial tiles (MFMA C layout, lane-linear)
+    uint32_t* counters;      // [ceil(ntiles / T)] arrival counters, zero between launches
+};
+
+template <int T, int U>
+__global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams kp) {
+    const GemmParams& p = kp.g;
+    __shared__ __attribute__((aligned(16))) float red_raw[kWaves * T * 64 * 4];
+    __shared__ int s_last;
+    float (*red)[T][64][4] = (float (*)[T][64][4])red_raw;
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = blockIdx.x, by = blockIdx.y, KS = p.KS, S = p.kslices;
+    int ks0, ks1;
+    wave_k_range<false>(p, by, wave, ks0, ks1);
+    int tile[T];
+    wg_tiles<T, EPI_ADD>(p, bx, tile);
+    f4 acc[1][T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[0][t] = z; }
+    const _Float16* wbase[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wbase[t] = p.wf + ((int64_t)tile[t] * KS * 64 + lane) * 8;
+    const _Float16* xh_base = p.xf_hi + lane * 8;
+    const _Float16* xl_base = p.xf_lo + lane * 8;
+    bool row_ok[1];
+    row_ok[0] = m < p.M;
+    // the residual tile the last arriver will add to, fetched now (clamped, unconditional; written by that lane only)
+    f4 yold;
+    {
+        const int tw = wave < T ? wave : T - 1;
+        const int unit = bx * T + tw < p.ntiles ? bx * T + tw : p.ntiles - 1;
+        yold = *(const f4*)(p.y + (int64_t)(m < p.M ? m : p.M - 1) * p.ldy + unit * 16 + g * 4);
+    }
+    int ks = ks0;
+    for (; ks + U <= ks1; ks += U) k_block<1, T, true, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
+    if (ks < ks1) k_block<1, T, true, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+
+    // ---- the eight waves' K shares through LDS, fixed order; wave t then holds this workgroup's partial of tile t ----
+#pragma unroll
+    for (int t = 0; t < T; ++t) *(f4*)red[wave][t][lane] = acc[0][t];
+    lds_barrier();
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    const bool mine = wave < T && bx * T + wave < p.ntiles;          // (clamped duplicate tiles are not stored)
+    if (wave < T) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const f4 x = *(const f4*)red[w][wave][lane];
+            v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+        }
+    }
+    const int my_tile = bx * T + wave;
+    if (mine) {
+        float* dst = kp.slabs + (((int64_t)by * p.ntiles + my_tile) * 64 + lane) * 4;
+        st_wt2(dst, v[0], v[1]);
+        st_wt2(dst + 2, v[2], v[3]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave: its stores are acknowledged
+    __syncthreads();
+    if (tid == 0) {
+        gu32* c = (gu32*)(kp.counters + bx);
+        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old + 1u == (uint32_t)S) ? 1 : 0;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last || !mine) return;
+    // ---- last arriver: the S partials of its tiles, slice order ----
+    float2 a[kMaxSlices], b[kMaxSlices];
+#pragma unroll
+    for (int s = 0; s < kMaxSlices; ++s) {
+        const int sc = s < S ? s : S - 1;                             // clamped re-read instead of a branch around the loads
+        const float* src = kp.slabs + (((int64_t)sc * p.ntiles + my_tile) * 64 + lane) * 4;
+        a[s] = ld_wt2(src);
+        b[s] = ld_wt2(src + 2);
+    }
+    f4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < kMaxSlices; ++s)
+        if (s < S) { r[0] += a[s].x; r[1] += a[s].y; r[2] += b[s].x; r[3] += b[s].y; }
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    tile_epilogue<EPI_ADD>(p, r, zero, m, my_tile, g, 0, false, zero, zero, true, yold);
+}
+
+template <int T, int U>
+int launch_ks(const KsParams& kp, hipStream_t s) {
+    const dim3 grid(pc_ceil_div(kp.g.ntiles, T), kp.g.kslices);
+    hipLaunchKernelGGL((gemm_skinny_ks_kernel<T, U>), grid, dim3(kThreads), 0, s, kp);
+    return pc_check_launch("gemm_skinny_ks_kernel");
+}
+
+}  // namespace
+
+PC_EXPORT int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices) {
+    if (N <= 0 || kslices <= 0) return 0;
+    return (int64_t)kslices * (N / 16) * 64 * 4 * (int64_t)sizeof(float);
+}
+
+// y[m][n] += sum_k x[m][k] W[n][k]   (M <= 16 rows, split-precision activation planes, fp16 weight image), K cut into
+// `kslices` (1..8) workgroup slices with `tiles_per_wg` (1, 2, 4 or 8) output tiles per workgroup; scratch >=
+// pc_gemm_skinny_ks_scratch_bytes(N, kslices) bytes; counters: ceil(N / 16 / tiles_per_wg) uint32 words, zero before the first
+// launch (every launch leaves them zero).  Deterministic: the partials are added in slice order whoever arrives last.
+PC_EXPORT int pc_gemm_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K, float* y,
+                                int64_t ldy, int32_t kslices, int32_t tiles_per_wg, void* scratch, int64_t scratch_bytes,
+                                void* counters, void* stream) {
+    PC_REQUIRE(wf && xf_hi && xf_lo && y && scratch && counters, PC_ERR_ARG, "pc_gemm_skinny_ks: null pointer");
+    PC_REQUIRE(M > 0 && M <= 16 && N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0 && ldy >= N && ldy % 4 == 0, PC_ERR_ARG,
+               "pc_gemm_skinny_ks: need 1 <= M <= 16, N %% 16 == 0, K %% 32 == 0");
+    PC_REQUIRE(kslices >= 1 && kslices <= kMaxSlices, PC_ERR_ARG, "pc_gemm_skinny_ks: kslices %d outside 1..8", kslices);
+    PC_REQUIRE(scratch_bytes >= pc_gemm_skinny_ks_scratch_bytes(N, kslices) && ((uintptr_t)scratch & 15) == 0, PC_ERR_WORKSPACE,
+               "pc_gemm_skinny_ks: scratch too small or misaligned");
+    KsParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.g.wf = (const _Float16*)wf; kp.g.xf_hi = (const _Float16*)xf_hi; kp.g.xf_lo = (const _Float16*)xf_lo;
+    kp.g.y = y; kp.g.ldy = ldy; kp.g.M = M; kp.g.ntiles = N / 16; kp.g.KS = K / 32; kp.g.kslices = kslices;
+    kp.slabs = (float*)scratch; kp.counters = (uint32_t*)counters;
+    hipStream_t s = (hipStream_t)stream;
+    // k-steps per block: a wave's K share is K / 32 / (8 kslices) k-steps -- keep the whole share in flight where it fits
+    const int share = pc_ceil_div(pc_ceil_div(K / 32, kslices), kWaves);
+    switch (tiles_per_wg) {
+        case 1: return share > 8 ? launch_ks<1, 16>(kp, s) : launch_ks<1, 8>(kp, s);
+        case 2: return share > 8 ? launch_ks<2, 12>(kp, s) : launch_ks<2, 8>(kp, s);
+        case 4: return share > 4 ? launch_ks<4, 8>(kp, s) : launch_ks<4, 4>(kp, s);
+        case 8: return share > 3 ? launch_ks<8, 4>(kp, s) : launch_ks<8, 3>(kp, s);
+        default: break;
+    }
+    pc_set_error("pc_gemm_skinny_ks: tiles_per_wg %d not in {1, 2, 4, 8}", tiles_per_wg);
+    return PC_ERR_ARG;
+}

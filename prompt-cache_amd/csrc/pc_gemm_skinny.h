@@ -92,7 +92,20 @@ struct GemmParams {
     // row (q|k|v's rotary permutation) or null
     const unsigned char* oflags; const _Float16* xraw; const signed char* cbt; int64_t ldt; const int32_t* row_perm;
     RopeEpi rope;
+    // K split inside a workgroup: the four waves dispatched first (one per SIMD, the OLDER wave of each SIMD) win the arbitration
+    // for the CU's memory pipe against their younger SIMD partners and finish an equal share ~30 % earlier; the younger half
+    // then streams on alone at half the memory parallelism (tools/gemm_trace.py: down_proj 11.8 vs 17.6 us).  kskew / 64 of an
+    // equal share moves from each younger wave to an older one (static: the summation order stays fixed).  prio_alt: the two
+    // halves swap s_setprio every k-block instead (fair on average, no tuning).
+    int32_t kskew, prio_alt;
+    // dev: per-wave wall-clock stamps [grid.x * grid.y][kWaves][4] (entry, K loop done, reduced, done); pc_dev_gemm_trace
+    unsigned long long* trace;
 };
+
+__device__ __forceinline__ void trace_stamp(const GemmParams& p, int bx, int by, int wave, int slot) {
+    if (p.trace && (threadIdx.x & 63) == 0)
+        p.trace[(((int64_t)by * gridDim.x + bx) * kWaves + wave) * 4 + slot] = wall_clock64();
+}
 
 __device__ __forceinline__ h8 ldg_h8(const _Float16* p) { return *(const h8*)p; }
 __device__ __forceinline__ h8 ldg_h8_nt(const _Float16* p) {
@@ -211,10 +224,48 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
 // planes), forms g*x as a split-precision pair and accumulates sum(x^2) of its K slice in `ss`.  The 1/rms factor
 // is a per-row scalar and the GEMM is linear in the activations, so it is applied to the reduced tile in the
 // epilogue -- LlamaRMSNorm (llama2.py:103-108) costs no launch and no pass over x of its own.  Needs |g*x| < 65504.
+// The RMSNorm gain of a wave's K range, staged ONCE per wave in LDS: a per-k-step global load of it was one of six (q|k|v)
+// / nine (gate|up) vector-memory instructions per k-step of a workgroup -- and what bounds these launches is the rate at which
+// a CU's vector memory pipe takes requests (~35-45 GB/s per CU, L2 hits included), not HBM itself.  The loads are issued in
+// front of the first k-block's weight loads and committed to the wave-private LDS slice after that block's loads are all in
+// flight (no workgroup barrier: the slice is read by the wave that wrote it); k-steps then read it with ds_read_b128 (four
+// distinct addresses per instruction, one per 16-lane group: broadcast, conflict-free).
+constexpr int kGamSteps = 64;                      // k-steps of gain per wave the LDS slice holds (K <= 16384)
+constexpr int kGamHalfs = kGamSteps * 32;
+constexpr int kGamJ = kGamHalfs / 512;            // 1-KiB wave-loads to fill it
+struct GammaStage {
+    h8 pre[kGamJ];
+    _Float16* dst;                                 // this wave's LDS slice
+    int nh, lane;                                  // halfs of gain in the wave's K range
+    bool done;
+    __device__ __forceinline__ void issue(const _Float16* src, _Float16* lds_slice, int nhalfs, int ln) {
+        dst = lds_slice; nh = nhalfs; lane = ln; done = false;
+#pragma unroll
+        for (int j = 0; j < kGamJ; ++j) {
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            pre[j] = z;
+            if (j * 512 < nh) {                    // (wave-uniform)
+                const int idx = j * 512 + lane * 8;
+                pre[j] = *(const h8*)(src + (idx < nh ? idx : nh - 8));
+            }
+        }
+    }
+    __device__ __forceinline__ void commit() {
+        if (done) return;
+        done = true;
+#pragma unroll
+        for (int j = 0; j < kGamJ; ++j)
+            if (j * 512 < nh) {
+                const int idx = j * 512 + lane * 8;
+                *(h8*)(dst + (idx < nh ? idx : nh - 8)) = pre[j];
+            }
+    }
+};
+
 template <int TT, int U, bool TAIL, bool W8 = false, bool PRE = false>
 __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT], const float* xrow, const _Float16* gam,
                                              int ks, int nvalid, bool row_ok, f4 (&acc)[1][TT], float& ss,
-                                             const h8 (*wpre)[TT] = nullptr) {
+                                             GammaStage& gst, const h8 (*wpre)[TT] = nullptr) {
     static_assert(!PRE || (!TAIL && !W8), "prefetched first blocks are full fp16 blocks");
     constexpr int NW = W8 ? U / 2 : U;                   // W8: k-step pairs per 16-byte load, see k_block
     static_assert(!W8 || U % 2 == 0, "int8 weights come in k-step pairs");
@@ -240,7 +291,6 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
         const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
         f4 z = {0.f, 0.f, 0.f, 0.f};
         xa[u][0] = z; xa[u][1] = z;
-        gw[u] = *(const h8*)(gam + (ks + uu) * 32);
     }
     if (row_ok) {
 #pragma unroll
@@ -251,6 +301,12 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    gst.commit();                                  // (first block of the wave only) the gain slice goes to LDS
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+        gw[u] = *(const h8*)(gam + (ks + uu) * 32);    // gam: the wave's LDS slice, rebased to absolute k-steps
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (TAIL && u >= nvalid) continue;              // the re-read k-step contributes nothing
@@ -281,7 +337,8 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
 template <int EPI>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, int row, int unit, int g, int slice,
                                               bool fused_corr = false, f4 fused_cv = f4{0.f, 0.f, 0.f, 0.f},
-                                              f4 fused_cu = f4{0.f, 0.f, 0.f, 0.f}) {
+                                              f4 fused_cu = f4{0.f, 0.f, 0.f, 0.f}, bool have_old = false,
+                                              f4 old_pre = f4{0.f, 0.f, 0.f, 0.f}) {
     const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
     if (p.wscale && unit < nunits) {        // int8 weights: per-output-feature scale (linear, so K-sliced partials scale too)
         const f4 sv = *(const f4*)(p.wscale + unit * 16 + g * 4);
@@ -339,7 +396,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
         } else {
             float* yp = p.y + (int64_t)slice * p.slab_stride + (int64_t)row * p.ldy + unit * 16 + g * 4;
             if (EPI == EPI_ADD) {
-                const f4 old = *(const f4*)yp;
+                // (have_old: the residual tile was fetched at kernel entry -- no dependent load behind the reduction)
+                const f4 old = have_old ? old_pre : *(const f4*)yp;
                 v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
             }
             *(f4*)yp = v;
@@ -411,8 +469,31 @@ __device__ __forceinline__ void wave_k_range(const GemmParams& p, int by, int wa
     const int kq1 = (kq0 + ksq < KS) ? kq0 + ksq : KS;
     int ksw = (kq1 - kq0 + kWaves - 1) / kWaves;
     if (W8) ksw = (ksw + 1) & ~1;
+    if (p.kskew > 0) {
+        // older half (waves 0..3): (64 + kskew) / 64 of an equal share each; the younger half divides the rest
+        const int n = kq1 - kq0;
+        int ko = (n * (64 + p.kskew) + 8 * 64 - 1) / (8 * 64);
+        if (W8) ko = (ko + 1) & ~1;
+        int rest = n - 4 * ko;
+        if (rest < 0) rest = 0;
+        int ky = (rest + 3) / 4;
+        if (W8) ky = (ky + 1) & ~1;
+        ks0 = wave < 4 ? kq0 + wave * ko : kq0 + 4 * ko + (wave - 4) * ky;
+        const int len = wave < 4 ? ko : ky;
+        if (ks0 > kq1) ks0 = kq1;
+        ks1 = (ks0 + len < kq1) ? ks0 + len : kq1;
+        return;
+    }
     ks0 = kq0 + wave * ksw;
     ks1 = (ks0 + ksw < kq1) ? ks0 + ksw : kq1;
+}
+
+// (prio_alt) the halves of the workgroup take turns at s_setprio 1, one k-block each
+__device__ __forceinline__ void alt_prio(const GemmParams& p, int wave, int& blk) {
+    if (p.prio_alt) {
+        if (((blk++) ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
 }
 
 // weight tile ids of workgroup bx (clamped: a clamped duplicate tile recomputes a valid tile and is not stored)
@@ -459,7 +540,7 @@ template <int MT, int T, int EPI, bool TWO, int U, bool NORM = false, bool W8 = 
 __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int bx, const int by,
                                                  float* red_raw, float (*ssl)[16],
                                                  const h8 (*wpre)[(EPI == EPI_SILU) ? 2 * T : T] = nullptr,
-                                                 AfterK after_k = AfterK()) {
+                                                 AfterK after_k = AfterK(), _Float16* gam_lds = nullptr) {
     static_assert(!NORM || (MT == 1 && TWO), "the fused-RMSNorm source is for one row tile");
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
     constexpr int TPI = (EPI == EPI_SILU) ? 2 : 1;                 // tiles per output item
@@ -472,10 +553,22 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
     const int KS = p.KS;
     // K range of this workgroup (grid.y slices K across workgroups; partial sums then go to per-slice slabs
     // that the consumer -- pc_rmsnorm_frag -- adds up in fixed order), then eight ways across the waves
+    trace_stamp(p, bx, by, wave, 0);
     int ks0, ks1;
     wave_k_range<W8>(p, by, wave, ks0, ks1);
     int tile[TT];
     wg_tiles<T, EPI>(p, bx, tile);
+    // EPI_ADD, one reduction round: the residual tile wave w will add to is fetched NOW (clamped, unconditional), so the
+    // epilogue does not end on a dependent load -> add -> store chain (the tile is written by this lane only)
+    constexpr bool kPreY = (EPI == EPI_ADD) && (MT * T <= IPR) && !W8;
+    [[maybe_unused]] f4 yold = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (kPreY) {
+        const int item = wave < MT * T ? wave : MT * T - 1;
+        const int a = item / T, t = item - a * T;
+        const int unit = bx * T + t < p.ntiles ? bx * T + t : p.ntiles - 1;
+        const int row = a * 16 + m < p.M ? a * 16 + m : p.M - 1;
+        yold = *(const f4*)(p.y + (int64_t)row * p.ldy + unit * 16 + g * 4);
+    }
 
     f4 acc[MT][TT];
 #pragma unroll
@@ -497,13 +590,19 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
     [[maybe_unused]] float ss = 0.f;
     if constexpr (NORM) {
         const float* xrow = p.xn + (int64_t)m * (KS * 32) + g * 8;
-        const _Float16* gam = p.gamma + g * 8;
+        // the RMSNorm gain of this wave's K range through its LDS slice (GammaStage; the launcher guarantees <= kGamSteps k-steps)
+        _Float16* gslice = gam_lds + wave * kGamHalfs;
+        GammaStage gst;
+        gst.issue(p.gamma + (int64_t)ks0 * 32, gslice, (ks1 - ks0) * 32, lane);
+        const _Float16* gam = gslice + g * 8 - ks0 * 32;
         if constexpr (PRE) {
-            k_block_norm<TT, U, false, W8, true>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss, wpre);
+            k_block_norm<TT, U, false, W8, true>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss, gst, wpre);
             ks += U;
         }
-        for (; ks + U <= ks1; ks += U) k_block_norm<TT, U, false, W8>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss);
-        if (ks < ks1) k_block_norm<TT, U, true, W8>(wbase, xrow, gam, ks, ks1 - ks, row_ok[0], acc, ss);
+        int blk = 0;
+        for (; ks + U <= ks1; ks += U) { alt_prio(p, wave, blk); k_block_norm<TT, U, false, W8>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss, gst); }
+        if (ks < ks1) { alt_prio(p, wave, blk); k_block_norm<TT, U, true, W8>(wbase, xrow, gam, ks, ks1 - ks, row_ok[0], acc, ss, gst); }
+        if (p.prio_alt) __builtin_amdgcn_s_setprio(0);
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         if (g == 0) ssl[wave][m] = ss;                   // this wave's share of sum(x^2) of row m
@@ -512,10 +611,13 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
             k_block<MT, TT, TWO, U, false, W8, true>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc, wpre);
             ks += U;
         }
-        for (; ks + U <= ks1; ks += U) k_block<MT, TT, TWO, U, false, W8>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
-        if (ks < ks1) k_block<MT, TT, TWO, U, true, W8>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+        int blk = 0;
+        for (; ks + U <= ks1; ks += U) { alt_prio(p, wave, blk); k_block<MT, TT, TWO, U, false, W8>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc); }
+        if (ks < ks1) { alt_prio(p, wave, blk); k_block<MT, TT, TWO, U, true, W8>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc); }
+        if (p.prio_alt) __builtin_amdgcn_s_setprio(0);
     }
     after_k();
+    trace_stamp(p, bx, by, wave, 1);
 
     // ---- LLM.int8 outlier correction inside the launch (pc_gemm_*_a8c) ----
     // corr[t][n] = sum over the outlier columns k of  X[t][k] * fp16(CB[n][k] * s[n])  -  CA[t][k] * CB[n][k] * xs[t] * s[n]
@@ -678,6 +780,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
         }
     }
     lds_barrier();       // (not __syncthreads: a chained caller has the next phase's weight loads in flight here)
+    if (r == 0) trace_stamp(p, bx, by, wave, 2);
 
     const int item = r * IPR + wave;
     if (wave < IPR && item < NOUT) {
@@ -702,9 +805,12 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
             u[0] *= rs; u[1] *= rs; u[2] *= rs; u[3] *= rs;
         }
         if constexpr (W8) tile_epilogue<EPI>(p, v, u, a * 16 + m, bx * T + t, g, by, fused, csv, csu);
+        else if constexpr (kPreY) tile_epilogue<EPI>(p, v, u, a * 16 + m, bx * T + t, g, by, false, f4{0.f, 0.f, 0.f, 0.f},
+                                                     f4{0.f, 0.f, 0.f, 0.f}, true, yold);
         else tile_epilogue<EPI>(p, v, u, a * 16 + m, bx * T + t, g, by);
     }
     }   // rounds
+    if (p.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_stamp(p, bx, by, wave, 3); }
 }
 
 template <int MT, int T, int EPI, bool TWO, int U, bool NORM = false, bool W8 = false>
@@ -713,7 +819,8 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     constexpr int kRT = (MT * TT < 8) ? MT * TT : 8;
     __shared__ __attribute__((aligned(16))) float red[kWaves * kRT * 64 * 4];
     __shared__ float ssl[kWaves][16];
-    gemm_skinny_body<MT, T, EPI, TWO, U, NORM, W8>(p, (int)blockIdx.x, (int)blockIdx.y, red, ssl);
+    __shared__ __attribute__((aligned(16))) _Float16 gam_lds[NORM ? kWaves * kGamHalfs : 8];
+    gemm_skinny_body<MT, T, EPI, TWO, U, NORM, W8>(p, (int)blockIdx.x, (int)blockIdx.y, red, ssl, nullptr, NoHook(), gam_lds);
 }
 
 template <int MT, int T, int EPI>

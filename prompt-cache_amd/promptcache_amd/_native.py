@@ -15,8 +15,31 @@ _lib: Optional[C.CDLL] = None
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _pi32 = C.POINTER(C.c_int32)
 
+
+
+class AttnArgs(C.Structure):
+    """``pc_attn_args`` of include/promptcache_hip.h (field for field)."""
+    _fields_ = [("struct_bytes", C.c_uint32),
+                ("q", _vp), ("q_lo", _vp), ("q_batch_stride", _i64), ("q_token_stride", _i64),
+                ("k", _vp), ("v", _vp), ("kv_batch_stride", _i64), ("kv_head_stride", _i64),
+                ("out", _vp), ("out_lo", _vp), ("out_batch_stride", _i64), ("out_token_stride", _i64),
+                ("out_frag_hi", _vp), ("out_frag_lo", _vp),
+                ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32),
+                ("softmax_scale", _f32),
+                ("workspace", _vp), ("workspace_bytes", _i64),
+                ("past_len_dev", _vp), ("past_lens", _vp),
+                ("key_pos", _vp), ("key_pos_batch_stride", _i64), ("slopes_log2", _vp),
+                ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64), ("lo_row0", _i32),
+                ("counters", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one
 SIGNATURES = {
+    "pc_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "pc_dev_gemm_trace": (C.c_int, [_vp]),
+    "pc_dev_attn_trace": (C.c_int, [_vp]),
+    "pc_gemm_skinny_ks_scratch_bytes": (C.c_int64, [_i32, _i32]),
+    "pc_gemm_skinny_ks": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_version": (C.c_int, []),
     "pc_last_error_string": (C.c_char_p, []),
     "pc_kv_gather": (C.c_int, [C.POINTER(_vp), _pi32, _pi32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -191,7 +214,7 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None, out_lo=None, kv_lo=None, past_lens=None) -> None:
+             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None) -> None:
     """``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum), pc_attn_fwd_var.
     ``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
     ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi).
@@ -199,6 +222,19 @@ def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q
     (written by ``rope_append(..., kv_lo=...)``), both via pc_attn_fwd_ex."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
+    if counters is not None:
+        # the struct-taking entry (pc_attn): everything the wrappers below take, plus the arrival counters of the
+        # single-launch split-KV merge (int32/uint32 [B*H], zero before first use; every launch leaves them zero)
+        kpos, slopes = (None, None) if alibi is None else alibi
+        lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
+        a = AttnArgs(C.sizeof(AttnArgs), q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
+                     _ptr(out), _ptr(out_lo), o_bs, o_ts, _ptr(fh), _ptr(fl), B, H, Hkv, D, q_len, past_len, scale,
+                     _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(past_lens), _ptr(kpos),
+                     0 if kpos is None else kpos.stride(0), _ptr(slopes), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4],
+                     counters.data_ptr())
+        rc = load().pc_attn(C.byref(a), current_stream() if stream is None else stream)
+        check(rc, "pc_attn")
+        return
     if past_lens is not None:
         assert alibi is None and out_frag is None and past_len_dev is None and (kv_lo is None or kv_lo[4] == 0)
         rc = load().pc_attn_fwd_var(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, _ptr(out),
@@ -249,6 +285,20 @@ def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None,
     rc = load().pc_gemm_skinny(wf.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue, _ptr(y), ldy,
                                _ptr(of_hi), _ptr(of_lo), kslices, current_stream() if stream is None else stream)
     check(rc, "pc_gemm_skinny")
+
+
+def gemm_skinny_ks_scratch_bytes(N: int, kslices: int) -> int:
+    return int(load().pc_gemm_skinny_ks_scratch_bytes(N, kslices))
+
+
+def gemm_skinny_ks(wf, xf_hi, xf_lo, M: int, N: int, K: int, y, ldy: int, kslices: int, tiles_per_wg: int, scratch, counters,
+                   stream: Optional[int] = None) -> None:
+    """``y += x @ W^T`` (M <= 16) with K split over ``kslices`` workgroup slices and the reduction inside the launch;
+    ``counters`` (int32 [ceil(N/16/tiles_per_wg)]) must be zero before the first launch (launches leave them zero)."""
+    rc = load().pc_gemm_skinny_ks(wf.data_ptr(), xf_hi.data_ptr(), xf_lo.data_ptr(), M, N, K, y.data_ptr(), ldy, kslices,
+                                  tiles_per_wg, scratch.data_ptr(), scratch.numel() * scratch.element_size(),
+                                  counters.data_ptr(), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_skinny_ks")
 
 
 def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,

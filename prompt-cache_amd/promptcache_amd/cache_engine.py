@@ -188,11 +188,13 @@ class SchemaCache:
         if not no_cache:
             self.encode(batch_size)
 
-    def encode(self, batch_size: int = 1, owner_rank: Optional[int] = None, async_exchange: bool = False) -> None:
-        """Run the module-KV precompute.  ``owner_rank``: encode the WHOLE schema on that rank (the others only receive:
-        schema-level sharding of a library, ``CacheEngine.add_schemas``); None: shard this schema's passes over the ranks.
+    def encode(self, batch_size: int = 1, owner_rank: Optional[int] = None, async_exchange: bool = False,
+               shards: Optional[List[List[int]]] = None) -> None:
+        """Run the module-KV precompute.  ``shards[r]`` = the passes rank r encodes (a library schedule,
+        ``parallel.plan_library`` through ``CacheEngine.add_schemas``); ``owner_rank``: the WHOLE schema on that rank (the
+        others only receive); neither: this schema's passes are levelled over all ranks.
         ``async_exchange``: leave the module-KV exchange in flight (``wait_exchange`` before the segments are read)."""
-        self._process(batch_size, owner_rank, async_exchange)
+        self._process(batch_size, owner_rank, async_exchange, shards)
         if self.module_memory == "host":
             self.wait_exchange()
             for c in self.cache_l1.values():
@@ -208,6 +210,15 @@ class SchemaCache:
         """Tokens this schema's encode runs through the model (suffixes behind the shared trunk prefix counted once, every
         pass cut behind its last owned token: exactly ``encode_stats["computed_tokens"]`` of a one-rank encode)."""
         return sum(self.pass_costs())
+
+    def plan_items(self) -> Tuple[int, List[int]]:
+        """``(trunk, costs)`` for ``parallel.plan_library``: rows every rank that takes a suffix pass of this schema runs first
+        (the root scaffold up to the longest shared prefix; 0 without trunk reuse) and the rows each pass then adds."""
+        jobs, prefix = self._plan_with_prefix()
+        need = self._need(jobs, prefix)
+        if any(prefix):
+            return need[0], [0] + [need[i] - prefix[i] for i in range(1, len(jobs))]
+        return 0, list(need)
 
     def pass_costs(self) -> List[int]:
         """Rows each pass of the plan runs through the model (job order of ``_plan_with_prefix``)."""
@@ -287,18 +298,24 @@ class SchemaCache:
         return [j for j in jobs if j["owned"]]
 
     @torch.inference_mode()
-    def _process(self, batch_size: int = 1, owner_rank: Optional[int] = None, async_exchange: bool = False):
+    def _process(self, batch_size: int = 1, owner_rank: Optional[int] = None, async_exchange: bool = False,
+                 shards: Optional[List[List[int]]] = None):
         lm = self.lm
         L, Hkv, D = lm.get_cache_shape()
         dev = lm.device
         jobs, prefix = self._plan_with_prefix()
         rank, world = parallel.rank_world()
-        if owner_rank is not None:
+        if shards is not None:
+            if len(shards) != world or sorted(i for sh in shards for i in sh) != list(range(len(jobs))):
+                raise ValueError("shards must partition the schema's passes over the ranks")
+            shards = [sorted(sh) for sh in shards]
+        elif owner_rank is not None:
             # schema-level sharding: one rank encodes every pass (and the trunk exactly once), the others receive
             shards = [list(range(len(jobs))) if r == owner_rank else [] for r in range(world)]
         else:
-            # shard by what a pass actually costs: its suffix behind the trunk prefix (world == 1 -> everything)
-            shards = parallel.shard_jobs([need_i - prefix[i] for i, need_i in enumerate(self._need(jobs, prefix))], world)   # (plan_cost's measure)
+            # level the passes over the ranks by what each really costs, the trunk a taker re-runs included (world == 1 ->
+            # everything on this rank)
+            shards = parallel.plan_library([self.plan_items()], world)[0][0]
         mine = shards[rank]
         # every rank's segments live back to back in ONE slab per rank (ascending job order, then plan order inside a
         # job): the encode writes its stores through views of the slab, and the exchange moves whole slabs in place
@@ -538,13 +555,12 @@ class CacheEngine:
     def add_schemas(self, schemas: Sequence[Union[str, Schema]], batch_size: int = 1, max_tokens: Optional[int] = None) -> None:
         """Encode a whole module LIBRARY (the reference loops ``add_schema`` over its schema files, eval.py:172-181).
         One GPU: the same loop.  Several GPUs (``torch.distributed`` initialised):
-          * at least as many schemas as ranks: SCHEMA-level sharding -- whole schemas are dealt to the ranks by
-            longest-processing-time-first on ``SchemaCache.plan_cost`` (the tokens a schema's encode really runs), so
-            every trunk is computed exactly once, on the rank that needs it, and no pass of one schema waits for another
-            rank's trunk; every other rank receives the schema's slab from its owner;
-          * fewer schemas than ranks: each schema's passes are sharded over all ranks (``SchemaCache._process``).
-        Either way the exchange of schema k is left in flight while schema k + 1 is encoded (RCCL runs on its own
-        stream), and all of them are waited for at the end."""
+        whole schemas are dealt to the ranks by longest-processing-time-first on the rows each encode really runs (every trunk
+        computed once, on the rank that needs it), then the residual imbalance -- 8 schemas on 8 ranks would leave the rank
+        with the largest schema 2.6x the average -- is levelled at PASS granularity: suffix passes of the most loaded ranks'
+        schemas move to the ranks below the water line, which re-run that schema's trunk (``library_schedule``).  The
+        exchange of a schema is left in flight while the next ones are encoded (RCCL runs on its own stream), and all of
+        them are waited for at the end."""
         parsed = [Schema(sc, self.lm, max_tokens=max_tokens) if isinstance(sc, str) else sc for sc in schemas]
         names = [sc.name for sc in parsed]
         for nm in names:
@@ -553,17 +569,27 @@ class CacheEngine:
         rank, world = parallel.rank_world()
         caches = [SchemaCache(sc, self.lm, batch_size, target_device=self.target_device, no_cache=True,
                               module_memory=self.module_memory) for sc in parsed]
-        owners: List[Optional[int]] = [None] * len(caches)
-        if world > 1 and len(caches) >= world:
-            shards = parallel.shard_jobs([c.plan_cost() for c in caches], world)
-            for r, idxs in enumerate(shards):
-                for k in idxs:
-                    owners[k] = r
-        for k, c in enumerate(caches):
-            c.encode(batch_size, owner_rank=owners[k], async_exchange=world > 1)
+        order, shards = self.library_schedule(caches, world)
+        for k in order:
+            caches[k].encode(batch_size, shards=shards[k] if world > 1 else None, async_exchange=world > 1)
+        for c in caches:
             self.schemas[c.schema.name] = c
         for c in caches:
             c.wait_exchange()
+
+    @staticmethod
+    def library_schedule(caches: Sequence["SchemaCache"], world: int):
+        """``(order, shards)`` of a library encode over ``world`` ranks: ``shards[k][r]`` = the passes of schema k rank r encodes
+        (``parallel.plan_library``: whole schemas by LPT, the residual imbalance levelled at pass granularity, a rank that takes
+        passes of a schema re-running its trunk), ``order`` = the sequence every rank walks the schemas in -- schemas with one
+        encoder first (their exchanges then overlap the later encodes), the shared ones last.  Host arithmetic on the token
+        layout only: the same on every rank, no GPU needed (``bench.py --plan-only``)."""
+        if world <= 1:
+            return list(range(len(caches))), [None] * len(caches)
+        shards, _ = parallel.plan_library([c.plan_items() for c in caches], world)
+        members = [sum(1 for sh in shards[k] if sh) for k in range(len(caches))]
+        order = sorted(range(len(caches)), key=lambda k: (members[k] > 1, k))
+        return order, shards
 
     def get_schema(self, name: str) -> Optional[Schema]:
         return self.schemas[name].schema if name in self.schemas else None

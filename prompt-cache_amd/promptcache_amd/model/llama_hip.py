@@ -171,6 +171,23 @@ class LlamaHIP:
         # attention reads residual tiles): decode logits 5e-5 from the oracle instead of 2-4e-3 -- both far inside the
         # 1e-2 bar -- for ~5 % of the decode rate.  Opt-in (PC_DECODE_TAIL=1 or model.decode_tail = True).
         self.decode_tail = os.environ.get("PC_DECODE_TAIL", "0") == "1"
+        # arrival counters of the single-launch split-KV merge (pc_attn `counters`: zero now, every launch leaves them zero).
+        # Opt-in (PC_ATTN_FUSED=1): measured on MI355X the in-launch hand-off (write-through partials, drain, arrival counter,
+        # the last arriver's read-back: ~4.5 us on the critical path) costs what the second launch costs -- persona step 3.922 /
+        # 3.933 ms fused against 3.907 / 3.908 ms with attn_combine_kernel (gpurun_out/r3b)
+        self._attn_counters = torch.zeros(8192, dtype=torch.int32, device=self.device) \
+            if os.environ.get("PC_ATTN_FUSED", "0") == "1" else None
+        # N = hidden projections of the <= 16-row stack with K split across workgroups and the reduction inside the launch
+        # (pc_gemm_skinny_ks): "tiles,slices" per projection, empty = the one-tile-per-workgroup EPI_ADD launch
+        def _ks(env, default):
+            v = os.environ.get(env, default)
+            return tuple(int(t) for t in v.split(",")) if v else None
+        # Measured at 12 rows (tools/ks_micro.py, in-graph): down_proj (K = 11008) 22.75 -> 20.16 us at 2 tiles x 2 slices, every
+        # other shape of either projection loses to the one-tile launch (o_proj 9.4 -> 10.4 .. 13.5 us; one row: 19.0 -> 20.3 us):
+        # the in-launch reduction costs ~3 us, only the long-K launch with its 2:1 activation traffic earns it back.
+        self.ks_o, self.ks_down = _ks("PC_KS_O", ""), _ks("PC_KS_DOWN", "2,2")
+        self.ks_min_rows = 5       # ... and only with more than 4 rows (decode keeps the one-tile launch)
+        self._ks_state = None      # (scratch, counters), lazily
         self._kv_only = False      # set per call (see __call__)
         self._past_lens = None     # set per call: per-row past lengths of a ragged-prefix encode batch
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
@@ -610,7 +627,7 @@ class LlamaHIP:
                                kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo)
+                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))
             cd, xs, corr, hs = self._i8_lin_frag(1, ah, H * D, lw, "wo", None, T, hid, bufs[1])
             n.gemm_skinny_a8(lw["wo_f"], lw["wo_s"], cd, zero, xs, corr, hs, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
             cd, xs, corr, hs = self._i8_lin_frag(2, xh, hid, lw, "wgu", None, T, 2 * inter, bufs[2], norm=(x, lw["ln2"], eps))
@@ -731,7 +748,7 @@ class LlamaHIP:
             qkv_done = False
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo)
+                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))
             if chain:
                 nxt = None
                 if li + 1 < len(layers):
@@ -748,10 +765,18 @@ class LlamaHIP:
                     continue
                 except RuntimeError:
                     chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
-            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"])  # x += attn @ Wo^T
+            if self.ks_o and lw["wo_s"] is None and T >= self.ks_min_rows:
+                sc, ctr = self._ks_buffers(hid)
+                n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr)
+            else:
+                n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"])  # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
                                wscale=lw["wgu_s"])
-            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wdown_s"])  # x += act @ Wd^T
+            if self.ks_down and lw["wdown_s"] is None and T >= self.ks_min_rows and inter >= 2 * hid:
+                sc, ctr = self._ks_buffers(hid)
+                n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, x, hid, self.ks_down[1], self.ks_down[0], sc, ctr)
+            else:
+                n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wdown_s"])  # x += act @ Wd^T
         if last_token_only:
             xs = x.view(B, q_len, hid)[:, -1, :].contiguous()
             logits = torch.empty((B, V), dtype=torch.float32, device=self.device)
@@ -761,9 +786,30 @@ class LlamaHIP:
         n.gemm_skinny_norm(self.lm_head_f, x, self.norm, eps, T, V, hid, n.EPI_STORE, y=logits, ldy=V)
         return logits.view(B, q_len, V)
 
+    # rows a captured small-q graph is padded to (B = 1, q > 1): a prompt of q new tokens replays the graph of its bucket with
+    # pad tokens BEHIND its own (under the causal mask nothing reaches back from them; their K/V rows lie past the arena's
+    # length and are overwritten by the first decode steps), so a question length seen for the first time does not pay an
+    # eager pass + capture (cold-shape TTFT 9.5-10.7 ms against ~4 ms warm) as long as its bucket was seen.  0 = exact q.
+    graph_row_bucket = int(os.environ.get("PC_GRAPH_BUCKET", "4"))
+
+    def _graph_rows(self, arena, B: int, q_len: int, past_len: int, last_token_only: bool) -> int:
+        g = self.graph_row_bucket
+        if g <= 1 or B != 1 or q_len == 1 or last_token_only or self.llm_int8 or self.use_chain:
+            return q_len          # (LLM.int8 picks its outlier columns over all rows of a call: no pad rows there)
+        qb = (q_len + g - 1) // g * g
+        if qb > self.SKINNY_MAX_ROWS or past_len + qb > arena.cap:
+            return q_len
+        if (qb + 15) // 16 != (q_len + 15) // 16 or (q_len <= 32) != (qb <= 32):
+            return q_len          # never across a row-tile count or the residual-tail regime of the attention
+        return qb
+
     def _graphed_skinny(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
         """Replay (capturing on first use) the hipGraph of the small-q forward for this shape."""
         n = _native
+        q_real = q_len
+        q_len = self._graph_rows(arena, B, q_len, past_len, last_token_only)
+        if q_len != q_real:
+            self._lo_mode = self._tail_mode(arena, q_len, past_len)
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
         mode = self._lo_mode
         key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm, self.use_chain,
@@ -778,7 +824,7 @@ class LlamaHIP:
             st_ids = torch.zeros(T, dtype=torch.int64, device=self.device)
             st_pos = torch.zeros(T, dtype=torch.int32, device=self.device)
             st_past = torch.zeros(2, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail}
-            st_ids.copy_(ids); st_pos.copy_(pos32); st_past[0:1].fill_(past_len)
+            st_ids[:q_real * B].copy_(ids); st_pos[:q_real * B].copy_(pos32); st_past[0:1].fill_(past_len)
             if mode == 2:
                 st_past[1:2].fill_(arena.tail_base)
             # one eager pass first (loads code objects / sizes the allocator), then capture
@@ -790,13 +836,19 @@ class LlamaHIP:
             ent = (g, st_ids, st_pos, st_past, out)
             self._graphs[key] = ent
         g, st_ids, st_pos, st_past, out = ent
-        st_ids.copy_(ids)
-        st_pos.copy_(pos32)
+        if q_len != q_real:
+            st_ids[:q_real].copy_(ids)
+            st_pos[:q_real].copy_(pos32)
+            st_ids[q_real:].fill_(0)
+            st_pos[q_real:].copy_(pos32[-1:] + torch.arange(1, q_len - q_real + 1, device=self.device, dtype=pos32.dtype))
+        else:
+            st_ids.copy_(ids)
+            st_pos.copy_(pos32)
         st_past[0:1].fill_(past_len)
         if mode == 2:
             st_past[1:2].fill_(arena.tail_base)
         g.replay()
-        return out.clone()
+        return out[:, :q_real].clone() if q_len != q_real else out.clone()
 
     @torch.inference_mode()
     def _loop_state(self) -> dict:
@@ -853,6 +905,18 @@ class LlamaHIP:
         arena, S = found
         arena.length = S
         return GreedyLoop(self, arena, token, position, max_new)
+
+    def _ks_buffers(self, hid: int):
+        """Scratch slabs + arrival counters of pc_gemm_skinny_ks (shared by every such launch of the model: they run one
+        after another on one stream; the counters are zero between launches)."""
+        if self._ks_state is None:
+            sc = torch.empty(_native.gemm_skinny_ks_scratch_bytes(hid, 8) // 4, dtype=torch.float32, device=self.device)
+            self._ks_state = (sc, torch.zeros(hid // 16, dtype=torch.int32, device=self.device))
+        return self._ks_state
+
+    def _counters_for(self, B: int, H: int):
+        c = self._attn_counters
+        return c if c is not None and B * H <= c.numel() else None
 
     def _tail_for(self, arena, past_dev):
         """Per-layer ``((k_lo, v_lo, batch_stride, head_stride, lo_row0) | None, lo_base)`` for the current tail mode."""
@@ -914,7 +978,7 @@ class LlamaHIP:
                             wscale=lw["wqkv_s"], lo_base=lo_base)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo)
+                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wo_s"])                                                    # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm

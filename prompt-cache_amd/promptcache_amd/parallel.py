@@ -44,6 +44,98 @@ def shard_jobs(costs: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
+def plan_library(items: Sequence[Tuple[int, Sequence[int]]], world: int) -> Tuple[List[List[List[int]]], List[int]]:
+    """Schedule a schema LIBRARY over ``world`` ranks.  ``items[k] = (trunk, costs)``: ``costs[i]`` = rows pass i of schema k runs
+    through the model on its own, ``trunk`` = rows every rank that takes ANY pass of schema k has to run first (the root
+    scaffold's prefix the suffix passes build on; 0 when the passes are independent).  Returns ``(shards, loads)``:
+    ``shards[k][r]`` = the passes of schema k rank r encodes (ascending), ``loads[r]`` = the rows rank r runs in total.
+
+    Whole schemas first (longest-processing-time-first: every trunk computed once, on the rank that needs it), then the
+    residual imbalance is levelled at PASS granularity: the schemas of the most loaded ranks are poured over the ranks below a
+    common water line, each rank that receives passes paying the schema's trunk once (recomputing a few hundred trunk rows
+    beats shipping ~1 MB per row of trunk K/V and its split-precision residuals behind the owner's encode).  The water line
+    is searched for the smallest makespan this greedy reaches; deterministic, identical on every rank."""
+    K = len(items)
+    total = [t + sum(c) for t, c in items]
+
+    def lpt_whole():
+        loads = [0] * world
+        owner = [0] * K
+        for k in sorted(range(K), key=lambda k: (-total[k], k)):
+            r = min(range(world), key=lambda r: (loads[r], r))
+            owner[k] = r
+            loads[r] += total[k]
+        return owner, loads
+
+    def as_shards(assign):
+        return [[sorted(assign[k].get(r, [])) for r in range(world)] for k in range(K)]
+
+    owner, loads0 = lpt_whole()
+    best_assign = [{owner[k]: list(range(len(items[k][1])))} for k in range(K)]
+    best_loads = list(loads0)
+    if world == 1 or K == 0:
+        return as_shards(best_assign), best_loads
+    ideal = sum(total) / world
+    for eps in (0.0, 0.02, 0.04, 0.07, 0.1, 0.15, 0.2, 0.3, 0.45, 0.7, 1.0):
+        line = ideal * (1.0 + eps)
+        # schemas that fit under the line as a whole keep one owner (largest first onto the least loaded rank that still has
+        # room); the others are poured
+        loads = [0.0] * world
+        assign: List[dict] = [dict() for _ in range(K)]
+        poured = []
+        for k in sorted(range(K), key=lambda k: (-total[k], k)):
+            trunk, costs = items[k]
+            r = min(range(world), key=lambda r: (loads[r], r))
+            if loads[r] + total[k] <= line or len(costs) <= 1:
+                assign[k][r] = list(range(len(costs)))
+                loads[r] += total[k]
+            else:
+                poured.append(k)
+        for k in poured:
+            trunk, costs = items[k]
+            rest = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+            while rest:
+                r = min(range(world), key=lambda r: (loads[r], r))
+                if r not in assign[k]:
+                    loads[r] += trunk                     # a rank pays the schema's trunk once
+                mine = assign[k].setdefault(r, [])
+                took = False
+                for i in list(rest):                      # largest passes that still fit under the line
+                    if loads[r] + costs[i] <= line or not took:
+                        mine.append(i)
+                        loads[r] += costs[i]
+                        rest.remove(i)
+                        took = True
+        # local improvement: passes move from the most loaded rank to the least loaded one while that lowers the makespan
+        for _ in range(4 * sum(len(c) for _, c in items)):
+            hi = max(range(world), key=lambda r: (loads[r], -r))
+            lo = min(range(world), key=lambda r: (loads[r], r))
+            move = None
+            for k in range(K):
+                mine = assign[k].get(hi)
+                if not mine or len(items[k][1]) <= 1:
+                    continue
+                trunk, costs = items[k]
+                join = 0 if assign[k].get(lo) else trunk                 # a new member recomputes the trunk
+                leave = trunk if len(mine) == 1 else 0                   # the last pass of hi takes its trunk share along
+                for i in mine:
+                    new_hi, new_lo = loads[hi] - costs[i] - leave, loads[lo] + costs[i] + join
+                    gain = loads[hi] - max(new_hi, new_lo)
+                    if gain > 1e-9 and (move is None or gain > move[0]):
+                        move = (gain, k, i, new_hi, new_lo)
+            if move is None:
+                break
+            _, k, i, new_hi, new_lo = move
+            assign[k][hi].remove(i)
+            if not assign[k][hi]:
+                del assign[k][hi]
+            assign[k].setdefault(lo, []).append(i)
+            loads[hi], loads[lo] = new_hi, new_lo
+        if max(loads) < max(best_loads) - 1e-9:
+            best_assign, best_loads = assign, [int(round(v)) for v in loads]
+    return as_shards(best_assign), best_loads
+
+
 def carve(sizes: Sequence[int], dtype, device, align: int = 8) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """One contiguous slab holding segments of ``sizes`` elements back to back (each start ``align``-element = 16-byte
     aligned) -> (slab, [flat view per segment]).  The encode writes the stores it owns through these views."""

@@ -370,13 +370,19 @@ def test_host_memory_tier_stages_the_same_bytes_and_logits():
         CacheEngine(64, lm, module_memory="disk")
 
 
-@pytest.mark.parametrize("mode", ["llm_int8", "weight_only"])
+@pytest.mark.parametrize("mode", ["llm_int8", "weight_only", "llm_int8_outlier_features"])
 @pytest.mark.parametrize("shape_name,seed", [("mid64", 21), ("mid64_gqa", 22)])
 def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed, mode, monkeypatch):
     """``load_in_8bit=True`` (the reference's GPU configs).  Default on the Llama family: LLM.int8() as published -- int8
     weights, vector-wise int8 activations, fp16 outlier columns (threshold 6.0) -- against oracle/llmint8_oracle.py through
     schema encode (many-row path), cached prefill and greedy decode (weight-streaming path).  ``PC_INT8_WEIGHT_ONLY=1``:
     round 1's weight-only mode against the ordinary fp32 oracle over the DEQUANTISED weights (oracle/int8_oracle.py)."""
+    # llm_int8_outlier_features: four residual-stream channels 60x the rest (embedding columns scaled), so EVERY layer's q|k|v and
+    # gate|up inputs carry outlier columns (|x| >= 6 after RMSNorm) -- where a trained Llama has them; the N(0, 0.02) model
+    # alone flags columns of down_proj's input only
+    outlier_features = mode == "llm_int8_outlier_features"
+    if outlier_features:
+        mode = "llm_int8"
     if mode == "weight_only":
         monkeypatch.setenv("PC_INT8_WEIGHT_ONLY", "1")
     from promptcache_amd import CacheEngine, Prompt
@@ -392,6 +398,8 @@ def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed
     # model's init scale -- the fp16-mode tests' choice -- fp32-ulp differences between two correct implementations flip
     # enough codes to move logits by 5e-2; at the init scale itself such events are rare and small.)
     w16 = make_weights_np(shape, seed, 2.0 if mode == "weight_only" else 1.0)
+    if outlier_features:
+        w16["embed"][:, [5, 130, 257, 400]] *= np.float16(60.0)
     lm = Llama2(name="x", shape=shape, weights=w16, device="cuda:0", load_in_8bit=True)
     assert lm.hf_model.int8_weights and lm.hf_model.layers[0]["wqkv_s"] is not None
     assert lm.hf_model.llm_int8 == (mode == "llm_int8")
@@ -439,9 +447,13 @@ def test_int8_weight_mode_matches_oracle_on_dequantised_weights(shape_name, seed
     # one code is 1/127 of the row's largest activation times one weight)
     gap = float(np.abs(logits16 - logits).max())
     if mode == "llm_int8":
-        # identical staged KV: the kernels against the oracle; end to end: inside the bar, or (a code-grid flip somewhere in
-        # the encode) well inside what int8 itself moves
-        assert err2 < 5e-3 and (err < LOGIT_TOL or err < gap), (err, err2, gap)
+        # identical staged KV: the kernels against the oracle.  End to end LLM.int8 is discontinuous (a code-grid flip somewhere
+        # in the encode moves a handful of logits by what one int8 code is worth), so the assertion is on the DISTRIBUTION:
+        # at most 1 % of the logits beyond the 1e-2 bar, the median far inside it, and nothing beyond what int8 itself moves
+        d_all = np.abs(out.logits[0].cpu().numpy() - logits[0])
+        frac = float((d_all > LOGIT_TOL).mean())
+        print(f"    logits beyond {LOGIT_TOL}: {100 * frac:.3f} %  median {np.median(d_all):.2e}  p99 {np.percentile(d_all, 99):.2e}")
+        assert err2 < 5e-3 and frac <= 0.01 and np.median(d_all) < 2e-3 and err < max(LOGIT_TOL, gap), (err, err2, gap, frac)
     else:
         assert err < LOGIT_TOL and err2 < 2e-3
     # four decode steps, teacher-forced with the oracle's greedy tokens (hipGraph replay, int8 images, M = 1)
@@ -732,3 +744,56 @@ def test_decode_default_precision_stays_inside_the_bar():
         worst = max(worst, float(np.abs(o.logits[0, -1].cpu().numpy() - olog[0, -1]).max()))
     print(f"[24 layers] default decode, 24 steps: max|dlogit| = {worst:.2e}")
     assert worst < LOGIT_TOL
+
+
+@pytest.mark.parametrize("q_words", [9, 21])
+def test_row_bucketed_graph_equals_the_exact_row_graph(q_words):
+    """A prompt whose new-token count is not a multiple of the graph row bucket replays the bucket's graph with pad tokens behind
+    its own (LlamaHIP._graph_rows): logits of its own rows, the staged cache and four decode steps must equal the exact-row
+    graph bit for bit, and a second question length of the same bucket must hit the captured graph."""
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    shape = SHAPES["mid_gqa"]
+    lm = Llama2(name="x", shape=shape, weights=make_weights_np(shape, 9, 3.0), device="cuda:0")
+    m = lm.hf_model
+    fmt = lm.get_formatter()
+    eng = CacheEngine(512, lm)
+    sp, pp = synth.flat_docs("bk", 12, (120, 90), q_words, seed=7)
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+
+    def run(bucket):
+        m.graph_row_bucket = bucket
+        eng.prompt_cache.reset()
+        ids, pos, _, cache = eng.process(prompt)
+        out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+                 past_key_values=cache, use_cache=True)
+        logits = [out.logits.clone()]
+        past, tok, p0 = out.past_key_values, int(out.logits[0, -1].argmax()), max(pos) + 1
+        for i in range(4):
+            o = lm(input_ids=torch.tensor([[tok]], device="cuda"), position_ids=torch.tensor([[p0 + 1 + i]], device="cuda"),
+                   past_key_values=past, use_cache=True)
+            logits.append(o.logits.clone())
+            past, tok = o.past_key_values, int(o.logits[0, -1].argmax())
+        return len(ids), logits, past[0][0][:, :, :past[0][0].shape[2]].clone()
+
+    q, exact, kv_exact = run(0)
+    n_graphs = len(m._graphs)
+    qb, bucketed, kv_b = run(4)
+    assert q == qb and q % 4 != 0, q                              # the case really pads
+    assert exact[0].shape == bucketed[0].shape == (1, q, shape.vocab_size)
+    for a, b in zip(exact, bucketed):
+        assert torch.equal(a, b)
+    assert torch.equal(kv_exact, kv_b)
+    assert len(m._graphs) == n_graphs + 1                         # one new graph (the bucket's); decode graphs are shared
+    # a neighbouring length of the same bucket replays it
+    sp2, pp2 = synth.flat_docs("bk", 12, (120, 90), q_words + 1, seed=7)
+    ids2, pos2, _, cache2 = eng.process(Prompt(pp2, [fmt]))
+    if (len(ids2) + 3) // 4 == (q + 3) // 4:
+        before = len(m._graphs)
+        lm(input_ids=torch.tensor([ids2], device="cuda"), position_ids=torch.tensor([pos2], device="cuda"), past_key_values=cache2,
+           use_cache=True)
+        assert len(m._graphs) == before
+    m.graph_row_bucket = type(m).graph_row_bucket

@@ -207,23 +207,24 @@ def test_mpt_7b_shape_alibi_cached_equals_nocache_and_oracle():
 _skip_full = pytest.mark.skipif(os.environ.get("PC_SKIP_FULL_PARITY", "0") == "1", reason="PC_SKIP_FULL_PARITY=1")
 
 
-@_skip_full
-def test_full_depth_7b_end_to_end_vs_numpy_oracle():
-    """All 32 layers at the true llama2-7b shape, end to end: schema encode (trunk reuse, dense + weight-streaming
-    paths), gather, cached prefill -- against the numpy oracle doing the reference's full per-scaffold encode in
-    fp32 on the host.  Small persona-structured schema so the oracle finishes in minutes."""
+def _full_depth_llama(tag, shape, seed, schema, outlier_channels=None):
+    """Every layer of a Llama-family shape, end to end: schema encode (trunk reuse, dense + weight-streaming paths), gather,
+    cached prefill -- against the numpy oracle doing the reference's full per-scaffold encode in fp32 on the host.
+    ``outlier_channels``: scale these hidden channels of the embedding by 60x, so the residual stream carries a handful of
+    massive channels through every layer the way a trained Llama's does (after RMSNorm: ~24 against ~0.4 for the rest) --
+    the regime the split-precision planes, the fp16 K/V stores and the LLM.int8 outlier columns exist for; N(0, 0.02)
+    init alone never produces it."""
     import time
     from oracle import engine_oracle as eo
     from oracle.llama_oracle import LlamaOracle, OracleConfig
     from promptcache_amd import CacheEngine, Prompt, synth
     from promptcache_amd.model import Llama2
-    from promptcache_amd.model.config import SHAPES
     from promptcache_amd.model.weights import random_weights_device
-    shape = SHAPES["llama2-7b"]
-    w = random_weights_device(shape, "cuda:0", torch.float16, seed=5)
-    lm = Llama2(name="llama2-7b", shape=shape, weights=w, device="cuda:0")
-    sp, pp = synth.persona_like("p7", system_len=120, intro_len=30,
-                                traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))), question_len=8, seed=9)
+    w = random_weights_device(shape, "cuda:0", torch.float16, seed=seed)
+    if outlier_channels:
+        w["embed"][:, list(outlier_channels)] *= 60.0
+    lm = Llama2(name=tag, shape=shape, weights=w, device="cuda:0")
+    sp, pp = synth.persona_like(tag, **schema)
     fmt = lm.get_formatter()
     eng = CacheEngine(2048, lm)
     eng.add_schema(fmt(sp))
@@ -238,7 +239,7 @@ def test_full_depth_7b_end_to_end_vs_numpy_oracle():
                        num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
                        rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
     model = LlamaOracle(cfg, {k: v.float().cpu().numpy() for k, v in w.items()})
-    sc = eng.get_schema("p7")
+    sc = eng.get_schema(tag)
     jobs = []
     for p in sc.encode_paths():
         sf = sc.get_scaffold(p)
@@ -247,10 +248,51 @@ def test_full_depth_7b_end_to_end_vs_numpy_oracle():
     used = [m.token_sequence for m in eng.prompt_cache.staged]
     _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
     err = np.abs(got - logits[0]).max()
-    st = eng.schemas["p7"].encode_stats
-    print(f"[full depth 7b] L=32 S={S} q={len(ids)} passes={st['total_passes']} (trunk-shared {st['trunk_shared_passes']}) "
-          f"max|dlogit| vs numpy oracle = {err:.2e}  (max|logit| {np.abs(logits).max():.2f}; oracle {time.perf_counter() - t0:.0f} s)")
+    st = eng.schemas[tag].encode_stats
+    print(f"[full depth {tag}] L={shape.num_hidden_layers} S={S} q={len(ids)} passes={st['total_passes']} (trunk-shared "
+          f"{st['trunk_shared_passes']}) max|dlogit| vs numpy oracle = {err:.2e}  (max|logit| {np.abs(logits).max():.2f}; "
+          f"oracle {time.perf_counter() - t0:.0f} s)")
     assert err < TOL
+    return err
+
+
+@_skip_full
+def test_full_depth_7b_end_to_end_vs_numpy_oracle():
+    """All 32 layers at the true llama2-7b shape.  Small persona-structured schema so the oracle finishes in minutes."""
+    from promptcache_amd.model.config import SHAPES
+    _full_depth_llama("p7", SHAPES["llama2-7b"], 5,
+                      dict(system_len=120, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))),
+                           question_len=8, seed=9))
+
+
+@_skip_full
+def test_full_depth_13b_40_layers_vs_numpy_oracle():
+    """BASELINE config 4's model: all 40 layers at the llama2-13b layer shape (small vocabulary: the oracle's lm_head / embedding
+    are not what depth tests), a short schema -- hidden 5120 / 40 heads take the two-tile N = hidden launches and 320-tile grids."""
+    from promptcache_amd.model.config import SHAPES
+    shape = dataclasses.replace(SHAPES["llama2-13b"], vocab_size=8192)
+    _full_depth_llama("p13", shape, 6, dict(system_len=60, intro_len=20, traits=(("age", (30, 26)), ("home", (41, 37))),
+                                            question_len=8, seed=11))
+
+
+@_skip_full
+def test_full_depth_codellama_theta_1e6_vs_numpy_oracle():
+    """BASELINE config 3's model: all 32 layers of the CodeLlama-7b shape (rope_theta 1e6, 16 k positions)."""
+    from promptcache_amd.model.config import SHAPES
+    shape = dataclasses.replace(SHAPES["codellama-7b"], vocab_size=8192)
+    assert shape.rope_theta == 1e6
+    _full_depth_llama("pcl", shape, 7, dict(system_len=70, intro_len=20, traits=(("age", (30, 26)), ("job", (25, 29))),
+                                            question_len=10, seed=12))
+
+
+@_skip_full
+def test_full_depth_7b_with_outlier_feature_channels_vs_numpy_oracle():
+    """The 32-layer 7b stack with six massive residual-stream channels (a trained Llama's activation pattern, see
+    _full_depth_llama): the first parity check in which |activation| >> typical in every layer's projections and K/V."""
+    from promptcache_amd.model.config import SHAPES
+    shape = dataclasses.replace(SHAPES["llama2-7b"], vocab_size=8192)
+    _full_depth_llama("pout", shape, 8, dict(system_len=70, intro_len=20, traits=(("age", (30, 26)), ("home", (41, 37))),
+                                             question_len=8, seed=13), outlier_channels=(7, 1415, 2533, 3000, 3431, 4001))
 
 
 @_skip_full

@@ -281,6 +281,87 @@ def test_attn_matches_oracle(B, H, Hkv, D, q_len, past):
     np.testing.assert_allclose(got, ref, atol=4e-3, rtol=1e-2)
 
 
+FUSED_CASES = [
+    # B, H, Hkv, D, q_len, past, tail (split-precision rows of the pass itself: the extra fp32 workgroup)
+    (1, 32, 32, 128, 12, 1725, True),     # the persona cached prefill (one layer): 8 stream splits + tail
+    (1, 32, 32, 128, 12, 1725, False),
+    (2, 4, 2, 128, 12, 300, True),        # batch + GQA: 15 + 1 splits (the 16-partial merge)
+    (1, 8, 8, 128, 1, 1000, False),       # decode step
+    (1, 40, 40, 128, 16, 511, True),      # 13b head count, a full 16-row tile
+    (1, 64, 64, 64, 3, 600, True),        # D = 64: 4 splits
+    (1, 4, 4, 32, 12, 400, False),        # D = 32
+    (1, 128, 128, 128, 7, 2100, True),    # 2 stream splits + tail, several tiles per wave
+]
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,tail", FUSED_CASES)
+@pytest.mark.parametrize("frag", [False, True])
+def test_attn_single_launch_merge_equals_two_launch_merge_and_oracle(B, H, Hkv, D, q_len, past, tail, frag):
+    """pc_attn with arrival counters (the last-arriving workgroup of a head merges the split-KV partials inside the launch)
+    against the two-launch form (attn_combine_kernel) -- same partials, same merge arithmetic in split order: bit-identical --
+    and against the oracle; repeated launches over the same counters (they must come back to zero), the consumer's L1 warm."""
+    n = _n()
+    rng = np.random.default_rng(11)
+    cap = past + q_len + 5
+    f16 = lambda a: torch.from_numpy(a.astype(np.float16)).to(DEV)             # noqa: E731
+    q32 = rng.standard_normal((B, q_len, H, D), dtype=np.float32)
+    q = f16(q32)
+    ql = f16(q32 - q.float().cpu().numpy())
+    k = f16(rng.standard_normal((B, Hkv, cap, D), dtype=np.float32))
+    v = f16(rng.standard_normal((B, Hkv, cap, D), dtype=np.float32))
+    k[:, :, past + q_len:] = float("nan")
+    v[:, :, past + q_len:] = float("nan")
+    klo = f16(1e-4 * rng.standard_normal((B, Hkv, q_len, D), dtype=np.float32))
+    vlo = f16(1e-4 * rng.standard_normal((B, Hkv, q_len, D), dtype=np.float32))
+    kv_lo = (klo, vlo, Hkv * q_len * D, q_len * D, -1) if tail else None
+    ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, past + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+    counters = torch.zeros(B * H, dtype=torch.int32, device=DEV)
+    mt = (B * q_len + 15) // 16
+    scale = 1.0 / np.sqrt(D)
+
+    def run(ctr):
+        ws.fill_(float("nan"))
+        if frag:
+            oh = torch.full((mt, H * D // 32, 64, 8), float("nan"), dtype=torch.float16, device=DEV)
+            ol = torch.full_like(oh, float("nan"))
+            n.attn_fwd(q, q_len * H * D, H * D, k, v, Hkv * cap * D, cap * D, None, 0, 0, B, H, Hkv, D, q_len, past, scale, ws,
+                       out_frag=(oh, ol), q_lo=ql, kv_lo=kv_lo, counters=ctr)
+        else:
+            oh = torch.full((B, q_len, H * D), float("nan"), dtype=torch.float16, device=DEV)
+            ol = torch.full_like(oh, float("nan"))
+            n.attn_fwd(q, q_len * H * D, H * D, k, v, Hkv * cap * D, cap * D, oh, q_len * H * D, H * D, B, H, Hkv, D, q_len, past,
+                       scale, ws, q_lo=ql, out_lo=ol, kv_lo=kv_lo, counters=ctr)
+        torch.cuda.synchronize()
+        return oh, ol
+
+    two_hi, two_lo = run(None)
+    for rep in range(3):
+        one_hi, one_lo = run(counters)
+        assert int(counters.abs().sum()) == 0, "every launch leaves the counters at zero"
+        # pad rows of the fragment planes are never written by either form: compare what both wrote
+        m = ~torch.isnan(two_hi.float())
+        assert torch.equal(~torch.isnan(one_hi.float()), m)
+        one = one_hi.float()[m].double() + one_lo.float()[m].double()
+        two = two_hi.float()[m].double() + two_lo.float()[m].double()
+        # the same partials through the same merge formula; the two kernels may contract a*b+c differently: fp32 round-off
+        d = (one - two).abs()
+        assert float(d.max()) <= 4e-7 * float(two.abs().max()) + 1e-9, (float(d.max()), int((d > 0).sum()), d.numel())
+        if rep == 0:
+            first = (one_hi.clone(), one_lo.clone())
+        else:     # run to run: bit-identical whatever the arrival order was
+            assert torch.equal(one_hi.view(torch.int16)[m], first[0].view(torch.int16)[m])
+            assert torch.equal(one_lo.view(torch.int16)[m], first[1].view(torch.int16)[m])
+    if not frag:
+        kf = k.float().clone(); vf = v.float().clone()
+        if tail:
+            kf[:, :, past:past + q_len] += klo.float(); vf[:, :, past:past + q_len] += vlo.float()
+        qn = (q.float() + ql.float()).cpu().numpy().transpose(0, 2, 1, 3)
+        ref = orc.attention_core(qn, kf[:, :, :past + q_len].cpu().numpy(), vf[:, :, :past + q_len].cpu().numpy(), past, H // Hkv)
+        ref = ref.transpose(0, 2, 1, 3).reshape(B, q_len, H * D)
+        got = (one_hi.float() + one_lo.float()).cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-4, rtol=2e-3)
+
+
 def test_attn_softmax_rescale_with_key_spike():
     """Force the running max to jump late in the KV stream (online-softmax rescale path) and early
     (later tiles contribute ~0): a spike row in K aligned with one query."""
@@ -468,6 +549,32 @@ def test_gemm_skinny_k_slices(M, N, K, kq):
     n.gemm_skinny(n.to_weight_frags(w), hi, lo, M, N, K, n.EPI_STORE, y=slabs, ldy=N, kslices=kq)
     ref = (x.double() @ w.double().t()).float()
     assert (slabs.sum(0) - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,S,T", [(12, 4096, 4096, 4, 4), (12, 4096, 11008, 8, 8), (12, 4096, 11008, 2, 1), (1, 4096, 11008, 4, 2),
+                                       (16, 5120, 13824, 8, 4), (3, 64, 96, 2, 1), (7, 80, 1376, 3, 2), (12, 4096, 4096, 1, 1)])
+def test_gemm_skinny_ks_in_launch_reduction(M, N, K, S, T):
+    """pc_gemm_skinny_ks: K split across workgroups, partials added inside the launch by the last arriver -- against an fp64
+    reference, bit-reproducible over repeated launches (slice-order sum whoever arrives last), counters back at zero."""
+    n = _n()
+    rng = np.random.default_rng(19)
+    w = torch.from_numpy((0.05 * rng.standard_normal((N, K), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    wf = n.to_weight_frags(w)
+    hi, lo = n.to_act_frags(x)
+    scratch = torch.full((n.gemm_skinny_ks_scratch_bytes(N, S) // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    counters = torch.zeros((N // 16 + T - 1) // T, dtype=torch.int32, device=DEV)
+    ref = (x.double() @ w.double().t()).float()
+    tol = 2e-4 * float(ref.abs().max()) + 1e-5
+    outs = []
+    for rep in range(4):
+        y = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+        n.gemm_skinny_ks(wf, hi, lo, M, N, K, y, N, S, T, scratch, counters)
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0
+        assert (y - 7.0 - ref).abs().max().item() < tol + 1e-5
+        outs.append(y)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 @pytest.mark.parametrize("B,H,Hkv,D,q_len,past", [(1, 32, 32, 128, 12, 1725), (1, 4, 4, 32, 17, 3), (2, 4, 2, 128, 12, 300),

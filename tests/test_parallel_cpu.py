@@ -101,3 +101,66 @@ def test_carve_lays_segments_out_16_byte_aligned():
     assert [v.numel() for v in parallel.carve_views(slab, [5, 16, 3])] == [5, 16, 3]
     empty, none = parallel.carve([], torch.float16, "cpu")
     assert empty.numel() == 0 and none == []
+
+
+def _bench_library_caches():
+    """The schema library bench.py encodes for BASELINE config 5 (five persona-structured schemas + three flat document
+    schemas), laid out on the CPU with the stand-in tokenizer -- no model, no GPU."""
+    import types
+    from tests import helpers as H
+    from promptcache_amd import pml, synth
+    from promptcache_amd.cache_engine import SchemaCache
+    lm = H.TokOnlyLM()
+    lm.hf_model = types.SimpleNamespace(batch_invariant=True)
+    fmt = H.llama_formatter()
+    texts = [synth.persona_like(name=f"lib-persona-{i}", system_len=200 + 40 * i, seed=20 + i)[0] for i in range(5)]
+    texts += [synth.flat_docs(f"lib-docs-{i}", 30, lens, 8, seed=30 + i)[0]
+              for i, lens in enumerate([(306, 76, 800, 800, 800), (1500, 1200), (400,) * 6])]
+    caches = []
+    for t in texts:
+        sc = SchemaCache.__new__(SchemaCache)
+        sc.lm, sc._jobs = lm, None
+        sc.schema = pml.Schema(fmt(t), lm)
+        caches.append(sc)
+    return caches
+
+
+def test_library_schedule_levels_the_bench_library_at_pass_granularity():
+    """schema-level LPT alone leaves the bench's own 8-schema library at 3.1x on 4 ranks and 6.1x on 8.  The
+    hybrid schedule (whole schemas first, residual imbalance moved pass by pass, a taker re-running the trunk) must reach
+    >= 3.7x / >= 7x of compute balance; every pass has exactly one encoder; every rank derives the same schedule."""
+    from promptcache_amd.cache_engine import CacheEngine
+    caches = _bench_library_caches()
+    items = [c.plan_items() for c in caches]
+    one = sum(t + sum(cs) for t, cs in items)
+    assert one == sum(c.plan_cost() for c in caches)            # world 1: exactly the rows a one-rank encode runs
+    want = {2: 1.9, 4: 3.7, 8: 7.0}
+    for world, floor in want.items():
+        order, shards = CacheEngine.library_schedule(caches, world)
+        assert sorted(order) == list(range(len(caches)))
+        loads = [0] * world
+        for k, (trunk, costs) in enumerate(items):
+            assert sorted(i for r in range(world) for i in shards[k][r]) == list(range(len(costs)))
+            for r in range(world):
+                if shards[k][r]:
+                    loads[r] += trunk + sum(costs[i] for i in shards[k][r])
+        assert one / max(loads) >= floor, (world, loads)
+        # single-encoder schemas are walked first: their exchanges overlap the shared schemas' encodes
+        members = [sum(1 for sh in shards[k] if sh) for k in order]
+        assert members == sorted(members, key=lambda m: m > 1)
+        assert (order, shards) == CacheEngine.library_schedule(caches, world)
+    # old behaviour for comparison: whole schemas only
+    lpt = parallel.shard_jobs([c.plan_cost() for c in caches], 8)
+    assert one / max(sum(caches[k].plan_cost() for k in idxs) for idxs in lpt) < 6.5
+
+
+def test_plan_library_edge_cases():
+    sh, loads = parallel.plan_library([], 4)
+    assert sh == [] and loads == [0, 0, 0, 0]
+    sh, loads = parallel.plan_library([(0, [5000]), (0, [100])], 4)             # indivisible schemas stay whole
+    assert sorted(loads) == [0, 0, 100, 5000]
+    sh, loads = parallel.plan_library([(1700, [0] + [250] * 28)], 8)             # ONE schema: every taker re-runs the trunk
+    assert sorted(i for r in range(8) for i in sh[0][r]) == list(range(29))
+    assert max(loads) <= 1700 + 4 * 250 and sum(1 for ld in loads if ld) == 8
+    sh1, loads1 = parallel.plan_library([(300, [0, 200, 210, 190])], 1)
+    assert sh1 == [[[0, 1, 2, 3]]] and loads1 == [900]

@@ -59,27 +59,31 @@ def _worker(rank, world, port, q):
         eng.add_schema(fmt(sp))                                    # world == 2: sharded passes + slab exchange
         lib2, st2 = library(eng)
         logits2 = serve(eng)
-        # a LIBRARY of three schemas through add_schemas: schema-level sharding (3 >= world), each schema encoded on one
-        # rank (its trunk exactly once) and broadcast; every rank must hold every schema, equal to the solo encode
+        # a LIBRARY of three schemas through add_schemas: whole schemas dealt by LPT, the residual imbalance levelled pass by
+        # pass (CacheEngine.library_schedule); every pass has exactly one encoder, both ranks carry about half of the rows,
+        # and every rank ends with every schema, equal to the solo encode
+        names = ("libA", "libB", "libC")
         texts = []
-        for k, nm in enumerate(("libA", "libB", "libC")):
+        for k, nm in enumerate(names):
             t, _ = synth.persona_like(nm, system_len=40 + 10 * k, intro_len=15, traits=(("a", (20, 24)), ("b", (30, 22, 27))), seed=7 + k)
             texts.append(fmt(t))
         eng.add_schemas(texts)
-        owners = [eng.schemas[nm].encode_stats["owner_rank"] for nm in ("libA", "libB", "libC")]
-        assert sorted(set(owners)) == [0, 1], owners
-        mine = [nm for nm, o in zip(("libA", "libB", "libC"), owners) if o == rank]
-        for nm in ("libA", "libB", "libC"):
-            st = eng.schemas[nm].encode_stats
-            assert (st["passes"] == st["total_passes"]) == (nm in mine) and (st["computed_tokens"] > 0) == (nm in mine)
+        mine = torch.tensor([[eng.schemas[nm].encode_stats["passes"], eng.schemas[nm].encode_stats["computed_tokens"]] for nm in names],
+                            dtype=torch.int64)
+        both = mine.clone()
+        dist.all_reduce(both)
+        for k, nm in enumerate(names):
+            assert int(both[k, 0]) == eng.schemas[nm].encode_stats["total_passes"], (nm, both)
+        rows = [int(mine[:, 1].sum()), int(both[:, 1].sum()) - int(mine[:, 1].sum())]
+        assert min(rows) > 0 and max(rows) <= 1.25 * min(rows), rows           # levelled, not 2 schemas against 1
         solo.add_schemas(texts)
         worst_lib = 0.0
-        for nm in ("libA", "libB", "libC"):
+        for nm in names:
             a = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in solo.schemas[nm].cache_l1.values()), key=lambda t: t[:2])
             b = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in eng.schemas[nm].cache_l1.values()), key=lambda t: t[:2])
             assert [(o, n) for o, n, _ in a] == [(o, n) for o, n, _ in b]
             worst_lib = max(worst_lib, max(float((x[2] - y[2]).abs().max()) for x, y in zip(a, b)))
-        assert worst_lib == 0.0, worst_lib          # same passes, same batches, same kernels on the owner: bit-identical
+        assert worst_lib < 4e-3, worst_lib          # same arithmetic per pass; only the batch a pass travels in differs
         dist.barrier()
         dist.destroy_process_group()
 

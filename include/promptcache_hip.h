@@ -87,7 +87,7 @@ int pc_rope_table(const int32_t* pos, const float* inv_freq, float* cs, int32_t 
  *          q_token_stride, batch stride q_batch_stride (elements of the input type)
  *   q_out  fp16 [B][q_len][H][D], strides qo_* (may alias q when the input is fp16: in-place rotation)
  *   q_out_lo  optional fp16 plane, same strides: fp16(q_rot - fp16(q_rot)), the low-order half of the
- *          split-precision q that pc_attn_fwd consumes in its small-q (HBM-bound) instantiation
+ *          split-precision q that pc_attn consumes in its small-q (HBM-bound) instantiation
  *   k_new  [B][q_len][Hkv][D] (pre-RoPE, same type as q), v_new likewise; strides kv_new_*
  *   k_arena, v_arena  fp16 [B][Hkv][cap][D]: head stride arena_head_stride, batch stride arena_batch_stride
  *   cs     from pc_rope_table, [B*q_len][D/2][2]
@@ -101,254 +101,46 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
                    int32_t past_len, int32_t cap, int32_t in_is_f32, const int32_t* past_len_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * pc_attn_fwd -- replaces llama2.py:368-398: repeat_kv, QK^T/sqrt(D), + mask, softmax(fp32), PV,
+ * pc_attn -- replaces llama2.py:368-398: repeat_kv, QK^T/sqrt(D), + mask, softmax(fp32), PV,
  *   transpose/reshape.  The mask of llama2.py:62-76 / :798-819 is implicit: new token i (input order)
  *   sees every staged key j < past_len and new keys past_len + i' with i' <= i.  fp32 softmax and
  *   accumulation, MFMA fp16 x fp16 -> fp32 for both contractions, flash-style (scores are never
  *   materialised), split over the KV axis when (heads x q-blocks) cannot fill the chip.
+ *   ONE struct-taking entry point (rounds 1-2 exported pc_attn_fwd / _alibi / _ex / _var: C callers find them as inline
+ *   wrappers over this one in promptcache_hip_compat.h).  Optional pointers are NULL when unused.
  *
- *   q    fp16 [B][q_len][H][D]  RoPE applied (q_lo: optional low-order plane, same layout, may be NULL);  k, v fp16 arena planes [B][Hkv][cap][D] holding
- *        past_len + q_len valid rows;  out fp16 [B][q_len][H*D] (token stride out_token_stride).
- *   workspace: >= pc_attn_workspace_bytes(...) bytes of device memory (split-KV partials).
- *   past_len_dev: optional device int32* (graph replay; then `past_len` is the upper bound used
- *        for sizing the launch).
- *   out_frag_hi/_lo: optional (both or neither; B*q_len <= 512): instead of `out`, write the result as
- *        split-precision fragment planes [ceil(B*q_len/16)][H*D/32][64][8] consumed by pc_gemm_skinny (o_proj).
+ *   struct_bytes  sizeof(pc_attn_args) of the caller's header (ABI check)
+ *   q, q_lo    fp16 [B][q_len][H][D], RoPE applied; q_lo: optional low-order plane (q = q_hi + q_lo: split precision)
+ *   k, v       fp16 arena planes [B][Hkv][cap][D] holding past_len + q_len valid rows
+ *   out, out_lo   fp16 [B][q_len][H*D] (token stride out_token_stride); out_lo: optional residual plane of out
+ *   out_frag_hi / out_frag_lo   optional (both or neither; B*q_len <= 512): instead of `out`, the result as
+ *              split-precision fragment planes [ceil(B*q_len/16)][H*D/32][64][8] consumed by pc_gemm (o_proj)
+ *   workspace  >= pc_attn_workspace_bytes(...) bytes of device memory (split-KV partials)
+ *   past_len_dev   optional device int32* (graph replay; `past_len` is then the upper bound that sizes the launch)
+ *   past_lens  optional device int32[B]: ONE PAST LENGTH PER BATCH ROW (ragged-prefix batches of the schema encode: scaffold
+ *              suffixes of different unions in one batch, each over its own trunk prefix -- the batched form of
+ *              cache_engine.py:217-304's per-scaffold forwards); past_len = their maximum.  Batch row b attends to keys
+ *              [0, past_lens[b]) plus the rows it appended, up to its own.  Excludes past_len_dev, ALiBi, fragment output;
+ *              residual planes must be arena-shaped (lo_row0 = 0)
+ *   key_pos, slopes_log2   the additive ALiBi term of the reference's MPT attention (promptcache/model/mpt.py:90-110 slopes,
+ *              :160-175 bias gathered at the POSITION IDS of the keys): score[q][key] = q.k * softmax_scale + slope[h] *
+ *              position_id[key] (the reference's extra -slope * max_pos is constant along a softmax row and drops out).
+ *              key_pos: fp32 [B][key_pos_batch_stride] position id of every cached and new key, padded with anything finite
+ *              up to a multiple of 64 entries past past_len + q_len, rows 16-byte aligned; slopes_log2: fp32 [H] = slope * log2 e
+ *   k_lo, v_lo fp16 residuals of K / V rows from key index lo_row0 on ([B][Hkv][rows][D] with the lo strides; written by
+ *              pc_rope_append_ex / pc_gemm): those rows enter the contractions in split precision, as in the reference's
+ *              fp32 pass (llama2.py:361-388); staged rows (< lo_row0) are the fp16 values the reference stages
+ *              (cache_engine.py:105-106).  lo_row0 = -1: "the rows of this pass" (= past_len, read from past_len_dev when
+ *              given; passes of <= 32 rows then run one extra KV split whose workgroup computes the attention over the
+ *              pass's own rows in fp32); -2: the residual tail starts at key past_len_dev[1] (decode steps)
+ *   counters   optional: B * H uint32 words, ZERO before the first launch that sees them; every launch leaves them
+ *              zero.  With them a pass of <= 16 query rows over a long staged cache is ONE launch: each workgroup writes its
+ *              split-KV partial through to memory, arrives at its head's counter, and the last arriver merges the partials in
+ *              split order (the result does not depend on the arrival order).  Without them the partials are merged by a
+ *              second launch -- which measures no slower on MI355X.  One launch at a time per workspace / counters.
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
 
-int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
-                const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride,
-                void* out, int64_t out_batch_stride, int64_t out_token_stride,
-                int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
-                float softmax_scale, void* workspace, int64_t workspace_bytes,
-                const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Elementwise / reduction pieces of the layer stack, fused for the small-q prefill (q_len rows):
- *   pc_rmsnorm      -- LlamaRMSNorm.forward, llama2.py:103-108 (fp32 statistics)
- *   pc_silu_mul     -- act_fn(gate) * up of LlamaMLP.forward, llama2.py:242 (gate_up: [rows][2*inter], fp32 or fp16)
- *   pc_embed_gather -- embed_tokens lookup, llama2.py:869
- * ------------------------------------------------------------------------------------------- */
-int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32_t hidden, float eps,
-               int32_t x_is_f32, void* stream);
-int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, int32_t in_is_f32, void* stream);
-int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,
-                    int32_t vocab, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Weight-streaming projections for the small-q regime (M = B*q_len <= 512), csrc/pc_gemm.hip.
- *   M <= 64:  eight waves split K over the same output tiles; split-precision (hi + lo) activations.
- *   M <= 512: the waves split the rows, weight tiles are staged through LDS by dedicated waves; the hi
- *             activation plane only (xf_lo is ignored), i.e. fp16 activations as in the dense path.
- *
- * Fragment-major layouts (register image of mfma_f32_16x16x32_f16 operands, fp16):
- *   weights      Wf[N/16][K/32][64][8]   lane l = 16*g + n  holds W[16*tile + n][32*ks + 8*g .. +8]
- *                (W is the nn.Linear [N][K] matrix; build once at load: view(N/16,16,K/32,4,8).permute(0,2,3,1,4))
- *   activations  Xf[M/16 rounded up][K/32][64][8]   lane l = 16*g + m  holds X[16*mt + m][32*ks + 8*g .. +8]
- *                two planes: hi = fp16(x), lo = fp16(x - hi)  (lo may be NULL: single-precision pass)
- *
- * pc_gemm_skinny -- replaces the nn.Linear calls of llama2.py:345-347 (q|k|v fused), :405 (+ residual add
- *   :638), :242 (gate/up + SiLU*up; down + residual add :644) and :1050 (lm_head) when M <= 512:
- *     epilogue 0  y[m][n]  = sum_k X[m][k] W[n][k]          fp32 [M][ldy]; with kslices > 1 the K axis is also
- *                 split across workgroups and slice s writes its partial sums to y + s*M*ldy (slabs
- *                 [kslices][M][ldy]) -- used for the N = hidden projections (o_proj, down_proj), whose few
- *                 output tiles would otherwise make every workgroup re-read the whole activation matrix;
- *                 pc_rmsnorm_frag adds the slabs to the residual stream in fixed order (deterministic)
- *     epilogue 1  y[m][n] += ...                            fp32 residual stream, in place
- *     epilogue 2  W = [gate ; up] (N = 2*inter): of[m][j] = silu(gate_j) * up_j written as fragment planes
- *                 [M/16][inter/32][64][8] (hi, lo) for the down projection
- * pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes;
- *   optional prologue x += slabs[0] + ... + slabs[nslabs-1] (each [rows][hidden], the residual adds of
- *   llama2.py:638 / :644 fed by a K-sliced pc_gemm_skinny), written back to x in place.
- * ------------------------------------------------------------------------------------------- */
-int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
-                   int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices, void* stream);
-/* pc_gemm_qkv_rope -- the fused q|k|v projection of the small-q path: llama2.py:345-347 (projections),
- *   :357-359 (RoPE at the supplied position ids) and :361-364 (KV concat) in ONE weight-streaming launch.
- *   wf_perm: fragment image of the row-PERMUTED [q;k;v] weight: inside every head, tile j (16 rows) holds
- *            features 8j..8j+7 followed by their rotary partners D/2+8j..D/2+8j+7
- *            (perm[h*D + 16j + r] = h*D + 8j + r for r < 8, h*D + D/2 + 8j + r - 8 otherwise).
- *   outputs: rotated q as split-precision planes q_hi/q_lo [B*q_len][H*D] (token stride q_token_stride);
- *            rotated k and v written in place at rows [past_len, past_len+q_len) of the arena planes.
- *            k_lo / v_lo (both or NULL): fp16 residuals (value - fp16(value)) of those new K / V rows, compact
- *            [B][Hkv][q_len][D] with the given strides, for pc_attn_fwd_ex(lo_row0 = -1): the rows a prefill pass
- *            appends enter its own attention in split precision, as in the reference's fp32 pass. */
-int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, int32_t M, int32_t K,
-                     const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
-                     int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
-                     int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
-                     void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
-int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
-                    float eps, const float* slabs, int32_t nslabs, void* stream);
-/* Fused-RMSNorm variants for M <= 16 rows: the activation operand is the fp32 residual stream x [M][K] itself; the
- *   launch computes y = W . (norm_weight * x) * rsqrt(mean(x^2) + eps) -- LlamaRMSNorm (llama2.py:103-108) folded
- *   into the projection that consumes it (:345-347 for q|k|v, :242 for gate/up, :1050 after the final norm), so the
- *   norm costs neither a launch nor a pass over x.  Epilogues 0 (store) and 2 (SiLU*up) for pc_gemm_skinny_norm;
- *   pc_gemm_qkv_rope_norm is pc_gemm_qkv_rope with this source.  Needs |norm_weight * x| < 65504 (fp16 range). */
-int pc_gemm_skinny_norm(const void* wf, const float* x, const void* norm_weight, float eps, int32_t M, int32_t N,
-                        int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
-int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_weight, float eps, int32_t M, int32_t K,
-                          const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
-                          int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
-                          int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
-                          void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Falcon adapter (promptcache/model/falcon.py; multi-query, parallel attention + MLP): the ops the Llama path does
- * not have.  Everything else (pc_kv_gather with Hkv = 1, pc_rope_*, pc_attn_fwd with H/Hkv = H, pc_gemm_*) is shared.
- *   pc_layernorm       torch.nn.LayerNorm (falcon.py:757, :1020) of fp32 x [rows][hidden] -> fp16
- *   pc_layernorm_frag  the same, written as split-precision fragment planes, with the slab-folding prologue of
- *                      pc_rmsnorm_frag (x += slabs[0] + ... first: the o_proj and dense_4h_to_h partial sums)
- *                      (bias may be NULL in both: MPT's LayerNorm carries no bias, mpt.py:207, :215)
- *   pc_gelu            nn.GELU() (falcon.py:726, mpt.py:187: erf form) fp32 -> fp16, n elements (n % 8 == 0)
- *   pc_gemm_skinny epilogue 4: of[m][j] = gelu(y[m][j]) as fragment planes [M/16][N/32][64][8] (dense_h_to_4h)
- * ------------------------------------------------------------------------------------------- */
-int pc_layernorm(const float* x, const void* weight, const void* bias, void* out, int32_t rows, int32_t hidden,
-                 float eps, void* stream);
-int pc_layernorm_frag(float* x, const void* weight, const void* bias, void* xf_hi, void* xf_lo, int32_t rows,
-                      int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream);
-int pc_gelu(const float* x, void* out, int64_t n, void* stream);
-
-/* pc_attn_fwd_alibi -- pc_attn_fwd plus the additive ALiBi term of the reference's MPT attention
- *   (promptcache/model/mpt.py:90-110 slopes, :160-175 bias gathered at the POSITION IDS of the keys):
- *     score[q][key] = q.k * softmax_scale + slope[h] * position_id[key]      (the reference's extra -slope*(max_pos)
- *   is constant along a softmax row and drops out).  key_pos: fp32 [B][key_pos_batch_stride] position id of every
- *   cached and new key, padded with anything finite up to a multiple of 64 entries past past_len + q_len, rows
- *   16-byte aligned;  slopes_log2: fp32 [H] = slope[h] * log2(e). */
-int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
-                      const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out, int64_t out_batch_stride,
-                      int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                      int32_t past_len, float softmax_scale, void* workspace, int64_t workspace_bytes,
-                      const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo, const float* key_pos,
-                      int64_t key_pos_batch_stride, const float* slopes_log2, void* stream);
-
-/* Split-precision variants for the dense (many-row) path.  fp16 activations cost 2^-11 per projection input; over 32
- * layers that alone moves 7b-shape logits by 2-3e-2 against the reference's fp32 path.  These write an activation as
- * hi = fp16(v) and lo = fp16(v - hi); the caller stacks [hi; lo] along the rows of one GEMM and adds the two halves of
- * the product (gate_up2 / x2 / pc_add3 take the second half):
- *   pc_rmsnorm_split, pc_layernorm_split   norm -> (hi, lo) [rows][hidden]
- *   pc_silu_mul_split   silu(g) * u of (gate_up + gate_up2) -> (hi, lo);  pc_gelu_split  gelu(x + x2) -> (hi, lo)
- *   pc_add3             x += a + b  (fp32 residual stream)
- *   pc_attn_fwd_ex      pc_attn_fwd / pc_attn_fwd_alibi with an optional row-major `out_lo` plane next to `out`
- *                       (key_pos / slopes_log2 NULL: no ALiBi) and optional k_lo / v_lo residual planes, see below;
- *                       lo_row0 = -2: the residual tail starts at key past_len_dev[1] (decode steps, see
- *                       pc_gemm_qkv_rope_ex); lo_row0 = -1 means "the rows of this pass" (= past_len, read from past_len_dev when given):
- *                       passes of <= 32 rows then run with one extra KV split whose workgroup computes the attention
- *                       over the pass's own rows in fp32 (size the workspace with pc_attn_workspace_bytes, it
- *                       accounts for that split);
- *                       out_frag_hi / out_frag_lo as in pc_attn_fwd (then `out` may be NULL). */
-int pc_rmsnorm_split(const float* x, const void* weight, void* out_hi, void* out_lo, int32_t rows, int32_t hidden,
-                     float eps, void* stream);
-int pc_layernorm_split(const float* x, const void* weight, const void* bias, void* out_hi, void* out_lo, int32_t rows,
-                       int32_t hidden, float eps, void* stream);
-int pc_silu_mul_split(const float* gate_up, const float* gate_up2, void* out_hi, void* out_lo, int32_t rows,
-                      int32_t inter, void* stream);
-int pc_gelu_split(const float* x, const float* x2, void* out_hi, void* out_lo, int64_t n, void* stream);
-int pc_add3(float* x, const float* a, const float* b, int64_t n, void* stream);
-int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
-                   const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out, void* out_lo,
-                   int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
-                   int32_t q_len, int32_t past_len, float softmax_scale, void* workspace, int64_t workspace_bytes,
-                   const int32_t* past_len_dev, const float* key_pos, int64_t key_pos_batch_stride,
-                   const float* slopes_log2, const void* k_lo, const void* v_lo, int64_t lo_batch_stride,
-                   int64_t lo_head_stride, int32_t lo_row0, void* out_frag_hi, void* out_frag_lo, void* stream);
-/* pc_rope_append_ex -- pc_rope_append that also writes the fp16 residuals of the appended K / V rows (k_lo, v_lo,
- *   both or neither: [B][Hkv][rows][D] with the given strides, row = key index - lo_row0; lo_row0 = past_len for a
- *   compact buffer of the new rows, 0 for an arena-shaped one that also carries residuals of earlier rows).  pc_attn_fwd_ex consumes them: the keys / values a pass appends enter
- *   (in2_offset != 0: every q / k_new / v_new input element is x[i] + x[i + in2_offset], the two row halves a stacked
- *   [hi; lo] projection leaves)
- *   its own attention in split precision, as in the reference's fp32 pass (llama2.py:361-388), while the arena keeps the
- *   fp16 value the reference stages (cache_engine.py:105-106).  Staged rows (< past_len) have no residual. */
-int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
-                      int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new, const void* v_new,
-                      int64_t kv_new_batch_stride, int64_t kv_new_token_stride, void* k_arena, void* v_arena,
-                      int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
-                      int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
-                      const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
-                      int64_t lo_head_stride, int32_t lo_row0, int64_t in2_offset, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * int8 weights (the reference's GPU configs pass load_in_8bit=True to from_pretrained,
- * config/llm_config_*.json:5, eval.py:36-42 -- bitsandbytes LLM.int8, a dependency that is not in the tree).
- * This is WEIGHT-ONLY int8: q[n][k] = round(w[n][k] / scale[n]), scale[n] = absmax_k |w[n][k]| / 127 (the row-wise
- * absmax quantiser LLM.int8 applies to weights); activations stay split-precision fp16 pairs, accumulation fp32, so a
- * launch returns scale[n] * sum_k q[n][k] * x[k] -- what an fp32 GEMM over the dequantised weights gives -- while
- * streaming half the weight bytes.  wf8: fragment image [N/16][K/64][64][16] of offset-binary bytes (q + 128), a lane's
- * 16 bytes = its 8 values of k-step 2s then of k-step 2s + 1 (K % 64 == 0);
- * w_scale: fp32 [N] in the row order of the image (16-byte aligned).  M <= 64.  Other arguments as in the fp16 entries;
- * pc_gemm_qkv_rope_w8 takes either the activation planes (x = norm_weight = NULL) or the fused-RMSNorm source
- * (xf_hi = xf_lo = NULL, M <= 16).
- * ------------------------------------------------------------------------------------------- */
-int pc_gemm_skinny_w8(const void* wf8, const float* w_scale, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N,
-                      int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
-                      void* stream);
-int pc_gemm_skinny_norm_w8(const void* wf8, const float* w_scale, const float* x, const void* norm_weight, float eps,
-                           int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi,
-                           void* of_lo, void* stream);
-int pc_gemm_qkv_rope_w8(const void* wf8_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo,
-                        const float* x, const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs,
-                        void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
-                        int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
-                        int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
-                        int64_t lo_batch_stride, int64_t lo_head_stride, void* stream);
-
-/* pc_gemm_qkv_rope_ex -- the union of the q|k|v entry points (fp16 weights: w_scale_perm = NULL, int8: not NULL;
- *   activation planes, or x + norm_weight for the fused-RMSNorm source) plus lo_base: where the residual row of token tt
- *   goes in k_lo / v_lo -- tt (-1: a buffer of this pass's rows), past_len + tt - lo_base (>= 0), or
- *   past_len + tt - past_len_dev[1] (-2).  The last two keep ONE residual tail per layer across a prefill and the decode
- *   steps after it (llama2.py:361-388 keeps those K / V rows in fp32 for the whole generation, generation_engine.py:123-147);
- *   pc_attn_fwd_ex(lo_row0 = -2) reads it, lo_row0 coming from the same device word. */
-int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo, const float* x,
-                        const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo,
-                        int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
-                        int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                        int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
-                        int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
-
-/* Ragged-prefix batches (schema encode: scaffold suffixes of different unions in one batch, each over its own trunk
- * prefix -- the batched form of cache_engine.py:217-304's per-scaffold forwards): pc_rope_append_ex / pc_attn_fwd_ex with
- * ONE PAST LENGTH PER BATCH ROW.  past_lens: device int32[B]; past_len = their maximum (bounds check, KV-split sizing).
- * Batch row b appends its q_len new rows at arena rows [past_lens[b], past_lens[b] + q_len) and attends to keys
- * [0, past_lens[b]) plus the new rows up to its own (index-order mask, llama2.py:62-76).  Residual planes, when given,
- * are arena-shaped (lo_row0 = 0). */
-int pc_rope_append_var(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
-                       int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new, const void* v_new,
-                       int64_t kv_new_batch_stride, int64_t kv_new_token_stride, void* k_arena, void* v_arena,
-                       int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
-                       int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
-                       const int32_t* past_lens, void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride,
-                       int32_t lo_row0, void* stream);
-int pc_attn_fwd_var(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
-                    const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out, void* out_lo,
-                    int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
-                    int32_t q_len, int32_t past_len, const int32_t* past_lens, float softmax_scale, void* workspace,
-                    int64_t workspace_bytes, const void* k_lo, const void* v_lo, int64_t lo_batch_stride,
-                    int64_t lo_head_stride, void* stream);
-
-/* pc_gemm_skinny_ks -- the N = hidden projections of a <= 16-row forward with their residual add (o_proj llama2.py:405 + :638,
- * down_proj :242 + :644):  y[m][n] += sum_k x[m][k] W[n][k],  K cut into `kslices` (1..8) slices that run as separate
- * workgroups of `tiles_per_wg` (1, 2, 4, 8) output tiles each, the slices' partial tiles added INSIDE the launch: every
- * workgroup writes its partial through to `scratch`, arrives at its tile group's counter, and the last arriver adds the
- * partials in slice order (deterministic), adds y and stores.  wf / xf_hi / xf_lo as in pc_gemm_skinny.
- *   scratch   >= pc_gemm_skinny_ks_scratch_bytes(N, kslices) bytes, 16-byte aligned
- *   counters  ceil(N / 16 / tiles_per_wg) uint32 words, ZERO before the first launch; every launch leaves them zero.
- *             One launch at a time may use a given scratch / counter pair. */
-int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
-int pc_gemm_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K, float* y,
-                      int64_t ldy, int32_t kslices, int32_t tiles_per_wg, void* scratch, int64_t scratch_bytes,
-                      void* counters, void* stream);
-
-/* pc_attn -- the struct-taking entry of the attention family (replaces llama2.py:368-398 + the implicit mask :62-76,
- * :798-819 like pc_attn_fwd; pc_attn_fwd / _alibi / _ex / _var fill a subset of this struct and stay as wrappers).
- * Every field means what the same-named argument of those entry points means; optional pointers are NULL when unused.
- *   struct_bytes  sizeof(pc_attn_args) of the caller's header (ABI check)
- *   counters      optional: B * H uint32 words, ZERO before the first launch that sees them; every launch leaves them
- *                 zero.  With them a pass of <= 16 query rows over a long staged cache (the cached prefill proper and every
- *                 decode step) is ONE launch: each workgroup writes its split-KV partial through to memory, arrives at its
- *                 head's counter, and the last arriver merges the partials in split order (the result does not depend on
- *                 the arrival order).  Without them the partials are merged by a second launch.  One launch at a time
- *                 may use a given workspace / counter pair. */
 typedef struct pc_attn_args {
     uint32_t struct_bytes;
     const void* q; const void* q_lo; int64_t q_batch_stride, q_token_stride;
@@ -365,6 +157,168 @@ typedef struct pc_attn_args {
     uint32_t* counters;
 } pc_attn_args;
 int pc_attn(const pc_attn_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise / reduction pieces of the layer stack, fused for the small-q prefill (q_len rows):
+ *   pc_rmsnorm      -- LlamaRMSNorm.forward, llama2.py:103-108 (fp32 statistics)
+ *   pc_silu_mul     -- act_fn(gate) * up of LlamaMLP.forward, llama2.py:242 (gate_up: [rows][2*inter], fp32 or fp16)
+ *   pc_embed_gather -- embed_tokens lookup, llama2.py:869
+ * ------------------------------------------------------------------------------------------- */
+int pc_rmsnorm(const void* x, const void* weight, void* out, int32_t rows, int32_t hidden, float eps,
+               int32_t x_is_f32, void* stream);
+int pc_silu_mul(const void* gate_up, void* out, int32_t rows, int32_t inter, int32_t in_is_f32, void* stream);
+int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_tok, int32_t hidden,
+                    int32_t vocab, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight-streaming projections for the small-q regime (M = B*q_len <= 512), csrc/pc_gemm*.hip: ONE entry point, pc_gemm.
+ *   M <= 64:  eight waves split K over the same output tiles; split-precision (hi + lo) activations.
+ *   M <= 512: the waves split the rows, weight tiles are staged through LDS by dedicated waves (hi + lo planes when both given).
+ *
+ * Fragment-major layouts (register image of mfma_f32_16x16x32_f16 operands, fp16):
+ *   weights      Wf[N/16][K/32][64][8]   lane l = 16*g + n  holds W[16*tile + n][32*ks + 8*g .. +8]
+ *                (W is the nn.Linear [N][K] matrix; build once at load: view(N/16,16,K/32,4,8).permute(0,2,3,1,4))
+ *   activations  Xf[M/16 rounded up][K/32][64][8]   lane l = 16*g + m  holds X[16*mt + m][32*ks + 8*g .. +8]
+ *                two planes: hi = fp16(x), lo = fp16(x - hi)  (lo may be NULL: single-precision pass)
+ *
+ * pc_gemm replaces the nn.Linear calls of llama2.py:345-347 (q|k|v fused), :405 (+ residual add :638), :242 (gate/up +
+ *   SiLU*up; down + residual add :644) and :1050 (lm_head) when M <= 512.  Fields of pc_gemm_args (NULL / 0 when unused):
+ *   struct_bytes  sizeof(pc_gemm_args) of the caller's header (ABI check)
+ *   epilogue   PC_GEMM_EPI_STORE     y[m][n]  = sum_k X[m][k] W[n][k]   fp32 [M][ldy]; kslices > 1: the K axis is also split
+ *                                    across workgroups, slice s writes its partial sums to y + s*M*ldy (slabs [kslices][M][ldy];
+ *                                    pc_rmsnorm_frag adds them to the residual stream in fixed order)
+ *              PC_GEMM_EPI_ADD       y[m][n] += ...   fp32 residual stream, in place.  With ks_counters (M <= 16, fp16 weights):
+ *                                    K is cut into `kslices` (1..8) slices that run as separate workgroups of `ks_tiles`
+ *                                    (1, 2, 4, 8) output tiles each, and the partial tiles are added INSIDE the launch -- every
+ *                                    workgroup writes its partial through to ks_scratch (>= pc_gemm_skinny_ks_scratch_bytes(N,
+ *                                    kslices) bytes, 16-byte aligned), arrives at its tile group's counter, the last arriver adds
+ *                                    the partials in slice order (deterministic), adds y and stores.  ks_counters: ceil(N/16/
+ *                                    ks_tiles) uint32 words, ZERO before the first launch; every launch leaves them zero
+ *              PC_GEMM_EPI_SILU      W = [gate ; up] (N = 2*inter): of[m][j] = silu(gate_j) * up_j as fragment planes
+ *                                    [M/16][inter/32][64][8] (of_hi, of_lo) for the down projection
+ *              PC_GEMM_EPI_GELU      of[m][n] = gelu(...) as fragment planes (Falcon / MPT MLP, falcon.py:726)
+ *              PC_GEMM_EPI_QKV_ROPE  the fused q|k|v projection: llama2.py:345-347 (projections), :357-359 (RoPE at the
+ *                                    supplied position ids) and :361-364 (KV concat) in ONE launch; N = (H + 2 Hkv) D, M = B q_len.
+ *                                    wf: fragment image of the row-PERMUTED [q;k;v] weight: inside every head, tile j (16 rows)
+ *                                    holds features 8j..8j+7 followed by their rotary partners D/2+8j..D/2+8j+7.  Outputs:
+ *                                    rotated q as split planes q_hi/q_lo [B*q_len][H*D] (token stride q_token_stride); rotated k
+ *                                    and v in place at rows [past_len, past_len+q_len) of the arena planes (cs: pc_rope_table);
+ *                                    k_lo / v_lo (both or NULL): fp16 residuals of those new rows; the residual row of token tt
+ *                                    is tt (lo_base -1: a buffer of this pass's rows), past_len + tt - lo_base (>= 0) or
+ *                                    past_len + tt - past_len_dev[1] (-2: ONE residual tail per layer across a prefill and the
+ *                                    decode steps after it; llama2.py:361-388 keeps those rows in fp32 for the whole generation)
+ *   wf, w_scale   fp16 fragment image; or (w_scale != NULL, M <= 64, K % 64 == 0) an INT8 image [N/16][K/64][64][16] of
+ *              offset-binary bytes (q + 128; a lane's 16 bytes = its 8 values of k-step 2s then of 2s + 1) with w_scale fp32 [N]
+ *              (row order of the image, 16-byte aligned): q[n][k] = round(w / scale[n]), scale[n] = absmax_k |w[n][k]| / 127 --
+ *              the row-wise quantiser LLM.int8 applies to weights (the reference's GPU configs pass load_in_8bit=True,
+ *              config/llm_config_*.json:5, eval.py:36-42); y = scale[n] * sum_k q[n][k] x[k]
+ *   xf_hi, xf_lo  activation planes; OR
+ *   x, norm_weight, eps   (M <= 16, K <= 16384; epilogues STORE / SILU / QKV_ROPE) the fp32 residual stream x [M][K] itself:
+ *              y = W . (norm_weight * x) * rsqrt(mean(x^2) + eps) -- LlamaRMSNorm (llama2.py:103-108) folded into the projection
+ *              that consumes it, no launch and no pass over x of its own.  Needs |norm_weight * x| < 65504
+ *   rows_dev   optional device int32*: the rows that really carry tokens (<= M; B = 1).  Rows behind it are pad rows of a
+ *              row-bucketed hipGraph: their results are unspecified and their activations are not loaded
+ *   x_scale, corr, ldc, corr_has   LLM.int8 activations (pc_quant_act_i8): the planes hold int8 CODES, x_scale[m] = SCA[m] / 127;
+ *              y = (sum_k code_w code_x) * w_scale[n] * x_scale[m] (+ corr[m][n] when *corr_has: pc_outlier_corr); OR
+ *   flags, x_raw, w_codes_t, ldt, row_perm   the outlier correction computed INSIDE the launch (M <= 64): the flag bytes of
+ *              pc_quant_act_i8 (>= 16384 bytes, zero behind K), the fp16 activations (fragment plane), the transposed int8 weight
+ *              codes [K][ldt] (original row order) and, for q|k|v, the image-row -> original-row permutation
+ * ------------------------------------------------------------------------------------------- */
+#define PC_GEMM_EPI_STORE 0
+#define PC_GEMM_EPI_ADD 1
+#define PC_GEMM_EPI_SILU 2
+#define PC_GEMM_EPI_QKV_ROPE 3
+#define PC_GEMM_EPI_GELU 4
+typedef struct pc_gemm_args {
+    uint32_t struct_bytes;
+    int32_t epilogue;
+    const void* wf; const float* w_scale;
+    const void* xf_hi; const void* xf_lo;
+    const float* x; const void* norm_weight; float eps;
+    int32_t M, N, K;
+    const int32_t* rows_dev;
+    float* y; int64_t ldy; void* of_hi; void* of_lo;
+    int32_t kslices;
+    int32_t ks_tiles; void* ks_scratch; int64_t ks_scratch_bytes; void* ks_counters;
+    const float* x_scale; const float* corr; int64_t ldc; const int32_t* corr_has;
+    const void* flags; const void* x_raw; const void* w_codes_t; int64_t ldt; const int32_t* row_perm;
+    const float* cs; void* q_hi; void* q_lo; int64_t q_token_stride; void* k_arena; void* v_arena;
+    int64_t arena_batch_stride, arena_head_stride;
+    int32_t B, H, Hkv, D, q_len, past_len, cap;
+    const int32_t* past_len_dev; void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_base;
+} pc_gemm_args;
+int pc_gemm(const pc_gemm_args* args, void* stream);
+int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
+/* pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes;
+ *   optional prologue x += slabs[0] + ... + slabs[nslabs-1] (each [rows][hidden], the residual adds of
+ *   llama2.py:638 / :644 fed by a K-sliced pc_gemm), written back to x in place. */
+int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows, int32_t hidden,
+                    float eps, const float* slabs, int32_t nslabs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Falcon adapter (promptcache/model/falcon.py; multi-query, parallel attention + MLP): the ops the Llama path does
+ * not have.  Everything else (pc_kv_gather with Hkv = 1, pc_rope_*, pc_attn with H/Hkv = H, pc_gemm*) is shared.
+ *   pc_layernorm       torch.nn.LayerNorm (falcon.py:757, :1020) of fp32 x [rows][hidden] -> fp16
+ *   pc_layernorm_frag  the same, written as split-precision fragment planes, with the slab-folding prologue of
+ *                      pc_rmsnorm_frag (x += slabs[0] + ... first: the o_proj and dense_4h_to_h partial sums)
+ *                      (bias may be NULL in both: MPT's LayerNorm carries no bias, mpt.py:207, :215)
+ *   pc_gelu            nn.GELU() (falcon.py:726, mpt.py:187: erf form) fp32 -> fp16, n elements (n % 8 == 0)
+ *   pc_gemm epilogue PC_GEMM_EPI_GELU: of[m][j] = gelu(y[m][j]) as fragment planes [M/16][N/32][64][8] (dense_h_to_4h)
+ * ------------------------------------------------------------------------------------------- */
+int pc_layernorm(const float* x, const void* weight, const void* bias, void* out, int32_t rows, int32_t hidden,
+                 float eps, void* stream);
+int pc_layernorm_frag(float* x, const void* weight, const void* bias, void* xf_hi, void* xf_lo, int32_t rows,
+                      int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream);
+int pc_gelu(const float* x, void* out, int64_t n, void* stream);
+
+
+/* Split-precision variants for the dense (many-row) path.  fp16 activations cost 2^-11 per projection input; over 32
+ * layers that alone moves 7b-shape logits by 2-3e-2 against the reference's fp32 path.  These write an activation as
+ * hi = fp16(v) and lo = fp16(v - hi); the caller stacks [hi; lo] along the rows of one GEMM and adds the two halves of
+ * the product (gate_up2 / x2 / pc_add3 take the second half):
+ *   pc_rmsnorm_split, pc_layernorm_split   norm -> (hi, lo) [rows][hidden]
+ *   pc_silu_mul_split   silu(g) * u of (gate_up + gate_up2) -> (hi, lo);  pc_gelu_split  gelu(x + x2) -> (hi, lo)
+ *   pc_add3             x += a + b  (fp32 residual stream)
+ *   (the attention takes the split planes through pc_attn: q_lo, out_lo, k_lo / v_lo) */
+int pc_rmsnorm_split(const float* x, const void* weight, void* out_hi, void* out_lo, int32_t rows, int32_t hidden,
+                     float eps, void* stream);
+int pc_layernorm_split(const float* x, const void* weight, const void* bias, void* out_hi, void* out_lo, int32_t rows,
+                       int32_t hidden, float eps, void* stream);
+int pc_silu_mul_split(const float* gate_up, const float* gate_up2, void* out_hi, void* out_lo, int32_t rows,
+                      int32_t inter, void* stream);
+int pc_gelu_split(const float* x, const float* x2, void* out_hi, void* out_lo, int64_t n, void* stream);
+int pc_add3(float* x, const float* a, const float* b, int64_t n, void* stream);
+/* pc_rope_append_ex -- pc_rope_append that also writes the fp16 residuals of the appended K / V rows (k_lo, v_lo,
+ *   both or neither: [B][Hkv][rows][D] with the given strides, row = key index - lo_row0; lo_row0 = past_len for a
+ *   compact buffer of the new rows, 0 for an arena-shaped one that also carries residuals of earlier rows).  pc_attn consumes them: the keys / values a pass appends enter
+ *   (in2_offset != 0: every q / k_new / v_new input element is x[i] + x[i + in2_offset], the two row halves a stacked
+ *   [hi; lo] projection leaves)
+ *   its own attention in split precision, as in the reference's fp32 pass (llama2.py:361-388), while the arena keeps the
+ *   fp16 value the reference stages (cache_engine.py:105-106).  Staged rows (< past_len) have no residual. */
+int pc_rope_append_ex(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                      int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new, const void* v_new,
+                      int64_t kv_new_batch_stride, int64_t kv_new_token_stride, void* k_arena, void* v_arena,
+                      int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
+                      int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
+                      const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
+                      int64_t lo_head_stride, int32_t lo_row0, int64_t in2_offset, void* stream);
+
+
+/* Ragged-prefix batches (schema encode: scaffold suffixes of different unions in one batch, each over its own trunk
+ * prefix -- the batched form of cache_engine.py:217-304's per-scaffold forwards): pc_rope_append_ex (and pc_attn.past_lens) with
+ * ONE PAST LENGTH PER BATCH ROW.  past_lens: device int32[B]; past_len = their maximum (bounds check, KV-split sizing).
+ * Batch row b appends its q_len new rows at arena rows [past_lens[b], past_lens[b] + q_len) and attends to keys
+ * [0, past_lens[b]) plus the new rows up to its own (index-order mask, llama2.py:62-76).  Residual planes, when given,
+ * are arena-shaped (lo_row0 = 0). */
+int pc_rope_append_var(const void* q, int64_t q_batch_stride, int64_t q_token_stride, void* q_out, void* q_out_lo,
+                       int64_t qo_batch_stride, int64_t qo_token_stride, const void* k_new, const void* v_new,
+                       int64_t kv_new_batch_stride, int64_t kv_new_token_stride, void* k_arena, void* v_arena,
+                       int64_t arena_batch_stride, int64_t arena_head_stride, const float* cs, int32_t B, int32_t H,
+                       int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap, int32_t in_is_f32,
+                       const int32_t* past_lens, void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride,
+                       int32_t lo_row0, void* stream);
+
+
 
 
 /* Many-row projection (schema encode / no-cache prefill / long questions; MFMA-bound), csrc/pc_gemm_dense.hip:
@@ -398,11 +352,11 @@ int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, const void
  *   phase 1  act = silu(gate(n2(x))) * up(n2(x))                post_attention_layernorm + gate / up + SiLU  llama2.py:640-643, :242
  *   phase 2  x += act @ Wdown^T                                 down_proj + residual     llama2.py:242, :644
  *   phase 3  (wqkv_f_next != NULL) the NEXT layer's input_layernorm + q|k|v + RoPE + in-place KV append  llama2.py:628, :345-364
- * i.e. pc_gemm_skinny(epilogue 1), pc_gemm_skinny_norm(epilogue 2), pc_gemm_skinny(epilogue 1), pc_gemm_qkv_rope_ex(norm
+ * i.e. pc_gemm(EPI_ADD), pc_gemm(x + norm_weight, EPI_SILU), pc_gemm(EPI_ADD), pc_gemm(x + norm_weight, EPI_QKV_ROPE; norm
  * source) with the same operands, tiles, K split and reduction order: the results are bit-identical to those four launches.
  * One workgroup per CU stays resident across the phases and meets the others at grid barriers; every wave fetches the first
  * weight block of the next phase before it waits, so the HBM stream does not stop at the seams.
- * attn_hi / attn_lo: fragment planes [1][attn_width/32][64][8] (pc_attn_fwd* out_frag_*), act_hi / act_lo: scratch planes
+ * attn_hi / attn_lo: fragment planes [1][attn_width/32][64][8] (pc_attn out_frag_*), act_hi / act_lo: scratch planes
  * [1][inter/32][64][8]; x: fp32 residual stream [M][hidden], updated in place; weights: fragment images (fp16).
  * sync_state: pc_chain_sync_words() uint32 words of device memory, zeroed ONCE by the caller and then owned by these calls
  * (monotonic counters: no reset between launches or graph replays; launches sharing a state must be stream-ordered).  Every
@@ -434,27 +388,14 @@ int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* attn_lo, in
  *   - codes[t][k] * w_codes[r][k] * x_scale[t] * w_scale[r],  r = row_perm ? row_perm[n] : n  (w_codes_t: the int8 weight
  *   codes TRANSPOSED, [K][ldt], so that a weight column is contiguous); *has = 1 when any column is flagged, else 0 and
  *   corr is left untouched.
- * pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 / pc_gemm_dense_a8: the projections over the codes,
- *   y = (sum_k w_code[n][k] * x_code[m][k]) * w_scale[n] * x_scale[m] + (*corr_has ? corr[m][n] : 0), then the epilogue of
- *   pc_gemm_skinny / pc_gemm_qkv_rope_ex / pc_gemm_dense (same epilogue codes and outputs). */
+ * pc_gemm (x_scale != NULL) / pc_gemm_dense_a8: the projections over the codes,
+ *   y = (sum_k w_code[n][k] * x_code[m][k]) * w_scale[n] * x_scale[m] + (*corr_has ? corr[m][n] : 0), then the epilogue
+ *   (same epilogue codes and outputs as with fp16 operands). */
 int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale, void* flags_set,
                     void* flags_clear, int32_t clear_len, float threshold, void* stream);
-/* pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 with the outlier correction computed INSIDE the launch (M <= 64): instead of corr /
- * corr_has the call takes what pc_outlier_corr would have read -- the flag bytes of pc_quant_act_i8 (a 16-byte aligned buffer of
- * >= 16384 bytes, zero behind K), the fp16 activations x_raw (fragment plane), the transposed int8 weight codes [K][ldt]
- * (original row order) and, for q|k|v, the image-row -> original-row permutation.  Every workgroup compacts the flags and its
- * eight waves share the outlier columns; the result equals pc_outlier_corr + pc_gemm_*_a8 up to the fp32 summation order over the
- * outlier columns.  Saves one launch per projection (~4 us even when no column is flagged). */
-int pc_gemm_skinny_a8c(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
-                       const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt, int32_t M, int32_t N, int32_t K,
-                       int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
-int pc_gemm_qkv_rope_a8c(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
-                         const float* x_scale, const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt,
-                         const int32_t* row_perm, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo,
-                         int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
-                         int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                         int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
-                         int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
+/* (pc_gemm with `flags` computes the outlier correction INSIDE the projection launch, M <= 64: every workgroup compacts the flags
+ * and its eight waves share the outlier columns; equal to pc_outlier_corr + the corr form up to the fp32 summation order over the
+ * outlier columns.  Saves one launch per projection, ~4 us even when no column is flagged.) */
 /* pc_rmsnorm_frag + pc_quant_act_i8 in one launch (T <= 64 rows, fragment planes), for the two projection inputs that come out of
  * an RMSNorm (input_layernorm -> q|k|v, post_attention_layernorm -> gate|up; llama2.py:628, :640): bit-identical to the pair.
  * x: fp32 residual stream [T][hidden]; x_hi: the normalised fp16 activations (read by pc_outlier_corr), codes / x_scale / flags as
@@ -464,15 +405,6 @@ int pc_rmsnorm_quant_i8(const float* x, const void* norm_weight, float eps, int3
 int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
                     const float* x_scale, const void* w_codes_t, int64_t ldt, const float* w_scale, const int32_t* row_perm,
                     int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream);
-int pc_gemm_skinny_a8(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
-                      const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K,
-                      int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream);
-int pc_gemm_qkv_rope_a8(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
-                        const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t K,
-                        const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
-                        int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D,
-                        int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
-                        int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream);
 int pc_gemm_dense_a8(const void* xq, int64_t ldx, const void* w_codes, int64_t ldw, const float* w_scale, const float* x_scale,
                      const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                      float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream);

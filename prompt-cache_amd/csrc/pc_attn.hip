@@ -1284,75 +1284,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
 }
 }  // namespace
 
-PC_EXPORT int pc_attn_fwd(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride, const void* k,
-                          const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
-                          int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
-                          int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
-                          int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
-                          void* stream) {
-    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
-                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, nullptr, 0, nullptr, nullptr, nullptr,
-                         nullptr, 0, 0, 0, stream);
-}
-
-PC_EXPORT int pc_attn_fwd_alibi(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
-                                const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
-                                int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H, int32_t Hkv,
-                                int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
-                                int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi,
-                                void* out_frag_lo, const float* key_pos, int64_t key_pos_batch_stride,
-                                const float* slopes_log2, void* stream) {
-    PC_REQUIRE(key_pos && slopes_log2 && key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0, PC_ERR_ARG,
-               "pc_attn_fwd_alibi: key_pos / slopes missing or key_pos rows not 16-byte aligned");
-    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
-                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
-                         slopes_log2, nullptr, nullptr, nullptr, 0, 0, 0, stream);
-}
-
-PC_EXPORT int pc_attn_fwd_ex(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
-                             const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
-                             void* out_lo, int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H,
-                             int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, float softmax_scale, void* workspace,
-                             int64_t workspace_bytes, const int32_t* past_len_dev, const float* key_pos,
-                             int64_t key_pos_batch_stride, const float* slopes_log2, const void* k_lo, const void* v_lo,
-                             int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_row0, void* out_frag_hi,
-                             void* out_frag_lo, void* stream) {
-    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || q_lo), PC_ERR_ARG,
-               "pc_attn_fwd_ex: k_lo / v_lo go together and need q_lo (split-precision Q)");
-    PC_REQUIRE(!k_lo || lo_row0 == -1 || (lo_row0 == -2 && past_len_dev) || (lo_row0 >= 0 && lo_row0 <= past_len && !past_len_dev),
-               PC_ERR_ARG, "pc_attn_fwd_ex: lo_row0 must be -1 (= past_len), -2 (= past_len_dev[1]) or lie in [0, past_len] of a host past_len");
-    PC_REQUIRE(!k_lo || lo_head_stride % 8 == 0, PC_ERR_ARG, "pc_attn_fwd_ex: the lo strides must keep 16-byte alignment");
-    PC_REQUIRE((key_pos == nullptr) == (slopes_log2 == nullptr), PC_ERR_ARG, "pc_attn_fwd_ex: key_pos and slopes go together");
-    PC_REQUIRE(!key_pos || (key_pos_batch_stride % 4 == 0 && ((uintptr_t)key_pos & 15) == 0), PC_ERR_ARG,
-               "pc_attn_fwd_ex: key_pos rows not 16-byte aligned");
-    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
-                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, past_len_dev, out_frag_hi, out_frag_lo, key_pos, key_pos_batch_stride,
-                         slopes_log2, out_lo, k_lo, v_lo, lo_batch_stride, lo_head_stride, lo_row0, stream);
-}
-
-// pc_attn_fwd_ex with one past length PER BATCH ROW (device int32[B]; `past_len` = their maximum: it sizes the KV splits):
-// batch row b attends to its keys [0, past_lens[b]) plus the new rows it appended behind them.  Residual planes, when
-// given, must be arena-shaped (lo_row0 = 0).  Replaces the same reference ops as pc_attn_fwd (llama2.py:368-398).
-PC_EXPORT int pc_attn_fwd_var(const void* q, const void* q_lo, int64_t q_batch_stride, int64_t q_token_stride,
-                              const void* k, const void* v, int64_t kv_batch_stride, int64_t kv_head_stride, void* out,
-                              void* out_lo, int64_t out_batch_stride, int64_t out_token_stride, int32_t B, int32_t H,
-                              int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, const int32_t* past_lens,
-                              float softmax_scale, void* workspace, int64_t workspace_bytes, const void* k_lo,
-                              const void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream) {
-    PC_REQUIRE(past_lens, PC_ERR_ARG, "pc_attn_fwd_var: past_lens is required");
-    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || q_lo), PC_ERR_ARG,
-               "pc_attn_fwd_var: k_lo / v_lo go together and need q_lo (split-precision Q)");
-    PC_REQUIRE(!k_lo || lo_head_stride % 8 == 0, PC_ERR_ARG, "pc_attn_fwd_var: the lo strides must keep 16-byte alignment");
-    return attn_fwd_impl(q, q_lo, q_batch_stride, q_token_stride, k, v, kv_batch_stride, kv_head_stride, out,
-                         out_batch_stride, out_token_stride, B, H, Hkv, D, q_len, past_len, softmax_scale, workspace,
-                         workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, nullptr, out_lo, k_lo, v_lo, lo_batch_stride,
-                         lo_head_stride, 0, stream, past_lens);
-}
-
-// pc_attn: the one struct-taking entry of the attention family (the entry points above are wrappers that fill a subset of it).
+// pc_attn: the one struct-taking entry of the attention family (include/promptcache_hip.h; the round 1-2 entry points are inline
+// wrappers over it in include/promptcache_hip_compat.h).
 // `counters` (optional, B*H zeroed uint32 words, left zero by every launch): launches of <= 16 query rows over a long staged
 // cache then merge their split-KV partials INSIDE the launch (last-arriving workgroup per head) instead of through a second one.
 PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {

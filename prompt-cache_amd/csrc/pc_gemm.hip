@@ -178,162 +178,103 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
 }  // namespace
 
 
-namespace {
-// operands of the in-launch LLM.int8 outlier correction (pc_gemm_*_a8c)
-struct A8Fused {
-    const void* flags; const void* xraw; const void* cbt; int64_t ldt; const int32_t* row_perm;
-};
+// ---------------------------------------------------------------------------------------------------
+// pc_gemm: THE entry point of the weight-streaming projections (M = B*q_len <= 512 rows).  One struct (include/promptcache_hip.h,
+// pc_gemm_args) covers what round 1-2 exported as thirteen functions: plain / residual-add / SiLU*up / GELU / q|k|v + RoPE + append
+// epilogues, activation planes or the fused-RMSNorm source, fp16 or int8 weight images, LLM.int8 code planes with a separate or
+// an in-launch outlier correction, K slices as slabs or reduced inside the launch.
+PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
+    PC_REQUIRE(a && a->struct_bytes == (uint32_t)sizeof(pc_gemm_args), PC_ERR_ARG,
+               "pc_gemm: args is NULL or struct_bytes != sizeof(pc_gemm_args) (ABI mismatch)");
+    const int epi = a->epilogue;
+    const bool qkv = epi == PC_GEMM_EPI_QKV_ROPE;
+    const int M = a->M, K = a->K;
+    const int N = qkv ? (a->H + 2 * a->Hkv) * a->D : a->N;
+    PC_REQUIRE(epi >= 0 && epi <= PC_GEMM_EPI_GELU, PC_ERR_ARG, "pc_gemm: unknown epilogue %d", epi);
+    PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm: M=%d outside 1..512 (use pc_gemm_dense above)", M);
+    PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm: need N%%16==0 and K%%32==0");
+    const bool norm = a->x != nullptr;
+    PC_REQUIRE(a->wf && (norm ? (a->norm_weight && !a->xf_hi) : (a->xf_hi != nullptr)), PC_ERR_ARG,
+               "pc_gemm: pass the weight image and either the activation planes or (x, norm_weight)");
+    PC_REQUIRE(!norm || (M <= 16 && K <= 32 * kGamSteps * kWaves &&
+                         (epi == PC_GEMM_EPI_STORE || epi == PC_GEMM_EPI_SILU || qkv) && a->kslices <= 1), PC_ERR_ARG,
+               "pc_gemm: the fused-RMSNorm source needs M <= 16, K <= 16384, no K-slicing, epilogue store / SiLU / q|k|v");
+    const int kslices = a->kslices < 1 ? 1 : a->kslices;
+    const bool fused = a->flags != nullptr;                       // in-launch LLM.int8 outlier correction
+    PC_REQUIRE(!a->w_scale || (M <= 64 && (norm || a->xf_lo) && ((uintptr_t)a->w_scale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
+               "pc_gemm: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
+    PC_REQUIRE(!a->x_scale || fused || (a->w_scale && a->corr && a->corr_has && a->ldc >= N && a->ldc % 4 == 0 &&
+                                        ((uintptr_t)a->corr & 15) == 0 && kslices == 1), PC_ERR_ARG,
+               "pc_gemm: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N), corr_has, no K-slices");
+    PC_REQUIRE(!fused || (a->x_scale && a->w_scale && kslices == 1 && a->x_raw && a->w_codes_t && a->ldt >= N && K <= 16384 &&
+                          ((uintptr_t)a->flags & 15) == 0 && (!qkv || a->row_perm)), PC_ERR_ARG,
+               "pc_gemm: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t "
+               "(ldt >= N), K <= 16384 (and row_perm for q|k|v)");
+    hipStream_t s = (hipStream_t)stream;
 
-int gemm_skinny_impl(const void* wf, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma, float eps,
-                     int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
-                     int32_t kslices, void* stream, const float* wscale = nullptr, const float* xscale = nullptr,
-                     const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr,
-                     const A8Fused* fz = nullptr) {
-    PC_REQUIRE(M > 0 && M <= kRowsMaxM, PC_ERR_ARG, "pc_gemm_skinny: M=%d outside 1..512 (use a dense GEMM above)", M);
-    PC_REQUIRE(!xscale || fz || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0 && kslices == 1),
-               PC_ERR_ARG, "pc_gemm_skinny_a8: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N), corr_has, no K-slices");
-    PC_REQUIRE(!fz || (xscale && wscale && kslices == 1 && fz->flags && fz->xraw && fz->cbt && fz->ldt >= N && K <= 16384 &&
-                       ((uintptr_t)fz->flags & 15) == 0), PC_ERR_ARG,
-               "pc_gemm_skinny_a8c: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t (ldt >= N), K <= 16384");
-    PC_REQUIRE(N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0, PC_ERR_ARG, "pc_gemm_skinny: need N%%16==0 and K%%32==0");
-    PC_REQUIRE(wf && (xf_hi || xn), PC_ERR_ARG, "pc_gemm_skinny: null pointer");
-    PC_REQUIRE(!xn || (gamma && M <= 16 && kslices == 1 && (epilogue == EPI_STORE || epilogue == EPI_SILU) && K <= 32 * kGamSteps * kWaves),
-               PC_ERR_ARG, "pc_gemm_skinny_norm: the fused-RMSNorm source needs M <= 16, K <= 16384, no K-slicing, epilogue 0 or 2");
+    // ---- residual add with K split across workgroups and the reduction inside the launch (pc_gemm_ks.hip) ----
+    if (epi == PC_GEMM_EPI_ADD && a->ks_counters) {
+        PC_REQUIRE(!a->w_scale && !norm && a->xf_lo && M <= 16, PC_ERR_ARG,
+                   "pc_gemm: the in-launch K reduction takes fp16 weights, both activation planes, M <= 16");
+        return launch_skinny_ks(a->wf, a->xf_hi, a->xf_lo, M, N, K, a->y, a->ldy, kslices, a->ks_tiles, a->ks_scratch,
+                                a->ks_scratch_bytes, a->ks_counters, a->rows_dev, s);
+    }
+
     GemmParams p;
     memset(&p, 0, sizeof(p));
-    p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
-    p.wf = (const _Float16*)wf; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
-    PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
-               "pc_gemm_skinny_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
-    p.wscale = wscale; p.w8 = wscale ? 1 : 0;
-    p.xscale = xscale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
-    if (fz) {
-        p.oflags = (const unsigned char*)fz->flags; p.xraw = (const _Float16*)fz->xraw; p.cbt = (const signed char*)fz->cbt;
-        p.ldt = fz->ldt; p.row_perm = fz->row_perm;
+    p.wf = (const _Float16*)a->wf; p.xf_hi = (const _Float16*)a->xf_hi; p.xf_lo = (const _Float16*)a->xf_lo;
+    p.xn = a->x; p.gamma = (const _Float16*)a->norm_weight; p.eps = a->eps;
+    p.wscale = a->w_scale; p.w8 = a->w_scale ? 1 : 0;
+    p.xscale = a->x_scale; p.corr = a->corr; p.ldc = a->ldc; p.corr_has = a->corr_has;
+    if (fused) {
+        p.oflags = (const unsigned char*)a->flags; p.xraw = (const _Float16*)a->x_raw; p.cbt = (const signed char*)a->w_codes_t;
+        p.ldt = a->ldt; p.row_perm = a->row_perm;
     }
-    p.y = y; p.ldy = ldy; p.of_hi = (_Float16*)of_hi; p.of_lo = (_Float16*)of_lo;
-    p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.KSo = 0;
-    PC_REQUIRE(kslices >= 1 && kslices <= 16 && (kslices == 1 || epilogue == EPI_STORE), PC_ERR_ARG,
-               "pc_gemm_skinny: K-slicing (kslices=%d) is available for the plain-store epilogue only", kslices);
-    p.kslices = kslices; p.slab_stride = (int64_t)M * ldy;
+    p.M = M; p.m_dev = a->rows_dev; p.ntiles = N / 16; p.KS = K / 32;
     p.trace = g_gemm_trace;
+
+    if (qkv) {
+        PC_REQUIRE(M == a->B * a->q_len, PC_ERR_ARG, "pc_gemm: q|k|v needs M=%d == B*q_len", M);
+        PC_REQUIRE(a->D % 16 == 0 && a->H > 0 && a->Hkv > 0, PC_ERR_ARG, "pc_gemm: bad q|k|v shape");
+        PC_REQUIRE(a->cs && a->q_hi && a->q_lo && a->k_arena && a->v_arena, PC_ERR_ARG, "pc_gemm: null q|k|v pointer");
+        PC_REQUIRE((int64_t)a->past_len + a->q_len <= a->cap, PC_ERR_BOUNDS,
+                   "pc_gemm: past_len %d + q_len %d exceeds arena rows %d", a->past_len, a->q_len, a->cap);
+        PC_REQUIRE(a->q_token_stride % 4 == 0 && a->arena_head_stride % 4 == 0, PC_ERR_ARG, "pc_gemm: strides must keep 8-byte alignment");
+        PC_REQUIRE((a->k_lo == nullptr) == (a->v_lo == nullptr) && (!a->k_lo || a->lo_head_stride % 4 == 0), PC_ERR_ARG,
+                   "pc_gemm: k_lo / v_lo go together, strides must keep 8-byte alignment");
+        PC_REQUIRE(a->lo_base >= -2 && (a->lo_base != -2 || a->past_len_dev) && (a->lo_base < 0 || a->lo_base <= a->past_len), PC_ERR_ARG,
+                   "pc_gemm: lo_base must be -1 (pass-relative rows), -2 (past_len_dev[1]) or lie in [0, past_len]");
+        p.kslices = 1;
+        p.rope.cs = (const float2*)a->cs; p.rope.q_hi = (_Float16*)a->q_hi; p.rope.q_lo = (_Float16*)a->q_lo; p.rope.q_ts = a->q_token_stride;
+        p.rope.k_arena = (_Float16*)a->k_arena; p.rope.v_arena = (_Float16*)a->v_arena; p.rope.a_bs = a->arena_batch_stride;
+        p.rope.a_hs = a->arena_head_stride; p.rope.past_len_dev = a->past_len_dev;
+        p.rope.k_lo = (_Float16*)a->k_lo; p.rope.v_lo = (_Float16*)a->v_lo; p.rope.lo_bs = a->lo_batch_stride; p.rope.lo_hs = a->lo_head_stride;
+        p.rope.lo_base = a->lo_base;
+        p.rope.H = a->H; p.rope.Hkv = a->Hkv; p.rope.D = a->D; p.rope.q_len = a->q_len; p.rope.past_len = a->past_len;
+        set_k_balance(p, K);
+        return launch_MT(EPI_ROPE, p, choose_T(p.ntiles), p.ntiles, s);
+    }
+
+    p.y = a->y; p.ldy = a->ldy; p.of_hi = (_Float16*)a->of_hi; p.of_lo = (_Float16*)a->of_lo;
+    PC_REQUIRE(kslices <= 16 && (kslices == 1 || epi == PC_GEMM_EPI_STORE), PC_ERR_ARG,
+               "pc_gemm: K slices as slabs (kslices=%d) go with the plain-store epilogue (residual add: pass ks_counters)", kslices);
+    p.kslices = kslices; p.slab_stride = (int64_t)M * a->ldy;
     set_k_balance(p, K);
-    hipStream_t s = (hipStream_t)stream;
-    if (epilogue == EPI_SILU) {
-        PC_REQUIRE(N % 64 == 0, PC_ERR_ARG, "pc_gemm_skinny: SiLU epilogue needs N = 2*inter with inter%%32==0");
-        PC_REQUIRE(of_hi && of_lo, PC_ERR_ARG, "pc_gemm_skinny: SiLU epilogue needs output planes");
+    if (epi == PC_GEMM_EPI_SILU) {
+        PC_REQUIRE(N % 64 == 0 && a->of_hi && a->of_lo, PC_ERR_ARG, "pc_gemm: the SiLU epilogue needs N = 2*inter with inter%%32==0 and output planes");
         p.npairs = N / 32;          // inter / 16
         p.KSo = (N / 2) / 32;       // k-steps of the consumer (down_proj, K = inter)
         return launch_MT(EPI_SILU, p, choose_T(p.npairs), p.npairs, s);
     }
-    if (epilogue == EPI_GELU) {
-        PC_REQUIRE(N % 32 == 0 && of_hi && of_lo, PC_ERR_ARG, "pc_gemm_skinny: GELU epilogue needs N%%32==0 and output planes");
+    if (epi == PC_GEMM_EPI_GELU) {
+        PC_REQUIRE(N % 32 == 0 && a->of_hi && a->of_lo, PC_ERR_ARG, "pc_gemm: the GELU epilogue needs N%%32==0 and output planes");
         p.KSo = N / 32;             // k-steps of the consumer (dense_4h_to_h, K = N)
         return launch_MT(EPI_GELU, p, choose_T(p.ntiles), p.ntiles, s);
     }
-    PC_REQUIRE(y && ldy >= N && ldy % 4 == 0, PC_ERR_ARG, "pc_gemm_skinny: bad output");
-    if (epilogue == EPI_ADD) return launch_MT(EPI_ADD, p, choose_T(p.ntiles), p.ntiles, s);
-    PC_REQUIRE(epilogue == EPI_STORE, PC_ERR_ARG, "pc_gemm_skinny: unknown epilogue %d", epilogue);
-    return launch_MT(EPI_STORE, p, choose_T(p.ntiles * kslices) , p.ntiles, s);
+    PC_REQUIRE(a->y && a->ldy >= N && a->ldy % 4 == 0, PC_ERR_ARG, "pc_gemm: bad output");
+    if (epi == PC_GEMM_EPI_ADD) return launch_MT(EPI_ADD, p, choose_T(p.ntiles), p.ntiles, s);
+    return launch_MT(EPI_STORE, p, choose_T(p.ntiles * kslices), p.ntiles, s);
 }
-
-int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma,
-                       float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
-                       void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
-                       int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
-                       const float* wscale = nullptr, int32_t lo_base = -1, const float* xscale = nullptr,
-                       const float* corr = nullptr, int64_t ldc = 0, const int32_t* corr_has = nullptr, const A8Fused* fz = nullptr);
-}  // namespace
-
-PC_EXPORT int pc_gemm_skinny(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K,
-                             int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, int32_t kslices,
-                             void* stream) {
-    PC_REQUIRE(xf_hi, PC_ERR_ARG, "pc_gemm_skinny: null pointer");
-    return gemm_skinny_impl(wf, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, kslices, stream);
-}
-
-PC_EXPORT int pc_gemm_skinny_norm(const void* wf, const float* x, const void* norm_weight, float eps, int32_t M, int32_t N,
-                                  int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
-                                  void* stream) {
-    PC_REQUIRE(x && norm_weight, PC_ERR_ARG, "pc_gemm_skinny_norm: null pointer");
-    return gemm_skinny_impl(wf, nullptr, nullptr, x, norm_weight, eps, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream);
-}
-
-PC_EXPORT int pc_gemm_qkv_rope(const void* wf_perm, const void* xf_hi, const void* xf_lo, int32_t M, int32_t K,
-                               const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena,
-                               void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
-                               int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                               const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
-                               int64_t lo_head_stride, void* stream) {
-    PC_REQUIRE(xf_hi, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
-    return gemm_qkv_rope_impl(wf_perm, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
-                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream);
-}
-
-PC_EXPORT int pc_gemm_qkv_rope_norm(const void* wf_perm, const float* x, const void* norm_weight, float eps, int32_t M,
-                                    int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
-                                    void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride,
-                                    int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len,
-                                    int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
-                                    int64_t lo_batch_stride, int64_t lo_head_stride, void* stream) {
-    PC_REQUIRE(x && norm_weight && M <= 16, PC_ERR_ARG, "pc_gemm_qkv_rope_norm: needs x, the norm weight and M <= 16");
-    return gemm_qkv_rope_impl(wf_perm, nullptr, nullptr, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
-                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream);
-}
-
-namespace {
-int gemm_qkv_rope_impl(const void* wf_perm, const void* xf_hi, const void* xf_lo, const float* xn, const void* gamma,
-                       float eps, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride,
-                       void* k_arena, void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B,
-                       int32_t H, int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                       const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_bs, int64_t lo_hs, void* stream,
-                       const float* wscale, int32_t lo_base, const float* xscale, const float* corr, int64_t ldc,
-                       const int32_t* corr_has, const A8Fused* fz) {
-    const int N = (H + 2 * Hkv) * D;
-    PC_REQUIRE(M > 0 && M <= kRowsMaxM && M == B * q_len, PC_ERR_ARG, "pc_gemm_qkv_rope: M=%d must equal B*q_len and be <= 512", M);
-    PC_REQUIRE(D % 16 == 0 && K > 0 && K % 32 == 0 && H > 0 && Hkv > 0, PC_ERR_ARG, "pc_gemm_qkv_rope: bad shape");
-    PC_REQUIRE(wf_perm && (xf_hi || xn) && cs && q_hi && q_lo && k_arena && v_arena, PC_ERR_ARG, "pc_gemm_qkv_rope: null pointer");
-    PC_REQUIRE(!xn || K <= 32 * kGamSteps * kWaves, PC_ERR_ARG, "pc_gemm_qkv_rope_norm: the fused-RMSNorm source needs K <= 16384");
-    PC_REQUIRE((int64_t)past_len + q_len <= cap, PC_ERR_BOUNDS,
-               "pc_gemm_qkv_rope: past_len %d + q_len %d exceeds arena rows %d", past_len, q_len, cap);
-    PC_REQUIRE(q_token_stride % 4 == 0 && arena_head_stride % 4 == 0, PC_ERR_ARG, "pc_gemm_qkv_rope: strides must keep 8-byte alignment");
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.wf = (const _Float16*)wf_perm; p.xf_hi = (const _Float16*)xf_hi; p.xf_lo = (const _Float16*)xf_lo;
-    p.xn = xn; p.gamma = (const _Float16*)gamma; p.eps = eps;
-    PC_REQUIRE(!wscale || (M <= 64 && (xn || xf_lo) && ((uintptr_t)wscale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,
-               "pc_gemm_qkv_rope_w8: int8 weights need M <= 64, K %% 64 == 0, split-precision activations and 16-byte aligned scales");
-    p.wscale = wscale; p.w8 = wscale ? 1 : 0;
-    PC_REQUIRE(!xscale || fz || (wscale && corr && corr_has && ldc >= N && ldc % 4 == 0 && ((uintptr_t)corr & 15) == 0), PC_ERR_ARG,
-               "pc_gemm_qkv_rope_a8: int8 activations need int8 weights, x_scale, corr (16-byte aligned, ldc >= N) and corr_has");
-    PC_REQUIRE(!fz || (xscale && wscale && fz->flags && fz->xraw && fz->cbt && fz->ldt >= N && K <= 16384 && ((uintptr_t)fz->flags & 15) == 0),
-               PC_ERR_ARG, "pc_gemm_qkv_rope_a8c: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t (ldt >= N), K <= 16384");
-    p.xscale = xscale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
-    if (fz) {
-        p.oflags = (const unsigned char*)fz->flags; p.xraw = (const _Float16*)fz->xraw; p.cbt = (const signed char*)fz->cbt;
-        p.ldt = fz->ldt; p.row_perm = fz->row_perm;
-    }
-    p.y = nullptr; p.ldy = 0; p.of_hi = nullptr; p.of_lo = nullptr; p.KSo = 0;
-    p.M = M; p.ntiles = N / 16; p.KS = K / 32; p.npairs = 0; p.kslices = 1; p.slab_stride = 0;
-    p.rope.cs = (const float2*)cs; p.rope.q_hi = (_Float16*)q_hi; p.rope.q_lo = (_Float16*)q_lo; p.rope.q_ts = q_token_stride;
-    p.rope.k_arena = (_Float16*)k_arena; p.rope.v_arena = (_Float16*)v_arena; p.rope.a_bs = arena_batch_stride;
-    p.rope.a_hs = arena_head_stride; p.rope.past_len_dev = past_len_dev;
-    PC_REQUIRE((k_lo == nullptr) == (v_lo == nullptr) && (!k_lo || lo_hs % 4 == 0), PC_ERR_ARG,
-               "pc_gemm_qkv_rope: k_lo / v_lo go together, strides must keep 8-byte alignment");
-    p.rope.k_lo = (_Float16*)k_lo; p.rope.v_lo = (_Float16*)v_lo; p.rope.lo_bs = lo_bs; p.rope.lo_hs = lo_hs;
-    PC_REQUIRE(lo_base >= -2 && (lo_base != -2 || past_len_dev) && (lo_base < 0 || lo_base <= past_len), PC_ERR_ARG,
-               "pc_gemm_qkv_rope: lo_base must be -1 (pass-relative rows), -2 (past_len_dev[1]) or lie in [0, past_len]");
-    p.rope.lo_base = lo_base;
-    p.rope.H = H; p.rope.Hkv = Hkv; p.rope.D = D; p.rope.q_len = q_len; p.rope.past_len = past_len;
-    p.trace = g_gemm_trace;
-    set_k_balance(p, K);
-    return launch_MT(EPI_ROPE, p, choose_T(p.ntiles), p.ntiles, (hipStream_t)stream);
-}
-}  // namespace
-
 
 PC_EXPORT int pc_rmsnorm_frag(float* x, const void* weight, void* xf_hi, void* xf_lo, int32_t rows,
                               int32_t hidden, float eps, const float* slabs, int32_t nslabs, void* stream) {
@@ -367,108 +308,3 @@ PC_EXPORT int pc_layernorm_frag(float* x, const void* weight, const void* bias, 
     return pc_check_launch("layernorm_frag_kernel");
 }
 
-// ---- int8 weights (the reference's GPU configs load the model with load_in_8bit) ----------------
-// Weight-only int8: wf8 is the fragment image [N/16][K/64][64][16] of OFFSET-BINARY bytes -- a lane's 16 bytes are its 8
-// values of k-step 2s followed by those of k-step 2s + 1 -- (q + 128, q = round(w / scale)
-// per output row, scale = absmax / 127), w_scale[N] fp32 in the row order of the image.  Activations stay split-precision
-// fp16 pairs and accumulation fp32, so y = scale[n] * sum_k q[n][k] * x[k] exactly as an fp32 GEMM over the dequantised
-// weights would give it -- half the weight bytes per launch.  M <= 64 (the weight-streaming regime proper).
-PC_EXPORT int pc_gemm_skinny_w8(const void* wf8, const float* w_scale, const void* xf_hi, const void* xf_lo, int32_t M,
-                                int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo,
-                                int32_t kslices, void* stream) {
-    PC_REQUIRE(xf_hi && xf_lo && w_scale, PC_ERR_ARG, "pc_gemm_skinny_w8: null pointer");
-    return gemm_skinny_impl(wf8, xf_hi, xf_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, kslices, stream,
-                            w_scale);
-}
-
-PC_EXPORT int pc_gemm_skinny_norm_w8(const void* wf8, const float* w_scale, const float* x, const void* norm_weight, float eps,
-                                     int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi,
-                                     void* of_lo, void* stream) {
-    PC_REQUIRE(x && norm_weight && w_scale, PC_ERR_ARG, "pc_gemm_skinny_norm_w8: null pointer");
-    return gemm_skinny_impl(wf8, nullptr, nullptr, x, norm_weight, eps, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream,
-                            w_scale);
-}
-
-PC_EXPORT int pc_gemm_qkv_rope_w8(const void* wf8_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo,
-                                  const float* x, const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs,
-                                  void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
-                                  int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
-                                  int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
-                                  void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, void* stream) {
-    PC_REQUIRE(w_scale_perm && ((xf_hi && xf_lo && !x) || (x && norm_weight && !xf_hi && M <= 16)), PC_ERR_ARG,
-               "pc_gemm_qkv_rope_w8: pass either the activation planes or (x, norm_weight) with M <= 16");
-    return gemm_qkv_rope_impl(wf8_perm, xf_hi, xf_lo, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
-                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm);
-}
-
-// pc_gemm_qkv_rope_ex: the union of the q|k|v entry points (fp16 or int8 weights: w_scale_perm NULL or not; activation
-// planes or the fused-RMSNorm source) plus lo_base, which places the residual rows in a buffer that outlives the pass:
-// row of token tt = tt (-1), past_len + tt - lo_base (>= 0) or past_len + tt - past_len_dev[1] (-2, decode under a hipGraph).
-PC_EXPORT int pc_gemm_qkv_rope_ex(const void* wf_perm, const float* w_scale_perm, const void* xf_hi, const void* xf_lo,
-                                  const float* x, const void* norm_weight, float eps, int32_t M, int32_t K, const float* cs,
-                                  void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena, void* v_arena,
-                                  int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv,
-                                  int32_t D, int32_t q_len, int32_t past_len, int32_t cap, const int32_t* past_len_dev,
-                                  void* k_lo, void* v_lo, int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base,
-                                  void* stream) {
-    PC_REQUIRE((xf_hi && !x) || (x && norm_weight && !xf_hi && M <= 16), PC_ERR_ARG,
-               "pc_gemm_qkv_rope_ex: pass either the activation planes or (x, norm_weight) with M <= 16");
-    return gemm_qkv_rope_impl(wf_perm, xf_hi, xf_lo, x, norm_weight, eps, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
-                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base);
-}
-
-// ---- LLM.int8 (int8 weights AND int8 activations, pc_int8.hip) -------------------------------------------------------
-// xq_hi holds the activation CODES of pc_quant_act_i8 as an fp16 fragment plane (|code| <= 127: exact), xq_lo a plane of zeros;
-// y = (sum_k code_w[n][k] * code_x[m][k]) * w_scale[n] * x_scale[m]  (+ corr[m][n] when *corr_has) through the epilogue.
-// The integer dot product is accumulated in fp32 by the fp16 MFMAs: exact below 2^24 per accumulator.
-PC_EXPORT int pc_gemm_skinny_a8(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
-                                const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K,
-                                int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream) {
-    PC_REQUIRE(xq_hi && xq_lo && w_scale && x_scale, PC_ERR_ARG, "pc_gemm_skinny_a8: null pointer");
-    return gemm_skinny_impl(wf8, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream, w_scale,
-                            x_scale, corr, ldc, corr_has);
-}
-
-PC_EXPORT int pc_gemm_qkv_rope_a8(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
-                                  const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M,
-                                  int32_t K, const float* cs, void* q_hi, void* q_lo, int64_t q_token_stride, void* k_arena,
-                                  void* v_arena, int64_t arena_batch_stride, int64_t arena_head_stride, int32_t B, int32_t H,
-                                  int32_t Hkv, int32_t D, int32_t q_len, int32_t past_len, int32_t cap,
-                                  const int32_t* past_len_dev, void* k_lo, void* v_lo, int64_t lo_batch_stride,
-                                  int64_t lo_head_stride, int32_t lo_base, void* stream) {
-    PC_REQUIRE(xq_hi && xq_lo && w_scale_perm && x_scale, PC_ERR_ARG, "pc_gemm_qkv_rope_a8: null pointer");
-    return gemm_qkv_rope_impl(wf8_perm, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
-                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base,
-                              x_scale, corr, ldc, corr_has);
-}
-
-// pc_gemm_skinny_a8 / pc_gemm_qkv_rope_a8 with the outlier correction computed INSIDE the launch (M <= 64): instead of corr /
-// corr_has the call takes what pc_outlier_corr would have read -- the flag bytes of pc_quant_act_i8 (a buffer of >= 16384 bytes,
-// zero behind K), the fp16 activations x_raw (fragment plane), the transposed int8 weight codes [K][ldt] (original row order) and,
-// for q|k|v, the image-row -> original-row permutation.  Same result up to the fp32 summation order over the outlier columns.
-PC_EXPORT int pc_gemm_skinny_a8c(const void* wf8, const float* w_scale, const void* xq_hi, const void* xq_lo, const float* x_scale,
-                                 const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt, int32_t M, int32_t N,
-                                 int32_t K, int32_t epilogue, float* y, int64_t ldy, void* of_hi, void* of_lo, void* stream) {
-    PC_REQUIRE(xq_hi && xq_lo && w_scale && x_scale, PC_ERR_ARG, "pc_gemm_skinny_a8c: null pointer");
-    const A8Fused fz = {flags, x_raw, w_codes_t, ldt, nullptr};
-    return gemm_skinny_impl(wf8, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, N, K, epilogue, y, ldy, of_hi, of_lo, 1, stream, w_scale,
-                            x_scale, nullptr, 0, nullptr, &fz);
-}
-
-PC_EXPORT int pc_gemm_qkv_rope_a8c(const void* wf8_perm, const float* w_scale_perm, const void* xq_hi, const void* xq_lo,
-                                   const float* x_scale, const void* flags, const void* x_raw, const void* w_codes_t, int64_t ldt,
-                                   const int32_t* row_perm, int32_t M, int32_t K, const float* cs, void* q_hi, void* q_lo,
-                                   int64_t q_token_stride, void* k_arena, void* v_arena, int64_t arena_batch_stride,
-                                   int64_t arena_head_stride, int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t q_len,
-                                   int32_t past_len, int32_t cap, const int32_t* past_len_dev, void* k_lo, void* v_lo,
-                                   int64_t lo_batch_stride, int64_t lo_head_stride, int32_t lo_base, void* stream) {
-    PC_REQUIRE(xq_hi && xq_lo && w_scale_perm && x_scale && row_perm, PC_ERR_ARG, "pc_gemm_qkv_rope_a8c: null pointer");
-    const A8Fused fz = {flags, x_raw, w_codes_t, ldt, row_perm};
-    return gemm_qkv_rope_impl(wf8_perm, xq_hi, xq_lo, nullptr, nullptr, 0.f, M, K, cs, q_hi, q_lo, q_token_stride, k_arena,
-                              v_arena, arena_batch_stride, arena_head_stride, B, H, Hkv, D, q_len, past_len, cap,
-                              past_len_dev, k_lo, v_lo, lo_batch_stride, lo_head_stride, stream, w_scale_perm, lo_base,
-                              x_scale, nullptr, 0, nullptr, &fz);
-}

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
     const _Float16* xh_base = p.xf_hi + lane * 8;
     const _Float16* xl_base = p.xf_lo + lane * 8;
     bool row_ok[1];
-    row_ok[0] = m < p.M;
+    row_ok[0] = m < (p.m_dev ? (*p.m_dev < p.M ? *p.m_dev : p.M) : p.M);
     // the residual tile the last arriver will add to, fetched now (clamped, unconditional; written by that lane only)
     f4 yold;
     {
@@ -132,25 +132,24 @@ PC_EXPORT int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices) {
     return (int64_t)kslices * (N / 16) * 64 * 4 * (int64_t)sizeof(float);
 }
 
+namespace pcg {
 // y[m][n] += sum_k x[m][k] W[n][k]   (M <= 16 rows, split-precision activation planes, fp16 weight image), K cut into
 // `kslices` (1..8) workgroup slices with `tiles_per_wg` (1, 2, 4 or 8) output tiles per workgroup; scratch >=
 // pc_gemm_skinny_ks_scratch_bytes(N, kslices) bytes; counters: ceil(N / 16 / tiles_per_wg) uint32 words, zero before the first
 // launch (every launch leaves them zero).  Deterministic: the partials are added in slice order whoever arrives last.
-PC_EXPORT int pc_gemm_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int32_t M, int32_t N, int32_t K, float* y,
-                                int64_t ldy, int32_t kslices, int32_t tiles_per_wg, void* scratch, int64_t scratch_bytes,
-                                void* counters, void* stream) {
-    PC_REQUIRE(wf && xf_hi && xf_lo && y && scratch && counters, PC_ERR_ARG, "pc_gemm_skinny_ks: null pointer");
+int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M, int N, int K, float* y, int64_t ldy, int kslices,
+                     int tiles_per_wg, void* scratch, int64_t scratch_bytes, void* counters, const int32_t* rows_dev, hipStream_t s) {
+    PC_REQUIRE(wf && xf_hi && xf_lo && y && scratch && counters, PC_ERR_ARG, "pc_gemm (ks): null pointer");
     PC_REQUIRE(M > 0 && M <= 16 && N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0 && ldy >= N && ldy % 4 == 0, PC_ERR_ARG,
-               "pc_gemm_skinny_ks: need 1 <= M <= 16, N %% 16 == 0, K %% 32 == 0");
-    PC_REQUIRE(kslices >= 1 && kslices <= kMaxSlices, PC_ERR_ARG, "pc_gemm_skinny_ks: kslices %d outside 1..8", kslices);
+               "pc_gemm (ks): need 1 <= M <= 16, N %% 16 == 0, K %% 32 == 0");
+    PC_REQUIRE(kslices >= 1 && kslices <= kMaxSlices, PC_ERR_ARG, "pc_gemm (ks): kslices %d outside 1..8", kslices);
     PC_REQUIRE(scratch_bytes >= pc_gemm_skinny_ks_scratch_bytes(N, kslices) && ((uintptr_t)scratch & 15) == 0, PC_ERR_WORKSPACE,
-               "pc_gemm_skinny_ks: scratch too small or misaligned");
+               "pc_gemm (ks): scratch too small or misaligned");
     KsParams kp;
     memset(&kp, 0, sizeof(kp));
     kp.g.wf = (const _Float16*)wf; kp.g.xf_hi = (const _Float16*)xf_hi; kp.g.xf_lo = (const _Float16*)xf_lo;
-    kp.g.y = y; kp.g.ldy = ldy; kp.g.M = M; kp.g.ntiles = N / 16; kp.g.KS = K / 32; kp.g.kslices = kslices;
+    kp.g.y = y; kp.g.ldy = ldy; kp.g.M = M; kp.g.m_dev = rows_dev; kp.g.ntiles = N / 16; kp.g.KS = K / 32; kp.g.kslices = kslices;
     kp.slabs = (float*)scratch; kp.counters = (uint32_t*)counters;
-    hipStream_t s = (hipStream_t)stream;
     // k-steps per block: a wave's K share is K / 32 / (8 kslices) k-steps -- keep the whole share in flight where it fits
     const int share = pc_ceil_div(pc_ceil_div(K / 32, kslices), kWaves);
     switch (tiles_per_wg) {
@@ -160,6 +159,7 @@ PC_EXPORT int pc_gemm_skinny_ks(const void* wf, const void* xf_hi, const void* x
         case 8: return share > 3 ? launch_ks<8, 4>(kp, s) : launch_ks<8, 3>(kp, s);
         default: break;
     }
-    pc_set_error("pc_gemm_skinny_ks: tiles_per_wg %d not in {1, 2, 4, 8}", tiles_per_wg);
+    pc_set_error("pc_gemm (ks): ks_tiles %d not in {1, 2, 4, 8}", tiles_per_wg);
     return PC_ERR_ARG;
 }
+}  // namespace pcg

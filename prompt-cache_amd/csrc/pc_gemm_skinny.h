@@ -76,6 +76,7 @@ struct GemmParams {
     float* y; int64_t ldy;   // EPI_STORE / EPI_ADD
     _Float16* of_hi; _Float16* of_lo; int32_t KSo;  // EPI_SILU: output planes [MT][KSo][64][8]
     int32_t M, ntiles, KS, npairs;
+    const int32_t* m_dev;    // optional device word: rows that really carry tokens (<= M): pad rows behind it are not loaded
     int32_t kslices; int64_t slab_stride;   // EPI_STORE only: grid.y K-slices, slice s writes y + s*slab_stride
     // NORM activation source (M <= 16): the fp32 residual stream itself; RMSNorm is folded into the launch
     const float* xn; const _Float16* gamma; float eps;
@@ -584,8 +585,9 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
     const _Float16* xl_base = TWO ? p.xf_lo + lane * 8 : nullptr;
 
     bool row_ok[MT];
+    const int rows_live = p.m_dev ? (*p.m_dev < p.M ? *p.m_dev : p.M) : p.M;
 #pragma unroll
-    for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < p.M;
+    for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < rows_live;
     int ks = ks0;
     [[maybe_unused]] float ss = 0.f;
     if constexpr (NORM) {
@@ -902,6 +904,9 @@ int launch_skinny_mt2(int epi, const GemmParams& p, int T, int units, hipStream_
 int launch_skinny_mt4(int epi, const GemmParams& p, int T, int units, hipStream_t s);
 // gemm_rows_kernel (65..512 rows), pc_gemm_rows.hip
 int launch_rows_epi(int epi, const GemmParams& p, int units, hipStream_t s);
+// residual add with K split across workgroups, reduced inside the launch (pc_gemm_ks.hip)
+int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M, int N, int K, float* y, int64_t ldy, int kslices,
+                     int tiles_per_wg, void* scratch, int64_t scratch_bytes, void* counters, const int32_t* rows_dev, hipStream_t s);
 int choose_T(int units);
 
 #define PC_SKINNY_MT_DEFINE(NAME, MTV)                                                    \

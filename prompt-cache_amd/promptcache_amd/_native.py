@@ -33,13 +33,30 @@ class AttnArgs(C.Structure):
                 ("counters", _vp)]
 
 
+class GemmArgs(C.Structure):
+    """``pc_gemm_args`` of include/promptcache_hip.h (field for field)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("epilogue", _i32),
+                ("wf", _vp), ("w_scale", _vp), ("xf_hi", _vp), ("xf_lo", _vp),
+                ("x", _vp), ("norm_weight", _vp), ("eps", _f32),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("rows_dev", _vp),
+                ("y", _vp), ("ldy", _i64), ("of_hi", _vp), ("of_lo", _vp), ("kslices", _i32),
+                ("ks_tiles", _i32), ("ks_scratch", _vp), ("ks_scratch_bytes", _i64), ("ks_counters", _vp),
+                ("x_scale", _vp), ("corr", _vp), ("ldc", _i64), ("corr_has", _vp),
+                ("flags", _vp), ("x_raw", _vp), ("w_codes_t", _vp), ("ldt", _i64), ("row_perm", _vp),
+                ("cs", _vp), ("q_hi", _vp), ("q_lo", _vp), ("q_token_stride", _i64), ("k_arena", _vp), ("v_arena", _vp),
+                ("arena_batch_stride", _i64), ("arena_head_stride", _i64),
+                ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
+                ("past_len_dev", _vp), ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64),
+                ("lo_base", _i32)]
+
+
 # name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one
 SIGNATURES = {
     "pc_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "pc_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "pc_dev_gemm_trace": (C.c_int, [_vp]),
     "pc_dev_attn_trace": (C.c_int, [_vp]),
     "pc_gemm_skinny_ks_scratch_bytes": (C.c_int64, [_i32, _i32]),
-    "pc_gemm_skinny_ks": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_version": (C.c_int, []),
     "pc_last_error_string": (C.c_char_p, []),
     "pc_kv_gather": (C.c_int, [C.POINTER(_vp), _pi32, _pi32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -48,13 +65,6 @@ SIGNATURES = {
     "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                  _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_attn_workspace_bytes": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
-    "pc_attn_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
-                              _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "pc_attn_fwd_alibi": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
-                                    _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "pc_attn_fwd_ex": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,
-                                 _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
-                                 _vp, _vp, _vp]),
     "pc_rope_append_ex": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp]),
     "pc_rmsnorm_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
@@ -62,19 +72,7 @@ SIGNATURES = {
     "pc_silu_mul_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pc_gelu_split": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "pc_add3": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "pc_gemm_skinny": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
-    "pc_gemm_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32,
-                                   _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "pc_gemm_skinny_w8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
-    "pc_gemm_skinny_norm_w8": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "pc_gemm_qkv_rope_w8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
-                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "pc_gemm_qkv_rope_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
-                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_rmsnorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
-    "pc_gemm_skinny_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "pc_gemm_qkv_rope_norm": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
-                                        _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "pc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "pc_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "pc_layernorm_frag": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
@@ -84,18 +82,10 @@ SIGNATURES = {
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
     "pc_rope_append_var": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
-    "pc_attn_fwd_var": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
-                                  _i32, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
-    "pc_gemm_skinny_a8c": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "pc_gemm_qkv_rope_a8c": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64,
-                                       _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_rmsnorm_quant_i8": (C.c_int, [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
-    "pc_gemm_skinny_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "pc_gemm_qkv_rope_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
-                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_gemm_dense_a8": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_chain_sync_words": (C.c_int32, []),
@@ -215,76 +205,58 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
              alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None) -> None:
-    """``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum), pc_attn_fwd_var.
-    ``out_frag=(hi, lo)``: write split-precision fragment planes for pc_gemm_skinny instead of ``out``.
-    ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias (pc_attn_fwd_alibi).
-    ``out_lo``: row-major residual plane of ``out``; ``kv_lo=(k_lo, v_lo, batch_stride, head_stride, row0)``: residuals of K/V rows from key index row0 on
-    (written by ``rope_append(..., kv_lo=...)``), both via pc_attn_fwd_ex."""
+    """The attention of one layer through ``pc_attn`` (struct entry; every option is a field).
+    ``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum).
+    ``out_frag=(hi, lo)``: write split-precision fragment planes for the o_proj launch instead of ``out``.
+    ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias.
+    ``out_lo``: row-major residual plane of ``out``; ``kv_lo=(k_lo, v_lo, batch_stride, head_stride, row0)``: residuals of K/V rows
+    from key index row0 on (written by ``rope_append(..., kv_lo=...)`` / the q|k|v projection).
+    ``counters`` (int32 [B*H], zero before first use): merge the split-KV partials inside the launch."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
-    if counters is not None:
-        # the struct-taking entry (pc_attn): everything the wrappers below take, plus the arrival counters of the
-        # single-launch split-KV merge (int32/uint32 [B*H], zero before first use; every launch leaves them zero)
-        kpos, slopes = (None, None) if alibi is None else alibi
-        lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
-        a = AttnArgs(C.sizeof(AttnArgs), q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
-                     _ptr(out), _ptr(out_lo), o_bs, o_ts, _ptr(fh), _ptr(fl), B, H, Hkv, D, q_len, past_len, scale,
-                     _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(past_lens), _ptr(kpos),
-                     0 if kpos is None else kpos.stride(0), _ptr(slopes), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4],
-                     counters.data_ptr())
-        rc = load().pc_attn(C.byref(a), current_stream() if stream is None else stream)
-        check(rc, "pc_attn")
-        return
-    if past_lens is not None:
-        assert alibi is None and out_frag is None and past_len_dev is None and (kv_lo is None or kv_lo[4] == 0)
-        rc = load().pc_attn_fwd_var(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, _ptr(out),
-                                    _ptr(out_lo), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, past_lens.data_ptr(), scale,
-                                    _ptr(workspace), ws_bytes, None if kv_lo is None else kv_lo[0].data_ptr(),
-                                    None if kv_lo is None else kv_lo[1].data_ptr(), 0 if kv_lo is None else kv_lo[2],
-                                    0 if kv_lo is None else kv_lo[3], current_stream() if stream is None else stream)
-        check(rc, "pc_attn_fwd_var")
-        return
-    if out_lo is not None or kv_lo is not None:
-        kpos, slopes = (None, None) if alibi is None else alibi
-        rc = load().pc_attn_fwd_ex(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
-                                   _ptr(out), _ptr(out_lo), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
-                                   _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(kpos),
-                                   0 if kpos is None else kpos.stride(0), _ptr(slopes),
-                                   None if kv_lo is None else kv_lo[0].data_ptr(), None if kv_lo is None else kv_lo[1].data_ptr(),
-                                   0 if kv_lo is None else kv_lo[2], 0 if kv_lo is None else kv_lo[3], 0 if kv_lo is None else kv_lo[4],
-                                   _ptr(fh), _ptr(fl), current_stream() if stream is None else stream)
-        check(rc, "pc_attn_fwd_ex")
-        return
-    if alibi is not None:
-        kpos, slopes = alibi
-        rc = load().pc_attn_fwd_alibi(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
-                                      _ptr(out), o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, _ptr(workspace), ws_bytes,
-                                      _ptr(past_len_dev), _ptr(fh), _ptr(fl), kpos.data_ptr(), kpos.stride(0),
-                                      slopes.data_ptr(), current_stream() if stream is None else stream)
-        check(rc, "pc_attn_fwd_alibi")
-        return
-    rc = load().pc_attn_fwd(q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs, _ptr(out),
-                            o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, _ptr(workspace), ws_bytes,
-                            _ptr(past_len_dev), _ptr(fh), _ptr(fl), current_stream() if stream is None else stream)
-    check(rc, "pc_attn_fwd")
+    kpos, slopes = (None, None) if alibi is None else alibi
+    lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
+    a = AttnArgs(C.sizeof(AttnArgs), q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
+                 _ptr(out), _ptr(out_lo), o_bs, o_ts, _ptr(fh), _ptr(fl), B, H, Hkv, D, q_len, past_len, scale,
+                 _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(past_lens), _ptr(kpos),
+                 0 if kpos is None else kpos.stride(0), _ptr(slopes), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4],
+                 _ptr(counters))
+    rc = load().pc_attn(C.byref(a), current_stream() if stream is None else stream)
+    check(rc, "pc_attn")
 
 
 EPI_STORE, EPI_ADD, EPI_SILU, EPI_GELU = 0, 1, 2, 4
 
 
+EPI_QKV_ROPE = 3
+
+
+def _gemm(stream=None, **f) -> None:
+    """One ``pc_gemm`` call: keyword = field of ``pc_gemm_args`` (tensors become pointers, everything else 0 / NULL)."""
+    a = GemmArgs()
+    a.struct_bytes = C.sizeof(GemmArgs)
+    a.kslices, a.lo_base = 1, -1
+    for k, v in f.items():
+        if v is None:
+            continue
+        setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    rc = load().pc_gemm(C.byref(a), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm")
+
+
+def _qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base):
+    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
+    return dict(epilogue=EPI_QKV_ROPE, cs=cs, q_hi=q_hi, q_lo=q_lo, q_token_stride=q_ts, k_arena=k_arena, v_arena=v_arena,
+                arena_batch_stride=a_bs, arena_head_stride=a_hs, B=B, H=H, Hkv=Hkv, D=D, q_len=q_len, past_len=past_len, cap=cap,
+                past_len_dev=past_len_dev, k_lo=lo[0], v_lo=lo[1], lo_batch_stride=lo[2], lo_head_stride=lo[3], lo_base=lo_base)
+
+
 def gemm_skinny(wf, xf_hi, xf_lo, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0, of_hi=None, of_lo=None,
-                kslices: int = 1, stream: Optional[int] = None, wscale=None) -> None:
+                kslices: int = 1, stream: Optional[int] = None, wscale=None, rows_dev=None) -> None:
     """``kslices > 1`` (plain-store epilogue): ``y`` is ``[kslices][M][ldy]`` slabs of partial sums.
-    ``wscale`` (fp32 [N]): ``wf`` is an int8 fragment image (``to_weight_frags_i8``) -> pc_gemm_skinny_w8."""
-    if wscale is not None:
-        rc = load().pc_gemm_skinny_w8(wf.data_ptr(), wscale.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue,
-                                      _ptr(y), ldy, _ptr(of_hi), _ptr(of_lo), kslices,
-                                      current_stream() if stream is None else stream)
-        check(rc, "pc_gemm_skinny_w8")
-        return
-    rc = load().pc_gemm_skinny(wf.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, N, K, epilogue, _ptr(y), ldy,
-                               _ptr(of_hi), _ptr(of_lo), kslices, current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_skinny")
+    ``wscale`` (fp32 [N]): ``wf`` is an int8 fragment image (``to_weight_frags_i8``)."""
+    _gemm(stream, epilogue=epilogue, wf=wf, w_scale=wscale, xf_hi=xf_hi, xf_lo=xf_lo, M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi,
+          of_lo=of_lo, kslices=kslices, rows_dev=rows_dev)
 
 
 def gemm_skinny_ks_scratch_bytes(N: int, kslices: int) -> int:
@@ -292,41 +264,21 @@ def gemm_skinny_ks_scratch_bytes(N: int, kslices: int) -> int:
 
 
 def gemm_skinny_ks(wf, xf_hi, xf_lo, M: int, N: int, K: int, y, ldy: int, kslices: int, tiles_per_wg: int, scratch, counters,
-                   stream: Optional[int] = None) -> None:
+                   stream: Optional[int] = None, rows_dev=None) -> None:
     """``y += x @ W^T`` (M <= 16) with K split over ``kslices`` workgroup slices and the reduction inside the launch;
     ``counters`` (int32 [ceil(N/16/tiles_per_wg)]) must be zero before the first launch (launches leave them zero)."""
-    rc = load().pc_gemm_skinny_ks(wf.data_ptr(), xf_hi.data_ptr(), xf_lo.data_ptr(), M, N, K, y.data_ptr(), ldy, kslices,
-                                  tiles_per_wg, scratch.data_ptr(), scratch.numel() * scratch.element_size(),
-                                  counters.data_ptr(), current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_skinny_ks")
+    _gemm(stream, epilogue=EPI_ADD, wf=wf, xf_hi=xf_hi, xf_lo=xf_lo, M=M, N=N, K=K, y=y, ldy=ldy, kslices=kslices,
+          ks_tiles=tiles_per_wg, ks_scratch=scratch, ks_scratch_bytes=scratch.numel() * scratch.element_size(), ks_counters=counters,
+          rows_dev=rows_dev)
 
 
 def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,
                   past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None, wscale=None,
-                  lo_base: int = -1) -> None:
-    """``kv_lo=(k_lo, v_lo, batch_stride, head_stride)``: also write the fp16 residuals of the new K / V rows (compact
-    ``[B][Hkv][q_len][D]``) for ``attn_fwd(..., kv_lo=(k_lo, v_lo, bs, hs, -1))``."""
-    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
-    if lo_base != -1:            # a residual tail that outlives the pass (decode): pc_gemm_qkv_rope_ex
-        rc = load().pc_gemm_qkv_rope_ex(wf_perm.data_ptr(), _ptr(wscale), xf_hi.data_ptr(), _ptr(xf_lo), None, None, 0.0,
-                                        M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
-                                        v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
-                                        _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo_base,
-                                        current_stream() if stream is None else stream)
-        check(rc, "pc_gemm_qkv_rope_ex")
-        return
-    if wscale is not None:
-        rc = load().pc_gemm_qkv_rope_w8(wf_perm.data_ptr(), wscale.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), None, None, 0.0,
-                                        M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
-                                        v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
-                                        _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], current_stream() if stream is None else stream)
-        check(rc, "pc_gemm_qkv_rope_w8")
-        return
-    rc = load().pc_gemm_qkv_rope(wf_perm.data_ptr(), xf_hi.data_ptr(), _ptr(xf_lo), M, K, cs.data_ptr(), q_hi.data_ptr(),
-                                 q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D,
-                                 q_len, past_len, cap, _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3],
-                                 current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_qkv_rope")
+                  lo_base: int = -1, rows_dev=None) -> None:
+    """``kv_lo=(k_lo, v_lo, batch_stride, head_stride)``: also write the fp16 residuals of the new K / V rows; ``lo_base``
+    places them (-1: compact ``[B][Hkv][q_len][D]`` rows of this pass; >= 0 / -2: a residual tail that outlives the pass)."""
+    _gemm(stream, wf=wf_perm, w_scale=wscale, xf_hi=xf_hi, xf_lo=xf_lo, M=M, K=K, rows_dev=rows_dev,
+          **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
 
 
 def layernorm(x_f32, weight, bias, out, rows: int, hidden: int, eps: float, stream: Optional[int] = None) -> None:
@@ -348,44 +300,17 @@ def gelu(x_f32, out, n: int, stream: Optional[int] = None) -> None:
 
 
 def gemm_skinny_norm(wf, x_f32, norm_weight, eps: float, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,
-                     of_hi=None, of_lo=None, stream: Optional[int] = None, wscale=None) -> None:
+                     of_hi=None, of_lo=None, stream: Optional[int] = None, wscale=None, rows_dev=None) -> None:
     """RMSNorm folded into the projection (M <= 16): y = W . (norm_weight * x) * rsqrt(mean(x^2) + eps)."""
-    if wscale is not None:
-        rc = load().pc_gemm_skinny_norm_w8(wf.data_ptr(), wscale.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, N,
-                                           K, epilogue, _ptr(y), ldy, _ptr(of_hi), _ptr(of_lo),
-                                           current_stream() if stream is None else stream)
-        check(rc, "pc_gemm_skinny_norm_w8")
-        return
-    rc = load().pc_gemm_skinny_norm(wf.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, N, K, epilogue, _ptr(y),
-                                    ldy, _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_skinny_norm")
+    _gemm(stream, epilogue=epilogue, wf=wf, w_scale=wscale, x=x_f32, norm_weight=norm_weight, eps=eps, M=M, N=N, K=K, y=y, ldy=ldy,
+          of_hi=of_hi, of_lo=of_lo, rows_dev=rows_dev)
 
 
 def gemm_qkv_rope_norm(wf_perm, x_f32, norm_weight, eps: float, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H,
                        Hkv, D, q_len, past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None,
-                       wscale=None, lo_base: int = -1) -> None:
-    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
-    if lo_base != -1:
-        rc = load().pc_gemm_qkv_rope_ex(wf_perm.data_ptr(), _ptr(wscale), None, None, x_f32.data_ptr(), norm_weight.data_ptr(),
-                                        eps, M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(),
-                                        v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev),
-                                        _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo_base,
-                                        current_stream() if stream is None else stream)
-        check(rc, "pc_gemm_qkv_rope_ex")
-        return
-    if wscale is not None:
-        rc = load().pc_gemm_qkv_rope_w8(wf_perm.data_ptr(), wscale.data_ptr(), None, None, x_f32.data_ptr(),
-                                        norm_weight.data_ptr(), eps, M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts,
-                                        k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap,
-                                        _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3],
-                                        current_stream() if stream is None else stream)
-        check(rc, "pc_gemm_qkv_rope_w8")
-        return
-    rc = load().pc_gemm_qkv_rope_norm(wf_perm.data_ptr(), x_f32.data_ptr(), norm_weight.data_ptr(), eps, M, K, cs.data_ptr(),
-                                      q_hi.data_ptr(), q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs,
-                                      a_hs, B, H, Hkv, D, q_len, past_len, cap, _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]),
-                                      lo[2], lo[3], current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_qkv_rope_norm")
+                       wscale=None, lo_base: int = -1, rows_dev=None) -> None:
+    _gemm(stream, wf=wf_perm, w_scale=wscale, x=x_f32, norm_weight=norm_weight, eps=eps, M=M, K=K, rows_dev=rows_dev,
+          **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
 
 
 def qkv_rope_row_perm(n_heads_total: int, D: int):
@@ -597,24 +522,17 @@ def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags
 
 def gemm_skinny_a8c(wf8, w_scale, xq, zeros, x_scale, flags, x_raw, w_codes_t, M: int, N: int, K: int, epilogue: int, y=None,
                     ldy: int = 0, of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
-    """pc_gemm_skinny_a8 with the LLM.int8 outlier correction inside the launch (``flags``: >= 16384 bytes)."""
-    rc = load().pc_gemm_skinny_a8c(wf8.data_ptr(), w_scale.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
-                                   flags.data_ptr(), x_raw.data_ptr(), w_codes_t.data_ptr(), w_codes_t.stride(-2), M, N, K, epilogue,
-                                   _ptr(y), ldy, _ptr(of_hi), _ptr(of_lo), current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_skinny_a8c")
+    """LLM.int8 projection over the code plane ``xq`` with the outlier correction inside the launch (``flags``: >= 16384 bytes)."""
+    _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, flags=flags, x_raw=x_raw,
+          w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi, of_lo=of_lo)
 
 
 def gemm_qkv_rope_a8c(wf8_perm, w_scale_perm, xq, zeros, x_scale, flags, x_raw, w_codes_t, row_perm, M, K, cs, q_hi, q_lo, q_ts,
                       k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev=None, kv_lo=None,
                       lo_base: int = -1, stream: Optional[int] = None) -> None:
-    lo = (None, None, 0, 0) if kv_lo is None else kv_lo
-    rc = load().pc_gemm_qkv_rope_a8c(wf8_perm.data_ptr(), w_scale_perm.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
-                                     flags.data_ptr(), x_raw.data_ptr(), w_codes_t.data_ptr(), w_codes_t.stride(-2),
-                                     row_perm.data_ptr(), M, K, cs.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), q_ts,
-                                     k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap,
-                                     _ptr(past_len_dev), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo_base,
-                                     current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_qkv_rope_a8c")
+    _gemm(stream, wf=wf8_perm, w_scale=w_scale_perm, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, flags=flags, x_raw=x_raw,
+          w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), row_perm=row_perm, M=M, K=K,
+          **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
 
 
 def rmsnorm_quant_i8(x, norm_weight, eps: float, T: int, hidden: int, x_hi, codes, x_scale, flags_set, flags_clear=None,
@@ -639,22 +557,16 @@ def outlier_corr(flags, K: int, x, codes, frag: bool, x_scale, w_codes_t, w_scal
 
 def gemm_skinny_a8(wf8, w_scale, xq, zeros, x_scale, corr, has, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,
                    of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
-    rc = load().pc_gemm_skinny_a8(wf8.data_ptr(), w_scale.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
-                                  corr.data_ptr(), corr.stride(-2), has.data_ptr(), M, N, K, epilogue, _ptr(y), ldy, _ptr(of_hi),
-                                  _ptr(of_lo), current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_skinny_a8")
+    _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, corr=corr, ldc=corr.stride(-2),
+          corr_has=has, M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi, of_lo=of_lo)
 
 
 def gemm_qkv_rope_a8(wf8, w_scale, xq, zeros, x_scale, corr, has, M: int, K: int, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs,
                      B, H, Hkv, D, q_len, past_len, cap, past_len_dev=None, kv_lo=None, lo_base: int = -1,
                      stream: Optional[int] = None) -> None:
-    rc = load().pc_gemm_qkv_rope_a8(wf8.data_ptr(), w_scale.data_ptr(), xq.data_ptr(), zeros.data_ptr(), x_scale.data_ptr(),
-                                    corr.data_ptr(), corr.stride(-2), has.data_ptr(), M, K, cs.data_ptr(), q_hi.data_ptr(),
-                                    q_lo.data_ptr(), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs, B, H, Hkv, D, q_len,
-                                    past_len, cap, _ptr(past_len_dev), None if not kv_lo else kv_lo[0].data_ptr(),
-                                    None if not kv_lo else kv_lo[1].data_ptr(), 0 if not kv_lo else kv_lo[2],
-                                    0 if not kv_lo else kv_lo[3], lo_base, current_stream() if stream is None else stream)
-    check(rc, "pc_gemm_qkv_rope_a8")
+    _gemm(stream, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, corr=corr, ldc=corr.stride(-2), corr_has=has, M=M, K=K,
+          **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev,
+                        kv_lo[:4] if kv_lo else None, lo_base))
 
 
 def gemm_dense_a8(xq, w_codes, w_scale, x_scale, corr, has, M: int, N: int, K: int, epilogue: int, y=None, out_hi=None, out_lo=None,

@@ -734,6 +734,7 @@ class LlamaHIP:
         # fp16 weights: everything between two attention calls -- o_proj, gate|up, down_proj and the NEXT layer's q|k|v -- is
         # one persistent launch (pc_gemm_chain: the same four bodies, bit-identical, but the weight stream runs through
         # the seams); three launches per layer instead of six.  Shapes without an instantiation fall back here.
+        rows_dev = past_dev[2:3] if (past_dev is not None and past_dev.numel() > 2 and B == 1) else None
         chain = self.use_chain and layers and layers[0]["wqkv_s"] is None
         if chain and self._chain_sync is None:
             self._chain_sync = n.chain_sync_state(self.device)
@@ -744,7 +745,7 @@ class LlamaHIP:
             if not qkv_done:
                 n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], eps, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                                      arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
-                                     kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"], lo_base=lo_base)
+                                     kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"], lo_base=lo_base, rows_dev=rows_dev)
             qkv_done = False
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
@@ -767,30 +768,32 @@ class LlamaHIP:
                     chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
             if self.ks_o and lw["wo_s"] is None and T >= self.ks_min_rows:
                 sc, ctr = self._ks_buffers(hid)
-                n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr)
+                n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr, rows_dev=rows_dev)
             else:
-                n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"])  # x += attn @ Wo^T
+                n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"], rows_dev=rows_dev)  # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
-                               wscale=lw["wgu_s"])
+                               wscale=lw["wgu_s"], rows_dev=rows_dev)
             if self.ks_down and lw["wdown_s"] is None and T >= self.ks_min_rows and inter >= 2 * hid:
                 sc, ctr = self._ks_buffers(hid)
-                n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, x, hid, self.ks_down[1], self.ks_down[0], sc, ctr)
+                n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, x, hid, self.ks_down[1], self.ks_down[0], sc, ctr, rows_dev=rows_dev)
             else:
-                n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wdown_s"])  # x += act @ Wd^T
+                n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wdown_s"], rows_dev=rows_dev)  # x += act @ Wd^T
         if last_token_only:
             xs = x.view(B, q_len, hid)[:, -1, :].contiguous()
             logits = torch.empty((B, V), dtype=torch.float32, device=self.device)
             n.gemm_skinny_norm(self.lm_head_f, xs, self.norm, eps, B, V, hid, n.EPI_STORE, y=logits, ldy=V)
             return logits.view(B, 1, V)
         logits = torch.empty((T, V), dtype=torch.float32, device=self.device)
-        n.gemm_skinny_norm(self.lm_head_f, x, self.norm, eps, T, V, hid, n.EPI_STORE, y=logits, ldy=V)
+        n.gemm_skinny_norm(self.lm_head_f, x, self.norm, eps, T, V, hid, n.EPI_STORE, y=logits, ldy=V, rows_dev=rows_dev)
         return logits.view(B, q_len, V)
 
     # rows a captured small-q graph is padded to (B = 1, q > 1): a prompt of q new tokens replays the graph of its bucket with
     # pad tokens BEHIND its own (under the causal mask nothing reaches back from them; their K/V rows lie past the arena's
     # length and are overwritten by the first decode steps), so a question length seen for the first time does not pay an
     # eager pass + capture (cold-shape TTFT 9.5-10.7 ms against ~4 ms warm) as long as its bucket was seen.  0 = exact q.
-    graph_row_bucket = int(os.environ.get("PC_GRAPH_BUCKET", "4"))
+    # The projections read the number of LIVE rows from a device word next to past_len (pc_gemm rows_dev) and do not load the
+    # pad rows' activations, so one graph per row tile (16) costs the 12-row headline prompt nothing measurable.
+    graph_row_bucket = int(os.environ.get("PC_GRAPH_BUCKET", "16"))
 
     def _graph_rows(self, arena, B: int, q_len: int, past_len: int, last_token_only: bool) -> int:
         g = self.graph_row_bucket
@@ -823,8 +826,9 @@ class LlamaHIP:
             T = B * q_len
             st_ids = torch.zeros(T, dtype=torch.int64, device=self.device)
             st_pos = torch.zeros(T, dtype=torch.int32, device=self.device)
-            st_past = torch.zeros(2, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail}
+            st_past = torch.zeros(3, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail, live rows}
             st_ids[:q_real * B].copy_(ids); st_pos[:q_real * B].copy_(pos32); st_past[0:1].fill_(past_len)
+            st_past[2:3].fill_(q_real * B)
             if mode == 2:
                 st_past[1:2].fill_(arena.tail_base)
             # one eager pass first (loads code objects / sizes the allocator), then capture
@@ -845,6 +849,7 @@ class LlamaHIP:
             st_ids.copy_(ids)
             st_pos.copy_(pos32)
         st_past[0:1].fill_(past_len)
+        st_past[2:3].fill_(q_real * B)       # rows that carry tokens: the projections do not load the pad rows' activations
         if mode == 2:
             st_past[1:2].fill_(arena.tail_base)
         g.replay()

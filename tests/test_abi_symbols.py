@@ -9,15 +9,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     names = []
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+    for h in _abi_headers():
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
         names += re.findall(r"\b(pc_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 
+def _abi_headers():
+    """The headers that DECLARE exported symbols (promptcache_hip_compat.h holds inline wrappers only: nothing to export)."""
+    return [h for h in glob.glob(os.path.join(ROOT, "include", "*.h")) if not h.endswith("_compat.h")]
+
+
 def test_header_declares_the_hot_path_entry_points():
     d = _declared()
-    for must in ("pc_kv_gather", "pc_kv_slice_store", "pc_rope_table", "pc_rope_append", "pc_attn_fwd",
+    for must in ("pc_kv_gather", "pc_kv_slice_store", "pc_rope_table", "pc_rope_append", "pc_attn", "pc_gemm",
                  "pc_attn_workspace_bytes", "pc_version", "pc_last_error_string"):
         assert must in d
 
@@ -45,7 +50,7 @@ def test_argument_errors_need_no_gpu():
 def _declared_arity():
     """name -> number of parameters of every ``pc_*`` prototype in include/*.h."""
     out = {}
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+    for h in _abi_headers():
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
         for m in re.finditer(r"\b(pc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
             params = m.group(2).strip()
@@ -60,3 +65,28 @@ def test_ctypes_signatures_have_the_arity_of_the_header_prototypes():
     assert sorted(arity) == _declared()
     for name, (_, argtypes) in _native.SIGNATURES.items():
         assert len(argtypes) == arity[name], (name, len(argtypes), arity[name])
+
+
+def test_struct_layouts_match_the_header_and_the_compat_wrappers_compile(tmp_path):
+    """ctypes mirrors of pc_attn_args / pc_gemm_args have the size and field offsets the C compiler gives the header's structs
+    (a field added on one side only would shift every later one silently), and include/promptcache_hip_compat.h -- the round
+    1-2 entry-point names as inline wrappers -- is valid C and C++."""
+    import subprocess
+    from promptcache_amd import _native
+    src = tmp_path / "layout.c"
+    fields = {"pc_attn_args": [f[0] for f in _native.AttnArgs._fields_], "pc_gemm_args": [f[0] for f in _native.GemmArgs._fields_]}
+    body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/promptcache_hip_compat.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        body.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            body.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    body += ['  return 0;', '}']
+    src.write_text("\n".join(body))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-unused-function", str(src), "-o", str(exe)])
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", str(src)])
+    got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).strip().splitlines())
+    for st, cls in (("pc_attn_args", _native.AttnArgs), ("pc_gemm_args", _native.GemmArgs)):
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for name, _ in cls._fields_:
+            assert int(got[f"{st}.{name}"]) == getattr(cls, name).offset, (st, name)

@@ -142,13 +142,14 @@ def gemm_rooflines(lm, T: int):
     """Event-time the weight-streaming launches of one decoder layer eagerly on every layer's real weights -- kernels inside
     the captured graph cannot be bracketed by events; the in-graph durations are in profiles/ (rocprofv3).  32 distinct weight
     sets (13 GB) are cycled, so nothing is served from the 256 MB Infinity Cache.
-    -> (dominant, gate_up): `dominant` = the N = hidden projections (o_proj + down_proj, EPI_ADD), the largest share of the
-    timed step by kernel time; `gate_up` = the heaviest single launch."""
+    -> (dominant, extra): `dominant` = the gate|up projection (RMSNorm + SiLU*up fused), the largest single kernel of the timed
+    step by time (profiles/r03_bench_kernel_stats.txt); `extra` = {"roofline_nhidden": o_proj + down_proj with the residual add
+    as the step dispatches them, "roofline_qkv": q|k|v + RMSNorm + RoPE + append}."""
     import torch
     from promptcache_amd import _native as n
     m = lm.hf_model
     c = m.config
-    hid, inter, HD = c.hidden_size, c.intermediate_size, m.H * m.D
+    hid, inter, HD, H, Hkv, D = c.hidden_size, c.intermediate_size, m.H * m.D, m.H, m.Hkv, m.D
     mt = (T + 15) // 16
     x = torch.randn((T, hid), device=m.device)
     xres = torch.zeros((T, hid), device=m.device)
@@ -157,8 +158,12 @@ def gemm_rooflines(lm, T: int):
     ch, cl = n.to_act_frags(torch.randn((T, inter), device=m.device))
     oh = torch.empty((mt, inter // 32, 64, 8), dtype=torch.float16, device=m.device)
     ol = torch.empty_like(oh)
+    cs = torch.zeros((T, D // 2, 2), dtype=torch.float32, device=m.device); cs[..., 0] = 1
+    q16 = torch.empty((T, HD), dtype=torch.float16, device=m.device); q16l = torch.empty_like(q16)
+    kv = torch.zeros((2, Hkv, 64, D), dtype=torch.float16, device=m.device)
     fused = T <= m.NORM_FUSED_MAX_ROWS and m.fuse_norm      # what the timed step launches for this many rows
-    ev = {"gu": [], "o": [], "down": []}
+    ks_down = fused and m.ks_down and T >= m.ks_min_rows and inter >= 2 * hid
+    ev = {"gu": [], "o": [], "down": [], "qkv": []}
 
     def timed(key, fn, keep):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -166,13 +171,22 @@ def gemm_rooflines(lm, T: int):
         if keep:
             ev[key].append((e0, e1))
 
+    def down(lw):
+        if ks_down:
+            sc, ctr = m._ks_buffers(hid)
+            n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, xres, hid, m.ks_down[1], m.ks_down[0], sc, ctr)
+        else:
+            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=xres, ldy=hid)
+
     for rep_ in range(3):
         for lw in m.layers:
             if fused:
+                timed("qkv", lambda: n.gemm_qkv_rope_norm(lw["wqkv_f"], x, lw["ln1"], c.rms_norm_eps, T, hid, cs, q16, q16l, HD, kv[0], kv[1],
+                                                          0, 64 * D, 1, H, Hkv, D, T, 0, 64), rep_ > 0)
                 timed("gu", lambda: n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], c.rms_norm_eps, T, 2 * inter, hid, n.EPI_SILU,
                                                        of_hi=oh, of_lo=ol), rep_ > 0)
                 timed("o", lambda: n.gemm_skinny(lw["wo_f"], ah, al, T, hid, HD, n.EPI_ADD, y=xres, ldy=hid), rep_ > 0)
-                timed("down", lambda: n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_ADD, y=xres, ldy=hid), rep_ > 0)
+                timed("down", lambda: down(lw), rep_ > 0)
             else:
                 timed("gu", lambda: n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=oh, of_lo=ol), rep_ > 0)
     torch.cuda.synchronize()
@@ -181,33 +195,41 @@ def gemm_rooflines(lm, T: int):
         v = sorted(a.elapsed_time(b) * 1e3 for a, b in ev[key])
         return (sum(v) / len(v), v[0], len(v)) if v else (None, None, 0)
 
+    how = ("HIP events on the launch stream around eager launches on each layer's weights right after the timed region (kernels "
+           "inside the captured hipGraph of the timed step cannot be bracketed; event pairs include ~2 us of launch gap); the "
+           "in-graph average of the same kernel is in profiles/r03_bench_kernel_stats.txt")
     sig = f"T={T},hid={hid},inter={inter}"
     gu_avg, gu_min, gu_n = us("gu")
     nb_gu = 2 * inter * hid * 2
     tr, src = _pmc_traffic("gemm_skinny_gate_up", sig)
-    gate_up = {"kernel": "gemm_skinny_kernel<EPI_SILU> (gate|up projection + SiLU*up)", "bound": "hbm",
+    gate_up = {"kernel": "gemm_skinny_kernel<1,3,EPI_SILU,NORM> (gate|up projection with RMSNorm and SiLU*up fused): the largest "
+                         "single kernel of the timed step by time", "bound": "hbm",
                "achieved": nb_gu / (gu_avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": nb_gu / (gu_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
                "algorithmic_bytes_per_launch": nb_gu, "avg_launch_us": gu_avg, "min_launch_us": gu_min, "launches_timed": gu_n,
-               "launches_per_step": c.num_hidden_layers}
-    dominant = None
+               "launches_per_step": c.num_hidden_layers, "how": how}
+    extra = {}
     if fused:
         o_avg, o_min, o_n = us("o")
         d_avg, d_min, _ = us("down")
-        nb_o, nb_d = hid * HD * 2, hid * inter * 2
+        q_avg, q_min, q_n = us("qkv")
+        nb_o, nb_d, nb_q = hid * HD * 2, hid * inter * 2, (H + 2 * Hkv) * D * hid * 2
         tr, src = _pmc_traffic("gemm_skinny_add", sig)
         ach = (nb_o + nb_d) / ((o_avg + d_avg) * 1e-6) / 1e9
-        dominant = {"kernel": "gemm_skinny_kernel<EPI_ADD> (o_proj + down_proj with the residual add: the N = hidden "
-                              "projections, largest share of the timed step by kernel time)", "bound": "hbm",
-                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr,
-                    "traffic_source": src, "algorithmic_bytes_per_launch": (nb_o + nb_d) / 2,
-                    "avg_launch_us": (o_avg + d_avg) / 2, "o_proj_us": o_avg, "down_proj_us": d_avg,
-                    "min_launch_us": min(o_min, d_min), "launches_timed": 2 * o_n, "launches_per_step": 2 * c.num_hidden_layers,
-                    "how": "HIP events on the launch stream around eager launches on each layer's weights right after the "
-                           "timed region (kernels inside the captured hipGraph of the timed step cannot be bracketed; event "
-                           "pairs include ~2 us of launch gap); the in-graph average of the same kernel is in "
-                           "profiles/r02_bench_kernel_stats.txt"}
-    return dominant, gate_up
+        extra["roofline_nhidden"] = {
+            "kernel": "o_proj (gemm_skinny_kernel<1,1,EPI_ADD>) + down_proj (" +
+                      (f"gemm_skinny_ks_kernel: {m.ks_down[0]} tiles x {m.ks_down[1]} K slices, reduced inside the launch"
+                       if ks_down else "gemm_skinny_kernel<1,1,EPI_ADD>") + "), residual add fused", "bound": "hbm",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
+            "algorithmic_bytes_per_launch": (nb_o + nb_d) / 2, "avg_launch_us": (o_avg + d_avg) / 2, "o_proj_us": o_avg,
+            "down_proj_us": d_avg, "min_launch_us": min(o_min, d_min), "launches_timed": 2 * o_n,
+            "launches_per_step": 2 * c.num_hidden_layers, "how": how}
+        extra["roofline_qkv"] = {"kernel": "gemm_skinny_kernel<1,3,EPI_ROPE,NORM> (q|k|v + RMSNorm + RoPE + in-place KV append)",
+                                 "bound": "hbm", "achieved": nb_q / (q_avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": nb_q / (q_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_launch": nb_q, "avg_launch_us": q_avg, "min_launch_us": q_min,
+                                 "launches_timed": q_n, "launches_per_step": c.num_hidden_layers, "how": how}
+    return gate_up, extra
 
 
 def attn_roofline(lm, staged, q_len: int):
@@ -236,14 +258,14 @@ def attn_roofline(lm, staged, q_len: int):
     us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
     avg = sum(us) / len(us)
     nbytes = 2 * Hkv * (S + q_len) * D * 2 + 2 * H * q_len * D * 2
-    return {"kernel": "attn_small_kernel<128> + attn_combine_kernel (pc_attn_fwd, cached prefill)", "bound": "hbm",
+    return {"kernel": "attn_small_kernel<128> + attn_combine_kernel (pc_attn, cached prefill)", "bound": "hbm",
             "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "traffic": _pmc_traffic("attn_cached", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[0],
             "traffic_source": _pmc_traffic("attn_cached", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[1],
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": avg, "min_launch_us": us[0],
             "launches_timed": len(us), "launches_per_step": m.L,
-            "how": "HIP events around eager pc_attn_fwd calls (two kernels: split-KV attention + merge) on each layer's "
+            "how": "HIP events around eager pc_attn calls (two kernels: split-KV attention + merge) on each layer's "
                    "staged K/V after the timed region; latency-bound at this size (28.5 MB per launch), see DESIGN.md 3.2"}
 
 
@@ -518,18 +540,26 @@ def main():
     planes = 2 if lm.hf_model.precise_dense else 1
     macs_tok = (mcfg.hidden_size * (lm.hf_model.H + 2 * lm.hf_model.Hkv) * lm.hf_model.D + lm.hf_model.H * lm.hf_model.D * mcfg.hidden_size
                 + 3 * mcfg.hidden_size * mcfg.intermediate_size)          # projection MACs per token per layer
-    enc_flops = 2.0 * planes * macs_tok * mcfg.num_hidden_layers * int(sc.encode_stats["computed_tokens"])
-    enc_per_rank = [int(sc.encode_stats["computed_tokens"])]
+    comp_tokens = int(sc.encode_stats["computed_tokens"])
+    enc_flops_alg = 2.0 * macs_tok * mcfg.num_hidden_layers * comp_tokens          # 2 * P per token that runs
+    enc_flops = planes * enc_flops_alg                                              # what the MFMAs execute (hi + lo planes)
+    enc_per_rank = [comp_tokens]
     if world > 1:
         t = torch.zeros(world, dtype=torch.int64, device=device)
         t[rank] = enc_per_rank[0]
         dist.all_reduce(t)
         enc_per_rank = [int(v) for v in t.tolist()]
-    encode = {"per_rank_computed_tokens": enc_per_rank, "roofline": {"bound": "mfma", "achieved": enc_flops / t_enc / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                           "frac": enc_flops / t_enc / 1e12 / 2500.0, "traffic": None,
-                           "what": f"projection flops executed by pc_gemm_dense ({planes} activation plane(s) x 2 x MACs x layers x "
-                                   "computed tokens, padding rows and attention not counted) / wall time of the whole add_schema "
-                                   "call, against the dense fp16 MFMA peak; kernel-level rates: profiles/r02_encode_kernel_stats.txt"},
+    encode = {"per_rank_computed_tokens": enc_per_rank,
+              "roofline": {"bound": "mfma", "achieved": enc_flops_alg / t_enc / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                           "frac": enc_flops_alg / t_enc / 1e12 / 2500.0, "traffic": None,
+                           "executed_TFLOPs": enc_flops / t_enc / 1e12, "executed_frac": enc_flops / t_enc / 1e12 / 2500.0,
+                           "reference_work_TFLOPs": 2.0 * macs_tok * mcfg.num_hidden_layers * enc_tokens / t_enc / 1e12,
+                           "what": "frac: ALGORITHMIC projection flops (2 x MACs x layers x the tokens that ran through the model; "
+                                   "padding rows and attention not counted) / wall time of the whole add_schema call, against the dense "
+                                   f"fp16 MFMA peak; executed_*: the same x {planes} activation plane(s) (what the MFMAs run for the "
+                                   "split-precision parity); reference_work_*: 2 x MACs x every scaffold token as the reference encodes "
+                                   "them (every scaffold in full) / the same wall time -- what trunk reuse and scaffold cutting buy; "
+                                   "kernel-level rates: profiles/r02_encode_kernel_stats.txt"},
               "passes": int(sc.encode_stats["total_passes"]), "tokens": int(enc_tokens),
               "cached_tokens": int(sc.encode_stats["cached_tokens"]), "seconds": t_enc,
               "tokens_per_s": enc_tokens / t_enc, "sharded_over": world,
@@ -648,9 +678,11 @@ def main():
     result["roofline_step"] = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_step": step_bytes, "ms_per_step": ttft_ms,
                                "what": "weights once + gather (read + write) + staged K/V once, divided by the driver-timed step"}
-    # `roofline` = the time-dominant hand-written kernel of the timed step (largest share in profiles/r02_bench_kernel_stats.txt)
+    # `roofline` = the time-dominant hand-written kernel of the timed step (largest share in profiles/r03_bench_kernel_stats.txt)
     if rank == 0 and not args.no_context:
-        result["roofline"], result["roofline_gemm"] = gemm_rooflines(lm, q)
+        result["roofline"], extra_rf = gemm_rooflines(lm, q)
+        result.update(extra_rf)
+        result["roofline_gemm"] = result["roofline"]          # (round 1-2 key of the gate|up figure)
     if result.get("roofline") is None:
         result["roofline"] = dict(result["roofline_gather"], note="context legs off: the event-timed gather stands in; the "
                                                                    "dominant kernel needs the eager legs (drop --no-context)")

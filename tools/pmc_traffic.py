@@ -49,7 +49,9 @@ src = "tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 tab = {
     "kv_copy_kernel": {"signature": "S=1725,L=32,Hkv=32,D=128", "hbm_bytes_per_launch": pick("kv_copy_kernel", largest=True), "source": src},
     "gemm_skinny_add": {"signature": "T=12,hid=4096,inter=11008",
-                        "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 1, 1"), "source": src + " (average of o_proj and down_proj)"},
+                        "hbm_bytes_per_launch": (lambda o, d: (o + d) // 2 if o and d else (o or d))(pick("gemm_skinny_kernel<1, 1, 1"),
+                                                                                                    pick("gemm_skinny_ks_kernel")),
+                        "source": src + " (average of o_proj = gemm_skinny_kernel<1,1,EPI_ADD> and down_proj = gemm_skinny_ks_kernel)"},
     "gemm_skinny_gate_up": {"signature": "T=12,hid=4096,inter=11008", "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 3, 2"), "source": src},
 }
 a, c = pick("attn_small_kernel"), pick("attn_combine_kernel")

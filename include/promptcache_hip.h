@@ -138,6 +138,12 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *              split-KV partial through to memory, arrives at its head's counter, and the last arriver merges the partials in
  *              split order (the result does not depend on the arrival order).  Without them the partials are merged by a
  *              second launch -- which measures no slower on MI355X.  One launch at a time per workspace / counters.
+ *   prefix_k, prefix_v   optional (with past_lens): a SHARED KEY PREFIX held somewhere else -- fp16 planes [Hkv][prefix rows][D]
+ *              with head stride prefix_head_stride (one layer of the root scaffold's arena).  Batch row b then attends to
+ *              prefix rows [0, past_lens[b]) followed by the rows of ITS pass, which `k` / `v` hold from row 0 on: a suffix
+ *              batch of the schema encode reads the trunk in place instead of carrying a copy of it in every batch row.
+ *              prefix_k_lo / prefix_v_lo: optional residual planes of the prefix rows (same strides); k_lo / v_lo then
+ *              cover the pass's rows from their row 0 (lo_row0 = 0).  Many-row kernel only (q_lo given or q_len > 16)
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
 
@@ -155,6 +161,7 @@ typedef struct pc_attn_args {
     const float* key_pos; int64_t key_pos_batch_stride; const float* slopes_log2;
     const void* k_lo; const void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_row0;
     uint32_t* counters;
+    const void* prefix_k; const void* prefix_v; const void* prefix_k_lo; const void* prefix_v_lo; int64_t prefix_head_stride;
 } pc_attn_args;
 int pc_attn(const pc_attn_args* args, void* stream);
 

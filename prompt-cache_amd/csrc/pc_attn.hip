@@ -66,6 +66,10 @@ struct AttnParams {
     // optional fp16 residuals of the NEW keys / values of this pass (rows past_len ..), compact [B][Hkv][q_len][D]:
     // the pass's own K/V then enter the MFMAs in split precision (staged rows are exact fp16 as the reference stages them)
     const _Float16* k_lo; const _Float16* v_lo; int64_t lo_bs, lo_hs; int32_t lo_row0;   // row = key - lo_row0
+    // optional shared key prefix (attn_fwd_kernel, with past_lens): keys [0, past_lens[b]) of batch row b are rows of these
+    // planes ([Hkv][rows][D], head stride pre_hs: the root scaffold's arena), keys from past_lens[b] on are rows 0.. of k / v
+    // (and of k_lo / v_lo).  pre_k_lo / pre_v_lo: residuals of the prefix rows (NULL: the prefix is plain fp16).
+    const _Float16* pre_k; const _Float16* pre_v; const _Float16* pre_k_lo; const _Float16* pre_v_lo; int64_t pre_hs;
     int32_t H, Hkv, q_len, past_len, nsplit;
     // tail != 0 (lo_row0 < 0 and q_len <= kTailMax: prefill of a short prompt over a staged cache): splits
     // 0 .. nsplit-2 stream the STAGED keys [0, past_len) only; the workgroup of split nsplit-1 computes the attention over
@@ -236,9 +240,12 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
 // enter the MFMAs as split-precision pairs (hi = fp16(x), lo = fp16(x - hi)), i.e. two MFMAs per fragment.
 // Against the reference's fp32 CPU path this removes the two largest rounding terms of the kernel (fp16 Q:
 // 2.5e-3, fp16 P: 1.7e-3 max |delta logit| on a 7b-shaped layer); K/V stay fp16 as staged.
-template <int D, bool HP, bool ALIBI = false, bool KVLO = false>
-__global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
+// PRE: the launch carries a shared key prefix (AttnParams::pre_k): its own instantiation, so that the others keep their
+// register allocation (the prefix walk costs the residual variant its second wave per SIMD).
+template <int D, bool HP, bool ALIBI, bool KVLO, bool PRE>
+__device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
     static_assert(!KVLO || HP, "K/V residual planes go with split-precision Q and P");
+    static_assert(!PRE || !ALIBI, "a shared prefix excludes ALiBi");
     constexpr int KS = D / 32;   // MFMA k-steps across the head dim (QK^T)
     constexpr int DB = D / 16;   // 16-wide head-dim blocks of O^T
     constexpr int CPR = D / 8;   // 16-byte chunks per K/V row
@@ -325,6 +332,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     for (int db = 0; db < DB; ++db) { f4 z = {0.f, 0.f, 0.f, 0.f}; o[db] = z; }
     float m_run = kNegBig, l_run = 0.f;
 
+    // a shared prefix shifts the pass's own planes: key index `pre + r` is their row r
+    const int pre = PRE ? past_len : 0;
     const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
     const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
     [[maybe_unused]] const float slope = ALIBI ? p.slopes[h] : 0.f;
@@ -334,11 +343,23 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     // has been written to LDS and stay in flight while tile i is consumed (HBM latency hides under the MFMAs).
     u32x4 kr[LPT], vr[LPT];
     [[maybe_unused]] u32x4 krl[KVLO ? LPT : 1], vrl[KVLO ? LPT : 1];
-    [[maybe_unused]] const _Float16* klb = KVLO ? p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
+    [[maybe_unused]] const _Float16* klb = KVLO ? p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;   // (per segment)
     [[maybe_unused]] const _Float16* vlb = KVLO ? p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs : nullptr;
     // lo_row0: -1 = the rows of this pass (past_len); -2 = the device word next to past_len (decode over a residual tail
     // that started at an earlier pass; hipGraph replays read both from the same static buffer)
-    [[maybe_unused]] const int lo_row0 = !KVLO ? 0 : (p.lo_row0 == -2 ? p.past_len_dev[1] : (p.lo_row0 < 0 ? past_len : p.lo_row0));
+    [[maybe_unused]] int lo_row0 = !KVLO ? 0 : (PRE ? pre : (p.lo_row0 == -2 ? p.past_len_dev[1] : (p.lo_row0 < 0 ? past_len : p.lo_row0)));
+    // The key range is walked in up to two SEGMENTS with workgroup-uniform base pointers: the shared prefix [0, pre) out of
+    // its own planes (when there is one), then the rows behind it out of k / v.  `kend` is the end of the current segment.
+    const int kend_all = kend;
+    int seg_key0 = ks0;
+    if (PRE) {
+        kend = kend_all < pre ? kend_all : pre;
+        kbase = p.pre_k + (int64_t)hkv * p.pre_hs; vbase = p.pre_v + (int64_t)hkv * p.pre_hs;
+        if (KVLO) {
+            lo_row0 = p.pre_k_lo ? 0 : 0x7fffffff;
+            if (p.pre_k_lo) { klb = p.pre_k_lo + (int64_t)hkv * p.pre_hs; vlb = p.pre_v_lo + (int64_t)hkv * p.pre_hs; }
+        }
+    }
     auto issue_loads = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -358,9 +379,20 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
             }
         }
     };
-    if (ks0 < kend) issue_loads(ks0);
+  for (int seg = PRE ? 0 : 1; seg < 2; ++seg) {
+    if (PRE && seg == 1) {           // (workgroup-uniform) the pass's own rows behind the prefix
+        kend = kend_all;
+        seg_key0 = ks0 > pre ? ks0 : pre;
+        kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs - (int64_t)pre * D;     // key index pre + r is row r
+        vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs - (int64_t)pre * D;
+        if (KVLO) {
+            lo_row0 = pre;
+            klb = p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs; vlb = p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs;
+        }
+    }
+    if (seg_key0 < kend) issue_loads(seg_key0);
 
-    for (int key0 = ks0; key0 < kend; key0 += kTK) {
+    for (int key0 = seg_key0; key0 < kend; key0 += kTK) {
         // (workgroup-uniform) does this tile hold any key with a residual?  Most tiles of a long staged cache do not: their
         // residual tiles are neither written nor read (a question of 259 rows over 8.3 k staged keys: 129 of 134 tiles)
         [[maybe_unused]] const bool tile_lo = KVLO && key0 + kTK > lo_row0;
@@ -476,6 +508,8 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
         __syncthreads();
     }
 
+  }   // segments
+
     if (!(wave_active && qi < q_len)) return;
     if (p.nsplit == 1) {
         const float inv = 1.0f / l_run;
@@ -517,6 +551,17 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
         for (int db = 0; db < DB; ++db) *(f4*)(po + db * 16) = o[db];
         if (g == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_run; }
     }
+}
+
+template <int D, bool HP, bool ALIBI = false, bool KVLO = false>
+__global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
+    attn_fwd_body<D, HP, ALIBI, KVLO, false>(p);
+}
+
+// the shared-prefix walk: held to two waves per SIMD (its segment switch otherwise costs the residual variant 36 registers past 256)
+template <int D, bool HP, bool KVLO>
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_pre_kernel(const AttnParams p) {
+    attn_fwd_body<D, HP, false, KVLO, true>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1149,7 +1194,7 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
     // a q_lo plane asks for split-precision Q and P at any q_len (the many-row path in its precise mode): 16-row kernel
     const bool want_hp = p.q_len <= kQB || p.q_lo != nullptr;
-    const bool rows32 = !p.q_lo && !p.k_lo && use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
+    const bool rows32 = !p.q_lo && !p.k_lo && !p.pre_k && use_rows32(B, p.H, p.q_len, p.past_len + p.q_len);
     p.nqblk = pc_ceil_div(p.q_len, rows32 ? kQB32 : kQB);
     p.nbatch = B;
     p.xcd_remap = (!p.small && p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
@@ -1172,6 +1217,10 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     } else if (rows32) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd32_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
+    } else if (p.pre_k) {        // shared prefix (pc_attn checked: past_lens, no ALiBi, many-row kernel)
+        if (p.k_lo) hipLaunchKernelGGL((attn_fwd_pre_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
+        else if (want_hp) hipLaunchKernelGGL((attn_fwd_pre_kernel<D, true, false>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_pre_kernel<D, false, false>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.k_lo && !p.tail) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, true>), grid, dim3(kThreads), 0, stream, p);
@@ -1223,7 +1272,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   int64_t workspace_bytes, const int32_t* past_len_dev, void* out_frag_hi, void* out_frag_lo,
                   const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo,
                   const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream,
-                  const int32_t* past_lens = nullptr, uint32_t* counters = nullptr) {
+                  const int32_t* past_lens = nullptr, uint32_t* counters = nullptr, const void* pre_k = nullptr,
+                  const void* pre_v = nullptr, const void* pre_k_lo = nullptr, const void* pre_v_lo = nullptr, int64_t pre_hs = 0) {
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -1244,6 +1294,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.past_len_dev = past_len_dev;
     p.past_lens = past_lens;
     p.counters = counters;
+    p.pre_k = (const _Float16*)pre_k; p.pre_v = (const _Float16*)pre_v;
+    p.pre_k_lo = (const _Float16*)pre_k_lo; p.pre_v_lo = (const _Float16*)pre_v_lo; p.pre_hs = pre_hs;
     p.trace = g_attn_trace;
     p.key_pos = key_pos; p.kp_bs = key_pos_batch_stride; p.slopes = slopes;
     p.k_lo = (const _Float16*)k_lo; p.v_lo = (const _Float16*)v_lo; p.lo_bs = lo_bs; p.lo_hs = lo_hs; p.lo_row0 = lo_row0;
@@ -1306,9 +1358,16 @@ PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {
                    "pc_attn: lo_row0 must be -1 (= past_len), -2 (= past_len_dev[1]) or lie in [0, past_len] of a host past_len");
     }
     PC_REQUIRE(!a->counters || ((uintptr_t)a->counters & 3) == 0, PC_ERR_ARG, "pc_attn: counters not 4-byte aligned");
+    if (a->prefix_k) {
+        PC_REQUIRE(a->prefix_v && a->past_lens && a->prefix_head_stride % 8 == 0 && (a->q_lo || a->q_len > 16), PC_ERR_ARG,
+                   "pc_attn: a shared prefix needs prefix_v, past_lens, a 16-byte aligned head stride and the many-row kernel");
+        PC_REQUIRE((a->prefix_k_lo == nullptr) == (a->prefix_v_lo == nullptr) && (!a->prefix_k_lo || a->k_lo), PC_ERR_ARG,
+                   "pc_attn: prefix_k_lo / prefix_v_lo go together and with k_lo / v_lo");
+    }
     return attn_fwd_impl(a->q, a->q_lo, a->q_batch_stride, a->q_token_stride, a->k, a->v, a->kv_batch_stride, a->kv_head_stride,
                          a->out, a->out_batch_stride, a->out_token_stride, a->B, a->H, a->Hkv, a->D, a->q_len, a->past_len,
                          a->softmax_scale, a->workspace, a->workspace_bytes, a->past_len_dev, a->out_frag_hi, a->out_frag_lo,
                          a->key_pos, a->key_pos_batch_stride, a->slopes_log2, a->out_lo, a->k_lo, a->v_lo, a->lo_batch_stride,
-                         a->lo_head_stride, a->lo_row0, stream, a->past_lens, a->counters);
+                         a->lo_head_stride, a->lo_row0, stream, a->past_lens, a->counters, a->prefix_k, a->prefix_v,
+                         a->prefix_k_lo, a->prefix_v_lo, a->prefix_head_stride);
 }

@@ -30,7 +30,8 @@ class AttnArgs(C.Structure):
                 ("past_len_dev", _vp), ("past_lens", _vp),
                 ("key_pos", _vp), ("key_pos_batch_stride", _i64), ("slopes_log2", _vp),
                 ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64), ("lo_row0", _i32),
-                ("counters", _vp)]
+                ("counters", _vp),
+                ("prefix_k", _vp), ("prefix_v", _vp), ("prefix_k_lo", _vp), ("prefix_v_lo", _vp), ("prefix_head_stride", _i64)]
 
 
 class GemmArgs(C.Structure):
@@ -204,23 +205,26 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None) -> None:
+             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None, prefix=None) -> None:
     """The attention of one layer through ``pc_attn`` (struct entry; every option is a field).
     ``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum).
     ``out_frag=(hi, lo)``: write split-precision fragment planes for the o_proj launch instead of ``out``.
     ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias.
     ``out_lo``: row-major residual plane of ``out``; ``kv_lo=(k_lo, v_lo, batch_stride, head_stride, row0)``: residuals of K/V rows
     from key index row0 on (written by ``rope_append(..., kv_lo=...)`` / the q|k|v projection).
-    ``counters`` (int32 [B*H], zero before first use): merge the split-KV partials inside the launch."""
+    ``counters`` (int32 [B*H], zero before first use): merge the split-KV partials inside the launch.
+    ``prefix=(k, v, k_lo | None, v_lo | None, head_stride)`` with ``past_lens``: batch row b attends to rows [0, past_lens[b]) of
+    these shared planes, then to its own rows, which ``k`` / ``v`` (and ``kv_lo``) hold from row 0 on."""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     fh, fl = (None, None) if out_frag is None else out_frag
     kpos, slopes = (None, None) if alibi is None else alibi
     lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
+    pf = (None, None, None, None, 0) if prefix is None else prefix
     a = AttnArgs(C.sizeof(AttnArgs), q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
                  _ptr(out), _ptr(out_lo), o_bs, o_ts, _ptr(fh), _ptr(fl), B, H, Hkv, D, q_len, past_len, scale,
                  _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(past_lens), _ptr(kpos),
                  0 if kpos is None else kpos.stride(0), _ptr(slopes), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4],
-                 _ptr(counters))
+                 _ptr(counters), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(pf[3]), pf[4])
     rc = load().pc_attn(C.byref(a), current_stream() if stream is None else stream)
     check(rc, "pc_attn")
 

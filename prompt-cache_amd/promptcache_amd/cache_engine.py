@@ -270,6 +270,12 @@ class SchemaCache:
                 # cut to the same ``max_tokens``) shares MORE than it has to run -- the prefix stops one row short of the cut.
                 if self.truncate_scaffolds:
                     n = min(n, self._owned_end(jobs[i]) - 1)
+                # never cut an owned segment in two: the prefix ends where a segment it runs into begins (its rows then
+                # come out of ONE arena when the suffix pass reads the trunk in place, see _process)
+                for tc in jobs[i]["owned"]:
+                    s0 = pos.index(tc.offset)
+                    if s0 < n < s0 + len(tc):
+                        n = s0
                 if n >= self.share_trunk_min and n >= len(ids) // 5:
                     prefix[i] = n
         self._jobs = (jobs, prefix)
@@ -335,14 +341,28 @@ class SchemaCache:
         custom_store_hooks = (type(lm).store_k_hook is not LanguageModel.store_k_hook or
                               type(lm).store_v_hook is not LanguageModel.store_v_hook)
 
-        def store_owned(job_idx: int, arena: KVArena, row: int):
+        def store_owned(job_idx: int, arena: KVArena, row: int, shared: Optional[Tuple[KVArena, int]] = None):
+            """``shared = (trunk arena, n_pre)``: the pass read its first n_pre keys out of the trunk arena in place, and
+            ``arena`` holds its rows from n_pre on (a segment lies on one side: _plan_with_prefix ends the prefix there)."""
             job = jobs[job_idx]
             pos, owned = job["position_ids"], job["owned"]
             # position ids of a scaffold may be interleaved, but each segment is contiguous (:275-279)
             src_off = [pos.index(tc.offset) for tc in owned]
             lens = [len(tc) for tc in owned]
             stores = [view_of[(job_idx, k)].view(L, 2, Hkv, n, D) for k, n in enumerate(lens)]
-            _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
+            if shared is None:
+                _native.kv_slice_store(arena.buf[row], arena.cap, src_off, lens, [s.data_ptr() for s in stores], L, Hkv, D)
+            else:
+                trunk, n_pre = shared
+                own = [k for k in range(len(owned)) if src_off[k] >= n_pre]
+                pre_ = [k for k in range(len(owned)) if src_off[k] < n_pre]
+                assert all(src_off[k] + lens[k] <= n_pre for k in pre_), "an owned segment straddles the shared prefix"
+                if own:
+                    _native.kv_slice_store(arena.buf[row], arena.cap, [src_off[k] - n_pre for k in own], [lens[k] for k in own],
+                                           [stores[k].data_ptr() for k in own], L, Hkv, D)
+                if pre_:
+                    _native.kv_slice_store(trunk.buf[0], trunk.cap, [src_off[k] for k in pre_], [lens[k] for k in pre_],
+                                           [stores[k].data_ptr() for k in pre_], L, Hkv, D)
             if custom_store_hooks:
                 # an adapter that overrides store_k_hook / store_v_hook (reference :284-285) sees the per-layer
                 # [Hkv, len, D] slices exactly as the reference hands them over; identity hooks cost nothing
@@ -392,7 +412,14 @@ class SchemaCache:
             self.ragged_suffix_batches
         suffix_len = [need[i] - prefix[i] for i in range(len(jobs))]
         row_bytes = L * 2 * Hkv * D * 2 * 2                  # K and V, fp16, + the residual planes of the encode arenas
-        if ragged:
+        # Where the attention kernel takes a shared key prefix (``supports_shared_prefix``: the split-precision many-row
+        # path) the suffix batch reads the trunk's rows IN PLACE, out of the trunk arena: its own arena holds the suffix
+        # rows only.  Otherwise every batch row carries a copy of its prefix (11 GB of device copies per persona encode).
+        in_place = ragged and self.shared_prefix_in_place and trunk_arena is not None and trunk_arena.lo is not None and \
+            bool(getattr(getattr(lm, "hf_model", None), "supports_shared_prefix", False))
+        if in_place:
+            groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size)]
+        elif ragged:
             groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size, prefix, row_bytes)]
         else:
             by_prefix: Dict[int, List[int]] = {}
@@ -405,6 +432,20 @@ class SchemaCache:
             pre = [prefix[i] for i in idxs]
             n_max = max(pre)
             width = max(suffix_len[i] for i in idxs)
+            if in_place:
+                ids_pad, mask = pad_batch([jobs[i]["token_ids"][prefix[i]:need[i]] for i in idxs], lm.eos_token_id)
+                pos_pad, _ = pad_batch([jobs[i]["position_ids"][prefix[i]:need[i]] for i in idxs], 0)
+                out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
+                         position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
+                         attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
+                         use_cache=True, many_rows=True, kv_only=True, shared_prefix=(trunk_arena, pre))
+                arena = out.past_key_values.arena
+                for row, i in enumerate(idxs):
+                    encoded_tokens += len(jobs[i]["token_ids"])
+                    computed_tokens += suffix_len[i]
+                    store_owned(i, arena, row, (trunk_arena, prefix[i]))
+                del out, arena
+                continue
             arena = KVArena(len(group), L, Hkv, n_max + width, D, dev)
             has_lo = trunk_arena.lo is not None and trunk_arena.lo_len >= n_max     # the trunk's keys stay split-precision
             if has_lo:
@@ -467,6 +508,8 @@ class SchemaCache:
     share_trunk_min = 32
     # pack suffix passes of different unions into one batch (per-row past lengths; models with supports_ragged_past)
     ragged_suffix_batches = os.environ.get("PC_RAGGED_SUFFIX", "1") != "0"
+    # suffix batches read the trunk's K/V in place instead of holding a copy per batch row (models with supports_shared_prefix)
+    shared_prefix_in_place = os.environ.get("PC_PREFIX_IN_PLACE", "1") != "0"
 
     def _batch_invariant(self) -> bool:
         """False when a row's result depends on which other rows travel in the same forward -- LLM.int8 picks its fp16

@@ -191,11 +191,20 @@ class LlamaHIP:
         self._kv_only = False      # set per call (see __call__)
         self._past_lens = None     # set per call: per-row past lengths of a ragged-prefix encode batch
         self.supports_ragged_past = True    # the many-row path takes past_lens (see __call__)
+        self._shared = None        # set per call: (trunk arena, per-row prefix lengths int32 [B], their maximum)
         self.supports_greedy_loop = True    # decode steps can run as a device-side loop (GreedyLoop)
         self.llm_int8 = False
         self._last_qt = None
         self.batch_invariant = True         # a row's result does not depend on the other rows of the forward (see llm_int8)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
+
+    # the many-row layer loop of THIS class hands the attention a shared key prefix (__call__'s ``shared_prefix``); a subclass
+    # with its own loop says so itself
+    _shared_prefix_loop = True
+
+    @property
+    def supports_shared_prefix(self) -> bool:
+        return bool(self._shared_prefix_loop and self.precise_dense and not self.llm_int8)
 
     def __init__(self, shape: LlamaShape, weights: Dict[str, torch.Tensor], device="cuda:0",
                  decode_headroom: int = 256, skinny: bool = True, int8_weights: bool = False):
@@ -379,8 +388,12 @@ class LlamaHIP:
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                  past_key_values=None, attention_mask: Optional[torch.Tensor] = None, use_cache: bool = True,
                  last_token_only: bool = False, num_layers: Optional[int] = None, many_rows: bool = False,
-                 kv_only: bool = False, past_lens: Optional[torch.Tensor] = None, **_unused) -> CausalLMOutput:
-        """``past_lens`` (int32 [B], many-row path over an encode arena): one past length per batch row -- row b appends
+                 kv_only: bool = False, past_lens: Optional[torch.Tensor] = None, shared_prefix=None,
+                 **_unused) -> CausalLMOutput:
+        """``shared_prefix = (trunk arena, [n_pre per batch row])`` (schema encode, split-precision many-row path): batch row b
+        attends to rows [0, n_pre[b]) of the trunk arena IN PLACE and then to its own rows, which go into a fresh arena from
+        row 0 on -- the suffix passes of an encode without a copy of the trunk per batch row.
+        ``past_lens`` (int32 [B], many-row path over an encode arena): one past length per batch row -- row b appends
         behind its own ``past_lens[b]`` rows and attends to those plus its new rows (scaffold suffixes of different
         unions batched over their trunk prefixes); the arena's ``length`` must be their maximum.
         ``kv_only`` (many-row path): stop after the last layer's K / V are in the arena and return no logits -- all a
@@ -392,6 +405,14 @@ class LlamaHIP:
         dev = self.device
         input_ids = input_ids.to(dev)
         B, q_len = input_ids.shape
+        self._shared = None
+        if shared_prefix is not None:
+            trunk, n_pre = shared_prefix
+            if not (many_rows and past_key_values is None and self.supports_shared_prefix and position_ids is not None
+                    and len(n_pre) == B and trunk.B == 1 and max(n_pre) <= trunk.length):
+                raise ValueError("shared_prefix goes with many_rows=True, explicit position ids, no past_key_values and a one-row "
+                                 "trunk arena that holds every prefix")
+            self._shared = (trunk, torch.tensor(list(n_pre), device=dev, dtype=torch.int32), int(max(n_pre)))
         arena, past_len = self._resolve_arena(past_key_values, B, q_len)
         if many_rows and self.precise_dense and past_key_values is None:
             arena.with_lo()           # a schema-encode pass: keep the residuals of every row it appends
@@ -487,7 +508,16 @@ class LlamaHIP:
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev) if two else None
         qkv = torch.empty((T, W), dtype=f32, device=dev)
         lo_for, full_lo = self._dense_pass_lo(arena, B, Hkv, q_len, past_len) if two else ((lambda li: None), False)
-        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len))
+        # shared prefix: the rows of this pass sit at arena rows [0, q_len) and the attention walks the trunk's planes first
+        trunk, pre_lens, pre_max = self._shared if self._shared is not None else (None, self._past_lens, past_len)
+        trunk_lo = trunk is not None and trunk.lo is not None and trunk.lo_len >= pre_max
+
+        def prefix_of(li):
+            if trunk is None:
+                return None
+            return (trunk.buf[0, li, 0], trunk.buf[0, li, 1], trunk.lo[0, li, 0] if trunk_lo else None,
+                    trunk.lo[0, li, 1] if trunk_lo else None, trunk.head_stride)
+        ws = self._workspace(n.attn_workspace_bytes(B, H, D, q_len, pre_max + q_len))
         lo = (lambda t: t[1]) if two else (lambda t: None)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
 
@@ -509,8 +539,8 @@ class LlamaHIP:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
-                       q_len * H * D, H * D, B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, q_lo=q16l,
-                       out_lo=lo(attn2), kv_lo=kv_lo, past_lens=self._past_lens)
+                       q_len * H * D, H * D, B, H, Hkv, D, q_len, pre_max, self.softmax_scale, ws, q_lo=q16l,
+                       out_lo=lo(attn2), kv_lo=kv_lo, past_lens=pre_lens, prefix=prefix_of(li))
             self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)                    # x += attn @ Wo^T
             norm(x, lw["ln2"], T)
             self._proj(h2[0], lo(h2), lw, "wgu", T, 2 * inter, hid, n.EPI_SILU, out_hi=act2[0], out_lo=lo(act2))

@@ -649,6 +649,44 @@ def test_ragged_suffix_batches_store_the_same_module_kv_as_per_union_batches():
     assert worst < 4e-3        # an fp16 ulp of O(1) values where fp32 sums in different tile shapes round across a tie
 
 
+def test_suffix_batches_over_the_trunk_in_place_store_the_module_kv_of_the_copied_prefix():
+    """Suffix batches that read the trunk's K/V IN PLACE (pc_attn's prefix_k / prefix_v; their arena holds the suffix rows only)
+    must store what the batches with a copy of the trunk in every row store: same keys in the same order -- only the key tiles
+    are cut at the prefix end, so a stored fp16 value may differ where its fp32 sum sat on a rounding tie."""
+    from promptcache_amd import CacheEngine, synth
+    from promptcache_amd.cache_engine import SchemaCache
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 5, 2.0), device="cuda:0")
+    assert lm.hf_model.supports_shared_prefix
+    sp, _ = synth.persona_like("p", system_len=70, intro_len=20,
+                               traits=(("age", (30, 26, 33)), ("home", (41, 37, 44, 35)), ("job", (25, 29, 22)), ("pet", (50, 12))), seed=4)
+    text = lm.get_formatter()(sp)
+    stores, stats = {}, {}
+    try:
+        for in_place in (True, False):
+            SchemaCache.shared_prefix_in_place = in_place
+            eng = CacheEngine(1024, lm)
+            torch.cuda.reset_peak_memory_stats()
+            eng.add_schema(text)
+            sc = eng.schemas["p"]
+            assert sc.encode_stats["trunk_shared_passes"] >= 6
+            stats[in_place] = (sc.encode_stats["computed_tokens"], torch.cuda.max_memory_allocated())
+            stores[in_place] = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in sc.cache_l1.values()),
+                                      key=lambda t: (t[0], t[1]))
+    finally:
+        SchemaCache.shared_prefix_in_place = True
+    assert [(a, b) for a, b, _ in stores[True]] == [(a, b) for a, b, _ in stores[False]]
+    assert stats[True][0] == stats[False][0]
+    diffs = [(x[2] - y[2]).abs() for x, y in zip(stores[True], stores[False])]
+    worst = max(float(d.max()) for d in diffs)
+    moved = sum(int((d > 0).sum()) for d in diffs) / sum(d.numel() for d in diffs)
+    print(f"in-place vs copied trunk prefix: max |dKV| = {worst:.2e}, {100 * moved:.3f} % of the stored values differ; "
+          f"peak memory {stats[True][1] >> 20} vs {stats[False][1] >> 20} MiB")
+    assert worst < 4e-3 and moved < 0.02
+
+
 @pytest.mark.parametrize("family", ["llama", "falcon"])
 def test_device_greedy_loop_equals_stepping_through_the_model(family):
     """GenerationEngine's device-side greedy loop (one hipGraph replay per token: forward + argmax + state advance, no host

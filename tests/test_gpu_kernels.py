@@ -1346,6 +1346,75 @@ def test_ragged_past_rope_append_and_attention_match_oracle_row_by_row(two):
         np.testing.assert_allclose(one[0].cpu().numpy(), ref, atol=4e-3 if not two else 2.5e-3, rtol=1e-2)
 
 
+@pytest.mark.parametrize("prefix_lo,q_len", [(True, 70), (False, 70), (True, 9), (True, 200)])
+def test_shared_prefix_attention_equals_the_prefix_copied_into_every_row(prefix_lo, q_len):
+    """pc_attn with prefix_k / prefix_v (the suffix batches of a schema encode read the trunk's K/V in place): batch row b sees
+    rows [0, past_lens[b]) of the SHARED planes and then its own rows, which its arena holds from row 0 on.  Must equal the
+    launch over arenas that carry a copy of the prefix in every batch row (same keys, same order; the tiles are cut at the
+    prefix end instead of every 64 keys, so the online softmax may round differently: fp32 round-off)."""
+    n = _n()
+    rng = np.random.default_rng(33)
+    B, H, Hkv, D = 3, 4, 2, 128
+    pres = [37, 300, 128]
+    n_trunk = 320
+    scale = 1.0 / np.sqrt(D)
+
+    def f16(*shape):
+        return torch.from_numpy((0.5 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float16)).to(DEV)
+
+    trunk, trunk_lo = f16(2, Hkv, n_trunk, D), f16(2, Hkv, n_trunk, D) * 2.0 ** -11
+    own, own_lo = f16(B, 2, Hkv, q_len, D), f16(B, 2, Hkv, q_len, D) * 2.0 ** -11
+    q, q_lo = f16(B, q_len, H * D), f16(B, q_len, H * D) * 2.0 ** -11
+    pl = torch.tensor(pres, dtype=torch.int32, device=DEV)
+    ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, max(pres) + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+
+    def launch(k, v, bs, hs, kvlo, prefix):
+        out = torch.full((B, q_len, H * D), float("nan"), dtype=torch.float16, device=DEV)
+        out_lo = torch.empty_like(out)
+        n.attn_fwd(q, q_len * H * D, H * D, k, v, bs, hs, out, q_len * H * D, H * D, B, H, Hkv, D, q_len, max(pres), scale, ws,
+                   q_lo=q_lo, out_lo=out_lo, kv_lo=kvlo, past_lens=pl, prefix=prefix)
+        torch.cuda.synchronize()
+        return out.double() + out_lo.double()
+
+    # in place: own arenas hold the pass's rows only
+    got = launch(own[:, 0], own[:, 1], 2 * Hkv * q_len * D, q_len * D, (own_lo[:, 0], own_lo[:, 1], 2 * Hkv * q_len * D, q_len * D, 0),
+                 (trunk[0], trunk[1], trunk_lo[0] if prefix_lo else None, trunk_lo[1] if prefix_lo else None, n_trunk * D))
+    # copies: row b = trunk[:pre_b] ++ own[b]
+    cap = max(pres) + q_len
+    full, full_lo = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV), torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    for b, pre in enumerate(pres):
+        full[b, :, :, :pre] = trunk[:, :, :pre]
+        full[b, :, :, pre:pre + q_len] = own[b]
+        if prefix_lo:
+            full_lo[b, :, :, :pre] = trunk_lo[:, :, :pre]
+        full_lo[b, :, :, pre:pre + q_len] = own_lo[b]
+    want = launch(full[:, 0], full[:, 1], 2 * Hkv * cap * D, cap * D, (full_lo[:, 0], full_lo[:, 1], 2 * Hkv * cap * D, cap * D, 0), None)
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-6 * max(1.0, want.abs().max().item()), err
+    # and the oracle, row by row, on the very keys
+    for b, pre in enumerate(pres):
+        kk = (full[b, 0].double() + full_lo[b, 0].double())[None, :, :pre + q_len].cpu().numpy()
+        vv = (full[b, 1].double() + full_lo[b, 1].double())[None, :, :pre + q_len].cpu().numpy()
+        qq = (q[b].double() + q_lo[b].double()).view(1, q_len, H, D).cpu().numpy().transpose(0, 2, 1, 3)
+        ref = orc.attention_core(qq, kk, vv, pre, H // Hkv).transpose(0, 2, 1, 3).reshape(q_len, H * D)
+        np.testing.assert_allclose(got[b].cpu().numpy(), ref, atol=3e-5, rtol=0)
+
+
+def test_shared_prefix_argument_checks():
+    n = _n()
+    t = torch.zeros((2, 2, 64, 128), dtype=torch.float16, device=DEV)
+    q = torch.zeros((1, 32, 256), dtype=torch.float16, device=DEV)
+    out = torch.empty_like(q)
+    pl = torch.tensor([8], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="shared prefix"):      # no past_lens
+        n.attn_fwd(q, 32 * 256, 256, t[0], t[1], 2 * 64 * 128, 64 * 128, out, 32 * 256, 256, 1, 2, 2, 128, 32, 8, 0.1, None,
+                   prefix=(t[0], t[1], None, None, 64 * 128))
+    with pytest.raises(RuntimeError, match="go together"):        # prefix residuals without k_lo / v_lo
+        n.attn_fwd(q, 32 * 256, 256, t[0], t[1], 2 * 64 * 128, 64 * 128, out, 32 * 256, 256, 1, 2, 2, 128, 32, 8, 0.1, None,
+                   past_lens=pl, prefix=(t[0], t[1], t[0], t[1], 64 * 128))
+
+
 def test_greedy_advance_argmax_ties_and_state_words():
     """pc_greedy_advance: argmax with the lowest index among equal maxima (torch.argmax on a contiguous row), written to
     the loop's device words; position and past length advance by one; the ring records the tokens in order."""

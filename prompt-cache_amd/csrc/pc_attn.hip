@@ -27,87 +27,11 @@
 //
 // Roofline: cached prefill (q << S) is HBM-bound on the K/V stream: bytes = 2*Hkv*(S+q)*D*2 per layer;
 // encode / no-cache (q = S) is MFMA-bound: flops = 4*H*D*q*(S + (q+1)/2) per layer.
-#include <hip/hip_fp16.h>
-
-#include "pc_common.h"
+#include "pc_attn_common.h"
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef short s4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kTK = 64;        // keys per LDS tile
-constexpr int kThreads = 256;  // 4 waves
-constexpr int kQB = 64;        // query rows per workgroup
-constexpr int kMaxSplit = 32;
-constexpr int kSmallQ = 16;    // most query rows per batch row attn_small_kernel takes
-constexpr float kNegBig = -1.0e30f;  // finite "-inf" for the running max
-
-struct AttnParams {
-    const _Float16* q; int64_t q_bs, q_ts;
-    const _Float16* q_lo;   // optional low-order plane of q (same strides), consumed when HP
-    const _Float16* k; const _Float16* v; int64_t kv_bs, kv_hs;
-    _Float16* out; int64_t o_bs, o_ts;
-    _Float16* out_lo;       // optional: fp16 residual of `out` (same strides): split-precision row-major output
-    _Float16* of_hi; _Float16* of_lo;   // optional: fragment-major split-precision output planes (pc_gemm.hip)
-    float* part_o; float* part_ml;
-    // fused split-KV merge (attn_small_kernel): one arrival counter per (batch row, head), zero before the first launch; every
-    // launch leaves them zero.  NULL: the partials are merged by attn_combine_kernel in a second launch.
-    uint32_t* counters;
-    unsigned long long* trace;   // dev (pc_dev_attn_trace): per-wave wall-clock stamps [workgroup][4 waves][4]
-    const int32_t* past_len_dev;
-    const int32_t* past_lens;   // optional [B]: one past length per batch row (ragged prefixes); p.past_len = their maximum
-    // ALiBi (MPT, promptcache/model/mpt.py:90-110, :160-175): score += slope[h] * key_pos[b][key]; both pre-scaled to
-    // the log2 domain by the host (slope * log2 e), key_pos = the POSITION ID of each cached / new key
-    const float* key_pos; int64_t kp_bs; const float* slopes;
-    // optional fp16 residuals of the NEW keys / values of this pass (rows past_len ..), compact [B][Hkv][q_len][D]:
-    // the pass's own K/V then enter the MFMAs in split precision (staged rows are exact fp16 as the reference stages them)
-    const _Float16* k_lo; const _Float16* v_lo; int64_t lo_bs, lo_hs; int32_t lo_row0;   // row = key - lo_row0
-    // optional shared key prefix (attn_fwd_kernel, with past_lens): keys [0, past_lens[b]) of batch row b are rows of these
-    // planes ([Hkv][rows][D], head stride pre_hs: the root scaffold's arena), keys from past_lens[b] on are rows 0.. of k / v
-    // (and of k_lo / v_lo).  pre_k_lo / pre_v_lo: residuals of the prefix rows (NULL: the prefix is plain fp16).
-    const _Float16* pre_k; const _Float16* pre_v; const _Float16* pre_k_lo; const _Float16* pre_v_lo; int64_t pre_hs;
-    int32_t H, Hkv, q_len, past_len, nsplit;
-    // tail != 0 (lo_row0 < 0 and q_len <= kTailMax: prefill of a short prompt over a staged cache): splits
-    // 0 .. nsplit-2 stream the STAGED keys [0, past_len) only; the workgroup of split nsplit-1 computes the attention over
-    // the rows this pass appended in fp32 (attn_tail_block) and leaves it as one more partial for the merge kernel.
-    int32_t tail;
-    int32_t small;          // attn_small_kernel launch (host-side dispatch flag)
-    int32_t xcd_remap, nqblk, nbatch;
-    float scale_log2;
-};
-
-// position of element (row m, feature k) in a fragment-major plane with KS k-steps (see pc_gemm.hip)
-__device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
-    return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
-}
-
-// v_exp_f32 directly: arguments here are <= 0 (or -inf), so the denormal-range scaling that exp2f() wraps
-// around the instruction (v_cmp + v_cndmask + v_ldexp per call) buys nothing.
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// Inter-workgroup hand-off inside one launch (fused split-KV merge): 8-byte agent-scope relaxed atomics on BOTH sides --
-// the stores go through to the coherence point (no release fence), the loads bypass this CU's L1 (no acquire fence).
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) uint32_t gu32;
-__device__ __forceinline__ void st_wt2(float* p, float a, float b) {
-    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
-    __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_wt2(const float* p) {
-    const unsigned long long x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32)));
-}
-
-__device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
-    // ds_read_b64_tr_b16: within a 16-lane group, lane i receives sub-element (i%4) of the 8 bytes
-    // addressed by lanes {i/4, 4+i/4, 8+i/4, 12+i/4} (verified by pc_probe_layouts on hardware).
-    s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p));
-    return __builtin_bit_cast(h4, r);
-}
+using namespace pca;
 
 #ifndef PC_TAIL_MAX
 #define PC_TAIL_MAX 32
@@ -808,11 +732,6 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
 //     kernel reads nstream (+1) partials per row instead of one per 3-tile split.
 // Q and P are split-precision pairs (HP).  Tail mode (see attn_tail_block) adds one workgroup per head for the pass's own
 // rows; without it the new rows are part of the stream under the index-order causal mask.
-__device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
-    // LDS-DMA: each lane's 16 bytes at `g` land at lds_wave_base + 16 * lane (no VGPR round trip; completion = vmcnt)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // Fused split-KV merge: the workgroup has written its (m, l, O) partial through to memory; it arrives at the (batch row,
 // head) counter and the LAST arriver merges all nsplit partials in split order (the result does not depend on who is last):
@@ -1200,7 +1119,8 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     p.xcd_remap = (!p.small && p.nsplit == 1 && p.nqblk >= (rows32 ? 2 : 4) && !no_remap) ? 1 : 0;
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
     if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
-    if (p.small && p.counters) {
+    const bool ring = D == 128 && ring_eligible(p, D);      // (attn_fwd_impl chose p.nsplit for it)
+    if (!ring && p.small && p.counters) {
         // one launch: the last-arriving workgroup of each head merges the partials (no attn_combine_kernel)
 #define PC_SMALL_FUSED(NSV)                                                                                          \
         do {                                                                                                       \
@@ -1211,7 +1131,11 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
 #undef PC_SMALL_FUSED
         return pc_check_launch("attn_small_kernel");
     }
-    if (p.small) {
+    if (ring) {
+        // > 64 split-precision rows at head_dim 128: 128 rows per workgroup, tiles by LDS-DMA (pc_attn_ring.hip)
+        const int rrc = launch_attn_ring(p, B, stream);
+        if (rrc != PC_OK) return rrc;
+    } else if (p.small) {
         if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_small_kernel<D, false, 0>), grid, dim3(kThreads), 0, stream, p);
     } else if (rows32) {
@@ -1256,6 +1180,7 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     if (q_len <= kTailMax) ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
     // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
     if (q_len <= kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;
+    if (D == 128 && q_len > 64) { const int nr = ring_nsplit(B, H, q_len, kv_len_max); ns = ns > nr ? ns : nr; }   // (pc_attn_ring.hip)
     if (ns <= 1) return 0;
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
@@ -1312,6 +1237,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
         if (ns >= 2) p.nsplit = ns; else small = false;
     }
     p.small = small ? 1 : 0;
+    if (ring_eligible(p, D)) p.nsplit = ring_nsplit(B, H, q_len, past_len + q_len);
     if (p.tail && !small) {
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
         // next instantiation of the merge kernel (4 / 8 / 16 / 32 partials per row)

@@ -1,0 +1,475 @@
+// Many-row split-precision attention for gfx950 (q_len > 64 at head_dim 128: long questions over a staged cache, the schema
+// encode, no-cache prefill): 128 query rows per workgroup, K / V tiles by LDS-DMA into a two-stage ring.
+//
+// Same math and operand layout as attn_fwd_kernel (pc_attn.hip: S^T = K . Q^T, O^T += V^T . P^T, 16 query rows per wave,
+// Q and P as split-precision pairs, residual tiles of the K / V rows that carry them) -- what changes is how the keys get to
+// the matrix cores:
+//   * workgroup = 8 waves = 128 query rows of one head (attn_fwd_kernel: 4 waves, 64 rows): a K / V tile crosses L2 -> LDS
+//     once per 128 rows.  At 259 rows over 8.3 k staged keys (BASELINE config 4) attn_fwd_kernel moves 872 MB of tiles per
+//     layer for 45 GFLOP -- it is bound by that stream, not by the MFMAs (19 % busy).
+//   * tiles travel by global_load_lds (16 B per lane, lane-linear destination; the K XOR swizzle and the V row rotation are
+//     applied to the SOURCE address of each lane): no staging registers (attn_fwd_kernel holds 64 VGPRs of them and sits at
+//     exactly 256).
+//   * one 64-KiB ring stage holds either TWO plain 64-key tiles (K0 V0 K1 V1: staged rows, exact fp16) or ONE tile with
+//     its residual planes (K V Klo Vlo: rows this pass or this encode appended): always 8 DMA instructions per wave and
+//     stage, so the vmcnt bookkeeping is the same for both.  Two stages = 128 KiB, one workgroup per CU, 2 waves per SIMD.
+//     While stage i is multiplied, stage i+1 is in flight; one barrier per stage.
+//   * the key range is walked in REGIONS with workgroup-uniform base pointers: [shared prefix, plain | shared prefix, with
+//     residuals | own rows, plain | own rows, with residuals].  A region ends exactly where the next begins (tiles need no
+//     64-key alignment: there is no ALiBi here), so no tile mixes rows with and without residuals and nothing is zero-filled;
+//     rows past the end of a region are clamped to its last row (finite data) and masked.
+// Replaces LlamaAttention.forward's core, promptcache/model/llama2.py:368-398 (see pc_attn.hip).
+// Roofline: MFMA.  flops = 4 * H * D * q * keys_visible * (2 planes of Q / P) (+ 1/2 more on residual tiles).
+#include <type_traits>
+
+#include "pc_attn_common.h"
+
+#ifndef PC_RING_EXP
+#define PC_RING_EXP 0
+#endif
+
+namespace pca {
+namespace {
+
+constexpr int RD = 128;                 // head dim
+constexpr int RKS = RD / 32, RDB = RD / 16, RCPR = RD / 8;
+constexpr int kRingThreads = 512, kRingQB = 128;
+constexpr int kPlane = kTK * RD * 2;    // bytes of one 64-key plane (16 KiB)
+constexpr int kStage = 4 * kPlane;      // 64 KiB
+
+// one region of the key walk (all workgroup-uniform): keys [a, e) are rows of k / v indexed BY KEY (bases are pre-shifted);
+// lo != 0: every key of the region has a residual row in kl / vl
+// LDS-DMA issued as raw instructions: 16 bytes per lane from `g` to LDS byte address `lds_addr` + 16 * lane.  The builtin form
+// makes hipcc wait vmcnt(0) in front of every ds_read_b64_tr_b16 that follows (it cannot tell the transposing reads from
+// the buffer the DMA is filling), which would serialise the ring; here the waits are the explicit ones in the ring loop.
+__device__ __forceinline__ void glds16_raw(const _Float16* g, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");   // (m0: no other instruction of this kernel uses it; checked in the ISA)
+}
+
+struct Region { const _Float16* k; const _Float16* v; const _Float16* kl; const _Float16* vl; int a, e, lo; };
+
+template <bool KVLO, bool PRE>
+__global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+    constexpr int D = RD, KS = RKS, DB = RDB, CPR = RCPR;
+    constexpr int NREG = (PRE ? 2 : 1) * (KVLO ? 2 : 1);
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int qblk, h, b, split;
+    if (p.xcd_remap) {
+        // 1-D grid, XCD-aware (see attn_fwd_kernel): heads are dealt to XCDs, an XCD walks the q-blocks of one head after
+        // another, heaviest first, so that head's K / V is served from that XCD's L2
+        const int nqb = p.nqblk, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int per_xcd = (p.H * p.nbatch + 7) >> 3;
+        const int pair = (slot / nqb) * 8 + xcd;
+        if (slot / nqb >= per_xcd || pair >= p.H * p.nbatch) return;
+        qblk = nqb - 1 - (slot % nqb);
+        b = pair / p.H; h = pair - b * p.H; split = 0;
+    } else {
+        qblk = blockIdx.x; h = blockIdx.y;
+        b = blockIdx.z / p.nsplit; split = blockIdx.z - b * p.nsplit;
+    }
+    const int hkv = h / (p.H / p.Hkv);
+    const int q_len = p.q_len;
+    const int past_len = __builtin_amdgcn_readfirstlane(p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len));
+    const int kv_len = past_len + q_len;
+
+    // this split's key range clipped by what the workgroup can causally see
+    int kps = (kv_len + p.nsplit - 1) / p.nsplit;
+    kps = (kps + kTK - 1) / kTK * kTK;
+    const int ks0 = split * kps;
+    const int wg_rows_end = (qblk * kRingQB + kRingQB < q_len) ? qblk * kRingQB + kRingQB : q_len;
+    int kend = ks0 + kps;
+    kend = kend < kv_len ? kend : kv_len;
+    kend = kend < past_len + wg_rows_end ? kend : past_len + wg_rows_end;
+
+    const int qrow0 = qblk * kRingQB + wave * 16;
+    const int qi = qrow0 + n;
+    const bool wave_active = qrow0 < q_len;
+    const int wave_rows_end = (qrow0 + 16 < q_len) ? qrow0 + 16 : q_len;
+    const int wave_vis_end = past_len + wave_rows_end;
+    const int row_vis_end = (qi < q_len) ? past_len + qi + 1 : 0;
+
+    // ---- regions ----
+    // own rows: key `key` is row (key - pre) of k / v (pre = 0 without a shared prefix), residual rows from own_lo0 on
+    const int pre = PRE ? past_len : 0;
+    const int own_lo0 = !KVLO ? 0x7fffffff
+                              : (PRE ? pre : (p.lo_row0 == -2 ? __builtin_amdgcn_readfirstlane(p.past_len_dev[1])
+                                                              : (p.lo_row0 < 0 ? past_len : p.lo_row0)));
+    Region reg[NREG];
+    {
+        int r = 0;
+        const int a0 = ks0, e0 = kend < pre ? kend : pre;            // prefix keys of this split
+        const int a1 = ks0 > pre ? ks0 : pre, e1 = kend;             // own keys of this split
+        if (PRE) {
+            const _Float16* pk = p.pre_k + (int64_t)hkv * p.pre_hs;
+            const _Float16* pv = p.pre_v + (int64_t)hkv * p.pre_hs;
+            if (KVLO) {
+                // the prefix either has residuals for all of its rows or for none
+                const bool plo = p.pre_k_lo != nullptr;
+                const _Float16* pkl = plo ? p.pre_k_lo + (int64_t)hkv * p.pre_hs : pk;
+                const _Float16* pvl = plo ? p.pre_v_lo + (int64_t)hkv * p.pre_hs : pv;
+                reg[r++] = Region{pk, pv, pkl, pvl, a0, plo ? a0 : e0, 0};
+                reg[r++] = Region{pk, pv, pkl, pvl, plo ? a0 : e0, e0, 1};
+            } else {
+                reg[r++] = Region{pk, pv, pk, pv, a0, e0, 0};
+            }
+        }
+        const _Float16* ok = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs - (int64_t)pre * D;
+        const _Float16* ov = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs - (int64_t)pre * D;
+        if (KVLO) {
+            const _Float16* okl = p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs - (int64_t)own_lo0 * D;
+            const _Float16* ovl = p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs - (int64_t)own_lo0 * D;
+            int m = own_lo0 < a1 ? a1 : own_lo0;
+            m = m > e1 ? e1 : m;
+            reg[r++] = Region{ok, ov, ok, ov, a1, m, 0};
+            reg[r++] = Region{ok, ov, okl, ovl, m, e1, 1};
+        } else {
+            reg[r++] = Region{ok, ov, ok, ov, a1, e1, 0};
+        }
+    }
+    // stages per region: plain regions advance 128 keys per stage (two tiles), residual regions 64
+    int nst_r[NREG], nst = 0;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int len = reg[r].e - reg[r].a;
+        nst_r[r] = len <= 0 ? 0 : (reg[r].lo ? (len + kTK - 1) / kTK : (len + 2 * kTK - 1) / (2 * kTK));
+        nst += nst_r[r];
+    }
+
+    // ---- Q fragments (hi, lo) ----
+    h8 qf[KS], qfl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[ks] = z; qfl[ks] = z;
+        if (wave_active && qi < q_len) {
+            const int64_t off = b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)h * D + ks * 32 + g * 8;
+            qf[ks] = *(const h8*)(p.q + off);
+            if (p.q_lo) qfl[ks] = *(const h8*)(p.q_lo + off);
+        }
+    }
+    f4 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { f4 z = {0.f, 0.f, 0.f, 0.f}; o[db] = z; }
+    float m_run = kNegBig, l_run = 0.f;
+
+    // ---- staging: lane -> (row of the plane, chunk position), source chunk by the tile's swizzle ----
+    // wave-instruction j of a plane covers rows 4 * (8 j + wave) .. + 4 (1 KiB); lane l: row + (l >> 4), position l & 15
+    int srow[2], skoff[2], svoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 4 * (8 * j + wave) + (lane >> 4), c = lane & 15;
+        srow[j] = r;
+        skoff[j] = (c ^ (r & 15)) << 3;                       // K: position c holds chunk c ^ (row & 15)
+        svoff[j] = ((c - 2 * (r & 7)) & 15) << 3;             // V: position c holds chunk (c - 2 (row & 7)) mod 16
+    }
+    // stage s of the walk -> its region and first key (workgroup-uniform; NREG <= 4, unrolled selects)
+    auto locate = [&](int s, Region& x, int& key0) {
+        x = reg[0];
+        key0 = reg[0].a;
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            if (s >= base && s < base + nst_r[r]) {
+                x = reg[r];
+                key0 = reg[r].a + (s - base) * (reg[r].lo ? kTK : 2 * kTK);
+            }
+            base += nst_r[r];
+        }
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    auto issue = [&](int stage, uint32_t buf) {
+        Region x;
+        int skey0;
+        locate(stage, x, skey0);
+        const int last = x.e - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t dst = buf + (8 * j + wave) * 1024;
+                if (x.lo) {
+                    // one tile with residuals: planes K V Klo Vlo (t = 0: K, V; t = 1: Klo, Vlo)
+                    int key = skey0 + srow[j];
+                    key = key < last ? key : last;
+                    const _Float16* kb = t ? x.kl : x.k;
+                    const _Float16* vb = t ? x.vl : x.v;
+                    glds16_raw(kb + (int64_t)key * D + skoff[j], dst + (2 * t) * kPlane);
+                    glds16_raw(vb + (int64_t)key * D + svoff[j], dst + (2 * t + 1) * kPlane);
+                } else {
+                    int key = skey0 + t * kTK + srow[j];
+                    key = key < last ? key : last;
+                    glds16_raw(x.k + (int64_t)key * D + skoff[j], dst + (2 * t) * kPlane);
+                    glds16_raw(x.v + (int64_t)key * D + svoff[j], dst + (2 * t + 1) * kPlane);
+                }
+            }
+        }
+    };
+
+    // one 64-key tile out of LDS: scores, online softmax, O^T update (the arithmetic of attn_fwd_kernel's tile body).
+    // The fragment reads run ONE BLOCK AHEAD of the MFMAs that consume them (two register sets, issue order pinned with
+    // sched_group_barrier): left alone hipcc puts every read right in front of its first use and the wave sits out one LDS
+    // round trip per 16-key block and per head-dim block (12 per tile).  attn_fwd_kernel has no registers for the second
+    // set; this kernel, without staging registers, does.
+    // MASKED = false: every key of the tile is visible to every row of the wave and inside the region -- no compares.
+    auto tile = [&](const _Float16* Kl, const _Float16* Vl, const _Float16* Kll, const _Float16* Vll, auto lo_tag, auto mask_tag,
+                    const int key0, const int key_end) {
+        constexpr bool tile_lo = KVLO && decltype(lo_tag)::value;
+        constexpr bool MASKED = decltype(mask_tag)::value;
+        constexpr int NRK = tile_lo ? 2 * KS : KS;          // K-fragment reads per 16-key block
+        constexpr int NMK = tile_lo ? 3 * KS : 2 * KS;      // MFMAs per 16-key block
+        float sv[4][4];
+        float mx = -INFINITY;
+        h8 ka[2][KS];
+        [[maybe_unused]] h8 kal[2][tile_lo ? KS : 1];
+        auto load_k = [&](int kb, int set) {
+            const int row = kb * 16 + n;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = row * D + (((ks * 4 + g) ^ (row & (CPR - 1))) << 3);
+                ka[set][ks] = *(const h8*)(Kl + off);
+                if constexpr (tile_lo) kal[set][ks] = *(const h8*)(Kll + off);
+            }
+        };
+        load_k(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRK, 0);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb + 1 < 4) load_k(kb + 1, (kb + 1) & 1);
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[kb & 1][ks], qf[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[kb & 1][ks], qfl[ks], acc, 0, 0, 0);
+                if constexpr (tile_lo) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kal[kb & 1][ks], qf[ks], acc, 0, 0, 0);
+            }
+            if (kb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, NRK, 0);      // the next block's reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, NMK, 0);                      // ... then this block's MFMAs
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = acc[r] * p.scale_log2;
+                float s_ = sc;
+                if constexpr (MASKED) {
+                    const int key = key0 + kb * 16 + g * 4 + r;
+                    s_ = (key < row_vis_end && key < key_end) ? sc : -INFINITY;
+                }
+                sv[kb][r] = s_;
+                mx = fmaxf(mx, s_);
+            }
+        }
+#if PC_RING_EXP == 1      // dev probe: no cross-lane max, no exponentials (timing attribution only; results are wrong)
+        const float m_new = m_run;
+#else
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+#endif
+        const float alpha = fast_exp2(m_run - m_new);
+        float rs = 0.f;
+        h8 pb[2], pbl[2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#if PC_RING_EXP == 1
+                const float e = sv[kb][r];
+#else
+                const float e = fast_exp2(sv[kb][r] - m_new);
+#endif
+                rs += e;
+                const _Float16 eh = (_Float16)e;
+                pb[kb >> 1][(kb & 1) * 4 + r] = eh;
+                pbl[kb >> 1][(kb & 1) * 4 + r] = (_Float16)(e - (float)eh);
+            }
+        }
+#if PC_RING_EXP != 1
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+#endif
+        l_run = l_run * alpha + rs;
+        if (__any(m_new > m_run)) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+            }
+        }
+        m_run = m_new;
+        // O^T += V^T . P^T: per 16-wide head-dim block two 32-key steps; its V^T fragments are read one block ahead
+        constexpr int NRV = tile_lo ? 8 : 4, NMV = tile_lo ? 6 : 4;
+        h4 va[2][4];
+        [[maybe_unused]] h4 val[2][tile_lo ? 4 : 1];
+        auto load_v = [&](int db, int set) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int vrow = t * 32 + g * 4 + (n >> 2);
+                const int off = vrow * D + ((db * 16 + (n & 3) * 4 + 16 * (vrow & 7)) & (D - 1));
+                va[set][2 * t] = lds_tr_read(Vl + off);
+                va[set][2 * t + 1] = lds_tr_read(Vl + off + 16 * D);
+                if constexpr (tile_lo) {
+                    val[set][2 * t] = lds_tr_read(Vll + off);
+                    val[set][2 * t + 1] = lds_tr_read(Vll + off + 16 * D);
+                }
+            }
+        };
+        load_v(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRV, 1);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            if (db + 1 < DB) load_v(db + 1, (db + 1) & 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const h4 lo = va[db & 1][2 * t], hi = va[db & 1][2 * t + 1];
+                const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
+                if constexpr (tile_lo) {
+                    const h4 llo = val[db & 1][2 * t], lhi = val[db & 1][2 * t + 1];
+                    const h8 al = {llo[0], llo[1], llo[2], llo[3], lhi[0], lhi[1], lhi[2], lhi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, pb[t], o[db], 0, 0, 0);
+                }
+            }
+            if (db + 1 < DB) __builtin_amdgcn_sched_group_barrier(0x100, NRV, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMV, 1);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // a tile whose every key is visible to every row of this wave (and lies inside its region) skips the mask compares
+    auto run_tile = [&](const _Float16* Kl, const _Float16* Vl, const _Float16* Kll, const _Float16* Vll, auto lo_tag, const int key0,
+                        const int key_end) {
+        const int full_end = past_len + qrow0 + 1;           // keys visible to the FIRST row of the wave
+        if (key0 + kTK <= key_end && key0 + kTK <= full_end && qrow0 + 16 <= q_len)
+            tile(Kl, Vl, Kll, Vll, lo_tag, F_{}, key0, key_end);
+        else
+            tile(Kl, Vl, Kll, Vll, lo_tag, T_{}, key0, key_end);
+    };
+
+    // ---- the ring ----
+    if (nst > 0) {
+        issue(0, lds0);
+        if (nst > 1) {
+            issue(1, lds0 + kStage);
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");      // stage 0 landed, everyone's
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // (the Q fragments are this kernel's only loads hipcc knows about: consumed here, its vmcnt(0) for them lands in
+        // front of the loop instead of in front of the first MFMA of every tile, where it would also drain the ring)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]), "v"(qfl[ks]));
+        for (int i = 0; i < nst; ++i) {
+            const char* buf = lds + (i & 1) * kStage;
+            Region x;
+            int key0;
+            locate(i, x, key0);
+            if (wave_active && key0 < wave_vis_end) {
+                if (KVLO && x.lo) {
+                    run_tile((const _Float16*)buf, (const _Float16*)(buf + kPlane), (const _Float16*)(buf + 2 * kPlane),
+                             (const _Float16*)(buf + 3 * kPlane), T_{}, key0, x.e);
+                } else {
+                    run_tile((const _Float16*)buf, (const _Float16*)(buf + kPlane), nullptr, nullptr, F_{}, key0, x.e);
+                    if (key0 + kTK < x.e && key0 + kTK < wave_vis_end)
+                        run_tile((const _Float16*)(buf + 2 * kPlane), (const _Float16*)(buf + 3 * kPlane), nullptr, nullptr, F_{},
+                                 key0 + kTK, x.e);
+                }
+            }
+            if (i + 1 < nst) {
+                // stage i+1 has landed (this wave's DMA drained, everyone's via the barrier) and every wave is done reading
+                // stage i: its buffer takes stage i+2, which then has the whole of stage i+1's arithmetic to arrive
+#if PC_RING_EXP != 2      // (2: dev probe without the ring's synchronisation and refills)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (i + 2 < nst) issue(i + 2, lds0 + (i & 1) * kStage);
+#endif
+            }
+        }
+    }
+
+    // ---- epilogue (as attn_fwd_kernel) ----
+    if (!(wave_active && qi < q_len)) return;
+    if (p.nsplit == 1) {
+        const float inv = 1.0f / l_run;
+        if (p.of_hi) {
+            const int row = b * q_len + qi, KSo = p.H * D / 32;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 vh, vl;
+                    pc_split(o[db][r] * inv, vh, vl);
+                    hi[r] = vh; lo[r] = vl;
+                }
+                const int64_t off = frag_off(row, h * D + db * 16 + g * 4, KSo);
+                *(h4*)(p.of_hi + off) = hi;
+                *(h4*)(p.of_lo + off) = lo;
+            }
+            return;
+        }
+        const int64_t ooff = b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)h * D + g * 4;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            h4 r, rl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 vh, vl;
+                pc_split(o[db][j] * inv, vh, vl);
+                r[j] = vh; rl[j] = vl;
+            }
+            *(h4*)(p.out + ooff + db * 16) = r;
+            if (p.out_lo) *(h4*)(p.out_lo + ooff + db * 16) = rl;
+        }
+    } else {
+        const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
+        float* po = p.part_o + slot * D + g * 4;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *(f4*)(po + db * 16) = o[db];
+        if (g == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_run; }
+    }
+}
+
+}  // namespace
+
+// Launches the ring kernel takes: head_dim 128, split-precision Q (q_lo), more than 64 query rows, no ALiBi, not the tail /
+// small-q modes.  PC_ATTN_NO_RING=1: off (A/B against attn_fwd_kernel).
+bool ring_eligible(const AttnParams& p, int D) {
+    const char* e = getenv("PC_ATTN_NO_RING");            // (read per call: tests and probes switch it inside one process)
+    const bool off = e && e[0] == '1';
+    static const int min_rows = [] { const char* m = getenv("PC_ATTN_RING_MIN"); return m ? atoi(m) : 65; }();
+    return !off && D == RD && p.q_lo && p.q_len >= min_rows && !p.key_pos && !p.tail && !p.small;
+}
+
+// KV splits of a ring launch: one workgroup per CU; minimise rounds x (stages per split + 1) + the merge
+int ring_nsplit(int B, int H, int q_len, int kv_len) {
+    const int units = B * H * pc_ceil_div(q_len, kRingQB);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 16; ++s) {
+        const int stages = pc_ceil_div(pc_ceil_div(kv_len, s), 2 * kTK);
+        if (s > 1 && stages < 4) break;
+        const int rounds = pc_ceil_div(units * s, 256);
+        const double cost = rounds * (stages + 1.0) + (s > 1 ? 2.0 + 0.25 * s : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+int launch_attn_ring(const AttnParams& p0, int B, hipStream_t stream) {
+    AttnParams p = p0;
+    static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
+    p.nqblk = pc_ceil_div(p.q_len, kRingQB);
+    p.nbatch = B;
+    p.xcd_remap = (p.nsplit == 1 && p.nqblk >= 2 && !no_remap) ? 1 : 0;
+    dim3 grid(p.nqblk, p.H, B * p.nsplit);
+    if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
+    const dim3 block(kRingThreads);
+    if (p.pre_k) {
+        if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_ring_kernel<false, true>), grid, block, 0, stream, p);
+    } else if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn_ring_kernel<false, false>), grid, block, 0, stream, p);
+    return pc_check_launch("attn_ring_kernel");
+}
+
+}  // namespace pca

@@ -1401,6 +1401,125 @@ def test_shared_prefix_attention_equals_the_prefix_copied_into_every_row(prefix_
         np.testing.assert_allclose(got[b].cpu().numpy(), ref, atol=3e-5, rtol=0)
 
 
+def _attn_ref64(q, k, v, past):
+    """float64 attention of q [T,H,D] over k / v [Hkv,S,D] under the index-order causal mask (row i sees keys < past + i + 1)."""
+    T, H, D = q.shape
+    rep = H // k.shape[0]
+    kk, vv = k.repeat_interleave(rep, 0), v.repeat_interleave(rep, 0)
+    sc = torch.einsum("thd,hsd->hts", q, kk) / np.sqrt(D)
+    S = kk.shape[1]
+    mask = torch.arange(S, device=q.device)[None, :] <= (past + torch.arange(T, device=q.device))[:, None]
+    sc = sc.masked_fill(~mask[None], float("-inf"))
+    return torch.einsum("hts,hsd->thd", torch.softmax(sc, -1), vv).reshape(T, H * D)
+
+
+@pytest.mark.parametrize("q_len,past,lo_mode,frag", [
+    (259, 1000, "own", True),      # config-4 shape class: staged plain keys, the pass's rows with residuals, fragment output, KV splits
+    (130, 77, "own", False),       # plain region shorter than one stage, not tile-aligned
+    (200, 0, "all", False),        # schema-encode pass: every key has a residual row, no past
+    (300, 513, "none", False),     # split-precision Q / P only
+    (65, 3000, "own", False),      # one q-block with one full wave-tile row block + 1 row, many splits
+    (128, 128, "all", False),
+])
+def test_ring_attention_matches_float64_and_the_64_row_kernel(q_len, past, lo_mode, frag, monkeypatch):
+    """attn_ring_kernel (pc_attn_ring.hip: > 64 split-precision rows at head_dim 128, 128 rows per workgroup, K / V tiles by
+    LDS-DMA) against a float64 reference on the very operands (hi + lo planes), and against attn_fwd_kernel on the same call
+    (PC_ATTN_NO_RING=1): same keys in the same order, only the tile boundaries differ -> fp32 round-off."""
+    n = _n()
+    rng = np.random.default_rng(q_len + past)
+    B, H, Hkv, D = 1, 8, 4, 128
+    S = past + q_len
+    cap = S + 7
+
+    def f16(*shape, scale=0.5):
+        return torch.from_numpy((scale * rng.standard_normal(shape, dtype=np.float32)).astype(np.float16)).to(DEV)
+
+    arena = f16(2, Hkv, cap, D)
+    q, q_lo = f16(q_len, H * D), f16(q_len, H * D, scale=2.0 ** -12)
+    kvlo, k_eff, v_eff = None, arena[0, :, :S].double(), arena[1, :, :S].double()
+    if lo_mode == "own":          # residual rows for the rows this pass appended (compact planes, lo_row0 = -1 -> past_len)
+        lo = f16(2, Hkv, q_len + 5, D, scale=2.0 ** -12)
+        kvlo = (lo[0], lo[1], Hkv * (q_len + 5) * D, (q_len + 5) * D, -1)
+        k_eff = k_eff.clone(); v_eff = v_eff.clone()
+        k_eff[:, past:] += lo[0, :, :q_len].double(); v_eff[:, past:] += lo[1, :, :q_len].double()
+    elif lo_mode == "all":        # arena-shaped residual planes (encode): every key
+        lo = f16(2, Hkv, cap, D, scale=2.0 ** -12)
+        kvlo = (lo[0], lo[1], Hkv * cap * D, cap * D, 0)
+        k_eff = k_eff + lo[0, :, :S].double(); v_eff = v_eff + lo[1, :, :S].double()
+    ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, S), 4) // 4, dtype=torch.float32, device=DEV)
+    mt = (q_len + 15) // 16
+
+    def run():
+        if frag:
+            ah = torch.zeros((mt, H * D // 32, 64, 8), dtype=torch.float16, device=DEV)
+            al = torch.zeros_like(ah)
+            n.attn_fwd(q, q_len * H * D, H * D, arena[0], arena[1], 2 * Hkv * cap * D, cap * D, None, 0, 0, B, H, Hkv, D, q_len, past,
+                       1.0 / np.sqrt(D), ws, out_frag=(ah, al), q_lo=q_lo, kv_lo=kvlo)
+            torch.cuda.synchronize()
+            full = (ah.double() + al.double()).view(mt, H * D // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(mt * 16, H * D)
+            return full[:q_len]
+        out = torch.full((q_len, H * D), float("nan"), dtype=torch.float16, device=DEV)
+        out_lo = torch.empty_like(out)
+        n.attn_fwd(q, q_len * H * D, H * D, arena[0], arena[1], 2 * Hkv * cap * D, cap * D, out, q_len * H * D, H * D, B, H, Hkv, D,
+                   q_len, past, 1.0 / np.sqrt(D), ws, q_lo=q_lo, out_lo=out_lo, kv_lo=kvlo)
+        torch.cuda.synchronize()
+        return out.double() + out_lo.double()
+
+    monkeypatch.delenv("PC_ATTN_NO_RING", raising=False)
+    got = run()
+    monkeypatch.setenv("PC_ATTN_NO_RING", "1")
+    old = run()
+    monkeypatch.delenv("PC_ATTN_NO_RING", raising=False)
+    ref = _attn_ref64((q.double() + q_lo.double()).view(q_len, H, D), k_eff, v_eff, past)
+    assert torch.isfinite(got).all()
+    err, err_old = (got - ref).abs().max().item(), (old - ref).abs().max().item()
+    assert err < 2e-5 and err <= 2.0 * err_old + 1e-6, (err, err_old)
+    assert (got - old).abs().max().item() < 4e-6
+    assert torch.equal(got, run())                      # run to run: same bits
+
+
+@pytest.mark.parametrize("prefix_lo", [True, False])
+def test_ring_attention_with_a_shared_prefix_and_ragged_batch_rows(prefix_lo, monkeypatch):
+    """The ring kernel's region walk [prefix plain | prefix with residuals | own plain | own with residuals] on a batch whose
+    rows sit behind prefixes of different lengths (the suffix batches of a schema encode), against the 64-row kernel."""
+    n = _n()
+    rng = np.random.default_rng(8)
+    B, H, Hkv, D, q_len = 3, 4, 2, 128, 150
+    pres, n_trunk = [37, 300, 128], 320
+
+    def f16(*shape, scale=0.5):
+        return torch.from_numpy((scale * rng.standard_normal(shape, dtype=np.float32)).astype(np.float16)).to(DEV)
+
+    trunk, trunk_lo = f16(2, Hkv, n_trunk, D), f16(2, Hkv, n_trunk, D, scale=2.0 ** -12)
+    own, own_lo = f16(B, 2, Hkv, q_len, D), f16(B, 2, Hkv, q_len, D, scale=2.0 ** -12)
+    q, q_lo = f16(B, q_len, H * D), f16(B, q_len, H * D, scale=2.0 ** -12)
+    pl = torch.tensor(pres, dtype=torch.int32, device=DEV)
+    ws = torch.empty(max(n.attn_workspace_bytes(B, H, D, q_len, max(pres) + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+
+    def run():
+        out = torch.full((B, q_len, H * D), float("nan"), dtype=torch.float16, device=DEV)
+        out_lo = torch.empty_like(out)
+        n.attn_fwd(q, q_len * H * D, H * D, own[:, 0], own[:, 1], 2 * Hkv * q_len * D, q_len * D, out, q_len * H * D, H * D, B, H, Hkv, D,
+                   q_len, max(pres), 1.0 / np.sqrt(D), ws, q_lo=q_lo, out_lo=out_lo, past_lens=pl,
+                   kv_lo=(own_lo[:, 0], own_lo[:, 1], 2 * Hkv * q_len * D, q_len * D, 0),
+                   prefix=(trunk[0], trunk[1], trunk_lo[0] if prefix_lo else None, trunk_lo[1] if prefix_lo else None, n_trunk * D))
+        torch.cuda.synchronize()
+        return out.double() + out_lo.double()
+
+    monkeypatch.delenv("PC_ATTN_NO_RING", raising=False)
+    got = run()
+    monkeypatch.setenv("PC_ATTN_NO_RING", "1")
+    old = run()
+    monkeypatch.delenv("PC_ATTN_NO_RING", raising=False)
+    assert torch.isfinite(got).all()
+    assert (got - old).abs().max().item() < 4e-6
+    for b, pre in enumerate(pres):
+        kk = torch.cat([trunk[0, :, :pre].double() + (trunk_lo[0, :, :pre].double() if prefix_lo else 0), own[b, 0].double() + own_lo[b, 0].double()], 1)
+        vv = torch.cat([trunk[1, :, :pre].double() + (trunk_lo[1, :, :pre].double() if prefix_lo else 0), own[b, 1].double() + own_lo[b, 1].double()], 1)
+        ref = _attn_ref64((q[b].double() + q_lo[b].double()).view(q_len, H, D), kk, vv, pre)
+        assert (got[b] - ref).abs().max().item() < 2e-5
+
+
 def test_shared_prefix_argument_checks():
     n = _n()
     t = torch.zeros((2, 2, 64, 128), dtype=torch.float16, device=DEV)

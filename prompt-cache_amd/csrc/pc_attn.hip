@@ -33,6 +33,17 @@ namespace {
 
 using namespace pca;
 
+// The past length of batch row b: per-row device word, the graph's device word, or the host value.  (The host value goes
+// through an opaque register first: hipcc otherwise makes this ONE load through a select between the device pointers and the
+// address of the kernel argument, and parks the argument in a scratch slot to have such an address.)
+__device__ __forceinline__ int row_past_len(const AttnParams& p, int b) {
+    int v = p.past_len;
+    asm volatile("" : "+s"(v));
+    if (p.past_lens) v = p.past_lens[b];
+    else if (p.past_len_dev) v = *p.past_len_dev;
+    return v;
+}
+
 #ifndef PC_TAIL_MAX
 #define PC_TAIL_MAX 32
 #endif
@@ -59,7 +70,7 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
     constexpr int DPT = D / LPR;           // output dims per lane in the O phase
     static_assert(NT * LPR == kThreads && JPT * LPR == NT && DPT * LPR == D && DPT % 2 == 0, "tail thread map");
     const int tid = threadIdx.x, q_len = p.q_len;
-    const int past = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int past = row_past_len(p, 0);
     const int hkv = h / (p.H / p.Hkv);
     const _Float16* kb = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs + (int64_t)past * D;
     const _Float16* vb = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs + (int64_t)past * D;
@@ -204,7 +215,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
     }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
-    const int past_len = p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len);
+    // (the residual-tile variant keeps the select form: it sits at exactly 256 registers and the branchy form costs it its
+    // second wave per SIMD; the select's scratch slot only shows up in the variants without residual tiles)
+    int past_len_sel;
+    if constexpr (KVLO && !PRE) past_len_sel = p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len);
+    else past_len_sel = row_past_len(p, b);
+    const int past_len = past_len_sel;
     int nsp = p.nsplit;
     if constexpr (HP && !KVLO) {
         if (p.tail) {
@@ -482,9 +498,10 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) 
     attn_fwd_body<D, HP, ALIBI, KVLO, false>(p);
 }
 
-// the shared-prefix walk: held to two waves per SIMD (its segment switch otherwise costs the residual variant 36 registers past 256)
+// the shared-prefix walk for passes of <= 64 rows (longer ones: pc_attn_ring.hip); its residual variant runs one wave per SIMD
+// (292 registers) rather than spill
 template <int D, bool HP, bool KVLO>
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_pre_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kThreads) void attn_fwd_pre_kernel(const AttnParams p) {
     attn_fwd_body<D, HP, false, KVLO, true>(p);
 }
 
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd32_kernel(const AttnParams p
     }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
-    const int past_len = p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len);
+    const int past_len = row_past_len(p, b);
     const int kv_len = past_len + q_len;
     int kps = (kv_len + p.nsplit - 1) / p.nsplit;
     kps = (kps + kTK - 1) / kTK * kTK;
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
     const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
-    const int past_len = p.past_len_dev ? *p.past_len_dev : p.past_len;
+    const int past_len = row_past_len(p, 0);
     const int nstream = p.tail ? p.nsplit - 1 : p.nsplit;
     auto stamp = [&](int slot) {
         if (p.trace && lane == 0)

@@ -14,8 +14,8 @@
 //     its residual planes (K V Klo Vlo: rows this pass or this encode appended): always 8 DMA instructions per wave and
 //     stage, so the vmcnt bookkeeping is the same for both.  Two stages = 128 KiB, one workgroup per CU, 2 waves per SIMD.
 //     While stage i is multiplied, stage i+1 is in flight; one barrier per stage.
-//   * the key range is walked in REGIONS with workgroup-uniform base pointers: [shared prefix, plain | shared prefix, with
-//     residuals | own rows, plain | own rows, with residuals].  A region ends exactly where the next begins (tiles need no
+//   * the key range is walked in REGIONS with workgroup-uniform base pointers: [own rows, plain | own rows, with residuals]
+//     or, behind a shared prefix, [prefix rows (all plain or all with residuals) | own rows, with residuals].  A region ends exactly where the next begins (tiles need no
 //     64-key alignment: there is no ALiBi here), so no tile mixes rows with and without residuals and nothing is zero-filled;
 //     rows past the end of a region are clamped to its last row (finite data) and masked.
 // Replaces LlamaAttention.forward's core, promptcache/model/llama2.py:368-398 (see pc_attn.hip).
@@ -52,7 +52,7 @@ template <bool KVLO, bool PRE>
 __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
     constexpr int D = RD, KS = RKS, DB = RDB, CPR = RCPR;
-    constexpr int NREG = (PRE ? 2 : 1) * (KVLO ? 2 : 1);
+    constexpr int NREG = (PRE || KVLO) ? 2 : 1;      // [prefix | own rows]  or  [own rows, plain | own rows, with residuals]
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +72,13 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
     }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
-    const int past_len = __builtin_amdgcn_readfirstlane(p.past_lens ? p.past_lens[b] : (p.past_len_dev ? *p.past_len_dev : p.past_len));
+    // (the host value goes through an opaque register first: hipcc otherwise turns this into ONE load through a select
+    // between the device pointers and the address of the kernel argument, which it has to park in a scratch slot for that)
+    int past_len_v = p.past_len;
+    asm volatile("" : "+s"(past_len_v));
+    if (p.past_lens) past_len_v = p.past_lens[b];
+    else if (p.past_len_dev) past_len_v = *p.past_len_dev;
+    const int past_len = __builtin_amdgcn_readfirstlane(past_len_v);
     const int kv_len = past_len + q_len;
 
     // this split's key range clipped by what the workgroup can causally see
@@ -106,12 +112,11 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             const _Float16* pk = p.pre_k + (int64_t)hkv * p.pre_hs;
             const _Float16* pv = p.pre_v + (int64_t)hkv * p.pre_hs;
             if (KVLO) {
-                // the prefix either has residuals for all of its rows or for none
+                // the prefix has residuals for all of its rows or for none (one region either way)
                 const bool plo = p.pre_k_lo != nullptr;
                 const _Float16* pkl = plo ? p.pre_k_lo + (int64_t)hkv * p.pre_hs : pk;
                 const _Float16* pvl = plo ? p.pre_v_lo + (int64_t)hkv * p.pre_hs : pv;
-                reg[r++] = Region{pk, pv, pkl, pvl, a0, plo ? a0 : e0, 0};
-                reg[r++] = Region{pk, pv, pkl, pvl, plo ? a0 : e0, e0, 1};
+                reg[r++] = Region{pk, pv, pkl, pvl, a0, e0, plo ? 1 : 0};
             } else {
                 reg[r++] = Region{pk, pv, pk, pv, a0, e0, 0};
             }
@@ -121,10 +126,14 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
         if (KVLO) {
             const _Float16* okl = p.k_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs - (int64_t)own_lo0 * D;
             const _Float16* ovl = p.v_lo + b * p.lo_bs + (int64_t)hkv * p.lo_hs - (int64_t)own_lo0 * D;
-            int m = own_lo0 < a1 ? a1 : own_lo0;
-            m = m > e1 ? e1 : m;
-            reg[r++] = Region{ok, ov, ok, ov, a1, m, 0};
-            reg[r++] = Region{ok, ov, okl, ovl, m, e1, 1};
+            if (PRE) {
+                reg[r++] = Region{ok, ov, okl, ovl, a1, e1, 1};      // (behind a shared prefix every own row has its residual)
+            } else {
+                int m = own_lo0 < a1 ? a1 : own_lo0;
+                m = m > e1 ? e1 : m;
+                reg[r++] = Region{ok, ov, ok, ov, a1, m, 0};
+                reg[r++] = Region{ok, ov, okl, ovl, m, e1, 1};
+            }
         } else {
             reg[r++] = Region{ok, ov, ok, ov, a1, e1, 0};
         }
@@ -443,6 +452,7 @@ bool ring_eligible(const AttnParams& p, int D) {
 // KV splits of a ring launch: one workgroup per CU; minimise rounds x (stages per split + 1) + the merge
 int ring_nsplit(int B, int H, int q_len, int kv_len) {
     const int units = B * H * pc_ceil_div(q_len, kRingQB);
+    if (units >= 256) return 1;             // the grid fills the chip by itself: splits only add partials to merge
     int best = 1;
     double best_cost = 1e30;
     for (int s = 1; s <= 16; ++s) {

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
 // as a whole did not gain -- q = 98: 5.8 -> 6.2 ms, config 4: 19.4 -> 20.1 ms.)
 // Launch shape of the rows kernel.  Rows per compute wave: 32 while that needs <= 12 compute waves (M <= 384; more,
 // narrower waves hide the L2 latency of the activation loads and spread evenly over the four SIMDs), else 64.
-// Weight tiles per workgroup: the smallest of {3,4,6,8} ({2,3,4} gate/up pairs) that fits the grid into one round.
+// Weight tiles per workgroup: the smallest of {3,4,6} ({2,3} gate/up pairs) that fits the grid into one round (else 6).
 template <int EPI>
 int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("PC_GEMM_ROWS_TT"); return e ? atoi(e) : 0; }();
@@ -209,13 +209,11 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
     const int work = units * p.kslices;
     if constexpr (EPI == EPI_SILU) {
         if (forced == 4 || two || (!forced && pc_ceil_div(work, 2) <= 256)) PC_ROWS(4);
-        if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(6);
-        PC_ROWS(8);
+        PC_ROWS(6);          // (8 tiles per workgroup spill at the 128 registers a 16-wave workgroup leaves)
     } else {
         if (forced == 3 || (!forced && pc_ceil_div(work, 3) <= 256)) PC_ROWS(3);
         if (forced == 4 || two || (!forced && pc_ceil_div(work, 4) <= 256)) PC_ROWS(4);
-        if (forced == 6 || !narrow || (!forced && pc_ceil_div(work, 6) <= 256)) PC_ROWS(6);
-        PC_ROWS(8);
+        PC_ROWS(6);
     }
 #undef PC_ROWS
 }

@@ -825,6 +825,25 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     gemm_skinny_body<MT, T, EPI, TWO, U, NORM, W8>(p, (int)blockIdx.x, (int)blockIdx.y, red, ssl, nullptr, NoHook(), gam_lds);
 }
 
+// int8 weight images (W8): more than 8 accumulator tiles next to the dequantised k-step pairs spill (36 .. 716 B per lane at
+// 12 .. 16 tiles), so those shapes are not instantiated -- launch_T keeps int8 launches at or below 8.
+template <int MT, int T, int EPI, int UW>
+void launch_w8(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s) {
+    constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
+    if constexpr (MT * TT <= 8) {
+        if constexpr (MT == 1 && EPI != EPI_ADD) {
+            if (p.xn) {
+                hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, true, true>), grid, block, 0, s, p);
+                return;
+            }
+        }
+        if (p.xscale)     // LLM.int8 codes: ONE activation plane (the "lo" plane of the a8 calls is all zeros)
+            hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UW, false, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, false, true>), grid, block, 0, s, p);
+    }
+}
+
 template <int MT, int T, int EPI>
 int launch_one(const GemmParams& p, int units, hipStream_t s) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
@@ -837,17 +856,7 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
         if (p.w8) {   /* int8 weights: split-precision activations only.  Same k-steps per block as fp16 (half the   */ \
                       /* bytes in flight): doubling them measured slower, 23.4 vs 21.6 us on the 7b gate|up launch */ \
             constexpr int UW = ((UV) < 2) ? 2 : (((UV) > 8) ? 8 : (UV));                              \
-            if constexpr (MT == 1 && EPI != EPI_ADD) {                                                \
-                if (p.xn) {                                                                           \
-                    hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, true, true>), grid, block, 0, s, p); \
-                    break;                                                                            \
-                }                                                                                     \
-            }                                                                                         \
-            if (p.xscale) {   /* LLM.int8 codes: ONE activation plane (the "lo" plane of the a8 calls is all zeros) */ \
-                hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UW, false, true>), grid, block, 0, s, p); \
-                break;                                                                                \
-            }                                                                                         \
-            hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, false, true>), grid, block, 0, s, p); \
+            launch_w8<MT, T, EPI, UW>(p, grid, block, s);                                             \
             break;                                                                                    \
         }                                                                                             \
         if constexpr (MT == 1 && EPI != EPI_ADD) {                                                    \
@@ -875,7 +884,12 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
         // one row; down_proj 24.3 / 24.7 / 23.2 at 12 rows, 19.1 / 20.9 / 21.8 at one row -- shallow blocks win except for
         // the long-K launch with its activation loads (more than 4 rows), which wants the deep one
         if (!forced) {
-            if (p.M > 4 && p.KS >= 256) { PC_GO(16); } else { PC_GO(4); }
+            // (the deep block only where it was measured: one tile, one row tile, residual add = down_proj; every other
+            // shape with U = 16 spills 100 .. 480 B per lane)
+            if constexpr (MT == 1 && TT == 1 && EPI == EPI_ADD) {
+                if (p.M > 4 && p.KS >= 256) { PC_GO(16); return pc_check_launch("gemm_skinny_kernel"); }
+            }
+            PC_GO(4);
             return pc_check_launch("gemm_skinny_kernel");
         }
     }
@@ -891,6 +905,8 @@ template <int MT, int EPI>
 int launch_T(const GemmParams& p, int T, int units, hipStream_t s) {
     constexpr int kMaxT = (MT == 4 ? 6 : 8) / (EPI == EPI_SILU ? 2 : 1);
     if (T > kMaxT) T = kMaxT;
+    constexpr int kMaxT8 = 8 / MT / (EPI == EPI_SILU ? 2 : 1);     // int8 images: at most 8 accumulator tiles (launch_w8)
+    if (p.w8 && T > kMaxT8) T = kMaxT8;
     if constexpr (kMaxT >= 8) { if (T >= 8) return launch_one<MT, 8, EPI>(p, units, s); }
     if constexpr (kMaxT >= 4) { if (T >= 4) return launch_one<MT, 4, EPI>(p, units, s); }
     if constexpr (kMaxT >= 3) { if (T == 3) return launch_one<MT, 3, EPI>(p, units, s); }

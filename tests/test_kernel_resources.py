@@ -1,0 +1,46 @@
+"""CPU-side check of the BUILT library's kernels (no GPU, no hipcc): the resource table hipcc wrote into the code objects.
+
+Every kernel the shared object carries can be reached by some dispatcher path (instantiations the dispatchers cannot pick are not
+compiled: csrc/pc_gemm_skinny.h ``launch_w8`` / ``launch_one``, csrc/pc_gemm_rows.hip), so "no reachable kernel spills" is
+checked as "no kernel of the library has a private (scratch) segment"."""
+import os
+
+from promptcache_amd import _native, codeobj
+
+
+def _rows():
+    assert os.path.exists(_native.lib_path()), "run __graft_entry__.build() first"
+    return codeobj.kernels(_native.lib_path())
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    rows = _rows()
+    assert len(rows) > 100, "the code-object metadata was not found in the library"
+    spilling = sorted(((r["scratch"], r["vgpr"], r["demangled"]) for r in rows if r["scratch"] > 0), reverse=True)
+    assert not spilling, "kernels with a scratch segment (bytes per lane, VGPRs, name):\n" + "\n".join(map(str, spilling[:40]))
+
+
+def test_kernel_count_and_the_hot_path_kernels_are_there():
+    rows = _rows()
+    names = [r["demangled"] for r in rows]
+    # round 2 shipped 748 instantiations of the weight-streaming template alone
+    assert len(rows) <= 600, len(rows)
+    for must in ("kv_copy_kernel", "attn_small_kernel<128, false, 0>", "pca::attn_ring_kernel<true, false>", "gemm_skinny_ks_kernel",
+                 "pcg::gemm_rows_kernel<4, 3, 2, true>", "gemm_dense_kernel<2, 2, true>", "rope_append_kernel"):
+        assert any(must in n for n in names), must
+    # register budgets the launch bounds promise: 512-thread kernels at most 256 registers, 768-thread ones 168, 1024-thread ones 128
+    for r in rows:
+        if r["max_threads"] > 768:
+            assert r["vgpr"] + r["agpr"] <= 128, r
+        elif r["max_threads"] > 512:
+            assert r["vgpr"] + r["agpr"] <= 168, r
+        elif r["max_threads"] > 256:
+            assert r["vgpr"] + r["agpr"] <= 256, r
+
+
+def test_timed_step_kernels_keep_two_waves_per_simd():
+    """The kernels of the timed step (cached prefill, <= 16 rows) and the many-row attention: at most 256 unified registers."""
+    rows = {r["demangled"]: r for r in _rows()}
+    for name, r in rows.items():
+        if name.startswith(("attn_small_kernel<128", "pca::attn_ring_kernel")):
+            assert r["vgpr"] + r["agpr"] <= 256, (name, r["vgpr"], r["agpr"])

@@ -345,6 +345,29 @@ int pc_gemm_dense(const void* x_hi, const void* x_lo, int64_t ldx, const void* w
                   int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
                   int64_t ldo, void* stream);
 
+/* The fused q|k|v projection of a many-row pass (head_dim 128): replaces llama2.py:345-347 (q / k / v projections), :357-359 (RoPE at the
+ * supplied position ids) and :361-364 (KV concat) for schema-encode passes, no-cache prefill and long questions -- one launch,
+ * no [M][(H + 2 Hkv) D] fp32 intermediate.
+ *   x_hi, x_lo   fp16 [M = B*q_len][K] activation planes (x_lo may be NULL), row stride ldx
+ *   w            fp16 [(H + 2 Hkv) * 128][K] = [q; k; v] weight rows as nn.Linear holds them (NOT permuted), row stride ldw
+ *   cs           fp32 [M][64][2] (cos, sin) from pc_rope_table at the position id of every row
+ *   q_hi, q_lo   rotated q as split planes fp16 [M][q_token_stride] (q_lo may be NULL)
+ *   k_arena, v_arena   layer planes [B][Hkv][cap][128] with the arena strides: rotated k and v of batch row b land at rows
+ *                past + t (past = past_lens[b] when given, else past_len)
+ *   k_lo, v_lo   optional residual planes of those rows ([B][Hkv][rows][128] with the lo strides, row = past + t - lo_row0) */
+typedef struct pc_dense_qkv_args {
+    uint32_t struct_bytes;
+    const void* x_hi; const void* x_lo; int64_t ldx;
+    const void* w; int64_t ldw; int32_t K;
+    const float* cs;
+    void* q_hi; void* q_lo; int64_t q_token_stride;
+    void* k_arena; void* v_arena; int64_t arena_batch_stride, arena_head_stride;
+    void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_row0;
+    int32_t B, H, Hkv, D, q_len, past_len, cap;
+    const int32_t* past_lens;
+} pc_dense_qkv_args;
+int pc_gemm_dense_qkv_rope(const pc_dense_qkv_args* args, void* stream);
+
 /* pc_gemm_dense with a caller-owned scratch buffer (16-byte aligned, workspace_bytes long).  A plain-store / residual-add
  * launch whose tile grid would leave most of the 256 CUs idle -- the N = hidden projections (llama2.py:405 o_proj, :242
  * down_proj) at a few hundred rows -- cuts K into up to 8 slices: partial slabs [slices][M][N] fp32 in the workspace, added

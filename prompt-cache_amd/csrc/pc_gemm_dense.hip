@@ -48,7 +48,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BK = 64;
 constexpr int kXT = BM * BK * 2;                 // bytes of one activation plane tile (16 KiB)
-enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2, EPI_GELU = 4 };
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SILU = 2, EPI_ROPE = 3, EPI_GELU = 4 };
 
 struct DenseParams {
     const _Float16* xh; const _Float16* xl; int64_t ldx;   // [M][K] planes (xl may be null), row stride in halfs
@@ -64,6 +64,12 @@ struct DenseParams {
     // split-K (EPI_STORE instantiation only): grid.y slices of `kper` K-steps, slice z stores its partial sums to
     // y + z * slab_stride; dense_reduce_kernel then adds the slabs in fixed order (launch_dense_splitk)
     int32_t kper; int64_t slab_stride;
+    // EPI_ROPE (the fused q|k|v projection at head_dim 128, llama2.py:345-364): rotation table [M][64] (cos, sin), rotated q as
+    // hi / lo planes [M][q_ts], rotated k and plain v into the arena planes (+ their residual planes) behind each batch row's past
+    const float2* cs; _Float16* q_hi; _Float16* q_lo; int64_t q_ts;
+    _Float16* k_arena; _Float16* v_arena; int64_t a_bs, a_hs;
+    _Float16* k_lo; _Float16* v_lo; int64_t lo_bs, lo_hs; int32_t lo_row0;
+    int32_t H, Hkv, q_len, past_len; const int32_t* past_lens;
 };
 
 __device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
@@ -96,6 +102,15 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         if (EPI == EPI_SILU) {
             const int f = (ni * WN + (r >> 6)) * 32 + (r & 31);
             return f < p.nfeat ? ((r >> 5) & 1) * p.nfeat + f : -1;
+        }
+        if (EPI == EPI_ROPE) {
+            // a wave tile (64 columns) = 32 features d of one head's first half next to their rotary partners d + 64, so
+            // x[d] and x[d + 64] meet in the same lane and accumulator index of the two 32-wide MFMA blocks
+            const int wt = r >> 6, c = r & 63;
+            const int hd = ni * (BN / 128) + (wt >> 1);
+            const int d = (c < 32) ? (wt & 1) * 32 + c : 64 + (wt & 1) * 32 + (c - 32);
+            const int n = hd * 128 + d;
+            return n < p.N ? n : -1;
         }
         const int n = ni * BN + r;
         return n < p.N ? n : -1;
@@ -295,6 +310,59 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         }
         return;
     }
+    if (EPI == EPI_ROPE) {
+        // RoPE at the supplied positions (llama2.py:200-213, :357-359) and the KV append (:361-364) on the accumulator tile:
+        // 8 lanes per row, a lane holds features d0 .. d0+3 and d0+64 .. d0+67 of head `hd`
+        const int hd = ni * (BN / 128) + (wn >> 1);
+        const int d0 = (wn & 1) * 32 + (lane & 7) * 4;
+        if (hd >= p.H + 2 * p.Hkv) return;
+        const bool rot = hd < p.H + p.Hkv;
+#pragma unroll
+        for (int it = 0; it < 4 * MT; ++it) {
+            const int row = it * 8 + (lane >> 3), m = mrow0 + row;
+            const f4 x0 = *(const f4*)(st + row * 64 + (lane & 7) * 4);
+            const f4 x1 = *(const f4*)(st + row * 64 + 32 + (lane & 7) * 4);
+            if (m >= p.M) continue;
+            f4 a = x0, c = x1;
+            if (rot) {
+                const f4 w01 = *(const f4*)(p.cs + (int64_t)m * 64 + d0);          // (cos, sin) of pairs d0, d0+1
+                const f4 w23 = *(const f4*)(p.cs + (int64_t)m * 64 + d0 + 2);      // ... d0+2, d0+3
+                const float cs_[4] = {w01[0], w01[2], w23[0], w23[2]}, sn_[4] = {w01[1], w01[3], w23[1], w23[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // q*cos + rotate_half(q)*sin (llama2.py:208): the low half pairs with -high, the high half with +low
+                    a[e] = x0[e] * cs_[e] - x1[e] * sn_[e];
+                    c[e] = x1[e] * cs_[e] + x0[e] * sn_[e];
+                }
+            }
+            h4 ah, al, ch, cl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 t0, t1, t2, t3;
+                pc_split(a[e], t0, t1);
+                pc_split(c[e], t2, t3);
+                ah[e] = t0; al[e] = t1; ch[e] = t2; cl[e] = t3;
+            }
+            _Float16* dh;
+            _Float16* dl = nullptr;
+            if (hd < p.H) {
+                const int64_t off = (int64_t)m * p.q_ts + hd * 128 + d0;
+                dh = p.q_hi + off;
+                if (p.q_lo) dl = p.q_lo + off;
+            } else {
+                const int b = m / p.q_len, t = m - b * p.q_len;
+                const int past = p.past_lens ? p.past_lens[b] : p.past_len;
+                const bool is_k = hd < p.H + p.Hkv;
+                const int kh = is_k ? hd - p.H : hd - p.H - p.Hkv;
+                dh = (is_k ? p.k_arena : p.v_arena) + b * p.a_bs + kh * p.a_hs + (int64_t)(past + t) * 128 + d0;
+                if (p.k_lo) dl = (is_k ? p.k_lo : p.v_lo) + b * p.lo_bs + kh * p.lo_hs + (int64_t)(past + t - p.lo_row0) * 128 + d0;
+            }
+            *(h4*)dh = ah;
+            *(h4*)(dh + 64) = ch;
+            if (dl) { *(h4*)dl = al; *(h4*)(dl + 64) = cl; }
+        }
+        return;
+    }
     const int n = ni * BN + wn * 64 + (lane & 15) * 4;
 #pragma unroll
     for (int it = 0; it < 8 * MT; ++it) {
@@ -488,6 +556,46 @@ PC_EXPORT int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, 
                                void* out_hi, void* out_lo, int64_t ldo, void* workspace, int64_t ws_bytes, void* stream) {
     return gemm_dense_impl(x_hi, x_lo, ldx, w, ldw, w_scale, nullptr, nullptr, 0, nullptr, M, N, K, epilogue, y, ldy, out_hi,
                            out_lo, ldo, stream, workspace, ws_bytes);
+}
+
+// The fused q|k|v projection of a many-row pass at head_dim 128 (include/promptcache_hip.h: pc_dense_qkv_args): projection,
+// RoPE at the supplied positions, rotated q as hi / lo planes, rotated k and v appended to the arena (+ residual planes) -- the
+// [M][(H + 2 Hkv) D] fp32 intermediate and the separate pc_rope_append launch of the round-2 encode are gone.
+PC_EXPORT int pc_gemm_dense_qkv_rope(const pc_dense_qkv_args* a, void* stream) {
+    PC_REQUIRE(a && a->struct_bytes == (uint32_t)sizeof(pc_dense_qkv_args), PC_ERR_ARG,
+               "pc_gemm_dense_qkv_rope: args is NULL or struct_bytes != sizeof(pc_dense_qkv_args) (ABI mismatch)");
+    PC_REQUIRE(a->D == 128 && a->B > 0 && a->H > 0 && a->Hkv > 0 && a->q_len > 0 && a->K > 0 && a->K % 8 == 0, PC_ERR_ARG,
+               "pc_gemm_dense_qkv_rope: head_dim must be 128 (got %d); B, H, Hkv, q_len, K > 0; K %% 8 == 0", a->D);
+    PC_REQUIRE(a->x_hi && a->w && a->cs && a->q_hi && a->k_arena && a->v_arena, PC_ERR_ARG, "pc_gemm_dense_qkv_rope: null pointer");
+    PC_REQUIRE(a->ldx >= a->K && a->ldw >= a->K && a->ldx % 8 == 0 && a->ldw % 8 == 0 && ((uintptr_t)a->x_hi & 15) == 0 &&
+               ((uintptr_t)a->w & 15) == 0 && ((uintptr_t)a->x_lo & 15) == 0 && ((uintptr_t)a->cs & 15) == 0, PC_ERR_ARG,
+               "pc_gemm_dense_qkv_rope: operands and the rotation table must be 16-byte aligned with row strides %% 8 == 0");
+    PC_REQUIRE(a->q_token_stride % 4 == 0 && a->arena_head_stride % 4 == 0 && a->arena_batch_stride % 4 == 0 &&
+               ((uintptr_t)a->q_hi & 7) == 0 && ((uintptr_t)a->q_lo & 7) == 0 && ((uintptr_t)a->k_arena & 7) == 0 &&
+               ((uintptr_t)a->v_arena & 7) == 0, PC_ERR_ARG, "pc_gemm_dense_qkv_rope: outputs must keep 8-byte alignment");
+    PC_REQUIRE((a->k_lo == nullptr) == (a->v_lo == nullptr), PC_ERR_ARG, "pc_gemm_dense_qkv_rope: k_lo and v_lo go together");
+    PC_REQUIRE(!a->k_lo || (a->lo_head_stride % 4 == 0 && a->lo_batch_stride % 4 == 0 && a->lo_row0 >= 0 &&
+                            (a->past_lens ? a->lo_row0 == 0 : a->lo_row0 <= a->past_len)), PC_ERR_ARG,
+               "pc_gemm_dense_qkv_rope: residual planes: 8-byte aligned strides, lo_row0 in [0, past_len] (0 with past_lens)");
+    PC_REQUIRE((int64_t)a->past_len + a->q_len <= a->cap, PC_ERR_BOUNDS,
+               "pc_gemm_dense_qkv_rope: past_len %d + q_len %d exceeds arena rows %d", a->past_len, a->q_len, a->cap);
+    DenseParams p;
+    memset(&p, 0, sizeof(p));
+    p.xh = (const _Float16*)a->x_hi; p.xl = (const _Float16*)a->x_lo; p.ldx = a->ldx;
+    p.w = (const _Float16*)a->w; p.ldw = a->ldw;
+    p.M = a->B * a->q_len; p.N = (a->H + 2 * a->Hkv) * 128; p.K = a->K;
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero_chunk)) != hipSuccess || !z) {
+        pc_set_error("pc_gemm_dense_qkv_rope: hipGetSymbolAddress failed");
+        return PC_ERR_ARG;
+    }
+    p.zeros = (const _Float16*)z;
+    p.cs = (const float2*)a->cs; p.q_hi = (_Float16*)a->q_hi; p.q_lo = (_Float16*)a->q_lo; p.q_ts = a->q_token_stride;
+    p.k_arena = (_Float16*)a->k_arena; p.v_arena = (_Float16*)a->v_arena; p.a_bs = a->arena_batch_stride; p.a_hs = a->arena_head_stride;
+    p.k_lo = (_Float16*)a->k_lo; p.v_lo = (_Float16*)a->v_lo; p.lo_bs = a->lo_batch_stride; p.lo_hs = a->lo_head_stride;
+    p.lo_row0 = a->lo_row0;
+    p.H = a->H; p.Hkv = a->Hkv; p.q_len = a->q_len; p.past_len = a->past_len; p.past_lens = a->past_lens;
+    return launch_dense_tile<EPI_ROPE>(p, (hipStream_t)stream);
 }
 
 // LLM.int8 form of pc_gemm_dense (pc_int8.hip): xq = activation CODES of pc_quant_act_i8 held in fp16 (row-major [M][K]), w =

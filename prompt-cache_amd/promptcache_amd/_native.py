@@ -34,6 +34,19 @@ class AttnArgs(C.Structure):
                 ("prefix_k", _vp), ("prefix_v", _vp), ("prefix_k_lo", _vp), ("prefix_v_lo", _vp), ("prefix_head_stride", _i64)]
 
 
+class DenseQkvArgs(C.Structure):
+    """``pc_dense_qkv_args`` of include/promptcache_hip.h (field for field)."""
+    _fields_ = [("struct_bytes", C.c_uint32),
+                ("x_hi", _vp), ("x_lo", _vp), ("ldx", _i64),
+                ("w", _vp), ("ldw", _i64), ("K", _i32),
+                ("cs", _vp),
+                ("q_hi", _vp), ("q_lo", _vp), ("q_token_stride", _i64),
+                ("k_arena", _vp), ("v_arena", _vp), ("arena_batch_stride", _i64), ("arena_head_stride", _i64),
+                ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64), ("lo_row0", _i32),
+                ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
+                ("past_lens", _vp)]
+
+
 class GemmArgs(C.Structure):
     """``pc_gemm_args`` of include/promptcache_hip.h (field for field)."""
     _fields_ = [("struct_bytes", C.c_uint32), ("epilogue", _i32),
@@ -94,6 +107,7 @@ SIGNATURES = {
     "pc_gemm_chain": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64,
                                 _i32, _vp, _vp]),
+    "pc_gemm_dense_qkv_rope": (C.c_int, [_vp, _vp]),
     "pc_gemm_dense_ws": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
@@ -471,6 +485,20 @@ def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out
                               (0 if y is None else y.stride(-2)) if ldy is None else ldy, _ptr(out_hi), _ptr(out_lo), ld_o,
                               current_stream() if stream is None else stream)
     check(rc, "pc_gemm_dense")
+
+
+def gemm_dense_qkv_rope(x_hi, x_lo, w, K: int, cs, q_hi, q_lo, q_ts: int, k_arena, v_arena, a_bs: int, a_hs: int, B: int, H: int,
+                        Hkv: int, D: int, q_len: int, past_len: int, cap: int, kv_lo=None, past_lens=None,
+                        stream: Optional[int] = None) -> None:
+    """The fused many-row q|k|v projection (``pc_gemm_dense_qkv_rope``): ``(x_hi + x_lo) @ [q; k; v]^T``, RoPE from the table
+    ``cs``, rotated q into ``q_hi`` / ``q_lo``, rotated k and v into the arena planes behind each batch row's past (and their
+    residuals into ``kv_lo = (k_lo, v_lo, batch_stride, head_stride, row0)``)."""
+    lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
+    a = DenseQkvArgs(C.sizeof(DenseQkvArgs), x_hi.data_ptr(), _ptr(x_lo), x_hi.stride(-2), w.data_ptr(), w.stride(-2), K,
+                     cs.data_ptr(), q_hi.data_ptr(), _ptr(q_lo), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
+                     _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4], B, H, Hkv, D, q_len, past_len, cap, _ptr(past_lens))
+    rc = load().pc_gemm_dense_qkv_rope(C.byref(a), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_dense_qkv_rope")
 
 
 def chain_sync_state(device) -> "torch.Tensor":

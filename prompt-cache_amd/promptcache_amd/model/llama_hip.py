@@ -162,6 +162,7 @@ class LlamaHIP:
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops
         self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
+        self.fused_dense_qkv = os.environ.get("PC_FUSED_DENSE_QKV", "1") != "0"   # RoPE + KV append in the many-row q|k|v epilogue
         # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
         # decoded token -- in the arena's residual tail and feed them to the attention (the reference keeps those rows in
         # fp32 for the whole generation, llama2.py:361-388, generation_engine.py:123-147; the arena still holds the fp16
@@ -506,7 +507,6 @@ class LlamaHIP:
         act2 = torch.empty((2, T, inter), dtype=self.dtype, device=dev)
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev) if two else None
-        qkv = torch.empty((T, W), dtype=f32, device=dev)
         lo_for, full_lo = self._dense_pass_lo(arena, B, Hkv, q_len, past_len) if two else ((lambda li: None), False)
         # shared prefix: the rows of this pass sit at arena rows [0, q_len) and the attention walks the trunk's planes first
         trunk, pre_lens, pre_max = self._shared if self._shared is not None else (None, self._past_lens, past_len)
@@ -527,14 +527,23 @@ class LlamaHIP:
             else:
                 n.rmsnorm(src, gain, h2[0], rows, hid, eps, True)
 
+        # head_dim 128, fp16 weights: RoPE and the KV append run in the q|k|v projection's epilogue (pc_gemm_dense_qkv_rope);
+        # otherwise the projection leaves fp32 [T, W] for pc_rope_append
+        fused_qkv = D == 128 and len(layers) > 0 and "wqkv_ds" not in layers[0] and self.fused_dense_qkv
+        qkv = None if fused_qkv else torch.empty((T, W), dtype=f32, device=dev)
         for li, lw in enumerate(layers):
             norm(x, lw["ln1"], T)
-            self._proj(h2[0], lo(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
-            n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
-                          kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
-                          q_out_lo=q16l, kv_lo=kv_lo, past_lens=self._past_lens)
+            if fused_qkv:
+                n.gemm_dense_qkv_rope(h2[0], lo(h2), lw["wqkv"], hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                                      arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, kv_lo=kv_lo,
+                                      past_lens=self._past_lens)
+            else:
+                self._proj(h2[0], lo(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)
+                n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
+                              kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
+                              q_out_lo=q16l, kv_lo=kv_lo, past_lens=self._past_lens)
             if self._kv_only and li == len(layers) - 1:
                 break             # schema encode: the K / V of the last layer are written; nothing after them is used
             # q_lo: split-precision Q and P in the attention as well (fp16 Q alone costs 1.6e-2 on 32-layer logits)

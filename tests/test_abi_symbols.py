@@ -74,7 +74,8 @@ def test_struct_layouts_match_the_header_and_the_compat_wrappers_compile(tmp_pat
     import subprocess
     from promptcache_amd import _native
     src = tmp_path / "layout.c"
-    fields = {"pc_attn_args": [f[0] for f in _native.AttnArgs._fields_], "pc_gemm_args": [f[0] for f in _native.GemmArgs._fields_]}
+    fields = {"pc_attn_args": [f[0] for f in _native.AttnArgs._fields_], "pc_gemm_args": [f[0] for f in _native.GemmArgs._fields_],
+              "pc_dense_qkv_args": [f[0] for f in _native.DenseQkvArgs._fields_]}
     body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/promptcache_hip_compat.h"', 'int main(void) {']
     for st, fs in fields.items():
         body.append(f'  printf("{st} %zu\\n", sizeof({st}));')
@@ -86,7 +87,7 @@ def test_struct_layouts_match_the_header_and_the_compat_wrappers_compile(tmp_pat
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-unused-function", str(src), "-o", str(exe)])
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", str(src)])
     got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).strip().splitlines())
-    for st, cls in (("pc_attn_args", _native.AttnArgs), ("pc_gemm_args", _native.GemmArgs)):
+    for st, cls in (("pc_attn_args", _native.AttnArgs), ("pc_gemm_args", _native.GemmArgs), ("pc_dense_qkv_args", _native.DenseQkvArgs)):
         assert int(got[st]) == ctypes.sizeof(cls), st
         for name, _ in cls._fields_:
             assert int(got[f"{st}.{name}"]) == getattr(cls, name).offset, (st, name)

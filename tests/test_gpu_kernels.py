@@ -1401,6 +1401,62 @@ def test_shared_prefix_attention_equals_the_prefix_copied_into_every_row(prefix_
         np.testing.assert_allclose(got[b].cpu().numpy(), ref, atol=3e-5, rtol=0)
 
 
+@pytest.mark.parametrize("B,q_len,H,Hkv,two,ragged", [(1, 300, 4, 4, True, False), (3, 70, 4, 2, True, True), (2, 129, 3, 1, False, False),
+                                                      (1, 5, 2, 2, True, False)])
+def test_dense_qkv_rope_epilogue_equals_projection_then_rope_append(B, q_len, H, Hkv, two, ragged):
+    """pc_gemm_dense_qkv_rope (RoPE + KV append in the epilogue of the many-row q|k|v projection, head_dim 128) against the two
+    launches it replaces: pc_gemm_dense (fp32 [M][W]) + pc_rope_append.  Same fp32 accumulators, same rotation formula:
+    identical bits for V and for every row the arena does not touch, fp32 round-off (an fma contraction) at most elsewhere."""
+    n = _n()
+    rng = np.random.default_rng(17 + q_len)
+    D, K = 128, 256
+    W, T = (H + 2 * Hkv) * D, B * q_len
+    pasts = [9, 40, 0][:B] if ragged else [11] * B
+    cap = max(pasts) + q_len + 3
+
+    def f16(*shape, scale=1.0):
+        return torch.from_numpy((scale * rng.standard_normal(shape, dtype=np.float32)).astype(np.float16)).to(DEV)
+
+    x_hi, x_lo = f16(T, K), (f16(T, K, scale=2.0 ** -11) if two else None)
+    w = f16(W, K, scale=0.08)
+    pos = torch.from_numpy(np.concatenate([np.arange(p, p + q_len) * 3 + 1 for p in pasts]).astype(np.int32)).to(DEV)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(pos, _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    pl = torch.tensor(pasts, dtype=torch.int32, device=DEV) if ragged else None
+    bs, hs = 2 * Hkv * cap * D, cap * D
+
+    def fresh():
+        arena = torch.full((B, 2, Hkv, cap, D), 7.0, dtype=torch.float16, device=DEV)
+        lo = torch.full((B, 2, Hkv, cap, D), 7.0, dtype=torch.float16, device=DEV) if two else None
+        q = torch.full((T, H * D), float("nan"), dtype=torch.float16, device=DEV)
+        ql = torch.full((T, H * D), float("nan"), dtype=torch.float16, device=DEV) if two else None
+        return arena, lo, q, ql
+
+    a1, l1, q1, ql1 = fresh()
+    kvlo1 = (l1[:, 0], l1[:, 1], bs, hs, 0) if two else None
+    n.gemm_dense_qkv_rope(x_hi, x_lo, w, K, cs, q1, ql1, H * D, a1[:, 0], a1[:, 1], bs, hs, B, H, Hkv, D, q_len, max(pasts), cap,
+                          kv_lo=kvlo1, past_lens=pl)
+    a2, l2, q2, ql2 = fresh()
+    kvlo2 = (l2[:, 0], l2[:, 1], bs, hs, 0) if two else None
+    qkv = torch.empty((T, W), dtype=torch.float32, device=DEV)
+    n.gemm_dense(x_hi, x_lo, w, T, W, K, n.EPI_STORE, y=qkv)
+    n.rope_append(qkv, q_len * W, W, q2, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
+                  a2[:, 0], a2[:, 1], bs, hs, cs, B, H, Hkv, D, q_len, max(pasts), cap, True, q_out_lo=ql2, kv_lo=kvlo2, past_lens=pl)
+    torch.cuda.synchronize()
+    assert torch.equal(a1[:, 1], a2[:, 1])                                     # V: no arithmetic between the accumulator and the split
+    for b, p in enumerate(pasts):                                              # untouched rows stay untouched
+        assert torch.equal(a1[b, :, :, :p], a2[b, :, :, :p]) and torch.equal(a1[b, :, :, p + q_len:], a2[b, :, :, p + q_len:])
+    full = lambda hi, lo_: hi.double() + (lo_.double() if lo_ is not None else 0.0)   # noqa: E731
+    tol = 1e-6 if two else 2e-3
+    assert (full(q1, ql1) - full(q2, ql2)).abs().max().item() <= tol * max(1.0, full(q2, ql2).abs().max().item())
+    for b, p in enumerate(pasts):
+        k1 = full(a1[b, 0, :, p:p + q_len], l1[b, 0, :, p:p + q_len] if two else None)
+        k2 = full(a2[b, 0, :, p:p + q_len], l2[b, 0, :, p:p + q_len] if two else None)
+        assert (k1 - k2).abs().max().item() <= tol * max(1.0, k2.abs().max().item())
+        if two:
+            assert torch.equal(l1[b, 1, :, p:p + q_len], l2[b, 1, :, p:p + q_len])
+
+
 def _attn_ref64(q, k, v, past):
     """float64 attention of q [T,H,D] over k / v [Hkv,S,D] under the index-order causal mask (row i sees keys < past + i + 1)."""
     T, H, D = q.shape

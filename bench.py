@@ -39,6 +39,7 @@ for _p in (ROOT, os.path.join(ROOT, "prompt-cache_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak (guides/MI355X_MICROARCH.md; the headline 5 PF includes 2:1 sparsity)
 
 
 def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: int = 2, parity_layers: int = 0):
@@ -269,6 +270,54 @@ def attn_roofline(lm, staged, q_len: int):
                    "staged K/V after the timed region; latency-bound at this size (28.5 MB per launch), see DESIGN.md 3.2"}
 
 
+def attn_many_roofline(lm, q_len: int, S: int):
+    """Event-time the many-row attention (> 64 new rows over S staged keys: pc_attn_ring.hip + the split-KV merge) on synthetic
+    operands of the model's shape, called as the forward calls it (split-precision Q, residual rows of the pass, fragment output
+    up to 512 rows).  MFMA-bound: algorithmic flops = 4 H D q (S + (q + 1) / 2) per launch; the kernel executes
+    twice that (Q and P enter as hi + lo pairs)."""
+    import torch
+    from promptcache_amd import _native as n
+    m = lm.hf_model
+    H, Hkv, D, dev = m.H, m.Hkv, m.D, m.device
+    cap, Lr = S + q_len + 64, 4
+    arena = torch.randn((Lr, 2, Hkv, cap, D), device=dev).half()
+    q16 = torch.randn((q_len, H * D), device=dev).half()
+    q16l = (torch.randn((q_len, H * D), device=dev) * 2 ** -11).half()
+    lo = torch.zeros((2, Hkv, q_len + 64, D), device=dev).half()
+    frag = q_len <= 512
+    mt = (q_len + 15) // 16
+    ah = torch.empty((mt, H * D // 32, 64, 8), dtype=torch.float16, device=dev)
+    al = torch.empty_like(ah)
+    out = torch.empty((q_len, H * D), dtype=torch.float16, device=dev)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, S + q_len), 4) // 4, dtype=torch.float32, device=dev)
+    kvlo = (lo[0], lo[1], Hkv * (q_len + 64) * D, (q_len + 64) * D, -1)
+    evs = []
+    for i in range(3 * m.L):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        li = i % Lr
+        if frag:
+            n.attn_fwd(q16, q_len * H * D, H * D, arena[li, 0], arena[li, 1], 2 * Hkv * cap * D, cap * D, None, 0, 0, 1, H, Hkv, D, q_len,
+                       S, m.softmax_scale, ws, out_frag=(ah, al), q_lo=q16l, kv_lo=kvlo)
+        else:
+            n.attn_fwd(q16, q_len * H * D, H * D, arena[li, 0], arena[li, 1], 2 * Hkv * cap * D, cap * D, out, q_len * H * D, H * D, 1, H,
+                       Hkv, D, q_len, S, m.softmax_scale, ws, q_lo=q16l, out_lo=torch.empty_like(out), kv_lo=kvlo)
+        e1.record()
+        if i >= m.L:
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    avg = sum(us) / len(us)
+    flops = 4.0 * H * D * q_len * (S + (q_len + 1) / 2)
+    return {"kernel": "attn_ring_kernel<KVLO> + attn_combine_kernel (pc_attn, > 64 split-precision rows; pc_attn_ring.hip)",
+            "bound": "mfma", "achieved": flops / (avg * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "executed_frac": 2 * flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+            "traffic": None, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg, "min_launch_us": us[0],
+            "launches_timed": len(us), "launches_per_step": m.L, "q_len": q_len, "staged_keys": S,
+            "how": "HIP events around eager pc_attn calls (ring kernel + split-KV merge) on synthetic K/V of the model's shape; frac = "
+                   "algorithmic flops (one plane) / 2.5 PFLOP/s, executed_frac counts the hi + lo planes of Q and P"}
+
+
 def config_workload(cfg: int):
     """BASELINE.json configs 2-4 as synthetic PML with each config's structure (no datasets or
     checkpoints offline) -> (model shape name, max_ctx, max_tokens, [(schema_pml, prompt_pml), ...], label)."""
@@ -363,6 +412,9 @@ def run_config(args, device, world, rank, barrier):
                            "note": "q > 64 rows (config 4) leaves the weight-streaming regime; per-kernel figures: bench.py --config 1"},
               "encode_seconds": t_enc, "entries": per_entry,
               "recipe": "reference eval.py:172-219: per entry cache_time + response_time, cached and no_cache, best of 3"}
+    q0, S0 = per_entry[0]["cached"]["new_tokens"], per_entry[0]["cached"]["staged_tokens"]
+    if rank == 0 and q0 > 64 and lm.hf_model.D == 128:
+        result["roofline_attention"] = attn_many_roofline(lm, q0, S0)
     if rank == 0:
         print(json.dumps(result))
 

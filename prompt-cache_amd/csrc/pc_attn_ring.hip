@@ -27,6 +27,9 @@
 #ifndef PC_RING_EXP
 #define PC_RING_EXP 0
 #endif
+#ifndef PC_RING_PRIO
+#define PC_RING_PRIO 0
+#endif
 
 namespace pca {
 namespace {
@@ -258,11 +261,11 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             __builtin_amdgcn_sched_group_barrier(0x008, NMK, 0);                      // ... then this block's MFMAs
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float sc = acc[r] * p.scale_log2;
-                float s_ = sc;
+                // (raw scores: the softmax scale is folded into the exponent below -- one fma per score instead of mul + sub)
+                float s_ = acc[r];
                 if constexpr (MASKED) {
                     const int key = key0 + kb * 16 + g * 4 + r;
-                    s_ = (key < row_vis_end && key < key_end) ? sc : -INFINITY;
+                    s_ = (key < row_vis_end && key < key_end) ? s_ : -INFINITY;
                 }
                 sv[kb][r] = s_;
                 mx = fmaxf(mx, s_);
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
 #endif
-        const float alpha = fast_exp2(m_run - m_new);
+        const float c_ = p.scale_log2, mc = m_new * c_;       // m_run / m_new are in raw-score units, the partials' m in log2 units
+        const float alpha = fast_exp2(m_run * c_ - mc);
         float rs = 0.f;
         h8 pb[2], pbl[2];
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
 #if PC_RING_EXP == 1
                 const float e = sv[kb][r];
 #else
-                const float e = fast_exp2(sv[kb][r] - m_new);
+                const float e = fast_exp2(__builtin_fmaf(sv[kb][r], c_, -mc));
 #endif
                 rs += e;
                 const _Float16 eh = (_Float16)e;
@@ -356,6 +360,11 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
     };
 
     // ---- the ring ----
+#if PC_RING_PRIO
+    // static priority for the second-dispatched half of the workgroup: at equal priority the older wave of a SIMD wins every
+    // VALU arbitration and waves 4-7 start each phase late
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     if (nst > 0) {
         issue(0, lds0);
         if (nst > 1) {
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
         float* po = p.part_o + slot * D + g * 4;
 #pragma unroll
         for (int db = 0; db < DB; ++db) *(f4*)(po + db * 16) = o[db];
-        if (g == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_run; }
+        if (g == 0) { p.part_ml[slot * 2] = m_run * p.scale_log2; p.part_ml[slot * 2 + 1] = l_run; }
     }
 }
 

@@ -529,7 +529,7 @@ class LlamaHIP:
 
         # head_dim 128, fp16 weights: RoPE and the KV append run in the q|k|v projection's epilogue (pc_gemm_dense_qkv_rope);
         # otherwise the projection leaves fp32 [T, W] for pc_rope_append
-        fused_qkv = D == 128 and len(layers) > 0 and "wqkv_ds" not in layers[0] and self.fused_dense_qkv
+        fused_qkv = D == 128 and len(layers) > 0 and layers[0].get("wqkv_ds") is None and self.fused_dense_qkv
         qkv = None if fused_qkv else torch.empty((T, W), dtype=f32, device=dev)
         for li, lw in enumerate(layers):
             norm(x, lw["ln1"], T)

@@ -30,9 +30,14 @@
 #ifndef PC_RING_PRIO
 #define PC_RING_PRIO 0
 #endif
+#ifndef PC_RING_PAIR
+#define PC_RING_PAIR 1
+#endif
 
 namespace pca {
 namespace {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RD = 128;                 // head dim
 constexpr int RKS = RD / 32, RDB = RD / 16, RCPR = RD / 8;
@@ -42,6 +47,20 @@ constexpr int kStage = 4 * kPlane;      // 64 KiB
 
 // one region of the key walk (all workgroup-uniform): keys [a, e) are rows of k / v indexed BY KEY (bases are pre-shifted);
 // lo != 0: every key of the region has a residual row in kl / vl
+// (hi, lo) fp16 pair planes of two fp32 values: hi = fp16(e), lo = fp16(e - hi), packed two per register.  The residual is ONE
+// v_fma_mix per value (f16 source widened inside the fma, result rounded to f16 into the low / high half) instead of
+// v_cvt_f32_f16 + v_sub_f32 + v_cvt_f16_f32 + a pack -- the softmax is a third of this kernel's issue slots.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float e0, float e1, uint32_t& hi, uint32_t& lo) {
+    const h2 hh = {(_Float16)e0, (_Float16)e1};
+    hi = __builtin_bit_cast(uint32_t, hh);
+    uint32_t d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(d) : "v"(hi), "v"(e0), "v"(e1));
+    lo = d;
+}
+
 // LDS-DMA issued as raw instructions: 16 bytes per lane from `g` to LDS byte address `lds_addr` + 16 * lane.  The builtin form
 // makes hipcc wait vmcnt(0) in front of every ds_read_b64_tr_b16 that follows (it cannot tell the transposing reads from
 // the buffer the DMA is filling), which would serialise the ring; here the waits are the explicit ones in the ring loop.
@@ -284,18 +303,23 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
         h8 pb[2], pbl[2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
+            float e[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #if PC_RING_EXP == 1
-                const float e = sv[kb][r];
+                e[r] = sv[kb][r];
 #else
-                const float e = fast_exp2(__builtin_fmaf(sv[kb][r], c_, -mc));
+                e[r] = fast_exp2(__builtin_fmaf(sv[kb][r], c_, -mc));
 #endif
-                rs += e;
-                const _Float16 eh = (_Float16)e;
-                pb[kb >> 1][(kb & 1) * 4 + r] = eh;
-                pbl[kb >> 1][(kb & 1) * 4 + r] = (_Float16)(e - (float)eh);
+                rs += e[r];
             }
+            uint32_t h01, l01, h23, l23;
+            split_pair(e[0], e[1], h01, l01);
+            split_pair(e[2], e[3], h23, l23);
+            const u32x2 hv = {h01, h23}, lv = {l01, l23};
+            const h4 hq = __builtin_bit_cast(h4, hv), lq = __builtin_bit_cast(h4, lv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pb[kb >> 1][(kb & 1) * 4 + r] = hq[r]; pbl[kb >> 1][(kb & 1) * 4 + r] = lq[r]; }
         }
 #if PC_RING_EXP != 1
         rs += __shfl_xor(rs, 16);
@@ -347,6 +371,110 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             __builtin_amdgcn_sched_group_barrier(0x008, NMV, 1);
         }
     };
+    // Two PLAIN, fully visible tiles (A, B) of one stage as a software pipeline: the MFMAs of one tile run beside the softmax
+    // arithmetic of the other -- QK(A) | QK(B) + softmax(A) | PV(A) + softmax(B) | PV(B) -- instead of QK, softmax, PV twice in a row
+    // (a wave issues in order: an MFMA occupies the matrix pipe for 16 cycles after its 4-cycle issue, and independent VALU
+    // instructions of the same wave fill that shadow; back to back, QK -> softmax -> PV leaves the pipe idle through every softmax).
+    auto pair = [&](const _Float16* KA, const _Float16* VA, const _Float16* KB, const _Float16* VB) {
+        const float c_ = p.scale_log2;
+        auto qk = [&](const _Float16* Kl, f4 (&acc)[4], int sync) {
+            h8 ka[2][KS];
+            auto load_k = [&](int kb, int set) {
+                const int row = kb * 16 + n;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) ka[set][ks] = *(const h8*)(Kl + row * D + (((ks * 4 + g) ^ (row & (CPR - 1))) << 3));
+            };
+            load_k(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                if (kb + 1 < 4) load_k(kb + 1, (kb + 1) & 1);
+                f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[kb & 1][ks], qf[ks], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[kb & 1][ks], qfl[ks], a, 0, 0, 0);
+                }
+                acc[kb] = a;
+            }
+            (void)sync;
+        };
+        // online softmax of one tile's raw scores: P as hi / lo operand pairs, the row sums and maxima, alpha for the rescale
+        auto soft = [&](const f4 (&acc)[4], h8 (&pb)[2], h8 (&pbl)[2], float& alpha, bool& moved) {
+            float mx = fmaxf(fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[0][2], acc[0][3])), fmaxf(fmaxf(acc[1][0], acc[1][1]), fmaxf(acc[1][2], acc[1][3])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(acc[2][0], acc[2][1]), fmaxf(acc[2][2], acc[2][3])), fmaxf(fmaxf(acc[3][0], acc[3][1]), fmaxf(acc[3][2], acc[3][3]))));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx), mc = m_new * c_;
+            alpha = fast_exp2(m_run * c_ - mc);
+            moved = m_new > m_run;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = fast_exp2(__builtin_fmaf(acc[kb][r], c_, -mc));
+                    rs += e[r];
+                }
+                uint32_t h01, l01, h23, l23;
+                split_pair(e[0], e[1], h01, l01);
+                split_pair(e[2], e[3], h23, l23);
+                const u32x2 hv = {h01, h23}, lv = {l01, l23};
+                const h4 hq = __builtin_bit_cast(h4, hv), lq = __builtin_bit_cast(h4, lv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pb[kb >> 1][(kb & 1) * 4 + r] = hq[r]; pbl[kb >> 1][(kb & 1) * 4 + r] = lq[r]; }
+            }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+        };
+        auto rescale = [&](float alpha, bool moved) {
+            if (__any(moved)) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+                }
+            }
+        };
+        auto pv = [&](const _Float16* Vl, const h8 (&pb)[2], const h8 (&pbl)[2]) {
+            h4 va[2][4];
+            auto load_v = [&](int db, int set) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int vrow = t * 32 + g * 4 + (n >> 2);
+                    const int off = vrow * D + ((db * 16 + (n & 3) * 4 + 16 * (vrow & 7)) & (D - 1));
+                    va[set][2 * t] = lds_tr_read(Vl + off);
+                    va[set][2 * t + 1] = lds_tr_read(Vl + off + 16 * D);
+                }
+            };
+            load_v(0, 0);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                if (db + 1 < DB) load_v(db + 1, (db + 1) & 1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const h4 lo = va[db & 1][2 * t], hi = va[db & 1][2 * t + 1];
+                    const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
+                }
+            }
+        };
+        f4 accA[4], accB[4];
+        h8 pA[2], pAl[2], pB[2], pBl[2];
+        float alA, alB;
+        bool mvA, mvB;
+        qk(KA, accA, 2);
+        qk(KB, accB, 3);                 // } one scheduling region: B's MFMAs beside A's exponentials
+        soft(accA, pA, pAl, alA, mvA);   // }
+        rescale(alA, mvA);
+        pv(VA, pA, pAl);                 // } and A's V^T . P^T beside B's exponentials
+        soft(accB, pB, pBl, alB, mvB);   // }
+        rescale(alB, mvB);
+        pv(VB, pB, pBl);
+    };
+
     using T_ = std::true_type;
     using F_ = std::false_type;
     // a tile whose every key is visible to every row of this wave (and lies inside its region) skips the mask compares
@@ -387,10 +515,17 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
                     run_tile((const _Float16*)buf, (const _Float16*)(buf + kPlane), (const _Float16*)(buf + 2 * kPlane),
                              (const _Float16*)(buf + 3 * kPlane), T_{}, key0, x.e);
                 } else {
-                    run_tile((const _Float16*)buf, (const _Float16*)(buf + kPlane), nullptr, nullptr, F_{}, key0, x.e);
-                    if (key0 + kTK < x.e && key0 + kTK < wave_vis_end)
-                        run_tile((const _Float16*)(buf + 2 * kPlane), (const _Float16*)(buf + 3 * kPlane), nullptr, nullptr, F_{},
-                                 key0 + kTK, x.e);
+                    const int full_end = (x.e < past_len + qrow0 + 1) ? x.e : past_len + qrow0 + 1;
+                    if (PC_RING_PAIR && key0 + 2 * kTK <= full_end && qrow0 + 16 <= q_len) {
+                        // both tiles whole and visible to every row of the wave: the pipelined pair
+                        pair((const _Float16*)buf, (const _Float16*)(buf + kPlane), (const _Float16*)(buf + 2 * kPlane),
+                             (const _Float16*)(buf + 3 * kPlane));
+                    } else {
+                        run_tile((const _Float16*)buf, (const _Float16*)(buf + kPlane), nullptr, nullptr, F_{}, key0, x.e);
+                        if (key0 + kTK < x.e && key0 + kTK < wave_vis_end)
+                            run_tile((const _Float16*)(buf + 2 * kPlane), (const _Float16*)(buf + 3 * kPlane), nullptr, nullptr, F_{},
+                                     key0 + kTK, x.e);
+                    }
                 }
             }
             if (i + 1 < nst) {

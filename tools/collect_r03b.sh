@@ -20,7 +20,7 @@ cd $R
 for c in 2 3 4; do timeout 900 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; done; echo "configs rc $?"
 timeout 600 bash tools/prof_config.sh r03b 4 > $OUT/prof_c4.log 2>&1; echo "prof c4 rc $?"
 timeout 600 bash tools/pmc_attn_mid.sh r03b/pmc_ring 40 8258 259 > $OUT/pmc_ring.txt 2>&1; echo "pmc ring rc $?"
-timeout 600 bash tools/run_r3r.sh > $OUT/decode.log 2>&1; cp gpurun_out/r3r/decode_kernel_stats.txt $OUT/ 2>/dev/null
+timeout 600 bash tools/decode_prof.sh > $OUT/decode.log 2>&1; cp gpurun_out/decode_prof/decode_kernel_stats.txt $OUT/ 2>/dev/null
 tail -2 $OUT/bench_default.err
 python3 - <<PY
 import json

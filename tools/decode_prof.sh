@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r3r
+OUT=$R/gpurun_out/decode_prof
 mkdir -p $OUT
 rocprofv3 --kernel-trace -d $OUT/dec -o d -f csv -- python $R/tools/decode_profile.py 96 > $OUT/dec.log 2>&1
 tail -3 $OUT/dec.log

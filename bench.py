@@ -631,11 +631,16 @@ def main():
         lib_schemas = [synth.persona_like(name=f"lib-persona-{i}", system_len=200 + 40 * i, seed=20 + i)[0] for i in range(5)]
         lib_schemas += [synth.flat_docs(f"lib-docs-{i}", 30, lens, 8, seed=30 + i)[0]
                         for i, lens in enumerate([(306, 76, 800, 800, 800), (1500, 1200), (400,) * 6])]
-        barrier()
-        t0 = time.perf_counter()
-        eng.add_schemas([fmt(text) for text in lib_schemas])       # schema-level sharding + overlapped exchange (N > 1)
-        barrier()
-        t_lib = time.perf_counter() - t0
+        lib_runs = []
+        for rep_ in range(2):       # (host tokenisation + planning are part of it: the first call also pays cold allocations)
+            for n in [n for n in eng.schemas if n.startswith("lib-")]:
+                eng.remove_schema(n)
+            barrier()
+            t0 = time.perf_counter()
+            eng.add_schemas([fmt(text) for text in lib_schemas])   # schema-level sharding + overlapped exchange (N > 1)
+            barrier()
+            lib_runs.append(time.perf_counter() - t0)
+        t_lib = min(lib_runs)
         names = [n for n in eng.schemas if n.startswith("lib-")]
         lib_tokens = sum(sum(len(j["token_ids"]) for j in eng.schemas[n]._plan()) for n in names)
         lib_passes = sum(int(eng.schemas[n].encode_stats["total_passes"]) for n in names)
@@ -650,6 +655,7 @@ def main():
         library = {"per_rank_computed_tokens": per_rank,
                    "schemas": len(names), "passes": lib_passes, "tokens": int(lib_tokens), "cached_tokens": lib_cached,
                    "module_kv_bytes": int(lib_cached) * lm.hf_model.config.kv_bytes_per_token, "seconds": t_lib,
+                   "seconds_runs": lib_runs,
                    "tokens_per_s": lib_tokens / t_lib, "sharded_over": world,
                    "note": "BASELINE config 5 stand-in: synthetic schema library through CacheEngine.add_schemas: whole schemas "
                            "dealt to the ranks (LPT on the tokens each encode really runs; every trunk computed once), slabs "

@@ -382,7 +382,13 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             auto load_k = [&](int kb, int set) {
                 const int row = kb * 16 + n;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) ka[set][ks] = *(const h8*)(Kl + row * D + (((ks * 4 + g) ^ (row & (CPR - 1))) << 3));
+                for (int ks = 0; ks < KS; ++ks) {
+#if PC_RING_EXP == 4      // dev probe: no K reads
+                    ka[set][ks] = h8{(_Float16)row, (_Float16)ks, 0, 0, 0, 0, 0, 0};
+#else
+                    ka[set][ks] = *(const h8*)(Kl + row * D + (((ks * 4 + g) ^ (row & (CPR - 1))) << 3));
+#endif
+                }
             };
             load_k(0, 0);
 #pragma unroll
@@ -444,8 +450,13 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
                 for (int t = 0; t < 2; ++t) {
                     const int vrow = t * 32 + g * 4 + (n >> 2);
                     const int off = vrow * D + ((db * 16 + (n & 3) * 4 + 16 * (vrow & 7)) & (D - 1));
+#if PC_RING_EXP == 3      // dev probe: no V^T reads (LDS-bandwidth attribution; results are wrong)
+                    va[set][2 * t] = h4{(_Float16)off, 0, 0, 0};
+                    va[set][2 * t + 1] = h4{0, (_Float16)off, 0, 0};
+#else
                     va[set][2 * t] = lds_tr_read(Vl + off);
                     va[set][2 * t + 1] = lds_tr_read(Vl + off + 16 * D);
+#endif
                 }
             };
             load_v(0, 0);

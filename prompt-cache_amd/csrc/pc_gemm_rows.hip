@@ -22,14 +22,15 @@ namespace pcg {
 constexpr int kStageWaves = 4;
 
 
-template <int TT, int EPI, int MTW, bool TWO>
-__global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const GemmParams p) {
+// SW staging waves, KCV k-steps per stage, PDV activation prefetch distance, LB launch bound (0 / -1 / 0: the defaults)
+template <int TT, int EPI, int MTW, bool TWO, int SW = kStageWaves, int KCV = 0, int PDV = -1, int LB = 0>
+__global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_kernel(const GemmParams p) {
     constexpr int T = (EPI == EPI_SILU) ? TT / 2 : TT;   // output units (tiles, or gate/up pairs) per workgroup
-    constexpr int KC = (TT <= 4) ? 8 : 4;                // k-steps per stage
+    constexpr int KC = KCV ? KCV : (TT <= 4) ? 8 : 4;    // k-steps per stage
     constexpr int F = TT * KC;                           // 1-KiB fragments per stage
-    constexpr int FPW = F / kStageWaves;
-    constexpr int PD = (MTW == 2) ? 3 : 1, NX = PD + 1;  // activation prefetch distance (k-steps) / register sets
-    static_assert(F % kStageWaves == 0 && KC % NX == 0, "stage must split evenly over the staging waves");
+    constexpr int FPW = F / SW;
+    constexpr int PD = PDV >= 0 ? PDV : (MTW == 2) ? 3 : 1, NX = PD + 1;  // activation prefetch distance (k-steps) / register sets
+    static_assert(F % SW == 0 && KC % NX == 0, "stage must split evenly over the staging waves");
     __shared__ __attribute__((aligned(16))) _Float16 wbuf[2][F][64][8];
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
         int kst[FPW];
 #pragma unroll
         for (int i = 0; i < FPW; ++i) {
-            const int f = sidx + kStageWaves * i;        // fragment of the stage: k-step-major, tile-minor
+            const int f = sidx + SW * i;                 // fragment of the stage: k-step-major, tile-minor
             const int kk = f / TT, tt = f - kk * TT;
             int unit = blockIdx.x * T + (EPI == EPI_SILU ? (tt < T ? tt : tt - T) : tt);
             if (unit >= nunits) unit = nunits - 1;       // clamped duplicates are computed and never stored
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(MTW == 2 ? 1024 : 768) void gemm_rows_kernel(const 
             const int se = (ST);                                                              \
             _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
                 const bool ok = kq0 + se * KC + kst[i] < kq1;                                 \
-                *(h8*)wbuf[(ST) & 1][sidx + kStageWaves * i][lane] = ok ? R[i] : zero;        \
+                *(h8*)wbuf[(ST) & 1][sidx + SW * i][lane] = ok ? R[i] : zero;                 \
             }                                                                                 \
         }
         // Loads are issued unconditionally (stages past the end re-read the last valid k-step): a load under a
@@ -206,6 +207,25 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
         else if constexpr ((TTV) <= 6) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4, false>), grid, block, 0, s, p); \
         return pc_check_launch("gemm_rows_kernel");                                                        \
     } while (0)
+    // Wide panels (round 3): up to 288 rows with split-precision planes, a workgroup takes EIGHT weight tiles (128 columns; four
+    // gate/up pairs) instead of four.  What bounds this kernel at a few hundred rows is the activation planes every workgroup
+    // re-reads from L2 (13b, 256 rows: 5.2 MB per workgroup against 0.65 MB of weights; launch time = HBM time of the weights +
+    // 1.2 us per row): half as many workgroups re-read half as much.  The accumulators of eight tiles need 156 registers, i.e.
+    // at most 12 waves per workgroup: 9 compute waves (288 rows) + THREE staging waves, 3 k-steps per stage, activation prefetch
+    // distance 2.  The caller fills the chip with K slices instead of narrow panels (o_proj / down_proj: slabs; see
+    // rows_kslices in model/llama_hip.py).  13b layer at 259 rows: 491 -> 338 us (tools/rows_bench.py).
+    {
+        static const bool no_wide = [] { const char* e = getenv("PC_ROWS_WIDE"); return e && e[0] == '0'; }();
+        static const bool wide_rope = [] { const char* e = getenv("PC_ROWS_WIDE_ROPE"); return e && e[0] == '1'; }();   // (q|k|v keeps four tiles: no K split under its epilogue)
+        const int mt = pc_ceil_div(p.M, 16);
+        if (two && !no_wide && !forced && mt <= 18 && (EPI != EPI_ROPE || wide_rope)) {
+            constexpr int TV = (EPI == EPI_SILU) ? 4 : 8;
+            const int rw = pc_ceil_div(mt, 2);
+            hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768>), dim3(pc_ceil_div(units, TV), p.kslices),
+                               dim3((rw + 3) * 64), 0, s, p);
+            return pc_check_launch("gemm_rows_kernel");
+        }
+    }
     const int work = units * p.kslices;
     if constexpr (EPI == EPI_SILU) {
         if (forced == 4 || two || (!forced && pc_ceil_div(work, 2) <= 256)) PC_ROWS(4);

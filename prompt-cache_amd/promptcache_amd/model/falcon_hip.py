@@ -166,7 +166,7 @@ class FalconHIP(LlamaHIP):
         xh, xl = planes(hid)
         ah, al = planes(H * D)
         ch, cl = planes(inter)
-        KQ = self.kslices
+        KQ = self.rows_kslices(T, hid)
         slabs = torch.empty((2 * KQ, T, hid), dtype=f32, device=dev)      # [0:KQ] attention branch, [KQ:] MLP branch
         pending = 0
         tail = self._tail_for(arena, past_dev)

@@ -465,6 +465,17 @@ class LlamaHIP:
         return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
 
     # ------------------------------------------------------------------------------------------
+    def rows_kslices(self, T: int, N: int) -> int:
+        """K slices of the N = hidden projections (o_proj, down_proj) of a T-row pass.  65..288 rows run the wide-panel form of
+        the row-split kernel (128 columns per workgroup, csrc/pc_gemm_rows.hip): N / 128 panels, so the slices are what fills the
+        256 CUs (13b: 40 panels x 6).  Other row counts keep 4."""
+        forced = os.environ.get("PC_ROWS_KQ")
+        if forced:
+            return int(forced)
+        if self.SKINNY_MAX_ROWS < T <= 288 and os.environ.get("PC_ROWS_WIDE", "1") != "0":
+            return max(1, min(8, 256 // -(-N // 128)))
+        return self.kslices
+
     def _proj(self, a_hi, a_lo, lw: dict, key: str, M: int, N: int, K: int, epi: int, **out) -> None:
         """One many-row projection on the hand-written MFMA kernel (pc_gemm_dense.hip): ``(a_hi + a_lo) @ W^T`` with the
         epilogue fused.  int8 mode: ``lw[key]`` holds the int8 codes as fp16 (exact) and the per-output scales
@@ -1005,7 +1016,7 @@ class LlamaHIP:
         ch, cl = planes(inter)
         # The two N = hidden projections (o_proj, down_proj) split K over KQ workgroup slices and leave KQ slabs of
         # partial sums; the next RMSNorm launch folds them into the residual stream (x += sum of slabs).
-        KQ = self.kslices
+        KQ = self.rows_kslices(T, hid)
         slabs = torch.empty((KQ, T, hid), dtype=torch.float32, device=dev)
         pending = 0                                   # slabs waiting to be added to x
         layers = self.layers if num_layers is None else self.layers[:num_layers]

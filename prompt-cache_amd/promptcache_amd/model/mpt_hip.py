@@ -269,7 +269,7 @@ class MptHIP(LlamaHIP):
         xh, xl = planes(hid)
         ah, al = planes(hid)
         ch, cl = planes(inter)
-        KQ = self.kslices
+        KQ = self.rows_kslices(T, hid)
         slabs = torch.empty((KQ, T, hid), dtype=f32, device=dev)
         pending = 0
         tail = self._tail_for(arena, past_dev)

@@ -175,6 +175,64 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
     }
 }
 
+// q|k|v with K split across workgroups (65..288 rows, wide panels): the projection leaves `nslabs` fp32 slabs [M][N] of partial
+// sums in the row-PERMUTED column order of the q|k|v weight image (inside every head, tile j = features 8j..8j+7 then their rotary
+// partners D/2+8j..); this kernel adds the slabs in slice order and does what tile_epilogue<EPI_ROPE> does on a tile: RoPE at the
+// row's table entries for q and k heads, hi / lo split, q into the planes, k and v (+ residuals) into the arena behind the past.
+// One thread = one (row, head, tile j, half-tile quad): 4 low-half values and their 4 partners.
+__global__ __launch_bounds__(256) void qkv_rope_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
+                                                             int M, int N, const RopeEpi e) {
+    const int tpd = e.D >> 4;                               // tiles per head
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = (N >> 4) * 2;                       // (tile, quad) pairs per row
+    if (idx >= (int64_t)M * per_row) return;
+    const int row = (int)(idx / per_row), rem = (int)(idx - (int64_t)row * per_row);
+    const int unit = rem >> 1, q4 = rem & 1;                // tile of the permuted image, which 4 of its 8 frequency slots
+    const int hh = unit / tpd, j = unit - hh * tpd;
+    const float* sp = slabs + (int64_t)row * N + unit * 16 + q4 * 4;
+    f4 lo4 = *(const f4*)sp, hi4 = *(const f4*)(sp + 8);
+    for (int z = 1; z < nslabs; ++z) {
+        const f4 a = *(const f4*)(sp + z * slab_stride), b = *(const f4*)(sp + z * slab_stride + 8);
+        lo4[0] += a[0]; lo4[1] += a[1]; lo4[2] += a[2]; lo4[3] += a[3];
+        hi4[0] += b[0]; hi4[1] += b[1]; hi4[2] += b[2]; hi4[3] += b[3];
+    }
+    const int i0 = 8 * j + 4 * q4;                          // rotary frequency index of element 0
+    const int bb = row / e.q_len, tt = row - bb * e.q_len;
+    const bool rot = hh < e.H + e.Hkv;
+    h4 ah, al, ch, cl;
+    const float2* cs = e.cs + (int64_t)row * (e.D >> 1) + i0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = lo4[r], c = hi4[r];
+        if (rot) {                                          // q*cos + rotate_half(q)*sin (llama2.py:208)
+            const float2 w = cs[r];
+            a = lo4[r] * w.x - hi4[r] * w.y;
+            c = hi4[r] * w.x + lo4[r] * w.y;
+        }
+        _Float16 t0, t1, t2, t3;
+        pc_split(a, t0, t1);
+        pc_split(c, t2, t3);
+        ah[r] = t0; al[r] = t1; ch[r] = t2; cl[r] = t3;
+    }
+    const int half = e.D >> 1;
+    if (hh < e.H) {
+        const int64_t off = (int64_t)row * e.q_ts + (int64_t)hh * e.D + i0;
+        *(h4*)(e.q_hi + off) = ah; *(h4*)(e.q_hi + off + half) = ch;
+        *(h4*)(e.q_lo + off) = al; *(h4*)(e.q_lo + off + half) = cl;
+        return;
+    }
+    const int past = e.past_len_dev ? *e.past_len_dev : e.past_len;
+    const bool is_k = hh < e.H + e.Hkv;
+    const int kh = is_k ? hh - e.H : hh - e.H - e.Hkv;
+    _Float16* dst = (is_k ? e.k_arena : e.v_arena) + bb * e.a_bs + (int64_t)kh * e.a_hs + (int64_t)(past + tt) * e.D + i0;
+    *(h4*)dst = ah; *(h4*)(dst + half) = ch;
+    if (e.k_lo) {
+        const int lr = e.lo_base == -1 ? tt : past + tt - (e.lo_base == -2 ? e.past_len_dev[1] : e.lo_base);
+        _Float16* dl = (is_k ? e.k_lo : e.v_lo) + bb * e.lo_bs + (int64_t)kh * e.lo_hs + (int64_t)lr * e.D + i0;
+        *(h4*)dl = al; *(h4*)(dl + half) = cl;
+    }
+}
+
 }  // namespace
 
 
@@ -251,6 +309,25 @@ PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
         p.rope.k_lo = (_Float16*)a->k_lo; p.rope.v_lo = (_Float16*)a->v_lo; p.rope.lo_bs = a->lo_batch_stride; p.rope.lo_hs = a->lo_head_stride;
         p.rope.lo_base = a->lo_base;
         p.rope.H = a->H; p.rope.Hkv = a->Hkv; p.rope.D = a->D; p.rope.q_len = a->q_len; p.rope.past_len = a->past_len;
+        if (kslices > 1) {
+            // K slices under the q|k|v epilogue (row-split kernel, wide panels): partial slabs in ks_scratch, then the rotation /
+            // append as a second launch over the slabs (qkv_rope_slabs_kernel)
+            PC_REQUIRE(M > 64 && a->xf_lo && !a->w_scale && !norm && kslices <= 8, PC_ERR_ARG,
+                       "pc_gemm: K slices under the q|k|v epilogue are for 65..512 rows, fp16 weights, both activation planes");
+            PC_REQUIRE(a->ks_scratch && ((uintptr_t)a->ks_scratch & 15) == 0 &&
+                       a->ks_scratch_bytes >= (int64_t)kslices * M * N * (int64_t)sizeof(float), PC_ERR_WORKSPACE,
+                       "pc_gemm: q|k|v with %d K slices needs ks_scratch >= %lld bytes (16-byte aligned)", kslices,
+                       (long long)kslices * M * N * (long long)sizeof(float));
+            p.y = (float*)a->ks_scratch; p.ldy = N;
+            p.kslices = kslices; p.slab_stride = (int64_t)M * N;
+            const RopeEpi e = p.rope;
+            int rc = launch_MT(EPI_STORE, p, choose_T(p.ntiles * kslices), p.ntiles, s);
+            if (rc != PC_OK) return rc;
+            const int64_t items = (int64_t)M * (N / 16) * 2;
+            hipLaunchKernelGGL(qkv_rope_slabs_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+                               (const float*)a->ks_scratch, kslices, (int64_t)M * N, M, N, e);
+            return pc_check_launch("qkv_rope_slabs_kernel");
+        }
         set_k_balance(p, K);
         return launch_MT(EPI_ROPE, p, choose_T(p.ntiles), p.ntiles, s);
     }

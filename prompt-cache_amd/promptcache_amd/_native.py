@@ -292,10 +292,13 @@ def gemm_skinny_ks(wf, xf_hi, xf_lo, M: int, N: int, K: int, y, ldy: int, kslice
 
 def gemm_qkv_rope(wf_perm, xf_hi, xf_lo, M, K, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len,
                   past_len, cap, past_len_dev=None, stream: Optional[int] = None, kv_lo=None, wscale=None,
-                  lo_base: int = -1, rows_dev=None) -> None:
+                  lo_base: int = -1, rows_dev=None, kslices: int = 1, scratch=None) -> None:
     """``kv_lo=(k_lo, v_lo, batch_stride, head_stride)``: also write the fp16 residuals of the new K / V rows; ``lo_base``
-    places them (-1: compact ``[B][Hkv][q_len][D]`` rows of this pass; >= 0 / -2: a residual tail that outlives the pass)."""
-    _gemm(stream, wf=wf_perm, w_scale=wscale, xf_hi=xf_hi, xf_lo=xf_lo, M=M, K=K, rows_dev=rows_dev,
+    places them (-1: compact ``[B][Hkv][q_len][D]`` rows of this pass; >= 0 / -2: a residual tail that outlives the pass).
+    ``kslices > 1`` (65..512 rows): K is cut across workgroups, the partial sums go through ``scratch`` (fp32, >= kslices * M * N
+    elements) and the rotation / append runs as a second launch over them."""
+    _gemm(stream, wf=wf_perm, w_scale=wscale, xf_hi=xf_hi, xf_lo=xf_lo, M=M, K=K, rows_dev=rows_dev, kslices=kslices,
+          ks_scratch=scratch, ks_scratch_bytes=0 if scratch is None else scratch.numel() * scratch.element_size(),
           **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
 
 

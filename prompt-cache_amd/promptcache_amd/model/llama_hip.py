@@ -36,6 +36,11 @@ from .config import LlamaShape
 from .kv_arena import KVArena, StagedKV, arena_from_past
 
 
+def lw0_fp16(layers) -> bool:
+    """fp16 weight images (no int8 scales) in the layer stack."""
+    return len(layers) > 0 and layers[0].get("wqkv_s") is None
+
+
 @dataclass
 class CausalLMOutput:
     logits: torch.Tensor
@@ -1018,6 +1023,10 @@ class LlamaHIP:
         # partial sums; the next RMSNorm launch folds them into the residual stream (x += sum of slabs).
         KQ = self.rows_kslices(T, hid)
         slabs = torch.empty((KQ, T, hid), dtype=torch.float32, device=dev)
+        # ... and so does q|k|v there: its 128-column panels are half as many as the CUs, so K is cut in two and the rotation /
+        # append runs over the two slabs (pc_gemm: q|k|v epilogue with kslices = 2)
+        QS = int(os.environ.get("PC_ROWS_QKV_KS", "2")) if (KQ != self.kslices and lw0_fp16(self.layers)) else 1
+        qkv_slabs = torch.empty((QS, T, W), dtype=torch.float32, device=dev) if QS > 1 else None
         pending = 0                                   # slabs waiting to be added to x
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         if T <= self.NORM_FUSED_MAX_ROWS and self.fuse_norm:
@@ -1030,7 +1039,7 @@ class LlamaHIP:
             # q|k|v projection + RoPE + in-place KV append in one weight-streaming launch
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                             arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
-                            wscale=lw["wqkv_s"], lo_base=lo_base)
+                            wscale=lw["wqkv_s"], lo_base=lo_base, kslices=QS, scratch=qkv_slabs)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))

@@ -732,6 +732,42 @@ def test_gemm_rows_qkv_rope(B, H, Hkv, D, q_len, past, hid):
     assert float(arena_b[:, :, :, past:past + q_len].abs().sum()) > 0 and float(arena_b[:, :, :, :past].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("B,H,Hkv,q_len,past,hid,ks", [(1, 40, 40, 259, 30, 5120, 2), (2, 4, 2, 70, 7, 512, 2), (1, 8, 8, 100, 0, 1024, 3)])
+def test_gemm_rows_qkv_rope_with_k_slices_equals_the_single_launch(B, H, Hkv, q_len, past, hid, ks):
+    """pc_gemm's q|k|v epilogue with K slices (65..288 rows: wide panels, partial slabs, qkv_rope_slabs_kernel) against the same
+    call without slices: same q planes, same arena rows and residual rows up to the fp32 order of the K sum."""
+    n = _n()
+    rng = np.random.default_rng(29)
+    D = 128
+    T, W = B * q_len, (H + 2 * Hkv) * D
+    cap = past + q_len + 2
+    w = torch.from_numpy((0.05 * rng.standard_normal((W, hid), dtype=np.float32)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((T, hid), dtype=np.float32)).to(DEV)
+    hi, lo = n.to_act_frags(x)
+    pos = rng.integers(0, 3000, size=T).astype(np.int32)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    n.rope_table(torch.from_numpy(pos).to(DEV), _inv_freq(D, 10000.0).to(DEV), cs, T, D)
+    wf = n.to_weight_frags(w[n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)].contiguous())
+    outs = []
+    for slices in (1, ks):
+        arena = torch.full((B, 2, Hkv, cap, D), 5.0, dtype=torch.float16, device=DEV)
+        klo = torch.full((B, 2, Hkv, q_len, D), 5.0, dtype=torch.float16, device=DEV)
+        q, ql = torch.zeros((T, H * D), dtype=torch.float16, device=DEV), torch.zeros((T, H * D), dtype=torch.float16, device=DEV)
+        scratch = torch.empty((slices, T, W), dtype=torch.float32, device=DEV) if slices > 1 else None
+        n.gemm_qkv_rope(wf, hi, lo, T, hid, cs, q, ql, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, B, H, Hkv, D,
+                        q_len, past, cap, kv_lo=(klo[:, 0], klo[:, 1], 2 * Hkv * q_len * D, q_len * D), lo_base=-1,
+                        kslices=slices, scratch=scratch)
+        torch.cuda.synchronize()
+        outs.append((q.double() + ql.double(), arena[:, :, :, past:past + q_len].double() + klo.double(), arena.clone()))
+    (q1, kv1, a1), (q2, kv2, a2) = outs
+    scale = max(1.0, float(q1.abs().max()), float(kv1.abs().max()))
+    assert (q1 - q2).abs().max().item() < 2e-6 * scale and (kv1 - kv2).abs().max().item() < 2e-6 * scale
+    assert torch.equal(a1[:, :, :, :past], a2[:, :, :, :past]) and torch.equal(a1[:, :, :, past + q_len:], a2[:, :, :, past + q_len:])
+    with pytest.raises(RuntimeError, match="ks_scratch"):
+        n.gemm_qkv_rope(wf, hi, lo, T, hid, cs, q, ql, H * D, arena[:, 0], arena[:, 1], 2 * Hkv * cap * D, cap * D, B, H, Hkv, D,
+                        q_len, past, cap, kslices=ks)
+
+
 # ---------------------------------------------------------------------------------------------------
 # RMSNorm folded into the projection (M <= 16)
 # ---------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 # PMC counters of gemm_rows_kernel at one shape: bash tools/pmc_rows.sh M N K epi
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r2r
+OUT=$R/gpurun_out/pmc_rows
 mkdir -p $OUT
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
@@ -10,7 +10,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
 done
 python3 - <<'PY'
 import csv,glob,os,collections
-out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r2r'
+out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_rows'
 for f in sorted(glob.glob(out+'/pmc*/**/*counter_collection.csv', recursive=True)):
     agg=collections.defaultdict(lambda: [0,0.0])
     for r in csv.DictReader(open(f)):

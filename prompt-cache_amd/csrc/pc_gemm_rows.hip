@@ -35,7 +35,10 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int RW = (p.M + 16 * MTW - 1) / (16 * MTW);
+    // rows of this workgroup: all of them, or block blockIdx.z of p.zrows rows (289..512 rows: two row blocks per column panel)
+    const int row0 = p.zrows ? (int)blockIdx.z * p.zrows : 0;
+    const int Mz = p.zrows ? ((p.M - row0 < p.zrows) ? p.M - row0 : p.zrows) : p.M;
+    const int RW = (Mz + 16 * MTW - 1) / (16 * MTW);
     const int KS = p.KS;
     const int ksq = (KS + p.kslices - 1) / p.kslices;
     const int kq0 = blockIdx.y * ksq;
@@ -118,12 +121,12 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
     // activation row m only, and rows >= M are never stored.
     const _Float16* xa[MTW];
     const int64_t lo_delta = TWO ? (p.xf_lo - p.xf_hi) : 0;          // lo plane = hi plane + lo_delta (same layout)
-    const int mt_last = ((p.M + 15) >> 4) - 1;
+    const int mt_last = ((Mz + 15) >> 4) - 1;            // (row tiles count from this block's first row)
 #pragma unroll
     for (int a = 0; a < MTW; ++a) {
         int mt = MTW * wave + a;
         mt = mt < mt_last ? mt : mt_last;
-        xa[a] = p.xf_hi + (((int64_t)mt * KS + kq0) * 64 + lane) * 8;
+        xa[a] = p.xf_hi + (((int64_t)((row0 >> 4) + mt) * KS + kq0) * 64 + lane) * 8;
     }
     // row tiles this wave really owns (wave-uniform, >= 1): the MFMAs of the clamped duplicates behind the last tile are skipped
     const int nva = __builtin_amdgcn_readfirstlane((mt_last + 1 - MTW * wave) < MTW ? (mt_last + 1 - MTW * wave) : MTW);
@@ -176,7 +179,9 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
         for (int t = 0; t < T; ++t) {
             f4 u = {0.f, 0.f, 0.f, 0.f};
             if (EPI == EPI_SILU) u = acc[a][T + t];
-            tile_epilogue<EPI>(p, acc[a][t], u, (MTW * wave + a) * 16 + m, (int)blockIdx.x * T + t, g, (int)blockIdx.y);
+            // (rows past this block's end belong to the next block or to nobody: they are not stored)
+            const int lrow = (MTW * wave + a) * 16 + m;
+            tile_epilogue<EPI>(p, acc[a][t], u, lrow < Mz ? row0 + lrow : p.M, (int)blockIdx.x * T + t, g, (int)blockIdx.y);
         }
 }
 
@@ -207,7 +212,7 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
         else if constexpr ((TTV) <= 6) hipLaunchKernelGGL((gemm_rows_kernel<TTV, EPI, 4, false>), grid, block, 0, s, p); \
         return pc_check_launch("gemm_rows_kernel");                                                        \
     } while (0)
-    // Wide panels (round 3): up to 288 rows with split-precision planes, a workgroup takes EIGHT weight tiles (128 columns; four
+    // Wide panels (round 3): up to 288 rows (two blocks of them up to 512) with split-precision planes, a workgroup takes EIGHT weight tiles (128 columns; four
     // gate/up pairs) instead of four.  What bounds this kernel at a few hundred rows is the activation planes every workgroup
     // re-reads from L2 (13b, 256 rows: 5.2 MB per workgroup against 0.65 MB of weights; launch time = HBM time of the weights +
     // 1.2 us per row): half as many workgroups re-read half as much.  The accumulators of eight tiles need 156 registers, i.e.
@@ -218,11 +223,16 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
         static const bool no_wide = [] { const char* e = getenv("PC_ROWS_WIDE"); return e && e[0] == '0'; }();
         static const bool wide_rope = [] { const char* e = getenv("PC_ROWS_WIDE_ROPE"); return e && e[0] == '1'; }();   // (q|k|v keeps four tiles: no K split under its epilogue)
         const int mt = pc_ceil_div(p.M, 16);
-        if (two && !no_wide && !forced && mt <= 18 && (EPI != EPI_ROPE || wide_rope)) {
+        // 289..512 rows: two row blocks per column panel (grid.z), each within the 9 compute waves -- the weights of a panel are
+        // then read twice (once from L2), the activations of a row block by half as many workgroups
+        const int nz = mt <= 18 ? 1 : 2;
+        if (two && !no_wide && !forced && mt <= 36 && (EPI != EPI_ROPE || wide_rope || nz == 2)) {
             constexpr int TV = (EPI == EPI_SILU) ? 4 : 8;
-            const int rw = pc_ceil_div(mt, 2);
-            hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768>), dim3(pc_ceil_div(units, TV), p.kslices),
-                               dim3((rw + 3) * 64), 0, s, p);
+            GemmParams pz = p;
+            pz.zrows = nz == 1 ? 0 : 16 * pc_ceil_div(mt, 2);
+            const int rw = pc_ceil_div(pc_ceil_div(mt, nz), 2);
+            hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768>), dim3(pc_ceil_div(units, TV), p.kslices, nz),
+                               dim3((rw + 3) * 64), 0, s, pz);
             return pc_check_launch("gemm_rows_kernel");
         }
     }

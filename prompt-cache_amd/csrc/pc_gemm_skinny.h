@@ -78,6 +78,7 @@ struct GemmParams {
     int32_t M, ntiles, KS, npairs;
     const int32_t* m_dev;    // optional device word: rows that really carry tokens (<= M): pad rows behind it are not loaded
     int32_t kslices; int64_t slab_stride;   // EPI_STORE only: grid.y K-slices, slice s writes y + s*slab_stride
+    int32_t zrows;           // gemm_rows_kernel: rows per grid.z block (a multiple of 16; 0: one block takes all M rows)
     // NORM activation source (M <= 16): the fp32 residual stream itself; RMSNorm is folded into the launch
     const float* xn; const _Float16* gamma; float eps;
     // int8 weights (W8 kernels, M <= 64): wf is the fragment image of OFFSET-BINARY bytes (q + 128), 8 B per lane per

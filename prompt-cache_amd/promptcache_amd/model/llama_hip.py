@@ -477,8 +477,9 @@ class LlamaHIP:
         forced = os.environ.get("PC_ROWS_KQ")
         if forced:
             return int(forced)
-        if self.SKINNY_MAX_ROWS < T <= 288 and os.environ.get("PC_ROWS_WIDE", "1") != "0":
-            return max(1, min(8, 256 // -(-N // 128)))
+        if self.SKINNY_MAX_ROWS < T <= 512 and os.environ.get("PC_ROWS_WIDE", "1") != "0":
+            blocks = 1 if T <= 288 else 2                     # (289..512 rows: two row blocks per column panel)
+            return max(1, min(8, 256 // (blocks * -(-N // 128))))
         return self.kslices
 
     def _proj(self, a_hi, a_lo, lw: dict, key: str, M: int, N: int, K: int, epi: int, **out) -> None:
@@ -1025,7 +1026,7 @@ class LlamaHIP:
         slabs = torch.empty((KQ, T, hid), dtype=torch.float32, device=dev)
         # ... and so does q|k|v there: its 128-column panels are half as many as the CUs, so K is cut in two and the rotation /
         # append runs over the two slabs (pc_gemm: q|k|v epilogue with kslices = 2)
-        QS = int(os.environ.get("PC_ROWS_QKV_KS", "2")) if (KQ != self.kslices and lw0_fp16(self.layers)) else 1
+        QS = int(os.environ.get("PC_ROWS_QKV_KS", "2")) if (self.SKINNY_MAX_ROWS < T <= 288 and KQ != self.kslices and lw0_fp16(self.layers)) else 1
         qkv_slabs = torch.empty((QS, T, W), dtype=torch.float32, device=dev) if QS > 1 else None
         pending = 0                                   # slabs waiting to be added to x
         layers = self.layers if num_layers is None else self.layers[:num_layers]

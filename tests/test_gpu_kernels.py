@@ -694,7 +694,8 @@ def test_gemm_rows_silu_epilogue(M, inter, K):
 
 
 @pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 100, 50, 4096), (1, 40, 40, 128, 259, 0, 5120),
-                                                       (2, 4, 2, 128, 40, 7, 512), (1, 4, 4, 32, 65, 3, 128)])
+                                                       (2, 4, 2, 128, 40, 7, 512), (1, 4, 4, 32, 65, 3, 128),
+                                                       (1, 8, 8, 128, 400, 5, 1024), (2, 4, 4, 128, 150, 0, 512)])   # 289..512 rows: two row blocks
 def test_gemm_rows_qkv_rope(B, H, Hkv, D, q_len, past, hid):
     """Row-split kernel with the fused RoPE / KV-append epilogue against the plain-store launch + pc_rope_append."""
     n = _n()

@@ -168,6 +168,7 @@ class LlamaHIP:
         # full-depth parity for 2x fewer GEMM flops
         self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
         self.fused_dense_qkv = os.environ.get("PC_FUSED_DENSE_QKV", "1") != "0"   # RoPE + KV append in the many-row q|k|v epilogue
+        self.encode_mid = os.environ.get("PC_ENC_MID", "1") != "0"    # encode passes of 65..512 rows on the row-split stack
         # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
         # decoded token -- in the arena's residual tail and feed them to the attention (the reference keeps those rows in
         # fp32 for the whole generation, llama2.py:361-388, generation_engine.py:123-147; the arena still holds the fp16
@@ -458,6 +459,17 @@ class LlamaHIP:
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
+        # an encode pass of 65..512 rows without per-row prefixes (the trunk of a schema, small whole scaffolds) runs the
+        # row-split weight-streaming stack as well: same split-precision arithmetic, residuals of every row into arena.lo
+        if (encode_pass and self.skinny and self.encode_mid and self._shared_prefix_loop and self._shared is None and self._past_lens is None
+                and not self.llm_int8 and self.SKINNY_MAX_ROWS < T <= self.MID_MAX_ROWS and arena.lo is not None
+                and arena.lo_len == past_len):
+            self._lo_mode = 3                                # residual rows go to arena.lo (arena-shaped, row = key index)
+            logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
+            arena.length = past_len + q_len
+            arena.lo_len = past_len + q_len
+            self._tail_done(arena, 0, q_len, past_len)
+            return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
         if mid:
             logits = self._forward_skinny(ids, pos32, None, arena, B, q_len, past_len, last_token_only, num_layers)
             arena.length = past_len + q_len
@@ -984,6 +996,8 @@ class LlamaHIP:
         mode = self._lo_mode
         if mode == 0:
             return lambda li: (None, -1)
+        if mode == 3:                                        # encode pass: the arena's own residual planes, row = key index
+            return lambda li: (arena.lo_planes(li), 0)
         base = -1 if mode == 1 else (-2 if past_dev is not None else arena.tail_base)
         return lambda li: (arena.tail_planes(li) + (base,), base)
 
@@ -1041,6 +1055,8 @@ class LlamaHIP:
             n.gemm_qkv_rope(lw["wqkv_f"], xh, xl, T, hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                             arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev, kv_lo=kvlo and kvlo[:4],
                             wscale=lw["wqkv_s"], lo_base=lo_base, kslices=QS, scratch=qkv_slabs)
+            if self._kv_only and li == len(layers) - 1:
+                return None       # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))

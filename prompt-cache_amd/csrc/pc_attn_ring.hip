@@ -82,12 +82,16 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
     if (p.xcd_remap) {
         // 1-D grid, XCD-aware (see attn_fwd_kernel): heads are dealt to XCDs, an XCD walks the q-blocks of one head after
         // another, heaviest first, so that head's K / V is served from that XCD's L2
+        // (with KV splits a "pair" is (batch row, head, split): its q-blocks stream the same key range)
         const int nqb = p.nqblk, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int per_xcd = (p.H * p.nbatch + 7) >> 3;
+        const int npairs = p.H * p.nbatch * p.nsplit;
+        const int per_xcd = (npairs + 7) >> 3;
         const int pair = (slot / nqb) * 8 + xcd;
-        if (slot / nqb >= per_xcd || pair >= p.H * p.nbatch) return;
+        if (slot / nqb >= per_xcd || pair >= npairs) return;
         qblk = nqb - 1 - (slot % nqb);
-        b = pair / p.H; h = pair - b * p.H; split = 0;
+        const int bh = pair / p.nsplit;
+        split = pair - bh * p.nsplit;
+        b = bh / p.H; h = bh - b * p.H;
     } else {
         qblk = blockIdx.x; h = blockIdx.y;
         b = blockIdx.z / p.nsplit; split = blockIdx.z - b * p.nsplit;
@@ -625,9 +629,9 @@ int launch_attn_ring(const AttnParams& p0, int B, hipStream_t stream) {
     static const bool no_remap = [] { const char* e = getenv("PC_ATTN_NO_XCD"); return e && e[0] == '1'; }();
     p.nqblk = pc_ceil_div(p.q_len, kRingQB);
     p.nbatch = B;
-    p.xcd_remap = (p.nsplit == 1 && p.nqblk >= 2 && !no_remap) ? 1 : 0;
+    p.xcd_remap = (p.nqblk >= 2 && !no_remap) ? 1 : 0;
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
-    if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
+    if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B * p.nsplit + 7) / 8), 1, 1);
     const dim3 block(kRingThreads);
     if (p.pre_k) {
         if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, true>), grid, block, 0, stream, p);

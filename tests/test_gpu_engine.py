@@ -687,6 +687,38 @@ def test_suffix_batches_over_the_trunk_in_place_store_the_module_kv_of_the_copie
     assert worst < 4e-3 and moved < 0.02
 
 
+def test_trunk_pass_on_the_row_split_stack_stores_the_module_kv_of_the_many_row_stack():
+    """An encode pass of 65..512 rows without per-row prefixes (a schema's trunk) runs the row-split weight-streaming stack
+    (``encode_mid``): same split-precision arithmetic as the many-row stack, different tile shapes -- the stored fp16 module KV
+    may differ where an fp32 value sat on a rounding tie, nowhere else."""
+    from promptcache_amd import CacheEngine, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 5, 2.0), device="cuda:0")
+    sp, _ = synth.persona_like("p", system_len=90, intro_len=30,
+                               traits=(("age", (30, 26, 33)), ("home", (41, 37, 44, 35)), ("job", (25, 29, 22))), seed=9)
+    text = lm.get_formatter()(sp)
+    stores = {}
+    try:
+        for mid in (True, False):
+            lm.hf_model.encode_mid = mid
+            eng = CacheEngine(1024, lm)
+            eng.add_schema(text)
+            sc = eng.schemas["p"]
+            assert sc.encode_stats["trunk_shared_passes"] >= 5
+            stores[mid] = sorted(((c.token_sequence.offset, len(c), c.store.float().cpu()) for c in sc.cache_l1.values()),
+                                 key=lambda t: (t[0], t[1]))
+    finally:
+        lm.hf_model.encode_mid = True
+    assert [(a, b) for a, b, _ in stores[True]] == [(a, b) for a, b, _ in stores[False]]
+    diffs = [(x[2] - y[2]).abs() for x, y in zip(stores[True], stores[False])]
+    worst = max(float(d.max()) for d in diffs)
+    moved = sum(int((d > 0).sum()) for d in diffs) / sum(d.numel() for d in diffs)
+    print(f"trunk on the row-split stack vs the many-row stack: max |dKV| = {worst:.2e}, {100 * moved:.3f} % of the stored values differ")
+    assert worst < 4e-3 and moved < 0.02
+
+
 @pytest.mark.parametrize("family", ["llama", "falcon"])
 def test_device_greedy_loop_equals_stepping_through_the_model(family):
     """GenerationEngine's device-side greedy loop (one hipGraph replay per token: forward + argmax + state advance, no host

@@ -1244,7 +1244,10 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.past_len = past_len;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.nsplit = choose_nsplit(B, H, q_len, past_len + q_len, q_len <= kQB || q_lo != nullptr);
-    p.tail = (k_lo && lo_row0 == -1 && q_len <= kTailMax && !past_lens) ? 1 : 0;
+    p.tail = 0; p.small = 0;
+    // (a pass the ring kernel takes carries its own rows as residual tiles in the stream: no fp32 tail workgroup)
+    const bool ring_first = ring_eligible(p, D);
+    p.tail = (!ring_first && k_lo && lo_row0 == -1 && q_len <= kTailMax && !past_lens) ? 1 : 0;
     // <= 16 rows over a long cache: one key slice per WAVE, partials merged per workgroup (attn_small_kernel).  Not for
     // launches that carry residual tiles in the stream (decode over a residual tail, lo_row0 != -1).
     static const bool small_off = [] { const char* e = getenv("PC_ATTN_NO_SMALL"); return e && e[0] == '1'; }();

@@ -1038,13 +1038,19 @@ int small_nstream(int B, int H, int tail = 0) {
 // Merge split-KV partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i.
 // One workgroup per (query row, head), one thread per head dim.  (A variant with one workgroup per head and
 // float4 items measured 8.0 us vs 6.3 us per launch inside the captured forward: more parallel, shorter chains win.)
-template <int D, int NS>   // NS: compile-time bound on nsplit, so every partial is loaded before anything is used
+// RPW > 1 (64 and more rows): a workgroup merges RPW rows one after the other -- at 259 rows x 40 heads the one-row form is
+// 10 360 two-wave workgroups and the launch is bound by their dispatch (9 us per layer of BASELINE config 4)
+template <int D, int NS, int RPW = 1>   // NS: compile-time bound on nsplit, so every partial is loaded before anything is used
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                     _Float16* __restrict__ out, int64_t o_bs, int64_t o_ts,
                                     _Float16* __restrict__ of_hi, _Float16* __restrict__ of_lo, int H, int q_len,
                                     int nsplit, _Float16* __restrict__ out_lo) {
-    const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
     const int64_t base = ((int64_t)b * H + h) * nsplit;
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int qi = (int)blockIdx.x * RPW + rr;
+    if (RPW > 1 && qi >= q_len) break;
     // one batch of independent loads (a loop over a runtime nsplit serialises them: max first, then one dependent
     // (m, l, o) round trip per split -- 6.2 us per launch for 1.9 MB of partials)
     float mv[NS], lv[NS], ov[NS];
@@ -1081,6 +1087,7 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
         out[off] = hi;
         if (out_lo) out_lo[off] = lo;
     }
+  }
 }
 
 // The 32-rows-per-wave kernel (attn_fwd32_kernel) halves the LDS traffic per flop but also the number of workgroups:
@@ -1174,8 +1181,14 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     if (rc != PC_OK) return rc;
     if (p.nsplit > 1) {
 #define PC_COMBINE(NSV)                                                                                         \
-        hipLaunchKernelGGL((attn_combine_kernel<D, NSV>), dim3(p.q_len, p.H, B), dim3(D), 0, stream, p.part_o,     \
-                           p.part_ml, p.out, p.o_bs, p.o_ts, p.of_hi, p.of_lo, p.H, p.q_len, p.nsplit, p.out_lo)
+        do {                                                                                                    \
+            if (p.q_len >= 64)                                                                                  \
+                hipLaunchKernelGGL((attn_combine_kernel<D, NSV, 4>), dim3(pc_ceil_div(p.q_len, 4), p.H, B), dim3(D), 0, stream, \
+                                   p.part_o, p.part_ml, p.out, p.o_bs, p.o_ts, p.of_hi, p.of_lo, p.H, p.q_len, p.nsplit, p.out_lo); \
+            else                                                                                                \
+                hipLaunchKernelGGL((attn_combine_kernel<D, NSV>), dim3(p.q_len, p.H, B), dim3(D), 0, stream, p.part_o, \
+                                   p.part_ml, p.out, p.o_bs, p.o_ts, p.of_hi, p.of_lo, p.H, p.q_len, p.nsplit, p.out_lo); \
+        } while (0)
         if (p.nsplit <= 4) PC_COMBINE(4);
         else if (p.nsplit <= 8) PC_COMBINE(8);
         else if (p.nsplit <= 16) PC_COMBINE(16);

@@ -54,6 +54,30 @@ int pc_kv_gather(const void* const* seg_src, const int32_t* seg_len, const int32
                  int32_t max_ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * pc_kv_row_table -- the same staging plan as pc_kv_gather, expanded to ONE ENTRY PER STAGED ROW, for the attention
+ *   that stages while it reads (pc_attn `gather_rows`): the first forward over a freshly assembled prompt then reads every
+ *   key / value row from its module store and writes the staged row as it goes, so PromptCache.update's copy
+ *   (cache_engine.py:135-151) and the attention's first read of the staged rows (llama2.py:361-388) move the K/V across the
+ *   chip once -- read 1x + write 1x -- instead of read + write + read.
+ *
+ *   segs      DEVICE array of segment descriptors in staging order (dst_row ascending, rows of a segment contiguous):
+ *             src = the segment's module KV [n_layers][2][n_kv_heads][len][head_dim] (as pc_kv_gather's seg_src)
+ *   nseg_dev  DEVICE int32: number of descriptors (<= max_seg) -- both come out of the caller's packed per-call input
+ *             block, so a captured hipGraph replays the expansion for every new prompt
+ *   dst, max_ctx   the staged buffer of pc_kv_gather.  Rows [0, total_rows_dev[0]) that no segment covers (rows a previous
+ *             prompt staged at the same place and this one keeps; rows the model itself appended) get an entry that points
+ *             at the staged buffer itself with PC_KV_ROW_STAGED set: read in place, not written
+ *   rows      out: max_ctx entries; entry r describes staged row r: `base` = address of its head_dim fp16 values in plane 0
+ *             (layer 0, K, head 0) of its source, `plane_stride16` = distance between consecutive planes of that source in
+ *             16-byte units (plane p = (layer * 2 + k|v) * n_kv_heads + head)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pc_kv_seg { const void* src; int32_t dst_row; int32_t len; } pc_kv_seg;
+typedef struct pc_kv_row { uint64_t base; uint32_t plane_stride16; uint32_t flags; } pc_kv_row;
+#define PC_KV_ROW_STAGED 1u   /* the row already lies in the staged buffer: the attention does not write it */
+int pc_kv_row_table(const pc_kv_seg* segs, const int32_t* nseg_dev, int32_t max_seg, const int32_t* total_rows_dev,
+                    const void* dst, int32_t n_kv_heads, int32_t head_dim, int32_t max_ctx, pc_kv_row* rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * pc_kv_slice_store -- replaces SchemaCache._process's slice-and-store, cache_engine.py:283-296
  *   (`k_cache[j, :, st:ed, :]` per layer per TokenSequence, then `.cpu()`): the module KV stays in HBM.
  *
@@ -144,6 +168,12 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *              batch of the schema encode reads the trunk in place instead of carrying a copy of it in every batch row.
  *              prefix_k_lo / prefix_v_lo: optional residual planes of the prefix rows (same strides); k_lo / v_lo then
  *              cover the pass's rows from their row 0 (lo_row0 = 0).  Many-row kernel only (q_lo given or q_len > 16)
+ *   gather_rows, gather_k_plane, gather_v_plane   optional (B = 1; pc_attn_gather_ok says whether this launch shape takes
+ *              it): STAGE WHILE READING.  Key row r < past_len is read from where gather_rows[r] (pc_kv_row_table) says it
+ *              lies -- plane gather_k_plane + kv_head for K, gather_v_plane + kv_head for V: (layer * 2 + 0|1) * Hkv of this
+ *              layer -- and, unless the entry carries PC_KV_ROW_STAGED, written to row r of `k` / `v`.  After the launch
+ *              rows [0, past_len) of `k` / `v` hold exactly what pc_kv_gather would have left there.  Rows from past_len on
+ *              (this pass's own) are read from `k` / `v` as always
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
 
@@ -162,8 +192,11 @@ typedef struct pc_attn_args {
     const void* k_lo; const void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_row0;
     uint32_t* counters;
     const void* prefix_k; const void* prefix_v; const void* prefix_k_lo; const void* prefix_v_lo; int64_t prefix_head_stride;
+    const pc_kv_row* gather_rows; int32_t gather_k_plane, gather_v_plane;
 } pc_attn_args;
 int pc_attn(const pc_attn_args* args, void* stream);
+/* 1 when pc_attn would run `args` (gather_rows ignored) on a kernel that implements gather_rows, else 0 */
+int pc_attn_gather_ok(const pc_attn_args* args);
 
 /* ---------------------------------------------------------------------------------------------
  * Elementwise / reduction pieces of the layer stack, fused for the small-q prefill (q_len rows):

@@ -826,15 +826,27 @@ __device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, i
 
 // NS > 0: ONE launch -- the split-KV partials are merged by the last-arriving workgroup of each head (small_arrive_merge,
 // at most NS partials per row); NS = 0: the partials are left for attn_combine_kernel.
-template <int D, bool ALIBI, int NS>
-__global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParams p) {
+// GATHER (pc_attn gather_rows; B = 1): STAGE WHILE READING.  Every key row of the stream is read from where its entry of the row
+// table (pc_kv_row_table) says it lies -- a module store for rows a fresh prompt stages, the arena itself for rows that are
+// already there -- and rows that are not staged yet are written to the arena as they pass: K from the MFMA operand registers,
+// V from the wave's LDS tile.  Each (kv head, key row) belongs to exactly one wave of one workgroup, so after the launch the
+// arena planes hold what pc_kv_gather would have put there, bit for bit; the module K/V crossed the chip once.  The 64 table
+// entries of a tile go through a wave-private LDS slice (one 16-byte load per lane, then the 4 + LPW entries a lane needs for
+// its K fragments and V chunks come back as ds_read_b128).  Stores are issued behind the tile's last wait: on gfx9 stores
+// count in vmcnt with the loads, and a store in front of the V wait would put its write acknowledgement on the critical path.
+// (The launch is sized to ONE workgroup per CU -- small_nstream -- so the staging variant, which keeps the K fragments alive until
+// they are stored, takes the registers of a one-wave-per-SIMD kernel instead of spilling at 256.)
+template <int D, bool ALIBI, int NS, bool GATHER = false>
+__global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(const AttnParams p) {
     constexpr bool FUSE = NS > 0;
+    static_assert(!(FUSE && GATHER), "the in-launch merge and the staging stream are separate instantiations");
     constexpr int KS = D / 32, DB = D / 16, CPR = D / 8;
     constexpr int LPW = kTK * CPR / 64;              // 16-byte V chunks per lane per tile
     constexpr int kTileHalfs = kTK * D;
     constexpr int kTailBytes = (2 * 16 * D + 16 * D + 16 * 16) * 4;
     constexpr int kLdsBytes = 4 * kTileHalfs * 2 > kTailBytes ? 4 * kTileHalfs * 2 : kTailBytes;
-    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes + 16];
+    constexpr int kTabBytes = GATHER ? 4 * kTK * 16 : 0;           // row-table entries of the four waves' tiles
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes + 16 + kTabBytes];
     int* s_last = (int*)(smem + kLdsBytes);
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
@@ -892,15 +904,39 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
     [[maybe_unused]] const float* kpos = ALIBI ? p.key_pos + b * p.kp_bs : nullptr;
     _Float16* Vw = (_Float16*)smem + wave * kTileHalfs;            // this wave's V tile
     char* Vwb = smem + wave * kTileHalfs * 2;                      // (the same, as the wave-uniform LDS-DMA base)
+    [[maybe_unused]] u32x4* etab = (u32x4*)(smem + kLdsBytes + 16) + wave * kTK;   // GATHER: this wave's 64 row-table entries
+    [[maybe_unused]] const bool g_writer = GATHER && (h % (p.H / p.Hkv)) == 0;        // one query head per kv head stages
+    [[maybe_unused]] const uint64_t g_koff = GATHER ? (uint64_t)(uint32_t)(p.g_kplane + hkv) : 0;
+    [[maybe_unused]] const uint64_t g_voff = GATHER ? (uint64_t)(uint32_t)(p.g_vplane + hkv) : 0;
 
     for (int key0 = k0; key0 < k1; key0 += kTK) {
         // ---- every load of the tile first: K as MFMA fragments (registers), V by LDS-DMA into the wave's tile ----
         u32x4 kr[4][KS];
+        [[maybe_unused]] uint32_t kflag[4];
+        if constexpr (GATHER) {
+            // lane = row of the tile: its entry becomes {address of the row in this head's K plane | STAGED flag in bit 0,
+            // address in the V plane} (rows are 16-byte aligned: the low address bits are free)
+            const int ek = key0 + lane < k1 ? key0 + lane : k1 - 1;
+            const u32x4 e = *(const u32x4*)(p.rows + ek);
+            const uint64_t base = ((uint64_t)e[1] << 32) | e[0];
+            const uint64_t ka = (base + ((g_koff * e[2]) << 4)) | (e[3] & PC_KV_ROW_STAGED);
+            const uint64_t va = base + ((g_voff * e[2]) << 4);
+            etab[lane] = u32x4{(uint32_t)ka, (uint32_t)(ka >> 32), (uint32_t)va, (uint32_t)(va >> 32)};
+            __builtin_amdgcn_wave_barrier();             // (a wave's LDS operations execute in order: no wait needed)
+        }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const int key = key0 + kb * 16 + n < k1 ? key0 + kb * 16 + n : k1 - 1;     // (keys past k1 are masked below)
+            if constexpr (GATHER) {
+                const uint64_t ka = *(const uint64_t*)(etab + (key - key0));
+                const char* src = (const char*)(uintptr_t)(ka & ~(uint64_t)15);
+                kflag[kb] = (uint32_t)ka & PC_KV_ROW_STAGED;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kr[kb][ks] = *(const u32x4*)(kbase + (int64_t)key * D + ks * 32 + g * 8);
+                for (int ks = 0; ks < KS; ++ks) kr[kb][ks] = *(const u32x4*)(src + (ks * 32 + g * 8) * 2);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kr[kb][ks] = *(const u32x4*)(kbase + (int64_t)key * D + ks * 32 + g * 8);
+            }
         }
         // V rows go straight to LDS, rotated by 32 B per row (see attn_fwd_kernel) -- the permutation sits on the per-lane
         // SOURCE address, LDS-DMA writes lane-linearly: chunk c = 64 i + lane of the tile = (row c / CPR, position c % CPR)
@@ -911,7 +947,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
             const int c = lane + i * 64, row = c / CPR, pos = c - row * CPR;
             const int col = (pos - 2 * (row & 7)) & (CPR - 1);
             const int rr = key0 + row < k1 ? key0 + row : k1 - 1;
-            glds16(vbase + (int64_t)rr * D + col * 8, Vwb + i * 1024);
+            if constexpr (GATHER) {
+                const char* src = (const char*)(uintptr_t)((const uint64_t*)(etab + (rr - key0)))[1];
+                glds16((const _Float16*)(src + col * 16), Vwb + i * 1024);
+            } else {
+                glds16(vbase + (int64_t)rr * D + col * 8, Vwb + i * 1024);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);               // the whole tile is in flight before the first wait
         // ---- S^T = K . Q^T ----
@@ -974,6 +1015,31 @@ __global__ __launch_bounds__(kThreads, 2) void attn_small_kernel(const AttnParam
                 const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
+            }
+        }
+        if constexpr (GATHER) {
+            // ---- stage the tile: rows that are not in the arena yet leave for it (K from registers, V from the LDS tile) ----
+            if (g_writer) {
+                _Float16* kdst = const_cast<_Float16*>(kbase);
+                _Float16* vdst = const_cast<_Float16*>(vbase);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int key = key0 + kb * 16 + n;
+                    if (key < k1 && !(kflag[kb] & PC_KV_ROW_STAGED)) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            __builtin_nontemporal_store(kr[kb][ks], (u32x4*)(kdst + (int64_t)key * D + ks * 32 + g * 8));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < LPW; ++i) {
+                    const int c = lane + i * 64, row = c / CPR, pos = c - row * CPR;
+                    const int col = (pos - 2 * (row & 7)) & (CPR - 1);
+                    const u32x4 chunk = *(const u32x4*)(Vwb + i * 1024 + lane * 16);
+                    const uint32_t fl = (key0 + row < k1) ? ((const uint32_t*)(etab + row))[0] : PC_KV_ROW_STAGED;
+                    if (!(fl & PC_KV_ROW_STAGED))
+                        __builtin_nontemporal_store(chunk, (u32x4*)(vdst + (int64_t)(key0 + row) * D + col * 8));
+                }
             }
         }
     }
@@ -1159,6 +1225,9 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
         // > 64 split-precision rows at head_dim 128: 128 rows per workgroup, tiles by LDS-DMA (pc_attn_ring.hip)
         const int rrc = launch_attn_ring(p, B, stream);
         if (rrc != PC_OK) return rrc;
+    } else if (p.small && p.rows) {       // stage while reading (pc_attn gather_rows)
+        if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0, true>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((attn_small_kernel<D, false, 0, true>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.small) {
         if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_small_kernel<D, false, 0>), grid, dim3(kThreads), 0, stream, p);
@@ -1228,7 +1297,9 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   const float* key_pos, int64_t key_pos_batch_stride, const float* slopes, void* out_lo,
                   const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream,
                   const int32_t* past_lens = nullptr, uint32_t* counters = nullptr, const void* pre_k = nullptr,
-                  const void* pre_v = nullptr, const void* pre_k_lo = nullptr, const void* pre_v_lo = nullptr, int64_t pre_hs = 0) {
+                  const void* pre_v = nullptr, const void* pre_k_lo = nullptr, const void* pre_v_lo = nullptr, int64_t pre_hs = 0,
+                  const pc_kv_row* gather_rows = nullptr, int32_t g_kplane = 0, int32_t g_vplane = 0, int* gather_ok = nullptr) {
+    // gather_ok != NULL: dry run -- *gather_ok = whether this launch shape would take gather_rows; nothing is launched
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
     PC_REQUIRE(D == 32 || D == 64 || D == 128, PC_ERR_ARG, "pc_attn_fwd: head_dim %d unsupported (32/64/128)", D);
@@ -1270,6 +1341,14 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
         if (ns >= 2) p.nsplit = ns; else small = false;
     }
     p.small = small ? 1 : 0;
+    // staging while reading lives in attn_small_kernel's two-launch form, one batch row
+    const bool can_gather = small && !counters && B == 1 && past_len > 0;
+    if (gather_ok) { *gather_ok = can_gather ? 1 : 0; return PC_OK; }
+    PC_REQUIRE(!gather_rows || can_gather, PC_ERR_ARG,
+               "pc_attn: gather_rows needs B = 1, <= %d query rows over >= 256 keys and no counters (ask pc_attn_gather_ok)", kSmallQ);
+    PC_REQUIRE(!gather_rows || (((uintptr_t)gather_rows & 15) == 0 && g_kplane >= 0 && g_vplane >= 0), PC_ERR_ARG,
+               "pc_attn: gather_rows must be 16-byte aligned, planes non-negative");
+    p.rows = gather_rows; p.g_kplane = g_kplane; p.g_vplane = g_vplane;
     if (ring_eligible(p, D)) p.nsplit = ring_nsplit(B, H, q_len, past_len + q_len);
     if (p.tail && !small) {
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
@@ -1296,7 +1375,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
 }  // namespace
 
 // pc_attn: the one struct-taking entry of the attention family (include/promptcache_hip.h; the round 1-2 entry points are inline
-// wrappers over it in include/promptcache_hip_compat.h).
+// wrappers over it until round 4).
 // `counters` (optional, B*H zeroed uint32 words, left zero by every launch): launches of <= 16 query rows over a long staged
 // cache then merge their split-KV partials INSIDE the launch (last-arriving workgroup per head) instead of through a second one.
 PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {
@@ -1328,5 +1407,20 @@ PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {
                          a->softmax_scale, a->workspace, a->workspace_bytes, a->past_len_dev, a->out_frag_hi, a->out_frag_lo,
                          a->key_pos, a->key_pos_batch_stride, a->slopes_log2, a->out_lo, a->k_lo, a->v_lo, a->lo_batch_stride,
                          a->lo_head_stride, a->lo_row0, stream, a->past_lens, a->counters, a->prefix_k, a->prefix_v,
-                         a->prefix_k_lo, a->prefix_v_lo, a->prefix_head_stride);
+                         a->prefix_k_lo, a->prefix_v_lo, a->prefix_head_stride, a->gather_rows, a->gather_k_plane, a->gather_v_plane);
+}
+
+// Whether pc_attn would run this launch shape on a kernel that implements gather_rows (the field itself is ignored here).
+PC_EXPORT int pc_attn_gather_ok(const pc_attn_args* a) {
+    if (!a || a->struct_bytes != (uint32_t)sizeof(pc_attn_args)) return 0;
+    if (a->past_lens || a->prefix_k || a->q_len <= 0) return 0;
+    if (!(a->D == 32 || a->D == 64 || a->D == 128) || a->B <= 0 || a->H <= 0 || a->Hkv <= 0 || a->H % a->Hkv) return 0;
+    int ok = 0;
+    const int rc = attn_fwd_impl(a->q, a->q_lo, a->q_batch_stride, a->q_token_stride, a->k, a->v, a->kv_batch_stride, a->kv_head_stride,
+                                 a->out, a->out_batch_stride, a->out_token_stride, a->B, a->H, a->Hkv, a->D, a->q_len, a->past_len,
+                                 a->softmax_scale, a->workspace, a->workspace_bytes, a->past_len_dev, a->out_frag_hi, a->out_frag_lo,
+                                 a->key_pos, a->key_pos_batch_stride, a->slopes_log2, a->out_lo, a->k_lo, a->v_lo, a->lo_batch_stride,
+                                 a->lo_head_stride, a->lo_row0, nullptr, nullptr, a->counters, nullptr, nullptr, nullptr, nullptr, 0,
+                                 nullptr, 0, 0, &ok);
+    return rc == PC_OK ? ok : 0;
 }

@@ -44,6 +44,9 @@ struct AttnParams {
     // planes ([Hkv][rows][D], head stride pre_hs: the root scaffold's arena), keys from past_lens[b] on are rows 0.. of k / v
     // (and of k_lo / v_lo).  pre_k_lo / pre_v_lo: residuals of the prefix rows (NULL: the prefix is plain fp16).
     const _Float16* pre_k; const _Float16* pre_v; const _Float16* pre_k_lo; const _Float16* pre_v_lo; int64_t pre_hs;
+    // optional (attn_small_kernel<.., GATHER>): one entry per key row -- where the row lies and whether the launch writes it to
+    // k / v (pc_kv_row_table); planes g_kplane + kv head / g_vplane + kv head of the entry's source
+    const pc_kv_row* rows; int32_t g_kplane, g_vplane;
     int32_t H, Hkv, q_len, past_len, nsplit;
     // tail != 0 (lo_row0 < 0 and q_len <= kTailMax: prefill of a short prompt over a staged cache): splits
     // 0 .. nsplit-2 stream the STAGED keys [0, past_len) only; the workgroup of split nsplit-1 computes the attention over

@@ -192,3 +192,56 @@ PC_EXPORT int pc_kv_slice_store(const void* src, int32_t src_cap, const int32_t*
     }
     return launch_batches(descs, n, n_layers * 2 * n_kv_heads, (hipStream_t)stream);
 }
+
+// ---- the staging plan as one entry per staged row (pc_attn `gather_rows`: the attention stages while it reads) --------------
+namespace {
+constexpr int kRowTabMaxSeg = 1024;   // descriptors one expansion handles (16 KiB of LDS)
+
+__global__ __launch_bounds__(256) void kv_row_table_kernel(const pc_kv_seg* __restrict__ segs, const int32_t* __restrict__ nseg_dev,
+                                                           int max_seg, const int32_t* __restrict__ total_dev, uint64_t dst,
+                                                           uint32_t row_bytes, uint32_t dst_plane_stride16, int max_ctx,
+                                                           pc_kv_row* __restrict__ rows) {
+    __shared__ pc_kv_seg s_seg[kRowTabMaxSeg];
+    int nseg = *nseg_dev;
+    nseg = nseg < 0 ? 0 : (nseg > max_seg ? max_seg : nseg);
+    for (int i = threadIdx.x; i < nseg; i += blockDim.x) s_seg[i] = segs[i];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = *total_dev;
+    total = total > max_ctx ? max_ctx : total;
+    if (r >= total) return;
+    // last descriptor with dst_row <= r (descriptors are in staging order)
+    int lo = 0, hi = nseg;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_seg[mid].dst_row <= r) lo = mid + 1; else hi = mid;
+    }
+    pc_kv_row e;
+    e.base = dst + (uint64_t)r * row_bytes;
+    e.plane_stride16 = dst_plane_stride16;
+    e.flags = PC_KV_ROW_STAGED;
+    if (lo > 0) {
+        const pc_kv_seg sg = s_seg[lo - 1];
+        if (r < sg.dst_row + sg.len) {
+            e.base = (uint64_t)sg.src + (uint64_t)(r - sg.dst_row) * row_bytes;
+            e.plane_stride16 = (uint32_t)(((uint64_t)sg.len * row_bytes) >> 4);
+            e.flags = 0;
+        }
+    }
+    rows[r] = e;
+}
+}  // namespace
+
+PC_EXPORT int pc_kv_row_table(const pc_kv_seg* segs, const int32_t* nseg_dev, int32_t max_seg, const int32_t* total_rows_dev,
+                              const void* dst, int32_t n_kv_heads, int32_t head_dim, int32_t max_ctx, pc_kv_row* rows, void* stream) {
+    PC_REQUIRE(segs && nseg_dev && total_rows_dev && dst && rows, PC_ERR_ARG, "pc_kv_row_table: null pointer");
+    PC_REQUIRE(max_seg > 0 && max_seg <= kRowTabMaxSeg, PC_ERR_ARG, "pc_kv_row_table: max_seg must lie in [1, %d]", kRowTabMaxSeg);
+    PC_REQUIRE(head_dim > 0 && head_dim % 8 == 0 && max_ctx > 0 && n_kv_heads > 0, PC_ERR_ARG, "pc_kv_row_table: bad sizes");
+    const uint32_t row_bytes = (uint32_t)head_dim * 2u;
+    PC_REQUIRE(((uint64_t)max_ctx * row_bytes >> 4) < (1ull << 32), PC_ERR_ARG, "pc_kv_row_table: max_ctx too large");
+    (void)n_kv_heads;
+    hipLaunchKernelGGL(kv_row_table_kernel, dim3(pc_ceil_div(max_ctx, 256)), dim3(256), 0, (hipStream_t)stream, segs, nseg_dev,
+                       max_seg, total_rows_dev, (uint64_t)(uintptr_t)dst, row_bytes, (uint32_t)(((uint64_t)max_ctx * row_bytes) >> 4),
+                       max_ctx, rows);
+    return pc_check_launch("kv_row_table_kernel");
+}

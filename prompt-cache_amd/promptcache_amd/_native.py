@@ -31,7 +31,22 @@ class AttnArgs(C.Structure):
                 ("key_pos", _vp), ("key_pos_batch_stride", _i64), ("slopes_log2", _vp),
                 ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64), ("lo_row0", _i32),
                 ("counters", _vp),
-                ("prefix_k", _vp), ("prefix_v", _vp), ("prefix_k_lo", _vp), ("prefix_v_lo", _vp), ("prefix_head_stride", _i64)]
+                ("prefix_k", _vp), ("prefix_v", _vp), ("prefix_k_lo", _vp), ("prefix_v_lo", _vp), ("prefix_head_stride", _i64),
+                ("gather_rows", _vp), ("gather_k_plane", _i32), ("gather_v_plane", _i32)]
+
+
+class KvSeg(C.Structure):
+    """``pc_kv_seg``: one staged segment of a prompt (module store, first staged row, rows)."""
+    _fields_ = [("src", _vp), ("dst_row", _i32), ("len", _i32)]
+
+
+class KvRow(C.Structure):
+    """``pc_kv_row``: where one staged row lies (pc_kv_row_table)."""
+    _fields_ = [("base", C.c_uint64), ("plane_stride16", C.c_uint32), ("flags", C.c_uint32)]
+
+
+KV_ROW_STAGED = 1
+KV_ROW_TABLE_MAX_SEG = 1024
 
 
 class DenseQkvArgs(C.Structure):
@@ -75,6 +90,8 @@ SIGNATURES = {
     "pc_last_error_string": (C.c_char_p, []),
     "pc_kv_gather": (C.c_int, [C.POINTER(_vp), _pi32, _pi32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pc_kv_slice_store": (C.c_int, [_vp, _i32, _pi32, _pi32, C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp]),
+    "pc_kv_row_table": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pc_attn_gather_ok": (C.c_int, [C.POINTER(AttnArgs)]),
     "pc_rope_table": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pc_rope_append": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                  _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -176,6 +193,15 @@ def kv_slice_store(src, src_cap: int, seg_src_off: Sequence[int], seg_lens: Sequ
     check(rc, "pc_kv_slice_store")
 
 
+def kv_row_table(segs_dev, nseg_dev, max_seg: int, total_rows_dev, dst, n_kv_heads: int, head_dim: int, max_ctx: int, rows,
+                 stream: Optional[int] = None) -> None:
+    """Expand the staging plan (device array of ``pc_kv_seg``, count and total row count in device words) to one ``pc_kv_row`` per
+    staged row of ``dst`` (the arena buffer of one batch row) -- what ``attn_fwd(..., gather=...)`` reads."""
+    rc = load().pc_kv_row_table(segs_dev.data_ptr(), nseg_dev.data_ptr(), max_seg, total_rows_dev.data_ptr(), dst.data_ptr(),
+                                n_kv_heads, head_dim, max_ctx, rows.data_ptr(), current_stream() if stream is None else stream)
+    check(rc, "pc_kv_row_table")
+
+
 def rope_table(pos_i32, inv_freq, cs_out, n_tok: int, head_dim: int, stream: Optional[int] = None) -> None:
     rc = load().pc_rope_table(pos_i32.data_ptr(), inv_freq.data_ptr(), cs_out.data_ptr(), n_tok, head_dim,
                               current_stream() if stream is None else stream)
@@ -217,9 +243,31 @@ def attn_workspace_bytes(B: int, H: int, D: int, q_len: int, kv_len_max: int) ->
     return int(load().pc_attn_workspace_bytes(B, H, D, q_len, kv_len_max))
 
 
+def _attn_args(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
+               workspace=None, past_len_dev=None, out_frag=None, q_lo=None, alibi=None, out_lo=None, kv_lo=None, past_lens=None,
+               counters=None, prefix=None, gather=None) -> AttnArgs:
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    fh, fl = (None, None) if out_frag is None else out_frag
+    kpos, slopes = (None, None) if alibi is None else alibi
+    lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
+    pf = (None, None, None, None, 0) if prefix is None else prefix
+    gr = (None, 0, 0) if gather is None else gather
+    return AttnArgs(C.sizeof(AttnArgs), q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
+                    _ptr(out), _ptr(out_lo), o_bs, o_ts, _ptr(fh), _ptr(fl), B, H, Hkv, D, q_len, past_len, scale,
+                    _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(past_lens), _ptr(kpos),
+                    0 if kpos is None else kpos.stride(0), _ptr(slopes), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4],
+                    _ptr(counters), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(pf[3]), pf[4], _ptr(gr[0]), gr[1], gr[2])
+
+
+def attn_gather_ok(*args, **kw) -> bool:
+    """Whether ``attn_fwd`` with these arguments runs on a kernel that takes ``gather`` (same arguments, nothing is launched)."""
+    a = _attn_args(*args, **kw)
+    return bool(load().pc_attn_gather_ok(C.byref(a)))
+
+
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None, prefix=None) -> None:
+             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None, prefix=None, gather=None) -> None:
     """The attention of one layer through ``pc_attn`` (struct entry; every option is a field).
     ``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum).
     ``out_frag=(hi, lo)``: write split-precision fragment planes for the o_proj launch instead of ``out``.
@@ -228,17 +276,11 @@ def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q
     from key index row0 on (written by ``rope_append(..., kv_lo=...)`` / the q|k|v projection).
     ``counters`` (int32 [B*H], zero before first use): merge the split-KV partials inside the launch.
     ``prefix=(k, v, k_lo | None, v_lo | None, head_stride)`` with ``past_lens``: batch row b attends to rows [0, past_lens[b]) of
-    these shared planes, then to its own rows, which ``k`` / ``v`` (and ``kv_lo``) hold from row 0 on."""
-    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
-    fh, fl = (None, None) if out_frag is None else out_frag
-    kpos, slopes = (None, None) if alibi is None else alibi
-    lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
-    pf = (None, None, None, None, 0) if prefix is None else prefix
-    a = AttnArgs(C.sizeof(AttnArgs), q.data_ptr(), _ptr(q_lo), q_bs, q_ts, k.data_ptr(), v.data_ptr(), kv_bs, kv_hs,
-                 _ptr(out), _ptr(out_lo), o_bs, o_ts, _ptr(fh), _ptr(fl), B, H, Hkv, D, q_len, past_len, scale,
-                 _ptr(workspace), ws_bytes, _ptr(past_len_dev), _ptr(past_lens), _ptr(kpos),
-                 0 if kpos is None else kpos.stride(0), _ptr(slopes), _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4],
-                 _ptr(counters), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(pf[3]), pf[4])
+    these shared planes, then to its own rows, which ``k`` / ``v`` (and ``kv_lo``) hold from row 0 on.
+    ``gather=(row table, k plane, v plane)`` (B = 1, ``attn_gather_ok``): stage while reading -- key rows below ``past_len`` are
+    read from where the table (``kv_row_table``) says they lie and written to ``k`` / ``v`` unless they are there already."""
+    a = _attn_args(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, workspace,
+                   past_len_dev, out_frag, q_lo, alibi, out_lo, kv_lo, past_lens, counters, prefix, gather)
     rc = load().pc_attn(C.byref(a), current_stream() if stream is None else stream)
     check(rc, "pc_attn")
 

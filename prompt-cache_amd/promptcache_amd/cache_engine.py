@@ -25,7 +25,7 @@ import torch
 
 from . import _native, parallel
 from .model import LanguageModel
-from .model.kv_arena import KVArena, StagedKV
+from .model.kv_arena import KVArena, StagedKV, StagingPlan
 from .pml import Module, ModuleRef, Path, Prompt, Schema, TokenSequence, UnionModule  # noqa: F401
 
 KVCache = List[Tuple[torch.Tensor, torch.Tensor]]
@@ -122,10 +122,17 @@ class PromptCache:
         self.record_events = False
         self.last_gather_events = None
         self.last_gather_tokens = 0
+        # Leave the copy to the first forward over the staged buffer (set by CacheEngine for models whose cached-prefill
+        # attention stages while it reads, ``supports_fused_gather``): update() then only records WHAT is staged
+        # (``KVArena.pending``); the rows arrive with the first ``lm()`` call -- or with one pc_kv_gather launch as soon as
+        # somebody looks at the returned views.  TTFT (cache_time + the first lm() call) moves the K/V once instead of
+        # gather read + gather write + attention read.
+        self.defer_gather = False
 
     def reset(self):
         self.staged, self.length = [], 0
         self.arena.tail_base, self.arena.tail_len = -1, 0
+        self.arena.pending = None
 
     @torch.inference_mode()
     def update(self, modules: Sequence[TokenSequenceCache]):
@@ -137,6 +144,9 @@ class PromptCache:
         concatenation of ``ordered``)."""
         ordered = sorted(modules, key=lambda e: e.usage_counter, reverse=True)
         keep = 0
+        if self.arena.pending is not None:       # the previous staging was never carried out: nothing of it can be kept
+            self.arena.pending = None
+            self.staged = []
         for m, prev in zip(ordered, self.staged):
             if m is prev or m.token_sequence is prev.token_sequence:
                 keep += 1
@@ -152,14 +162,20 @@ class PromptCache:
         if offset > self.max_ctx_length:
             raise ValueError(f"prompt modules need {offset} staged tokens but max_ctx_length is {self.max_ctx_length}")
         a = self.arena
-        if self.record_events:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        _native.kv_gather(ptrs, lens, offs, a.buf, a.L, a.Hkv, a.D, a.cap)
-        if self.record_events:
-            ev[1].record()
-            self.last_gather_events = ev
-            self.last_gather_tokens = sum(lens)
+        if self.defer_gather and ptrs and all(m.device_store is not None for m in ordered[keep:]):
+            # module KV in HBM: the first forward stages (segments in the host tier keep the explicit gather: the copy kernel
+            # streams them over PCIe, the attention would fetch them in latency-bound pieces)
+            a.pending = StagingPlan(list(zip(ptrs, lens, offs)), offset, [m.device_store for m in ordered[keep:]])
+            self.last_gather_events = None
+        else:
+            if self.record_events:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            _native.kv_gather(ptrs, lens, offs, a.buf, a.L, a.Hkv, a.D, a.cap)
+            if self.record_events:
+                ev[1].record()
+                self.last_gather_events = ev
+                self.last_gather_tokens = sum(lens)
         self.staged = list(ordered)
         self.length = offset
         a.length = offset
@@ -585,6 +601,9 @@ class CacheEngine:
         num_layers, num_head, head_dim = lm.get_cache_shape()
         self.prompt_cache = PromptCache(max_ctx_length=max_ctx_length, num_layers=num_layers, num_head=num_head,
                                         head_dim=head_dim, target_device=self.target_device)
+        # PC_DEFER_GATHER=0: PromptCache.update copies at once, as rounds 1-3 did
+        self.prompt_cache.defer_gather = bool(getattr(getattr(lm, "hf_model", None), "supports_fused_gather", False)) and \
+            os.environ.get("PC_DEFER_GATHER", "1") != "0"
 
     def add_schema(self, schema: Union[str, Schema], batch_size: int = 1, max_tokens: Optional[int] = None,
                    no_cache: bool = False):
@@ -724,8 +743,9 @@ class CacheEngine:
         end.record()
         torch.cuda.synchronize()
         cache_time = start.elapsed_time(end)
-        for i in range(len(cache)):
-            cache[i] = (self.lm.read_k_hook(cache[i][0]), self.lm.read_v_hook(cache[i][1]))
+        if type(self.lm).read_k_hook is not LanguageModel.read_k_hook or type(self.lm).read_v_hook is not LanguageModel.read_v_hook:
+            for i in range(len(cache)):          # (looking at the views carries out a deferred staging first; identity hooks do not)
+                cache[i] = (self.lm.read_k_hook(cache[i][0]), self.lm.read_v_hook(cache[i][1]))
         if return_full_position_ids:
             # positions of the cached keys in the order they are STAGED (most-used first, PromptCache.update), not in the
             # DFS order of `used`: an ALiBi model reads position_ids[:S] as the positions of arena rows [0, S).  (The

@@ -96,9 +96,11 @@ class GenerationEngine:
 
     # -- pieces of the loop ---------------------------------------------------------------------
     def _forward(self, ids: List[int], positions: List[int], past) -> Tuple[torch.Tensor, object, float]:
-        dev = self.lm.device
-        ids_t = torch.tensor([ids], device=dev, dtype=torch.long)
-        pos_t = torch.tensor([positions], device=dev, dtype=torch.long)
+        # Host tensors: the model's captured small-q forward takes token ids, positions, past length and a pending staging plan
+        # in ONE pinned host-to-device copy (model/llama_hip.py _InputBlock); the reference uploads ids and positions as two
+        # pageable copies in front of the timed call (:96-97).  Paths that want device tensors move them themselves.
+        ids_t = torch.tensor([ids], dtype=torch.long)
+        pos_t = torch.tensor([positions], dtype=torch.long)
         with _Timer() as t:
             out = self.lm(input_ids=ids_t, position_ids=pos_t, past_key_values=past, use_cache=True)
         return out.logits, out.past_key_values, t.ms

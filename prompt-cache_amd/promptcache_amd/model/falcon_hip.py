@@ -28,6 +28,7 @@ from .llama_hip import LlamaHIP
 
 class FalconHIP(LlamaHIP):
     _shared_prefix_loop = False     # (its many-row loop keeps a copy of the trunk per batch row)
+    supports_fused_gather = False   # (its layer loops read staged rows from the arena: PromptCache.update copies at once)
 
     def __init__(self, shape: FalconShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
                  skinny: bool = True, int8_weights: bool = False):

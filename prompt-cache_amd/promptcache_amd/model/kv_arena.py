@@ -23,6 +23,28 @@ import torch
 _LIVE: "weakref.WeakValueDictionary[int, KVArena]" = weakref.WeakValueDictionary()
 
 
+class StagingPlan:
+    """What ``PromptCache.update`` decided to stage and has not copied yet: ``(module store address, rows, first staged row)``
+    per segment in staging order.  The first forward over the arena either consumes it inside its attention launches (the
+    <= 16-row cached prefill reads every staged row from its module store and writes it to the arena as it goes: the K/V
+    crosses the chip once) or the arena materialises it with one ``pc_kv_gather`` -- whichever comes first."""
+
+    __slots__ = ("segs", "total", "keep", "_arr")
+
+    def __init__(self, segs: List[Tuple[int, int, int]], total: int, keep: list):
+        self.segs = segs          # [(src ptr, len, dst row)]
+        self.total = total        # staged rows once the plan is carried out (= the arena's length)
+        self.keep = keep          # the stores behind the pointers, kept alive until the plan is carried out
+        self._arr = None
+
+    def seg_array(self, dtype):
+        """The segments as a numpy array of ``pc_kv_seg`` records (src, dst_row, len)."""
+        if self._arr is None:
+            import numpy as np
+            self._arr = np.array([(p, off, ln) for p, ln, off in self.segs], dtype=dtype)
+        return self._arr
+
+
 class KVArena:
     def __init__(self, batch: int, n_layers: int, n_kv_heads: int, cap: int, head_dim: int, device,
                  dtype=torch.float16):
@@ -41,6 +63,21 @@ class KVArena:
         self.tail_lo: Optional[torch.Tensor] = None
         self.tail_base = -1
         self.tail_len = 0
+        self.pending: Optional[StagingPlan] = None     # a staging that has not been carried out yet (see StagingPlan)
+        self.row_tab: Optional[torch.Tensor] = None    # pc_kv_row[cap]: the plan expanded per staged row (device scratch)
+
+    def materialize(self) -> None:
+        """Carry out a pending staging with one ``pc_kv_gather`` launch (no-op without one)."""
+        plan, self.pending = self.pending, None
+        if plan is not None and plan.segs:
+            from .. import _native
+            _native.kv_gather([s[0] for s in plan.segs], [s[1] for s in plan.segs], [s[2] for s in plan.segs], self.buf,
+                              self.L, self.Hkv, self.D, self.cap)
+
+    def row_table(self) -> torch.Tensor:
+        if self.row_tab is None:
+            self.row_tab = torch.empty(self.cap * 16, dtype=torch.uint8, device=self.buf.device)
+        return self.row_tab
 
     def with_lo(self) -> "KVArena":
         if self.lo is None:
@@ -90,6 +127,7 @@ class KVArena:
 
     def grown(self, new_cap: int) -> "KVArena":
         """A larger arena holding the same ``length`` rows (rare path: generation ran past ``cap``)."""
+        self.materialize()
         a = KVArena(self.B, self.L, self.Hkv, new_cap, self.D, self.buf.device, self.buf.dtype)
         a.buf[:, :, :, :, :self.length].copy_(self.buf[:, :, :, :, :self.length])
         if self.lo is not None:
@@ -109,10 +147,27 @@ class StagedKV(list):
         self.arena = arena
         self.length = length
 
+    # A staging that is still pending (KVArena.pending) is carried out the moment anybody LOOKS at the views -- indexing or
+    # iterating, which is what a caller that inspects or rebuilds the list does (the reference's GenerationEngine,
+    # generation_engine.py:101-102).  Handing the object itself to the model does not: the model finds the arena through
+    # ``.arena`` and may stage inside its first attention launches instead.
+    def _ensure_staged(self) -> None:
+        a = getattr(self, "arena", None)
+        if a is not None and a.pending is not None:
+            a.materialize()
+
+    def __getitem__(self, i):
+        self._ensure_staged()
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        self._ensure_staged()
+        return list.__iter__(self)
+
     def unbatched(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         """``[Hkv, length, D]`` views: what ``CacheEngine.process`` returns (``cache_engine.py:161-165``)."""
         out = StagedKV.__new__(StagedKV)
-        list.__init__(out, ((k[0], v[0]) for k, v in self))
+        list.__init__(out, ((k[0], v[0]) for k, v in list.__iter__(self)))
         out.arena = self.arena
         out.length = self.length
         return out
@@ -167,6 +222,7 @@ def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Opti
         a.length = S
         a.lo, a.lo_len = None, 0
         a.tail_lo, a.tail_base, a.tail_len = None, -1, 0
+        a.pending, a.row_tab = None, None
         return a, S
     except Exception:
         return None

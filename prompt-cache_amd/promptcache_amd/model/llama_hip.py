@@ -31,9 +31,62 @@ from typing import Dict, Optional
 
 import torch
 
+import numpy as np
+
 from .. import _native
 from .config import LlamaShape
 from .kv_arena import KVArena, StagedKV, arena_from_past
+
+_SEG_DTYPE = np.dtype([("src", "<u8"), ("dst_row", "<i4"), ("len", "<i4")])      # pc_kv_seg
+
+
+class _InputBlock:
+    """Everything a captured small-q forward reads per call, in ONE device allocation filled by ONE host-to-device copy:
+
+        ids   int64 [T] | pos int32 [T] | words int32 [8] = {past_len, residual-tail base, live rows, segments, rows of the row
+        table, -, -, -} | pc_kv_seg [max_seg]  (the staging plan, when the forward stages while it reads)
+
+    The host side is a small ring of pinned mirrors of the same layout (numpy views): a call fills the next mirror and enqueues
+    one asynchronous copy; a mirror is reused only after its copy has run (event)."""
+
+    SLOTS = 4
+
+    def __init__(self, device, T: int, max_seg: int):
+        self.T, self.max_seg = T, max_seg
+        self.o_pos = 8 * T
+        self.o_words = 12 * T
+        self.o_segs = (self.o_words + 32 + 15) // 16 * 16
+        self.nbytes = self.o_segs + 16 * max_seg
+        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.ids = self.dev[:8 * T].view(torch.int64)
+        self.pos = self.dev[self.o_pos:self.o_pos + 4 * T].view(torch.int32)
+        self.words = self.dev[self.o_words:self.o_words + 32].view(torch.int32)
+        self.segs = self.dev[self.o_segs:]
+        self._host = [torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS)]
+        self._np = []
+        for h in self._host:
+            a = h.numpy()
+            self._np.append((a[:8 * T].view(np.int64), a[self.o_pos:self.o_pos + 4 * T].view(np.int32),
+                             a[self.o_words:self.o_words + 32].view(np.int32),
+                             a[self.o_segs:].view(_SEG_DTYPE) if max_seg else None))
+        self._ev = [None] * self.SLOTS
+        self._i = 0
+
+    def mirror(self):
+        """-> (slot, ids, pos, words, segs) numpy views of the next free pinned mirror."""
+        i = self._i
+        self._i = (i + 1) % self.SLOTS
+        if self._ev[i] is not None:
+            self._ev[i].synchronize()
+        return (i,) + self._np[i]
+
+    def upload(self, slot: int, from_byte: int = 0, to_byte: Optional[int] = None) -> None:
+        end = self.nbytes if to_byte is None else to_byte
+        self.dev[from_byte:end].copy_(self._host[slot][from_byte:end], non_blocking=True)
+        ev = self._ev[slot]
+        if ev is None:
+            ev = self._ev[slot] = torch.cuda.Event()
+        ev.record()
 
 
 def lw0_fp16(layers) -> bool:
@@ -204,10 +257,16 @@ class LlamaHIP:
         self._last_qt = None
         self.batch_invariant = True         # a row's result does not depend on the other rows of the forward (see llm_int8)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
+        self._gather = None         # set per forward: the row table while the attention launches stage as they read
+        self.stats = {"fused_gather": 0}     # forwards that carried out a pending staging inside their attention launches
 
     # the many-row layer loop of THIS class hands the attention a shared key prefix (__call__'s ``shared_prefix``); a subclass
     # with its own loop says so itself
     _shared_prefix_loop = True
+    # The <= 16-row cached prefill of THIS class's layer loops can carry out a pending staging (KVArena.pending) inside its
+    # attention launches (pc_attn gather_rows): CacheEngine then defers PromptCache.update's copy to the first lm() call.
+    supports_fused_gather = True
+    GATHER_MAX_SEG = 512            # segments of a staging plan the captured forward has room for (longer plans: pc_kv_gather)
 
     @property
     def supports_shared_prefix(self) -> bool:
@@ -364,11 +423,14 @@ class LlamaHIP:
             self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
         return self._ws
 
-    def _resolve_arena(self, past, B: int, q_len: int):
-        """-> (arena, past_len) with room for q_len more rows."""
+    def _resolve_arena(self, past, B: int, q_len: int, keep_pending: bool = False):
+        """-> (arena, past_len) with room for q_len more rows.  A staging the arena still owes (``KVArena.pending``) is carried
+        out here unless the caller takes care of it itself (``keep_pending``)."""
         if past is None:
             return self.new_arena(B, q_len + self.decode_headroom), 0
         found = arena_from_past(past, self.L, self.Hkv, self.D)
+        if found is not None and not keep_pending:
+            found[0].materialize()
         if found is None:
             # foreign tensors (e.g. a caller-built legacy cache): copy once into an arena
             k0 = past[0][0]
@@ -410,7 +472,6 @@ class LlamaHIP:
         are the product)."""
         n = _native
         dev = self.device
-        input_ids = input_ids.to(dev)
         B, q_len = input_ids.shape
         self._shared = None
         if shared_prefix is not None:
@@ -420,12 +481,12 @@ class LlamaHIP:
                 raise ValueError("shared_prefix goes with many_rows=True, explicit position ids, no past_key_values and a one-row "
                                  "trunk arena that holds every prefix")
             self._shared = (trunk, torch.tensor(list(n_pre), device=dev, dtype=torch.int32), int(max(n_pre)))
-        arena, past_len = self._resolve_arena(past_key_values, B, q_len)
+        arena, past_len = self._resolve_arena(past_key_values, B, q_len, keep_pending=True)
         if many_rows and self.precise_dense and past_key_values is None:
             arena.with_lo()           # a schema-encode pass: keep the residuals of every row it appends
         if position_ids is None:  # llama2.py:859-864
             position_ids = torch.arange(past_len, past_len + q_len, device=dev).unsqueeze(0).expand(B, q_len)
-        position_ids = position_ids.to(dev).view(-1, q_len)
+        position_ids = position_ids.view(-1, q_len)
         if attention_mask is not None:
             am = attention_mask.to(dev)
             # only right padding is expressible without an explicit mask (cache_engine.py:38-47 pads right)
@@ -450,13 +511,16 @@ class LlamaHIP:
         streaming = graphed or mid
         self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
         if graphed:
-            # the graph's static int64 / int32 input buffers are filled straight from the caller's tensors
-            # (copy_ converts), so no separate dtype-conversion launches sit in front of the replay
+            # Token ids and positions on the HOST (what GenerationEngine hands over) travel with the call's other words in one
+            # pinned copy (_InputBlock); device tensors (the reference's calling convention, generation_engine.py:96-97) are
+            # copied into the graph's input block on the device.  A pending staging is consumed by the attention launches.
             logits = self._graphed_skinny(input_ids.reshape(-1), position_ids.reshape(-1), arena, B, q_len, past_len,
                                           last_token_only, num_layers)
             arena.length = past_len + q_len
             self._tail_done(arena, self._lo_mode, q_len, past_len)
             return CausalLMOutput(logits=logits, past_key_values=arena.views() if use_cache else None)
+        arena.materialize()           # every other path reads staged rows from the arena itself
+        input_ids, position_ids = input_ids.to(dev), position_ids.to(dev)
         pos32 = position_ids.reshape(-1).to(torch.int32).contiguous()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
         # an encode pass of 65..512 rows without per-row prefixes (the trunk of a schema, small whole scaffolds) runs the
@@ -817,7 +881,8 @@ class LlamaHIP:
             qkv_done = False
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))
+                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
+                       gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
             if chain:
                 nxt = None
                 if li + 1 < len(layers):
@@ -874,53 +939,96 @@ class LlamaHIP:
             return q_len          # never across a row-tile count or the residual-tail regime of the attention
         return qb
 
-    def _graphed_skinny(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
-        """Replay (capturing on first use) the hipGraph of the small-q forward for this shape."""
+    def _gather_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
+        """Will the attention launches of this (bucketed) forward run on the kernel that stages while it reads?  Asked of the
+        library itself (pc_attn_gather_ok) with the arguments _forward_skinny passes."""
+        plan = arena.pending
+        if plan is None or not self.supports_fused_gather or self.llm_int8 or B != 1 or plan.total != past_len or \
+                len(plan.segs) > self.GATHER_MAX_SEG or self.use_chain:
+            return False
+        buf = arena.buf
+        kvlo = (arena.tail_planes(0) + (-1,)) if self._lo_mode == 1 else None
+        H, D = self.H, self.D
+        return _native.attn_gather_ok(buf, q_len * H * D, H * D, arena.k_plane(0), arena.v_plane(0), arena.batch_stride,
+                                      arena.head_stride, None, 0, 0, B, H, self.Hkv, D, q_len, past_len, self.softmax_scale,
+                                      None, past_len_dev=buf, out_frag=(buf, buf), q_lo=buf, kv_lo=kvlo,
+                                      counters=self._counters_for(B, H))
+
+    def _graphed_skinny(self, ids, pos, arena, B, q_len, past_len, last_token_only, num_layers):
+        """Replay (capturing on first use) the hipGraph of the small-q forward for this shape.  ``ids`` / ``pos``: flat integer
+        tensors, on the host (one pinned copy carries them with the call's other words) or on the device."""
         n = _native
         q_real = q_len
         q_len = self._graph_rows(arena, B, q_len, past_len, last_token_only)
         if q_len != q_real:
             self._lo_mode = self._tail_mode(arena, q_len, past_len)
+        gather = self._gather_ok(arena, B, q_len, past_len)
+        plan = arena.pending if gather else None
+        if not gather:
+            arena.materialize()
         nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
         mode = self._lo_mode
         key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm, self.use_chain,
-               mode, arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0)
+               mode, arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0, gather)
         ent = self._graphs.pop(key, None)
-        if ent is not None:
-            self._graphs[key] = ent                      # LRU: a hit moves the entry to the young end
-        else:
+        T = B * q_len
+        fresh = ent is None
+        if fresh:
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))   # evict the least recently used
-            T = B * q_len
-            st_ids = torch.zeros(T, dtype=torch.int64, device=self.device)
-            st_pos = torch.zeros(T, dtype=torch.int32, device=self.device)
-            st_past = torch.zeros(3, dtype=torch.int32, device=self.device)      # {past_len, base of the residual tail, live rows}
-            st_ids[:q_real * B].copy_(ids); st_pos[:q_real * B].copy_(pos32); st_past[0:1].fill_(past_len)
-            st_past[2:3].fill_(q_real * B)
-            if mode == 2:
-                st_past[1:2].fill_(arena.tail_base)
+            ent = [None, _InputBlock(self.device, T, self.GATHER_MAX_SEG if gather else 0), None]
+        self._graphs[key] = ent                              # LRU: a hit moves the entry to the young end
+        blk = ent[1]
+        # ---- this call's inputs: one pinned mirror, one copy ----
+        slot, h_ids, h_pos, h_words, h_segs = blk.mirror()
+        n_real = q_real * B
+        host_ids = not ids.is_cuda and not pos.is_cuda
+        if host_ids:
+            h_ids[:n_real] = ids.numpy()
+            h_pos[:n_real] = pos.numpy()
+            if q_len != q_real:                              # pad rows BEHIND the prompt's own (see _graph_rows)
+                h_ids[n_real:] = 0
+                h_pos[n_real:] = int(h_pos[n_real - 1]) + np.arange(1, T - n_real + 1, dtype=np.int32)
+        h_words[0] = past_len
+        h_words[1] = arena.tail_base if mode == 2 else 0
+        h_words[2] = n_real                                  # rows that carry tokens: the projections do not load the pad rows' activations
+        h_words[3] = len(plan.segs) if gather else 0
+        h_words[4] = min(past_len + q_len, arena.cap)        # rows of the row table (this pass's own rows: entries that point at the arena)
+        if gather:
+            h_segs[:len(plan.segs)] = plan.seg_array(_SEG_DTYPE)
+        if host_ids:
+            blk.upload(slot)
+        else:
+            blk.upload(slot, blk.o_words)
+            blk.ids[:n_real].copy_(ids)
+            blk.pos[:n_real].copy_(pos)
+            if q_len != q_real:
+                blk.ids[n_real:].fill_(0)
+                blk.pos[n_real:].copy_(pos[-1:].to(self.device) + torch.arange(1, T - n_real + 1, device=self.device, dtype=torch.int32))
+
+        def run():
+            if gather:
+                n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
+                               arena.row_table())
+                self._gather = arena.row_tab
+            try:
+                return self._forward_skinny(blk.ids, blk.pos, blk.words, arena, B, q_len, past_len, last_token_only, num_layers)
+            finally:
+                self._gather = None
+
+        if fresh:
             # one eager pass first (loads code objects / sizes the allocator), then capture
-            self._forward_skinny(st_ids, st_pos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
+            run()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._forward_skinny(st_ids, st_pos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
-            ent = (g, st_ids, st_pos, st_past, out)
-            self._graphs[key] = ent
-        g, st_ids, st_pos, st_past, out = ent
-        if q_len != q_real:
-            st_ids[:q_real].copy_(ids)
-            st_pos[:q_real].copy_(pos32)
-            st_ids[q_real:].fill_(0)
-            st_pos[q_real:].copy_(pos32[-1:] + torch.arange(1, q_len - q_real + 1, device=self.device, dtype=pos32.dtype))
-        else:
-            st_ids.copy_(ids)
-            st_pos.copy_(pos32)
-        st_past[0:1].fill_(past_len)
-        st_past[2:3].fill_(q_real * B)       # rows that carry tokens: the projections do not load the pad rows' activations
-        if mode == 2:
-            st_past[1:2].fill_(arena.tail_base)
+                out = run()
+            ent[0], ent[2] = g, out
+        g, out = ent[0], ent[2]
         g.replay()
+        if gather:
+            arena.pending = None                             # the staged rows are in the arena now
+            self.stats["fused_gather"] += 1
         return out[:, :q_real].clone() if q_len != q_real else out.clone()
 
     @torch.inference_mode()
@@ -1059,7 +1167,8 @@ class LlamaHIP:
                 return None       # schema encode: the K / V of the last layer are written; nothing after them is used
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))
+                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
+                       gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wo_s"])                                                    # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm

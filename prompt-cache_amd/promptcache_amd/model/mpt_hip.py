@@ -37,6 +37,7 @@ def alibi_slopes(num_heads: int, alibi_bias_max: int = 8) -> torch.Tensor:
 
 class MptHIP(LlamaHIP):
     _shared_prefix_loop = False     # (its many-row loop keeps a copy of the trunk per batch row)
+    supports_fused_gather = False   # (its layer loops read staged rows from the arena: PromptCache.update copies at once)
 
     def __init__(self, shape: MptShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
                  skinny: bool = True, int8_weights: bool = False):

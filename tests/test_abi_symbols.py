@@ -16,8 +16,8 @@ def _declared():
 
 
 def _abi_headers():
-    """The headers that DECLARE exported symbols (promptcache_hip_compat.h holds inline wrappers only: nothing to export)."""
-    return [h for h in glob.glob(os.path.join(ROOT, "include", "*.h")) if not h.endswith("_compat.h")]
+    """The headers that DECLARE exported symbols."""
+    return glob.glob(os.path.join(ROOT, "include", "*.h"))
 
 
 def test_header_declares_the_hot_path_entry_points():
@@ -67,27 +67,27 @@ def test_ctypes_signatures_have_the_arity_of_the_header_prototypes():
         assert len(argtypes) == arity[name], (name, len(argtypes), arity[name])
 
 
-def test_struct_layouts_match_the_header_and_the_compat_wrappers_compile(tmp_path):
-    """ctypes mirrors of pc_attn_args / pc_gemm_args have the size and field offsets the C compiler gives the header's structs
-    (a field added on one side only would shift every later one silently), and include/promptcache_hip_compat.h -- the round
-    1-2 entry-point names as inline wrappers -- is valid C and C++."""
+def test_struct_layouts_match_the_header(tmp_path):
+    """ctypes mirrors of the header's structs have the size and field offsets the C compiler gives them (a field added on one
+    side only would shift every later one silently), and the header is valid C99 and C++17."""
     import subprocess
     from promptcache_amd import _native
     src = tmp_path / "layout.c"
-    fields = {"pc_attn_args": [f[0] for f in _native.AttnArgs._fields_], "pc_gemm_args": [f[0] for f in _native.GemmArgs._fields_],
-              "pc_dense_qkv_args": [f[0] for f in _native.DenseQkvArgs._fields_]}
-    body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/promptcache_hip_compat.h"', 'int main(void) {']
-    for st, fs in fields.items():
+    structs = (("pc_attn_args", _native.AttnArgs), ("pc_gemm_args", _native.GemmArgs), ("pc_dense_qkv_args", _native.DenseQkvArgs),
+               ("pc_kv_seg", _native.KvSeg), ("pc_kv_row", _native.KvRow))
+    body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/promptcache_hip.h"', 'int main(void) {']
+    for st, cls in structs:
         body.append(f'  printf("{st} %zu\\n", sizeof({st}));')
-        for f in fs:
+        for f, _ in cls._fields_:
             body.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
-    body += ['  return 0;', '}']
+    body += [f'  printf("PC_KV_ROW_STAGED %u\\n", PC_KV_ROW_STAGED);', '  return 0;', '}']
     src.write_text("\n".join(body))
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-unused-function", str(src), "-o", str(exe)])
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", str(src)])
     got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).strip().splitlines())
-    for st, cls in (("pc_attn_args", _native.AttnArgs), ("pc_gemm_args", _native.GemmArgs), ("pc_dense_qkv_args", _native.DenseQkvArgs)):
+    for st, cls in structs:
         assert int(got[st]) == ctypes.sizeof(cls), st
         for name, _ in cls._fields_:
             assert int(got[f"{st}.{name}"]) == getattr(cls, name).offset, (st, name)
+    assert int(got["PC_KV_ROW_STAGED"]) == _native.KV_ROW_STAGED

@@ -1,0 +1,242 @@
+"""The attention that stages while it reads (pc_attn `gather_rows` + pc_kv_row_table): what PromptCache.update's
+copy loop (promptcache/cache_engine.py:135-151) leaves in the staged buffer must be there after the first forward, bit for bit,
+and the forward's result must not depend on which way the rows got there."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _n():
+    from promptcache_amd import _native
+    return _native
+
+
+def _rand_half(shape, rng, scale=1.0):
+    return torch.from_numpy((scale * rng.standard_normal(shape, dtype=np.float32)).astype(np.float16)).to(DEV)
+
+
+def _plan_block(n, ptrs, lens, offs, total):
+    """Device copy of a staging plan the way the model's input block holds it: (segs, nseg word, total word)."""
+    arr = np.zeros(max(len(ptrs), 1), dtype=np.dtype([("src", "<u8"), ("dst_row", "<i4"), ("len", "<i4")]))
+    for i, (p, ln, o) in enumerate(zip(ptrs, lens, offs)):
+        arr[i] = (p, o, ln)
+    segs = torch.from_numpy(arr.view(np.uint8).copy()).to(DEV)
+    words = torch.tensor([len(ptrs), total], dtype=torch.int32, device=DEV)
+    return segs, words
+
+
+def test_row_table_expands_the_plan_and_marks_rows_nobody_stages():
+    n = _n()
+    L, Hkv, D, cap = 2, 3, 128, 64
+    lens, offs = [5, 1, 17], [4, 9, 10]                 # rows 0..3 kept from a previous prompt, 27.. = this pass's own rows
+    stores = [torch.zeros((L, 2, Hkv, ln, D), dtype=torch.float16, device=DEV) for ln in lens]
+    arena = torch.zeros((L, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    segs, words = _plan_block(n, [s.data_ptr() for s in stores], lens, offs, 30)
+    rows = torch.full((cap * 16,), 0xAB, dtype=torch.uint8, device=DEV)
+    n.kv_row_table(segs, words[0:1], 8, words[1:2], arena, Hkv, D, cap, rows)
+    torch.cuda.synchronize()
+    tab = rows.cpu().numpy().view(np.dtype([("base", "<u8"), ("ps16", "<u4"), ("flags", "<u4")]))
+    rb = D * 2
+    for r in range(30):
+        seg = [i for i in range(3) if offs[i] <= r < offs[i] + lens[i]]
+        if seg:
+            i = seg[0]
+            assert tab[r]["base"] == stores[i].data_ptr() + (r - offs[i]) * rb and tab[r]["ps16"] == lens[i] * rb // 16
+            assert tab[r]["flags"] == 0
+        else:
+            assert tab[r]["base"] == arena.data_ptr() + r * rb and tab[r]["ps16"] == cap * rb // 16
+            assert tab[r]["flags"] == n.KV_ROW_STAGED
+    assert (rows.cpu().numpy()[30 * 16:] == 0xAB).all()           # entries behind the total are not touched
+
+
+GATHER_CASES = [
+    # H, Hkv, D, q_len, segment lengths, rows kept from a previous staging, tail (split-precision rows of the pass itself)
+    (32, 32, 128, 12, [275, 1, 1, 1, 1, 1, 84, 1, 1, 174, 1, 1, 256, 1, 1, 155, 1, 1, 267, 1, 1, 265, 1, 1, 232], 0, True),   # persona
+    (32, 32, 128, 12, [275, 1, 1, 1, 1, 1, 84, 1, 1, 174, 1, 1, 256, 1, 1, 155, 1, 1, 267, 1, 1, 265, 1, 1, 232], 0, False),
+    (32, 32, 128, 14, [306, 2, 2, 2, 2, 76, 800, 800, 800, 800, 800], 0, True),        # game prompt: several tiles per wave
+    (8, 2, 128, 16, [40, 1, 300, 7, 129], 0, True),                                    # GQA: one query head per kv head stages
+    (8, 2, 128, 5, [40, 1, 300, 7, 129], 41, True),                                    # first two segments kept in place
+    (40, 40, 128, 9, [1000, 3, 500], 0, True),                                         # 13b head count (5 + 1 splits)
+    (16, 16, 64, 3, [100, 1, 1, 250], 0, True),                                        # D = 64
+    (4, 4, 32, 12, [64, 64, 1, 200], 0, False),                                        # D = 32
+    (32, 32, 128, 1, [500, 1, 120], 0, False),                                         # one row (a decode-shaped first call)
+]
+
+
+@pytest.mark.parametrize("H,Hkv,D,q_len,lens,kept,tail", GATHER_CASES)
+def test_attention_stages_while_it_reads_bit_exact(H, Hkv, D, q_len, lens, kept, tail):
+    """pc_attn(gather_rows) on a poisoned arena vs pc_kv_gather + pc_attn on a second arena: same output bits, same staged
+    bytes, nothing else written (layer 1 of a 3-layer store, so the plane arithmetic is exercised)."""
+    n = _n()
+    rng = np.random.default_rng(7)
+    L, li = 3, 1
+    S = sum(lens)
+    cap = S + q_len + 5
+    stores = [_rand_half((L, 2, Hkv, ln, D), rng) for ln in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(int).tolist()
+    q32 = rng.standard_normal((1, q_len, H, D), dtype=np.float32)
+    q = torch.from_numpy(q32.astype(np.float16)).to(DEV)
+    ql = torch.from_numpy((q32 - q.float().cpu().numpy()).astype(np.float16)).to(DEV)
+    new_kv = _rand_half((L, 2, Hkv, q_len, D), rng)
+    klo, vlo = _rand_half((1, Hkv, q_len, D), rng, 1e-4), _rand_half((1, Hkv, q_len, D), rng, 1e-4)
+    kv_lo = (klo, vlo, Hkv * q_len * D, q_len * D, -1) if tail else None
+    scale = 1.0 / np.sqrt(D)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, S + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+    mt = (q_len + 15) // 16
+
+    def arena_with(staged_upto):
+        a = torch.full((L, 2, Hkv, cap, D), float("nan"), dtype=torch.float16, device=DEV)
+        a[:, :, :, S:S + q_len] = new_kv                                  # the pass's own rows (appended by the q|k|v launch)
+        k = [i for i in range(len(lens)) if offs[i] + lens[i] <= staged_upto]
+        if k:
+            n.kv_gather([stores[i].data_ptr() for i in k], [lens[i] for i in k], [offs[i] for i in k], a, L, Hkv, D, cap)
+        return a
+
+    def attn(a, gather):
+        oh = torch.full((mt, H * D // 32, 64, 8), float("nan"), dtype=torch.float16, device=DEV)
+        ol = torch.full_like(oh, float("nan"))
+        n.attn_fwd(q, q_len * H * D, H * D, a[li, 0].unsqueeze(0), a[li, 1].unsqueeze(0), L * 2 * Hkv * cap * D, cap * D, None, 0, 0,
+                   1, H, Hkv, D, q_len, S, scale, ws, out_frag=(oh, ol), q_lo=ql, kv_lo=kv_lo, gather=gather)
+        torch.cuda.synchronize()
+        return oh, ol
+
+    # reference: everything staged by the copy kernel, plain attention
+    ref_arena = arena_with(S)
+    ref = attn(ref_arena, None)
+    # staging attention: only the kept rows are there; the plan covers the rest
+    got_arena = arena_with(kept)
+    todo = [i for i in range(len(lens)) if offs[i] >= kept]
+    assert sum(lens[i] for i in range(len(lens)) if i not in todo) == kept
+    segs, words = _plan_block(n, [stores[i].data_ptr() for i in todo], [lens[i] for i in todo], [offs[i] for i in todo], S + q_len)
+    rows = torch.zeros(cap * 16, dtype=torch.uint8, device=DEV)
+    n.kv_row_table(segs, words[0:1], 64, words[1:2], got_arena, Hkv, D, cap, rows)
+    assert n.attn_gather_ok(q, q_len * H * D, H * D, got_arena[li, 0].unsqueeze(0), got_arena[li, 1].unsqueeze(0),
+                            L * 2 * Hkv * cap * D, cap * D, None, 0, 0, 1, H, Hkv, D, q_len, S, scale, ws,
+                            out_frag=(ws, ws), q_lo=ql, kv_lo=kv_lo)
+    got = attn(got_arena, (rows, li * 2 * Hkv, (li * 2 + 1) * Hkv))
+    assert torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16)) and torch.equal(got[1].view(torch.int16), ref[1].view(torch.int16))
+    # layer li now holds what pc_kv_gather leaves; the other layers and the rows behind S + q are untouched (still NaN / kept)
+    assert torch.equal(got_arena[li].view(torch.int16), ref_arena[li].view(torch.int16))
+    other = [x for x in range(L) if x != li]
+    exp_other = arena_with(kept)
+    assert torch.equal(got_arena[other].view(torch.int16), exp_other[other].view(torch.int16))
+
+
+def test_gather_rows_is_refused_where_no_kernel_implements_it():
+    n = _n()
+    H, D, cap = 4, 128, 600
+    a = torch.zeros((1, 2, H, cap, D), dtype=torch.float16, device=DEV)
+    q = torch.zeros((1, 40, H, D), dtype=torch.float16, device=DEV)
+    rows = torch.zeros(cap * 16, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, 40, 540), 4) // 4, dtype=torch.float32, device=DEV)
+    out = torch.zeros((1, 40, H * D), dtype=torch.float16, device=DEV)
+    args = (q, 40 * H * D, H * D, a[0, 0].unsqueeze(0), a[0, 1].unsqueeze(0), 2 * H * cap * D, cap * D, out, 40 * H * D, H * D,
+            1, H, H, D, 40, 500, 0.1, ws)
+    assert not n.attn_gather_ok(*args)                        # 40 rows: the 64-row kernel, which reads the arena only
+    with pytest.raises(RuntimeError, match="gather_rows needs"):
+        n.attn_fwd(*args, gather=(rows, 0, H))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# engine level: CacheEngine.process defers the copy, the first lm() call stages
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _engine(defer: bool, shape_name="mid", seed=5):
+    from promptcache_amd import CacheEngine
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    from promptcache_amd import synth
+    shape = SHAPES[shape_name]
+    lm = Llama2(name="t", shape=shape, weights=make_weights_np(shape, seed, 0.05), device="cuda:0")
+    eng = CacheEngine(2048, lm)
+    eng.prompt_cache.defer_gather = defer
+    schema, prompt = synth.persona_like(system_len=120, seed=3)
+    eng.add_schema(lm.get_formatter()(schema))
+    return lm, eng, prompt
+
+
+def test_first_forward_stages_what_the_copy_kernel_would_have_staged():
+    from promptcache_amd import Prompt
+    out = {}
+    for defer in (False, True):
+        lm, eng, prompt_pml = _engine(defer)
+        prompt = Prompt(prompt_pml, [lm.get_formatter()])
+        ids, pos, _, cache = eng.process(prompt)
+        arena = eng.prompt_cache.arena
+        S = len(eng.prompt_cache)
+        assert S + len(ids) >= 256 and len(ids) <= 16, "the synthetic prompt must land in the staging kernel's regime"
+        assert (arena.pending is not None) == defer
+        if defer:
+            arena.buf.fill_(float("nan"))                         # nothing may be read from the arena before it is staged
+        # host tensors: the engine's own calling convention (one pinned copy per call)
+        o = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+        torch.cuda.synchronize()
+        assert arena.pending is None
+        assert lm.hf_model.stats["fused_gather"] == (1 if defer else 0)
+        # ... and a decode step on top
+        o2 = lm(input_ids=torch.tensor([[7]]), position_ids=torch.tensor([[max(pos) + 2]]), past_key_values=o.past_key_values, use_cache=True)
+        out[defer] = (o.logits.clone(), arena.buf[0, :, :, :, :S + len(ids) + 1].clone(), o2.logits.clone())
+    assert torch.isfinite(out[True][0]).all()
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
+    assert torch.equal(out[True][1].view(torch.int16), out[False][1].view(torch.int16))
+
+
+def test_looking_at_the_returned_views_carries_the_staging_out():
+    from promptcache_amd import Prompt
+    lm, eng, prompt_pml = _engine(True)
+    lm2, eng2, _ = _engine(False)
+    prompt = Prompt(prompt_pml, [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    ids2, pos2, _, cache2 = eng2.process(prompt)
+    arena = eng.prompt_cache.arena
+    assert arena.pending is not None
+    k0 = cache[0][0]                                              # indexing = looking
+    assert arena.pending is None
+    assert torch.equal(k0.view(torch.int16), cache2[0][0].view(torch.int16))
+    # the reference's calling convention: device tensors, the cache rebuilt as a plain list (generation_engine.py:96-102)
+    o = lm(input_ids=torch.tensor([ids], device=DEV), position_ids=torch.tensor([pos], device=DEV),
+           past_key_values=[(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache], use_cache=True)
+    o2 = lm2(input_ids=torch.tensor([ids2], device=DEV), position_ids=torch.tensor([pos2], device=DEV),
+             past_key_values=[(k.unsqueeze(0), v.unsqueeze(0)) for k, v in cache2], use_cache=True)
+    assert lm.hf_model.stats["fused_gather"] == 0
+    assert torch.equal(o.logits, o2.logits)
+
+
+def test_a_second_prompt_keeps_the_common_prefix_and_stages_the_rest():
+    """Two prompts over one schema back to back: the segments both stage at the same place are kept (flagged STAGED in the row
+    table: read in place, not rewritten), the rest arrives with the second prompt's first forward."""
+    from promptcache_amd import Prompt, synth
+    res = {}
+    for defer in (False, True):
+        lm, eng, prompt_pml = _engine(defer)
+        fmt = lm.get_formatter()
+        _, prompt_b = synth.persona_like(system_len=120, seed=3, pick=(0, 0, 3, 0, 1, 2))      # other members of four unions
+        logits = []
+        for pml in (prompt_pml, prompt_b, prompt_pml):
+            ids, pos, _, cache = eng.process(Prompt(pml, [fmt]))
+            o = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+            logits.append(o.logits.clone())
+        S = len(eng.prompt_cache)
+        res[defer] = (logits, eng.prompt_cache.arena.buf[0, :, :, :, :S].clone())
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][1].view(torch.int16), res[False][1].view(torch.int16))
+
+
+def test_generate_through_the_deferred_staging_matches_the_copy_first_engine():
+    from promptcache_amd import GenerationEngine, GenerationParameters, Prompt
+    texts = {}
+    for defer in (False, True):
+        lm, eng, prompt_pml = _engine(defer)
+        ids, pos, _, cache = eng.process(Prompt(prompt_pml, [lm.get_formatter()]))
+        params = GenerationParameters(temperature=0.0, max_new_tokens=12, stop_token_ids=[], stop_str=[])
+        outs = list(GenerationEngine(lm).generate(ids, pos, params, cache, stream_interval=1))
+        texts[defer] = outs[-1].new_text
+        assert lm.hf_model.stats["fused_gather"] == (1 if defer else 0)
+    assert texts[True] == texts[False] and len(texts[True]) > 0

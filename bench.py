@@ -692,6 +692,7 @@ def main():
         e0.record()
         out = lm(input_ids=ids_t, position_ids=pos_t, past_key_values=cache, use_cache=True)
         e1.record()
+        torch.cuda.synchronize()      # TTFT ends when the logits are there: the next request's assembly must not hide under this one's forward
         if record:
             if pc.last_gather_events is not None:
                 gather_evs.append(pc.last_gather_events)

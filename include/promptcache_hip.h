@@ -472,6 +472,14 @@ int pc_gemm_dense_a8(const void* xq, int64_t ldx, const void* w_codes, int64_t l
                      const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                      float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream);
 
+/* pc_fetch_block -- replaces the per-call uploads `torch.tensor(ids, device=)` / `torch.tensor(position_ids, device=)` of
+ * generation_engine.py:96-97 (and :125-132 for every decode step): the FIRST node of a captured forward pulls the call's whole
+ * input block -- token ids, position ids, past length, staging plan -- out of one pinned (device-mapped) host buffer into device
+ * memory; per call the host writes that buffer and replays the graph, nothing else.  host_src: pinned host memory (8-byte
+ * aligned, read with system-scope loads); nbytes: multiple of 8, <= 1 MiB.  The host must not rewrite the buffer before the
+ * replay that reads it has finished. */
+int pc_fetch_block(const void* host_src, void* dst, int32_t nbytes, void* stream);
+
 /* Greedy decode without a host round trip per token (generation_engine.py:123-168, greedy branch :159): the tail of a
  * captured decode step.  token = argmax(logits[0..vocab)) (lowest index among equal maxima); ids[0] = token, pos[0] += 1,
  * past_len[0] += 1 -- the device words the NEXT replay of the same hipGraph reads its token id, position id and past

@@ -836,6 +836,11 @@ __device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, i
 // count in vmcnt with the loads, and a store in front of the V wait would put its write acknowledgement on the critical path.
 // (The launch is sized to ONE workgroup per CU -- small_nstream -- so the staging variant, which keeps the K fragments alive until
 // they are stored, takes the registers of a one-wave-per-SIMD kernel instead of spilling at 256.)
+#ifdef PC_GATHER_STORE_PLAIN
+#define PC_GATHER_ST(v, p) (*(p) = (v))
+#else
+#define PC_GATHER_ST(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 template <int D, bool ALIBI, int NS, bool GATHER = false>
 __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(const AttnParams p) {
     constexpr bool FUSE = NS > 0;
@@ -932,7 +937,13 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
                 const char* src = (const char*)(uintptr_t)(ka & ~(uint64_t)15);
                 kflag[kb] = (uint32_t)ka & PC_KV_ROW_STAGED;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kr[kb][ks] = *(const u32x4*)(src + (ks * 32 + g * 8) * 2);
+                for (int ks = 0; ks < KS; ++ks) {
+#ifndef PC_GATHER_LOAD_PLAIN
+                    kr[kb][ks] = __builtin_nontemporal_load((const u32x4*)(src + (ks * 32 + g * 8) * 2));
+#else
+                    kr[kb][ks] = *(const u32x4*)(src + (ks * 32 + g * 8) * 2);
+#endif
+                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kr[kb][ks] = *(const u32x4*)(kbase + (int64_t)key * D + ks * 32 + g * 8);
@@ -949,7 +960,11 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
             const int rr = key0 + row < k1 ? key0 + row : k1 - 1;
             if constexpr (GATHER) {
                 const char* src = (const char*)(uintptr_t)((const uint64_t*)(etab + (rr - key0)))[1];
+#ifndef PC_GATHER_LOAD_PLAIN
+                glds16_nt((const _Float16*)(src + col * 16), Vwb + i * 1024);
+#else
                 glds16((const _Float16*)(src + col * 16), Vwb + i * 1024);
+#endif
             } else {
                 glds16(vbase + (int64_t)rr * D + col * 8, Vwb + i * 1024);
             }
@@ -1028,7 +1043,7 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
                     if (key < k1 && !(kflag[kb] & PC_KV_ROW_STAGED)) {
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
-                            __builtin_nontemporal_store(kr[kb][ks], (u32x4*)(kdst + (int64_t)key * D + ks * 32 + g * 8));
+                            PC_GATHER_ST(kr[kb][ks], (u32x4*)(kdst + (int64_t)key * D + ks * 32 + g * 8));
                     }
                 }
 #pragma unroll
@@ -1038,7 +1053,7 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
                     const u32x4 chunk = *(const u32x4*)(Vwb + i * 1024 + lane * 16);
                     const uint32_t fl = (key0 + row < k1) ? ((const uint32_t*)(etab + row))[0] : PC_KV_ROW_STAGED;
                     if (!(fl & PC_KV_ROW_STAGED))
-                        __builtin_nontemporal_store(chunk, (u32x4*)(vdst + (int64_t)(key0 + row) * D + col * 8));
+                        PC_GATHER_ST(chunk, (u32x4*)(vdst + (int64_t)(key0 + row) * D + col * 8));
                 }
             }
         }

@@ -92,6 +92,12 @@ __device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void glds16_nt(const _Float16* g, char* lds_wave_base) {
+    // the same with the non-temporal cache policy (aux = 2): rows that are read exactly once by exactly one CU
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 // the many-row ring kernel (pc_attn_ring.hip): 128 query rows per workgroup, K / V tiles by LDS-DMA
 bool ring_eligible(const AttnParams& p, int D);
 int ring_nsplit(int B, int H, int q_len, int kv_len);

@@ -406,6 +406,28 @@ PC_EXPORT int pc_embed_gather(const void* table, const int64_t* ids, void* out, 
     return pc_check_launch("embed_gather_kernel");
 }
 
+// pc_fetch_block: the per-call inputs of a captured forward (token ids, position ids, past length, staging plan) come out of
+// ONE pinned host block that the graph's first node pulls into device memory itself -- the host only writes the block and
+// replays the graph; no copy is enqueued per call (the reference uploads ids and positions with two pageable copies per call,
+// generation_engine.py:96-97).  System-scope loads: the block is rewritten by the host between replays and must never be
+// served from a device cache.
+__global__ __launch_bounds__(256) void fetch_block_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+                                                          int n8) {
+    typedef __attribute__((address_space(1))) unsigned long long g64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x)
+        dst[i] = __hip_atomic_load((g64*)(src + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+PC_EXPORT int pc_fetch_block(const void* host_src, void* dst, int32_t nbytes, void* stream) {
+    PC_REQUIRE(host_src && dst && nbytes > 0 && nbytes % 8 == 0 && nbytes <= (1 << 20), PC_ERR_ARG,
+               "pc_fetch_block: need non-null pointers and 8 | nbytes <= 1 MiB");
+    PC_REQUIRE((((uintptr_t)host_src | (uintptr_t)dst) & 7) == 0, PC_ERR_ARG, "pc_fetch_block: pointers must be 8-byte aligned");
+    const int n8 = nbytes / 8;
+    hipLaunchKernelGGL(fetch_block_kernel, dim3(pc_ceil_div(n8, 1024) < 8 ? pc_ceil_div(n8, 1024) : 8), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)host_src, (unsigned long long*)dst, n8);
+    return pc_check_launch("fetch_block_kernel");
+}
+
 PC_EXPORT int pc_probe_layouts(float* out_mfma, float* out_tr, void* stream) {
     PC_REQUIRE(out_mfma && out_tr, PC_ERR_ARG, "pc_probe_layouts: null pointer");
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_mfma, out_tr);

@@ -111,6 +111,7 @@ SIGNATURES = {
     "pc_silu_mul": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
+    "pc_fetch_block": (C.c_int, [_vp, _vp, _i32, _vp]),
     "pc_rope_append_var": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
@@ -500,6 +501,12 @@ def embed_gather(table, ids_i64, out, n_tok: int, hidden: int, vocab: int, strea
     rc = load().pc_embed_gather(table.data_ptr(), ids_i64.data_ptr(), out.data_ptr(), n_tok, hidden, vocab,
                                 current_stream() if stream is None else stream)
     check(rc, "pc_embed_gather")
+
+
+def fetch_block(host_pinned, dst, nbytes: int, stream: Optional[int] = None) -> None:
+    """Graph node: pull ``nbytes`` of a pinned host tensor into the device tensor ``dst`` (``pc_fetch_block``)."""
+    rc = load().pc_fetch_block(host_pinned.data_ptr(), dst.data_ptr(), nbytes, current_stream() if stream is None else stream)
+    check(rc, "pc_fetch_block")
 
 
 def probe_layouts(out_mfma, out_tr, stream: Optional[int] = None) -> None:

@@ -19,6 +19,7 @@ from __future__ import annotations
 import gc
 import os
 import itertools
+import time
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -678,9 +679,14 @@ class CacheEngine:
         Request assembly follows the reference step by step (:411-474): explicit-stack DFS over
         (module reference, schema module) pairs, arguments fill the first positions of their
         parameter, trailing text continues after the schema."""
-        start = torch.cuda.Event(enable_timing=True)
-        end = torch.cuda.Event(enable_timing=True)
-        start.record()
+        # cache_time: the reference brackets request assembly + PromptCache.update with device events (:391-394, :507-509).
+        # When the staging is left to the first forward there is no device work in here to bracket: host wall-clock then.
+        host_timed = self.prompt_cache.defer_gather and not no_cache
+        t_host = time.perf_counter()
+        if not host_timed:
+            start = torch.cuda.Event(enable_timing=True)
+            end = torch.cuda.Event(enable_timing=True)
+            start.record()
 
         if prompt.schema not in self.schemas:
             raise ValueError(f"There is no such layout named {prompt.schema} in the cache")
@@ -740,9 +746,14 @@ class CacheEngine:
             seq_caches.append(sc)
         self.prompt_cache.update(seq_caches)
         cache = self.prompt_cache.cache
-        end.record()
-        torch.cuda.synchronize()
-        cache_time = start.elapsed_time(end)
+        if host_timed:
+            if self.prompt_cache.arena.pending is None:      # update() launched the copy after all (host-tier segments)
+                torch.cuda.synchronize()
+            cache_time = (time.perf_counter() - t_host) * 1e3
+        else:
+            end.record()
+            torch.cuda.synchronize()
+            cache_time = start.elapsed_time(end)
         if type(self.lm).read_k_hook is not LanguageModel.read_k_hook or type(self.lm).read_v_hook is not LanguageModel.read_v_hook:
             for i in range(len(cache)):          # (looking at the views carries out a deferred staging first; identity hooks do not)
                 cache[i] = (self.lm.read_k_hook(cache[i][0]), self.lm.read_v_hook(cache[i][1]))

@@ -140,37 +140,52 @@ class KVArena:
 
 class StagedKV(list):
     """``past_key_values`` as the reference's callers index it (``[layer][0|1]``), plus the arena it
-    aliases so the model can append in place.  Entries are ``[B, Hkv, length, D]`` views."""
+    aliases so the model can append in place.  Entries are ``[B, Hkv, length, D]`` views (``[Hkv, length, D]`` for the
+    unbatched form ``CacheEngine.process`` returns).
 
-    def __init__(self, arena: KVArena, length: int):
-        super().__init__((arena.buf[:, i, 0, :, :length], arena.buf[:, i, 1, :, :length]) for i in range(arena.L))
+    The 2 x n_layers views are built when somebody first LOOKS at them -- indexing, iterating, assigning -- which is what a
+    caller that inspects or rebuilds the list does (the reference's GenerationEngine, generation_engine.py:101-102); at that
+    moment a staging the arena still owes (``KVArena.pending``) is carried out too.  Handing the object itself to the model
+    does neither: the model finds the arena through ``.arena`` and may stage inside its first attention launches -- and the
+    engines' own hot path never pays for 64 tensor views per call."""
+
+    def __init__(self, arena: KVArena, length: int, batched: bool = True):
+        super().__init__()
         self.arena = arena
         self.length = length
+        self._batched = batched
+        self._built = False
 
-    # A staging that is still pending (KVArena.pending) is carried out the moment anybody LOOKS at the views -- indexing or
-    # iterating, which is what a caller that inspects or rebuilds the list does (the reference's GenerationEngine,
-    # generation_engine.py:101-102).  Handing the object itself to the model does not: the model finds the arena through
-    # ``.arena`` and may stage inside its first attention launches instead.
-    def _ensure_staged(self) -> None:
-        a = getattr(self, "arena", None)
-        if a is not None and a.pending is not None:
+    def _look(self) -> None:
+        a = self.arena
+        if a.pending is not None:
             a.materialize()
+        if not self._built:
+            self._built = True
+            n, buf = self.length, a.buf
+            if self._batched:
+                list.extend(self, ((buf[:, i, 0, :, :n], buf[:, i, 1, :, :n]) for i in range(a.L)))
+            else:
+                list.extend(self, ((buf[0, i, 0, :, :n], buf[0, i, 1, :, :n]) for i in range(a.L)))
+
+    def __len__(self):
+        return self.arena.L
 
     def __getitem__(self, i):
-        self._ensure_staged()
+        self._look()
         return list.__getitem__(self, i)
 
+    def __setitem__(self, i, v):
+        self._look()
+        list.__setitem__(self, i, v)
+
     def __iter__(self):
-        self._ensure_staged()
+        self._look()
         return list.__iter__(self)
 
-    def unbatched(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    def unbatched(self) -> "StagedKV":
         """``[Hkv, length, D]`` views: what ``CacheEngine.process`` returns (``cache_engine.py:161-165``)."""
-        out = StagedKV.__new__(StagedKV)
-        list.__init__(out, ((k[0], v[0]) for k, v in list.__iter__(self)))
-        out.arena = self.arena
-        out.length = self.length
-        return out
+        return StagedKV(self.arena, self.length, batched=False)
 
 
 def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Optional[Tuple[KVArena, int]]:

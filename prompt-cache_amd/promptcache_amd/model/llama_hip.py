@@ -41,15 +41,14 @@ _SEG_DTYPE = np.dtype([("src", "<u8"), ("dst_row", "<i4"), ("len", "<i4")])     
 
 
 class _InputBlock:
-    """Everything a captured small-q forward reads per call, in ONE device allocation filled by ONE host-to-device copy:
+    """Everything a captured small-q forward reads per call, in ONE pinned host block that the graph's first node
+    (``pc_fetch_block``) pulls into its device twin:
 
         ids   int64 [T] | pos int32 [T] | words int32 [8] = {past_len, residual-tail base, live rows, segments, rows of the row
         table, -, -, -} | pc_kv_seg [max_seg]  (the staging plan, when the forward stages while it reads)
 
-    The host side is a small ring of pinned mirrors of the same layout (numpy views): a call fills the next mirror and enqueues
-    one asynchronous copy; a mirror is reused only after its copy has run (event)."""
-
-    SLOTS = 4
+    Per call the host writes the block (numpy views) and replays the graph: no copy is enqueued, no fill kernel launched.  The
+    block may be rewritten once the replay that read it has finished (``acquire`` waits for the event ``release`` records)."""
 
     def __init__(self, device, T: int, max_seg: int):
         self.T, self.max_seg = T, max_seg
@@ -62,31 +61,27 @@ class _InputBlock:
         self.pos = self.dev[self.o_pos:self.o_pos + 4 * T].view(torch.int32)
         self.words = self.dev[self.o_words:self.o_words + 32].view(torch.int32)
         self.segs = self.dev[self.o_segs:]
-        self._host = [torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS)]
-        self._np = []
-        for h in self._host:
-            a = h.numpy()
-            self._np.append((a[:8 * T].view(np.int64), a[self.o_pos:self.o_pos + 4 * T].view(np.int32),
-                             a[self.o_words:self.o_words + 32].view(np.int32),
-                             a[self.o_segs:].view(_SEG_DTYPE) if max_seg else None))
-        self._ev = [None] * self.SLOTS
-        self._i = 0
+        self.host = torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True)
+        a = self.host.numpy()
+        self.h_ids = a[:8 * T].view(np.int64)
+        self.h_pos = a[self.o_pos:self.o_pos + 4 * T].view(np.int32)
+        self.h_words = a[self.o_words:self.o_words + 32].view(np.int32)
+        self.h_segs = a[self.o_segs:].view(_SEG_DTYPE) if max_seg else None
+        self._done = torch.cuda.Event()
+        self._busy = False
 
-    def mirror(self):
-        """-> (slot, ids, pos, words, segs) numpy views of the next free pinned mirror."""
-        i = self._i
-        self._i = (i + 1) % self.SLOTS
-        if self._ev[i] is not None:
-            self._ev[i].synchronize()
-        return (i,) + self._np[i]
+    def acquire(self) -> None:
+        if self._busy:
+            self._done.synchronize()
+            self._busy = False
 
-    def upload(self, slot: int, from_byte: int = 0, to_byte: Optional[int] = None) -> None:
-        end = self.nbytes if to_byte is None else to_byte
-        self.dev[from_byte:end].copy_(self._host[slot][from_byte:end], non_blocking=True)
-        ev = self._ev[slot]
-        if ev is None:
-            ev = self._ev[slot] = torch.cuda.Event()
-        ev.record()
+    def fetch(self) -> None:
+        """(graph node) host block -> device block"""
+        _native.fetch_block(self.host, self.dev, self.nbytes)
+
+    def release(self) -> None:
+        self._done.record()
+        self._busy = True
 
 
 def lw0_fp16(layers) -> bool:
@@ -259,6 +254,7 @@ class LlamaHIP:
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
         self._gather = None         # set per forward: the row table while the attention launches stage as they read
         self.stats = {"fused_gather": 0}     # forwards that carried out a pending staging inside their attention launches
+        self._gather_ok_cache, self._nsplit_cache = {}, {}
 
     # the many-row layer loop of THIS class hands the attention a shared key prefix (__call__'s ``shared_prefix``); a subclass
     # with its own loop says so itself
@@ -941,22 +937,37 @@ class LlamaHIP:
 
     def _gather_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
         """Will the attention launches of this (bucketed) forward run on the kernel that stages while it reads?  Asked of the
-        library itself (pc_attn_gather_ok) with the arguments _forward_skinny passes."""
+        library itself (pc_attn_gather_ok) with the arguments _forward_skinny passes; the answer only depends on the row count,
+        the residual mode and whether the key range reaches the streaming kernel's minimum, so it is remembered."""
         plan = arena.pending
         if plan is None or not self.supports_fused_gather or self.llm_int8 or B != 1 or plan.total != past_len or \
                 len(plan.segs) > self.GATHER_MAX_SEG or self.use_chain:
             return False
-        buf = arena.buf
-        kvlo = (arena.tail_planes(0) + (-1,)) if self._lo_mode == 1 else None
-        H, D = self.H, self.D
-        return _native.attn_gather_ok(buf, q_len * H * D, H * D, arena.k_plane(0), arena.v_plane(0), arena.batch_stride,
-                                      arena.head_stride, None, 0, 0, B, H, self.Hkv, D, q_len, past_len, self.softmax_scale,
-                                      None, past_len_dev=buf, out_frag=(buf, buf), q_lo=buf, kv_lo=kvlo,
-                                      counters=self._counters_for(B, H))
+        ck = (q_len, self._lo_mode, past_len + q_len >= 256, self._attn_counters is None)
+        ok = self._gather_ok_cache.get(ck)
+        if ok is None:
+            buf = arena.buf
+            kvlo = (arena.tail_planes(0) + (-1,)) if self._lo_mode == 1 else None
+            H, D = self.H, self.D
+            ok = _native.attn_gather_ok(buf, q_len * H * D, H * D, arena.k_plane(0), arena.v_plane(0), arena.batch_stride,
+                                        arena.head_stride, None, 0, 0, B, H, self.Hkv, D, q_len, past_len, self.softmax_scale,
+                                        None, past_len_dev=buf, out_frag=(buf, buf), q_lo=buf, kv_lo=kvlo,
+                                        counters=self._counters_for(B, H))
+            self._gather_ok_cache[ck] = ok
+        return ok
+
+    def _nsplit_key(self, B: int, q_len: int, kv_len: int) -> int:
+        k = (B, q_len, kv_len)
+        v = self._nsplit_cache.get(k)
+        if v is None:
+            if len(self._nsplit_cache) > 4096:
+                self._nsplit_cache.clear()
+            v = self._nsplit_cache[k] = _native.attn_workspace_bytes(B, self.H, self.D, q_len, kv_len)   # monotone in the split count
+        return v
 
     def _graphed_skinny(self, ids, pos, arena, B, q_len, past_len, last_token_only, num_layers):
         """Replay (capturing on first use) the hipGraph of the small-q forward for this shape.  ``ids`` / ``pos``: flat integer
-        tensors, on the host (one pinned copy carries them with the call's other words) or on the device."""
+        tensors; host tensors are the fast path (device tensors -- the reference's calling convention -- are read back first)."""
         n = _native
         q_real = q_len
         q_len = self._graph_rows(arena, B, q_len, past_len, last_token_only)
@@ -966,10 +977,10 @@ class LlamaHIP:
         plan = arena.pending if gather else None
         if not gather:
             arena.materialize()
-        nsplit_key = n.attn_workspace_bytes(B, self.H, self.D, q_len, past_len + q_len)   # monotone in the split count
         mode = self._lo_mode
-        key = (B, q_len, arena.buf.data_ptr(), arena.cap, nsplit_key, bool(last_token_only), num_layers, self.fuse_norm, self.use_chain,
-               mode, arena.tail_lo.data_ptr() if mode else 0, arena.tail_lo.shape[4] if mode else 0, gather)
+        tail = arena.tail_lo if mode else None
+        key = (B, q_len, arena.buf.data_ptr(), arena.cap, self._nsplit_key(B, q_len, past_len + q_len), bool(last_token_only), num_layers,
+               self.fuse_norm, self.use_chain, mode, tail.data_ptr() if mode else 0, tail.shape[4] if mode else 0, gather)
         ent = self._graphs.pop(key, None)
         T = B * q_len
         fresh = ent is None
@@ -979,44 +990,37 @@ class LlamaHIP:
             ent = [None, _InputBlock(self.device, T, self.GATHER_MAX_SEG if gather else 0), None]
         self._graphs[key] = ent                              # LRU: a hit moves the entry to the young end
         blk = ent[1]
-        # ---- this call's inputs: one pinned mirror, one copy ----
-        slot, h_ids, h_pos, h_words, h_segs = blk.mirror()
+        # ---- this call's inputs: written into the pinned block the graph's first node fetches ----
+        blk.acquire()
         n_real = q_real * B
-        host_ids = not ids.is_cuda and not pos.is_cuda
-        if host_ids:
-            h_ids[:n_real] = ids.numpy()
-            h_pos[:n_real] = pos.numpy()
-            if q_len != q_real:                              # pad rows BEHIND the prompt's own (see _graph_rows)
-                h_ids[n_real:] = 0
-                h_pos[n_real:] = int(h_pos[n_real - 1]) + np.arange(1, T - n_real + 1, dtype=np.int32)
-        h_words[0] = past_len
-        h_words[1] = arena.tail_base if mode == 2 else 0
-        h_words[2] = n_real                                  # rows that carry tokens: the projections do not load the pad rows' activations
-        h_words[3] = len(plan.segs) if gather else 0
-        h_words[4] = min(past_len + q_len, arena.cap)        # rows of the row table (this pass's own rows: entries that point at the arena)
+        if ids.is_cuda or pos.is_cuda:
+            ids, pos = ids.cpu(), pos.cpu()
+        blk.h_ids[:n_real] = ids.numpy()
+        blk.h_pos[:n_real] = pos.numpy()
+        if q_len != q_real:                                  # pad rows BEHIND the prompt's own (see _graph_rows)
+            blk.h_ids[n_real:] = 0
+            blk.h_pos[n_real:] = int(blk.h_pos[n_real - 1]) + np.arange(1, T - n_real + 1, dtype=np.int32)
+        w = blk.h_words
+        w[0] = past_len
+        w[1] = arena.tail_base if mode == 2 else 0
+        w[2] = n_real                                        # rows that carry tokens: the projections do not load the pad rows' activations
+        w[4] = min(past_len + q_len, arena.cap)              # rows of the row table (this pass's own rows: entries that point at the arena)
         if gather:
-            h_segs[:len(plan.segs)] = plan.seg_array(_SEG_DTYPE)
-        if host_ids:
-            blk.upload(slot)
-        else:
-            blk.upload(slot, blk.o_words)
-            blk.ids[:n_real].copy_(ids)
-            blk.pos[:n_real].copy_(pos)
-            if q_len != q_real:
-                blk.ids[n_real:].fill_(0)
-                blk.pos[n_real:].copy_(pos[-1:].to(self.device) + torch.arange(1, T - n_real + 1, device=self.device, dtype=torch.int32))
-
-        def run():
-            if gather:
-                n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
-                               arena.row_table())
-                self._gather = arena.row_tab
-            try:
-                return self._forward_skinny(blk.ids, blk.pos, blk.words, arena, B, q_len, past_len, last_token_only, num_layers)
-            finally:
-                self._gather = None
+            w[3] = len(plan.segs)
+            blk.h_segs[:len(plan.segs)] = plan.seg_array(_SEG_DTYPE)
 
         if fresh:
+            def run():
+                blk.fetch()
+                if gather:
+                    n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
+                                   arena.row_table())
+                    self._gather = arena.row_tab
+                try:
+                    return self._forward_skinny(blk.ids, blk.pos, blk.words, arena, B, q_len, past_len, last_token_only, num_layers)
+                finally:
+                    self._gather = None
+
             # one eager pass first (loads code objects / sizes the allocator), then capture
             run()
             torch.cuda.synchronize()
@@ -1026,6 +1030,7 @@ class LlamaHIP:
             ent[0], ent[2] = g, out
         g, out = ent[0], ent[2]
         g.replay()
+        blk.release()
         if gather:
             arena.pending = None                             # the staged rows are in the arena now
             self.stats["fused_gather"] += 1

@@ -763,7 +763,12 @@ __device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, i
     __syncthreads();
     if (tid == 0) {
         gu32* c = (gu32*)(p.counters + b * p.H + h);
+        // (same hand-off contract as gemm_skinny_ks_kernel, pc_gemm_ks.hip: gfx9 vmcnt semantics; -DPC_FORMAL_HANDOFF = acq_rel)
+#ifdef PC_FORMAL_HANDOFF
+        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         const int last = (old + 1u == (uint32_t)p.nsplit) ? 1 : 0;
         if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last = last;
@@ -1294,7 +1299,7 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     if (q_len <= kTailMax) ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
     // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
     if (q_len <= kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;
-    if (D == 128 && q_len > 32) { const int nr = ring_nsplit(B, H, q_len, kv_len_max); ns = ns > nr ? ns : nr; }   // (pc_attn_ring.hip)
+    if (D == 128 && q_len >= ring_min_rows()) { const int nr = ring_nsplit(B, H, q_len, kv_len_max); ns = ns > nr ? ns : nr; }   // (pc_attn_ring.hip)
     if (ns <= 1) return 0;
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }

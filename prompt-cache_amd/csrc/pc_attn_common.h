@@ -100,6 +100,7 @@ __device__ __forceinline__ void glds16_nt(const _Float16* g, char* lds_wave_base
 
 // the many-row ring kernel (pc_attn_ring.hip): 128 query rows per workgroup, K / V tiles by LDS-DMA
 bool ring_eligible(const AttnParams& p, int D);
+int ring_min_rows();
 int ring_nsplit(int B, int H, int q_len, int kv_len);
 int launch_attn_ring(const AttnParams& p, int B, hipStream_t stream);
 

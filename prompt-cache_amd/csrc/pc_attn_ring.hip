@@ -601,11 +601,15 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
 
 // Launches the ring kernel takes: head_dim 128, split-precision Q (q_lo), more than 32 query rows, no ALiBi, not the tail /
 // small-q modes.  PC_ATTN_NO_RING=1: off (A/B against attn_fwd_kernel).
+// fewest query rows the ring kernel takes (PC_ATTN_RING_MIN; pc_attn_workspace_bytes sizes the split-KV workspace with the same number)
+int ring_min_rows() {
+    static const int min_rows = [] { const char* m = getenv("PC_ATTN_RING_MIN"); return m ? atoi(m) : 33; }();
+    return min_rows;
+}
 bool ring_eligible(const AttnParams& p, int D) {
     const char* e = getenv("PC_ATTN_NO_RING");            // (read per call: tests and probes switch it inside one process)
     const bool off = e && e[0] == '1';
-    static const int min_rows = [] { const char* m = getenv("PC_ATTN_RING_MIN"); return m ? atoi(m) : 33; }();
-    return !off && D == RD && p.q_lo && p.q_len >= min_rows && !p.key_pos && !p.tail && !p.small;
+    return !off && D == RD && p.q_lo && p.q_len >= ring_min_rows() && !p.key_pos && !p.tail && !p.small;
 }
 
 // KV splits of a ring launch: one workgroup per CU; minimise rounds x (stages per split + 1) + the merge

@@ -38,7 +38,11 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
     // rows of this workgroup: all of them, or block blockIdx.z of p.zrows rows (289..512 rows: two row blocks per column panel)
     const int row0 = p.zrows ? (int)blockIdx.z * p.zrows : 0;
     const int Mz = p.zrows ? ((p.M - row0 < p.zrows) ? p.M - row0 : p.zrows) : p.M;
-    const int RW = (Mz + 16 * MTW - 1) / (16 * MTW);
+    // compute waves: what the LAUNCH was sized for -- the rows of a full block.  (Counting them from this block's own Mz gave the
+    // shorter second block of a two-block launch one compute wave fewer than the host launched: a fourth wave then took the
+    // staging branch of a three-wave staging split and wrote fragment slot 24 of a 24-slot stage -- M = 321..336, 385..400,
+    // 449..464.)  A compute wave whose rows all lie behind Mz only keeps the barriers: nva <= 0, nothing stored.
+    const int RW = ((p.zrows ? p.zrows : p.M) + 16 * MTW - 1) / (16 * MTW);
     const int KS = p.KS;
     const int ksq = (KS + p.kslices - 1) / p.kslices;
     const int kq0 = blockIdx.y * ksq;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
         mt = mt < mt_last ? mt : mt_last;
         xa[a] = p.xf_hi + (((int64_t)((row0 >> 4) + mt) * KS + kq0) * 64 + lane) * 8;
     }
-    // row tiles this wave really owns (wave-uniform, >= 1): the MFMAs of the clamped duplicates behind the last tile are skipped
+    // row tiles this wave really owns (wave-uniform; <= 0 for a wave behind the block's last row): the MFMAs of the clamped duplicates behind the last tile are skipped
     const int nva = __builtin_amdgcn_readfirstlane((mt_last + 1 - MTW * wave) < MTW ? (mt_last + 1 - MTW * wave) : MTW);
     const int klast = kq1 - 1 - kq0;                     // last valid k-step, relative to kq0
     // k-step (relative to kq0) loaded for sequence position i; positions past the end repeat the last one

@@ -51,6 +51,7 @@ class TokenSequenceCache:
 
     def __init__(self, seq: TokenSequence, store: torch.Tensor):
         self.token_sequence = seq
+        self._n = len(seq)
         self.usage_counter = 0
         self.device_store: Optional[torch.Tensor] = store if store.is_cuda else None
         self.host_store: Optional[torch.Tensor] = None if store.is_cuda else self._pinned(store)
@@ -105,7 +106,7 @@ class TokenSequenceCache:
         return self._views(self.store)
 
     def __len__(self):
-        return len(self.token_sequence)
+        return self._n
 
 
 class PromptCache:

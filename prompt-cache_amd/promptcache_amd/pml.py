@@ -331,7 +331,12 @@ class Module(Element):
         return [t for c in self.children for t in c.position_ids()]
 
     def select(self, path: Union[str, Path]) -> Optional["Module"]:
-        path = Path(path) if isinstance(path, str) else path
+        if isinstance(path, str):
+            # (request assembly selects by plain module name once per referenced module, on the TTFT path: remembered)
+            memo = self.__dict__.setdefault("_select_memo", {})
+            if path not in memo:
+                memo[path] = self.select(Path(path))
+            return memo[path]
         if path.is_root:
             return self
         for m in self.modules():

@@ -25,23 +25,31 @@ def _lm(shape_name, layers, seed=0, **over):
     return Llama2(shape_name, shape=shape, device="cuda:0", random_init=True, seed=seed)
 
 
-def _cached_vs_nocache(lm, schema_pml, prompt_pml, max_ctx, max_tokens=None):
+def _cached_vs_nocache(lm, schema_pml, prompt_pml, max_ctx, max_tokens=None, defer=None):
+    """``defer``: True / False force where the module KV is staged (inside the first forward's attention launches / by
+    pc_kv_gather in process()); None = the engine's default for this model."""
     from promptcache_amd import CacheEngine, Prompt
     fmt = lm.get_formatter()
     eng = CacheEngine(max_ctx, lm)
+    if defer is not None:
+        eng.prompt_cache.defer_gather = defer
     eng.add_schema(fmt(schema_pml), max_tokens=max_tokens)
     prompt = Prompt(prompt_pml, [fmt])
     ids, pos, _, cache = eng.process(prompt)
-    S = cache[0][0].shape[1]
-    # full-size gather property: staged == concatenation of the staged module stores, bit-exact
+    S = len(eng.prompt_cache)
+    fused0 = lm.hf_model.stats["fused_gather"]
+    if eng.prompt_cache.arena.pending is not None:
+        eng.prompt_cache.arena.buf.fill_(float("nan"))      # nothing is staged yet: the forward must not read the arena's old bytes
+    out_c = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+    if defer is not None:
+        assert (lm.hf_model.stats["fused_gather"] - fused0 == 1) == (defer and len(ids) <= 16)
+    # full-size gather property: staged == concatenation of the staged module stores, bit-exact (whoever staged them)
     off = 0
     for m in eng.prompt_cache.staged:
         n = len(m)
         assert torch.equal(eng.prompt_cache.arena.buf[0, :, :, :, off:off + n], m.store)
         off += n
     assert off == S
-    out_c = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
-               past_key_values=cache, use_cache=True)
     nids, npos, _, _ = eng.process(prompt, no_cache=True)
     assert len(nids) == S + len(ids) and npos == list(range(len(nids)))
     out_n = lm(input_ids=torch.tensor([list(nids)], device="cuda"), position_ids=torch.tensor([npos], device="cuda"),
@@ -55,11 +63,12 @@ def _cached_vs_nocache(lm, schema_pml, prompt_pml, max_ctx, max_tokens=None):
     return S, q, err, kv_err
 
 
-def test_config2_game_schema_7b_shape_cached_equals_nocache():
+@pytest.mark.parametrize("defer", [True, False])
+def test_config2_game_schema_7b_shape_cached_equals_nocache(defer):
     from promptcache_amd import synth
     lm = _lm("llama2-7b", layers=3)
     sp, pp = synth.flat_docs("game", 30, (306, 76, 800, 800, 800, 800, 800), 12)
-    S, q, err, kv_err = _cached_vs_nocache(lm, sp, pp, max_ctx=5000)
+    S, q, err, kv_err = _cached_vs_nocache(lm, sp, pp, max_ctx=5000, defer=defer)
     print(f"[config2] S={S} q={q} max|dlogit| cached vs no-cache = {err:.2e}, staged-vs-recomputed K = {kv_err:.2e}")
     assert S > 4300 and q <= 16 and err < TOL and kv_err < 5e-3
 

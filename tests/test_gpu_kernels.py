@@ -652,7 +652,10 @@ def test_gemm_qkv_rope_fused_equals_unfused(B, H, Hkv, D, q_len, past, hid):
 
 @pytest.mark.parametrize("M,N,K,kq", [(65, 4096, 4096, 1), (100, 12288, 4096, 1), (259, 15360, 5120, 1), (512, 4096, 4096, 1),
                                       (130, 48, 32, 1), (70, 64, 96, 2), (259, 5120, 13824, 4), (200, 4096, 11008, 4),
-                                      (96, 32000, 4096, 1), (70, 32, 64, 4)])     # last: two of the four K slices are empty
+                                      (96, 32000, 4096, 1), (70, 32, 64, 4),      # (70, ..., 4): two of the four K slices are empty
+                                      # two row blocks whose SECOND block is a compute wave shorter than the first (21 / 25 / 29 row
+                                      # tiles: M = 321..336, 385..400, 449..464) -- the launch and the kernel must agree on the wave split
+                                      (330, 4096, 4096, 2), (450, 5120, 13824, 4), (336, 4096, 11008, 3), (390, 2048, 1024, 1)])
 def test_gemm_rows_store_add_slices(M, N, K, kq):
     n = _n()
     rng = np.random.default_rng(21)

@@ -227,7 +227,8 @@ def gemm_rooflines(lm, T: int):
             "launches_per_step": 2 * c.num_hidden_layers, "how": how}
         extra["roofline_qkv"] = {"kernel": "gemm_skinny_kernel<1,3,EPI_ROPE,NORM> (q|k|v + RMSNorm + RoPE + in-place KV append)",
                                  "bound": "hbm", "achieved": nb_q / (q_avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": nb_q / (q_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "frac": nb_q / (q_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": _pmc_traffic("gemm_skinny_qkv", sig)[0],
+                                 "traffic_source": _pmc_traffic("gemm_skinny_qkv", sig)[1],
                                  "algorithmic_bytes_per_launch": nb_q, "avg_launch_us": q_avg, "min_launch_us": q_min,
                                  "launches_timed": q_n, "launches_per_step": c.num_hidden_layers, "how": how}
     return gate_up, extra
@@ -444,8 +445,27 @@ def plan_only(args):
     from promptcache_amd.model.tokenizer import StandInTokenizer
     shape = SHAPES[args.model]
     tok = StandInTokenizer(shape.vocab_size)
-    lm = types.SimpleNamespace(hf_tokenizer=tok, unk_token_id=0, eos_token_id=2, encode=tok.encode,
-                               hf_model=types.SimpleNamespace(batch_invariant=True))
+    lm = types.SimpleNamespace(hf_tokenizer=tok, unk_token_id=0, eos_token_id=2, encode=tok.encode, use_full_position_ids=False,
+                               hf_model=types.SimpleNamespace(batch_invariant=True, supports_ragged_past=True, supports_shared_prefix=True))
+    # measured rows-per-forward -> seconds curve of the 1-GPU encode (tools/encode_rate_curve.py, committed under profiles/): a
+    # forward of a few hundred rows runs well below the large-M rate, so pricing every rank's rows at ONE rate over-predicts
+    curve = None
+    cpath = args.plan_curve or os.path.join(ROOT, "profiles", "r04_encode_rate_curve.json")
+    if os.path.exists(cpath):
+        with open(cpath) as f:
+            cj = json.load(f)
+        if cj.get("model") == args.model:
+            curve = sorted((int(p_["rows"]), float(p_["seconds"])) for p_ in cj["points"])
+
+    def fwd_seconds(rows: int) -> float:
+        """Piecewise-linear interpolation of the measured curve (through the origin below its first point, the last point's rate
+        beyond its end)."""
+        if rows <= curve[0][0]:
+            return curve[0][1] * max(rows, 1) / curve[0][0] if rows > curve[0][0] // 2 else curve[0][1] * 0.75
+        for (r0, t0), (r1, t1) in zip(curve, curve[1:]):
+            if rows <= r1:
+                return t0 + (t1 - t0) * (rows - r0) / (r1 - r0)
+        return curve[-1][1] * rows / curve[-1][0]
     fmt = _llama_formatter()
     texts = [synth.persona_like(name=f"lib-persona-{i}", system_len=200 + 40 * i, seed=20 + i)[0] for i in range(5)]
     texts += [synth.flat_docs(f"lib-docs-{i}", 30, lens, 8, seed=30 + i)[0]
@@ -469,19 +489,22 @@ def plan_only(args):
                          ("persona schema alone (the headline schema)", caches_of([synth.persona_like()[0]]))):
         items = [c.plan_items() for c in caches]
         scaffold_tokens = sum(len(j["token_ids"]) for c in caches for j in c._plan())
-        one = sum(t + sum(cs) for t, cs in items)
+        one = sum(c.plan_cost() for c in caches)
         rows = []
+        t_one_curve = None
         for world in (1, 2, 4, 8):
             order, shards = CacheEngine.library_schedule(caches, world)
-            loads, rx, rx_last = [0] * world, [0] * world, [0] * world
+            loads, rx, rx_last, t_curve = [0] * world, [0] * world, [0] * world, [0.0] * world
             for k in order:
-                trunk, costs = items[k]
+                trunk, costs, needs = items[k]
                 jobs = caches[k]._plan_with_prefix()[0]
                 own = [0] * world
                 for r in range(world):
                     mine = list(range(len(costs))) if world == 1 else shards[k][r]
                     if mine:
-                        loads[r] += trunk + sum(costs[i] for i in mine)
+                        loads[r] += (trunk if any(needs[i] for i in mine) else 0) + sum(costs[i] for i in mine)
+                        if curve:
+                            t_curve[r] += sum(fwd_seconds(f) for f in caches[k].plan_forwards(mine))
                     own[r] = sum(len(tc) for i in mine for tc in jobs[i]["owned"]) * kvb
                 for r in range(world):
                     rx[r] += sum(own) - own[r]
@@ -491,7 +514,14 @@ def plan_only(args):
             t_comp = max(loads) / row_rate
             links = max(world - 1, 1) * link
             t_rx_all, t_rx_last = max(rx) / links, max(rx_last) / links
-            rows.append({"ranks": world, "per_rank_computed_rows": loads, "compute_speedup": round(one / max(loads), 2),
+            extra = {}
+            if curve:
+                if world == 1:
+                    t_one_curve = t_curve[0]
+                extra = {"seconds_compute_by_measured_curve": round(max(t_curve), 4),
+                         "predicted_speedup_by_measured_curve": round(t_one_curve / (max(t_curve) + t_rx_last), 2),
+                         "predicted_speedup_by_measured_curve_exchange_exposed": round(t_one_curve / (max(t_curve) + t_rx_all), 2)}
+            rows.append({"ranks": world, "per_rank_computed_rows": loads, "compute_speedup": round(one / max(loads), 2), **extra,
                          "exchange_rx_bytes_per_rank_max": int(max(rx)),
                          "seconds_compute": round(t_comp, 4), "seconds_exchange_if_fully_exposed": round(t_rx_all, 4),
                          "seconds_exchange_last_schema": round(t_rx_last, 4),
@@ -499,6 +529,9 @@ def plan_only(args):
                          "predicted_speedup_exchange_exposed": round((one / row_rate) / (t_comp + t_rx_all), 2)})
         out["workloads"][name] = {"schemas": len(caches), "scaffold_tokens": scaffold_tokens, "computed_rows_one_rank": one,
                                   "by_ranks": rows}
+    out["measured_curve"] = None if not curve else {"file": os.path.relpath(cpath, ROOT), "points": len(curve),
+                                                     "what": "seconds of ONE encode forward (many_rows, kv_only) by its row count, 1 GPU; "
+                                                             "*_by_measured_curve price every forward of every rank on it instead of one rate"}
     out["note"] = ("compute_speedup = rows of a one-rank encode / rows of the most loaded rank (a rank that takes passes of a schema "
                    "re-runs its trunk); seconds_* price rows at the assumed scaffold-token rate (computed rows cost "
                    "scaffold_tokens / computed_rows of a scaffold token each) and the exchange at (ranks - 1) links of the "
@@ -528,6 +561,8 @@ def main():
                     help="CPU only: print the predicted 1/2/4/8-GPU schedule of the schema-library encode and exit")
     ap.add_argument("--plan-rate", type=float, default=72000.0, help="--plan-only: 1-GPU library encode rate, scaffold tokens/s")
     ap.add_argument("--plan-link-gbs", type=float, default=153.0, help="--plan-only: one xGMI link, GB/s per direction")
+    ap.add_argument("--plan-curve", default="", help="--plan-only: JSON of measured (rows per forward, seconds) points "
+                                                      "(default profiles/r04_encode_rate_curve.json when present)")
     args = ap.parse_args()
     if args.plan_only:
         plan_only(args)
@@ -614,7 +649,17 @@ def main():
         t[rank] = enc_per_rank[0]
         dist.all_reduce(t)
         enc_per_rank = [int(v) for v in t.tolist()]
-    encode = {"per_rank_computed_tokens": enc_per_rank,
+    exchange = None
+    if world > 1:
+        # the module-KV exchange of this schema, alone and blocking (seconds) next to what the encode did not hide of it (exposed)
+        t = torch.tensor([sc.reexchange_seconds(), float(sc.encode_stats.get("exchange_exposed_s", 0.0)),
+                          float(sc.encode_stats.get("exchange_bytes_rx", 0))], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange = {"seconds": float(t[0]), "exposed_seconds": float(t[1]), "bytes_received_per_rank_max": int(t[2]),
+                    "GBps_per_rank": float(t[2]) / max(float(t[0]), 1e-9) / 1e9,
+                    "what": "seconds: the grouped point-to-point exchange (parallel.exchange_slabs) run again alone, blocking, max over "
+                            "ranks; exposed_seconds: what the timed encode waited for it (a single schema has nothing to hide it under)"}
+    encode = {"per_rank_computed_tokens": enc_per_rank, "exchange": exchange,
               "roofline": {"bound": "mfma", "achieved": enc_flops_alg / t_enc / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                            "frac": enc_flops_alg / t_enc / 1e12 / 2500.0, "traffic": None,
                            "executed_TFLOPs": enc_flops / t_enc / 1e12, "executed_frac": enc_flops / t_enc / 1e12 / 2500.0,
@@ -665,7 +710,19 @@ def main():
             t[rank] = mine_comp
             dist.all_reduce(t)
             per_rank = [int(v) for v in t.tolist()]
-        library = {"per_rank_computed_tokens": per_rank,
+        lib_exchange = None
+        if world > 1:
+            t = torch.tensor([sum(eng.schemas[n].reexchange_seconds() for n in names),
+                              sum(float(eng.schemas[n].encode_stats.get("exchange_exposed_s", 0.0)) for n in names),
+                              float(sum(eng.schemas[n].encode_stats.get("exchange_bytes_rx", 0) for n in names))],
+                             device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lib_exchange = {"seconds": float(t[0]), "exposed_seconds": float(t[1]), "bytes_received_per_rank_max": int(t[2]),
+                            "GBps_per_rank": float(t[2]) / max(float(t[0]), 1e-9) / 1e9,
+                            "what": "seconds: every schema's exchange run again alone and blocking, summed, max over ranks; "
+                                    "exposed_seconds: what the (last) library encode actually waited for -- the exchange of schema k "
+                                    "runs under the encode of schema k + 1"}
+        library = {"per_rank_computed_tokens": per_rank, "exchange": lib_exchange,
                    "schemas": len(names), "passes": lib_passes, "tokens": int(lib_tokens), "cached_tokens": lib_cached,
                    "module_kv_bytes": int(lib_cached) * lm.hf_model.config.kv_bytes_per_token, "seconds": t_lib,
                    "seconds_runs": lib_runs,

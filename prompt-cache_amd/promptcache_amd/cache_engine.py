@@ -220,23 +220,87 @@ class SchemaCache:
             gc.collect()
 
     def wait_exchange(self) -> None:
+        """Wait for the module-KV exchange left in flight by an asynchronous encode.  ``encode_stats["exchange_exposed_s"]``
+        accumulates what the wait cost: host time blocked (gloo) or the time the compute stream stalled behind the collective
+        (RCCL: ``work.wait()`` is a stream wait, bracketed by events) -- the part of the exchange later encodes did NOT hide."""
+        if not self._pending:
+            return
+        on_gpu = torch.cuda.is_available() and torch.device(self.target_device).type == "cuda"
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
         for h in self._pending:
             h.wait()
+        host = time.perf_counter() - t0
         self._pending = []
+        stall = 0.0
+        if on_gpu:
+            e1.record()
+            e1.synchronize()
+            stall = e0.elapsed_time(e1) * 1e-3
+        self.encode_stats["exchange_exposed_s"] = self.encode_stats.get("exchange_exposed_s", 0.0) + max(host, stall)
+
+    def reexchange_seconds(self) -> float:
+        """Measurement only (bench.py --gpus N): run this schema's module-KV exchange AGAIN, alone and blocking -- every rank
+        sends the slab it encoded to every peer into scratch slabs -- and return its wall time on this rank.  Collective: every
+        rank must call it, in the same order.  0.0 for a schema that was encoded on one rank."""
+        ex = getattr(self, "_exchange", None)
+        rank, world = parallel.rank_world()
+        if ex is None or world <= 1:
+            return 0.0
+        self.wait_exchange()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        parallel.exchange_slabs(ex["slab"], ex["sizes"], rank, world, ex["slab"].device)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0
 
     def plan_cost(self) -> int:
         """Tokens this schema's encode runs through the model (suffixes behind the shared trunk prefix counted once, every
         pass cut behind its last owned token: exactly ``encode_stats["computed_tokens"]`` of a one-rank encode)."""
         return sum(self.pass_costs())
 
-    def plan_items(self) -> Tuple[int, List[int]]:
-        """``(trunk, costs)`` for ``parallel.plan_library``: rows every rank that takes a suffix pass of this schema runs first
-        (the root scaffold up to the longest shared prefix; 0 without trunk reuse) and the rows each pass then adds."""
+    def plan_items(self) -> Tuple[int, List[int], List[bool]]:
+        """``(trunk, costs, needs_trunk)`` for ``parallel.plan_library``: rows a rank runs first when it takes a pass that builds on
+        the trunk (the root scaffold up to the longest shared prefix; 0 without trunk reuse), the rows each pass then adds, and
+        which passes those are -- the root pass itself and every suffix pass; a scaffold encoded in full (prefix 0) runs without
+        the trunk, so a rank that holds only such passes is not charged for it."""
         jobs, prefix = self._plan_with_prefix()
         need = self._need(jobs, prefix)
         if any(prefix):
-            return need[0], [0] + [need[i] - prefix[i] for i in range(1, len(jobs))]
-        return 0, list(need)
+            return need[0], [0] + [need[i] - prefix[i] for i in range(1, len(jobs))], [True] + [p > 0 for p in prefix[1:]]
+        return 0, list(need), [False] * len(jobs)
+
+    def plan_forwards(self, mine: Optional[Sequence[int]] = None, batch_size: int = 1) -> List[int]:
+        """Rows (padding included) of every forward a rank runs for its share ``mine`` of this schema's passes (default: all),
+        in the order ``_process`` runs them: the trunk, the packed whole scaffolds, the packed suffix groups.  Host arithmetic
+        on the token layout (``bench.py --plan-only`` prices each forward on a measured rows -> seconds curve)."""
+        jobs, prefix = self._plan_with_prefix()
+        need = self._need(jobs, prefix)
+        mine = list(range(len(jobs))) if mine is None else list(mine)
+        shared = [i for i in mine if prefix[i] > 0]
+        whole = [i for i in mine if prefix[i] == 0]
+        out: List[int] = []
+        if shared:
+            out.append(need[0])
+            if 0 in whole:
+                whole.remove(0)
+        for idxs in self._pack(whole, need, batch_size):
+            out.append(len(idxs) * max(need[i] for i in idxs))
+        suffix_len = [need[i] - prefix[i] for i in range(len(jobs))]
+        if self._ragged_possible():
+            groups = self._pack(shared, suffix_len, batch_size)
+        else:
+            by_prefix: Dict[int, List[int]] = {}
+            for i in shared:
+                by_prefix.setdefault(prefix[i], []).append(i)
+            groups = [g for _, members in sorted(by_prefix.items()) for g in self._pack(members, suffix_len, batch_size)]
+        for idxs in groups:
+            out.append(len(idxs) * max(suffix_len[i] for i in idxs))
+        return out
 
     def pass_costs(self) -> List[int]:
         """Rows each pass of the plan runs through the model (job order of ``_plan_with_prefix``)."""
@@ -289,15 +353,27 @@ class SchemaCache:
                 if self.truncate_scaffolds:
                     n = min(n, self._owned_end(jobs[i]) - 1)
                 # never cut an owned segment in two: the prefix ends where a segment it runs into begins (its rows then
-                # come out of ONE arena when the suffix pass reads the trunk in place, see _process)
-                for tc in jobs[i]["owned"]:
-                    s0 = pos.index(tc.offset)
-                    if s0 < n < s0 + len(tc):
-                        n = s0
+                # come out of ONE arena when the suffix pass reads the trunk in place, see _process).  Only where that path
+                # exists: a model whose suffix batches carry a copy of the trunk keeps the longer prefix (less recompute).
+                if self._in_place_possible():
+                    for tc in jobs[i]["owned"]:
+                        s0 = pos.index(tc.offset)
+                        if s0 < n < s0 + len(tc):
+                            n = s0
                 if n >= self.share_trunk_min and n >= len(ids) // 5:
                     prefix[i] = n
         self._jobs = (jobs, prefix)
         return self._jobs
+
+    def _ragged_possible(self) -> bool:
+        hf = getattr(self.lm, "hf_model", None)
+        return bool(getattr(hf, "supports_ragged_past", False)) and not bool(getattr(self.lm, "use_full_position_ids", False)) and \
+            self.ragged_suffix_batches
+
+    def _in_place_possible(self) -> bool:
+        """Can the suffix batches of this model read the trunk's rows in place (pc_attn's shared prefix)?"""
+        return self._ragged_possible() and self.shared_prefix_in_place and \
+            bool(getattr(getattr(self.lm, "hf_model", None), "supports_shared_prefix", False))
 
     # ------------------------------------------------------------------------------------------
     def _plan(self):
@@ -426,15 +502,16 @@ class SchemaCache:
         # run in the MFMA-bound regime (members of a single union alone are a few hundred rows: ~65 % of that rate).
         # Otherwise (ALiBi: one position row per batch row) scaffolds sharing the same prefix length -- the members of
         # one union -- go through one batched forward.
-        ragged = bool(getattr(getattr(lm, "hf_model", None), "supports_ragged_past", False)) and not full_pos and \
-            self.ragged_suffix_batches
+        ragged = self._ragged_possible()
         suffix_len = [need[i] - prefix[i] for i in range(len(jobs))]
         row_bytes = L * 2 * Hkv * D * 2 * 2                  # K and V, fp16, + the residual planes of the encode arenas
         # Where the attention kernel takes a shared key prefix (``supports_shared_prefix``: the split-precision many-row
         # path) the suffix batch reads the trunk's rows IN PLACE, out of the trunk arena: its own arena holds the suffix
         # rows only.  Otherwise every batch row carries a copy of its prefix (11 GB of device copies per persona encode).
-        in_place = ragged and self.shared_prefix_in_place and trunk_arena is not None and trunk_arena.lo is not None and \
-            bool(getattr(getattr(lm, "hf_model", None), "supports_shared_prefix", False))
+        in_place = self._in_place_possible() and trunk_arena is not None and trunk_arena.lo is not None
+        if self._in_place_possible() and trunk_arena is not None and not in_place:
+            # (planned for in-place reading, served by copies: fine -- a prefix that ends on a segment boundary is valid for both)
+            pass
         if in_place:
             groups = [(None, idxs) for idxs in self._pack(shared, suffix_len, batch_size)]
         elif ragged:
@@ -499,8 +576,13 @@ class SchemaCache:
         if world > 1:
             # one exchange step: every GPU ends with the whole module library (slabs travel as they are: no padding to
             # the largest shard, no pack copy; see parallel.exchange_slabs)
+            t_x = time.perf_counter()
             views_by_rank, handles = parallel.exchange_slabs(my_slab, sizes_by_rank, rank, world, dev, async_op=async_exchange)
+            if not async_exchange and torch.device(dev).type == "cuda":
+                torch.cuda.synchronize()
+            blocking_s = 0.0 if async_exchange else time.perf_counter() - t_x      # a blocking exchange is exposed in full
             self._pending.extend(handles)
+            self._exchange = dict(slab=my_slab, sizes=sizes_by_rank, bytes_rx=parallel.exchange_bytes(sizes_by_rank)[rank])
             for r, idxs in enumerate(shards):
                 vit = iter(views_by_rank[r])
                 for i in idxs:
@@ -512,7 +594,9 @@ class SchemaCache:
                     self.cache_l1[id(tc)] = TokenSequenceCache(tc, store)
         self.encode_stats = dict(passes=len(mine), total_passes=len(jobs), encoded_tokens=encoded_tokens,
                                  computed_tokens=computed_tokens, trunk_shared_passes=len(shared), owner_rank=owner_rank,
-                                 cached_tokens=sum(len(c) for c in self.cache_l1.values()))
+                                 cached_tokens=sum(len(c) for c in self.cache_l1.values()),
+                                 exchange_bytes_rx=(self._exchange["bytes_rx"] if world > 1 else 0),
+                                 exchange_exposed_s=(blocking_s if world > 1 else 0.0))
         gc.collect()
 
     # tokens (padding included) one encode forward may carry when scaffolds are packed into a batch

@@ -143,14 +143,43 @@ class GenerationEngine:
         want_loop = params.greedy and params.repetition_penalty <= 1.0 and not use_full_position_ids and \
             hasattr(getattr(self.lm, "hf_model", None), "greedy_loop") and self.device_greedy_loop
 
-        for step in range(params.max_new_tokens):
-            if loop is not None:
-                if loop.n <= step and loop.n < params.max_new_tokens - 1:
-                    loop.enqueue()                             # the replay AFTER the one whose token is read below
-                token = loop.token(step - 1)
-                total_ms += loop.elapsed_ms(step - 1)
+        try:
+            for step in range(params.max_new_tokens):
+                if loop is not None:
+                    if loop.n <= step and loop.n < params.max_new_tokens - 1:
+                        loop.enqueue()                             # the replay AFTER the one whose token is read below
+                    token = loop.token(step - 1)
+                    total_ms += loop.elapsed_ms(step - 1)
+                    output_ids.append(token)
+                    new_ids.append(token)
+                    done = token in params.stop_token_ids
+                    if step % stream_interval == 0 or step == params.max_new_tokens - 1 or done:
+                        text, new_text, hit, partial = self._render(output_ids, new_ids, params.stop_str)
+                        done = done or hit
+                        if not partial:
+                            yield Output(text, new_text, total_ms, ttft_ms)
+                    if done:
+                        break
+                    continue
+                if step == 0:
+                    if cache is not None and not isinstance(cache, StagedKV):
+                        # a plain list of [Hkv, S, D] views: add the batch dim like the reference does (:101-102)
+                        cache = [(k.unsqueeze(0), v.unsqueeze(0)) if k.dim() == 3 else (k, v) for k, v in cache]
+                    logits, past, ms = self._forward(list(token_ids), prompt_positions, cache)
+                    ttft_ms = ms
+                    if self.verbose:
+                        print(f"Prefill latency: {ms:.2f} ms")
+                else:
+                    positions = (prompt_positions + list(range(first_free, first_free + step))) if use_full_position_ids \
+                        else [first_free + step]
+                    logits, past, ms = self._forward([new_ids[-1]], positions, past)
+                total_ms += ms
+
+                history = torch.as_tensor([output_ids], device=self.lm.device) if params.repetition_penalty > 1.0 else None
+                token = self._pick(processors(history, logits[:, -1, :])[0], params.greedy)
                 output_ids.append(token)
                 new_ids.append(token)
+
                 done = token in params.stop_token_ids
                 if step % stream_interval == 0 or step == params.max_new_tokens - 1 or done:
                     text, new_text, hit, partial = self._render(output_ids, new_ids, params.stop_str)
@@ -159,41 +188,15 @@ class GenerationEngine:
                         yield Output(text, new_text, total_ms, ttft_ms)
                 if done:
                     break
-                continue
-            if step == 0:
-                if cache is not None and not isinstance(cache, StagedKV):
-                    # a plain list of [Hkv, S, D] views: add the batch dim like the reference does (:101-102)
-                    cache = [(k.unsqueeze(0), v.unsqueeze(0)) if k.dim() == 3 else (k, v) for k, v in cache]
-                logits, past, ms = self._forward(list(token_ids), prompt_positions, cache)
-                ttft_ms = ms
-                if self.verbose:
-                    print(f"Prefill latency: {ms:.2f} ms")
-            else:
-                positions = (prompt_positions + list(range(first_free, first_free + step))) if use_full_position_ids \
-                    else [first_free + step]
-                logits, past, ms = self._forward([new_ids[-1]], positions, past)
-            total_ms += ms
-
-            history = torch.as_tensor([output_ids], device=self.lm.device) if params.repetition_penalty > 1.0 else None
-            token = self._pick(processors(history, logits[:, -1, :])[0], params.greedy)
-            output_ids.append(token)
-            new_ids.append(token)
-
-            done = token in params.stop_token_ids
-            if step % stream_interval == 0 or step == params.max_new_tokens - 1 or done:
-                text, new_text, hit, partial = self._render(output_ids, new_ids, params.stop_str)
-                done = done or hit
-                if not partial:
-                    yield Output(text, new_text, total_ms, ttft_ms)
-            if done:
-                break
-            if step == 0 and want_loop and params.max_new_tokens > 1:
-                # the first decoded token sits at position first_free + 1 (the reference's loop index starts at 1, :132)
-                loop = self.lm.hf_model.greedy_loop(past, token, first_free + 1, params.max_new_tokens)
-                if loop is not None:
-                    loop.enqueue()
-
-        if loop is not None:
-            loop.close(len(new_ids) - 1)                     # steps of the loop that produced a token (the first came from the prefill)
-        del past, loop
-        gc.collect()
+                if step == 0 and want_loop and params.max_new_tokens > 1:
+                    # the first decoded token sits at position first_free + 1 (the reference's loop index starts at 1, :132)
+                    loop = self.lm.hf_model.greedy_loop(past, token, first_free + 1, params.max_new_tokens)
+                    if loop is not None:
+                        loop.enqueue()
+        finally:
+            # also when the consumer abandons the generator at a yield (GeneratorExit): a look-ahead replay enqueued past the last
+            # token the caller saw wrote one arena row too many, and the model's loop state must be released
+            if loop is not None:
+                loop.close(len(new_ids) - 1)                 # steps of the loop that produced a token (the first came from the prefill)
+            del past, loop
+            gc.collect()

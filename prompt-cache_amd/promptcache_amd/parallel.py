@@ -44,19 +44,24 @@ def shard_jobs(costs: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
-def plan_library(items: Sequence[Tuple[int, Sequence[int]]], world: int) -> Tuple[List[List[List[int]]], List[int]]:
-    """Schedule a schema LIBRARY over ``world`` ranks.  ``items[k] = (trunk, costs)``: ``costs[i]`` = rows pass i of schema k runs
-    through the model on its own, ``trunk`` = rows every rank that takes ANY pass of schema k has to run first (the root
-    scaffold's prefix the suffix passes build on; 0 when the passes are independent).  Returns ``(shards, loads)``:
-    ``shards[k][r]`` = the passes of schema k rank r encodes (ascending), ``loads[r]`` = the rows rank r runs in total.
+def plan_library(items: Sequence[tuple], world: int) -> Tuple[List[List[List[int]]], List[int]]:
+    """Schedule a schema LIBRARY over ``world`` ranks.  ``items[k] = (trunk, costs[, needs_trunk])``: ``costs[i]`` = rows pass i of
+    schema k runs through the model on its own, ``trunk`` = rows a rank has to run first when it takes a pass that BUILDS ON the
+    trunk (the root scaffold's prefix the suffix passes read; 0 when the passes are independent), ``needs_trunk[i]`` = whether
+    pass i is such a pass (default: all of them; a scaffold encoded in full is not, and a rank that holds only those is not
+    charged).  Returns ``(shards, loads)``: ``shards[k][r]`` = the passes of schema k rank r encodes (ascending), ``loads[r]`` =
+    the rows rank r runs in total.
 
     Whole schemas first (longest-processing-time-first: every trunk computed once, on the rank that needs it), then the
     residual imbalance is levelled at PASS granularity: the schemas of the most loaded ranks are poured over the ranks below a
-    common water line, each rank that receives passes paying the schema's trunk once (recomputing a few hundred trunk rows
-    beats shipping ~1 MB per row of trunk K/V and its split-precision residuals behind the owner's encode).  The water line
-    is searched for the smallest makespan this greedy reaches; deterministic, identical on every rank."""
+    common water line, each rank that receives trunk-dependent passes paying the schema's trunk once (recomputing a few hundred
+    trunk rows beats shipping ~1 MB per row of trunk K/V and its split-precision residuals behind the owner's encode).  The
+    water line is searched for the smallest makespan this greedy reaches; deterministic, identical on every rank."""
     K = len(items)
-    total = [t + sum(c) for t, c in items]
+    trunks = [it[0] for it in items]
+    costs_of = [list(it[1]) for it in items]
+    needs = [list(it[2]) if len(it) > 2 else [True] * len(it[1]) for it in items]
+    total = [(trunks[k] if any(needs[k]) else 0) + sum(costs_of[k]) for k in range(K)]
 
     def lpt_whole():
         loads = [0] * world
@@ -70,8 +75,11 @@ def plan_library(items: Sequence[Tuple[int, Sequence[int]]], world: int) -> Tupl
     def as_shards(assign):
         return [[sorted(assign[k].get(r, [])) for r in range(world)] for k in range(K)]
 
+    def holds_trunk(k, passes):
+        return any(needs[k][i] for i in passes)
+
     owner, loads0 = lpt_whole()
-    best_assign = [{owner[k]: list(range(len(items[k][1])))} for k in range(K)]
+    best_assign = [{owner[k]: list(range(len(costs_of[k])))} for k in range(K)]
     best_loads = list(loads0)
     if world == 1 or K == 0:
         return as_shards(best_assign), best_loads
@@ -84,7 +92,7 @@ def plan_library(items: Sequence[Tuple[int, Sequence[int]]], world: int) -> Tupl
         assign: List[dict] = [dict() for _ in range(K)]
         poured = []
         for k in sorted(range(K), key=lambda k: (-total[k], k)):
-            trunk, costs = items[k]
+            costs = costs_of[k]
             r = min(range(world), key=lambda r: (loads[r], r))
             if loads[r] + total[k] <= line or len(costs) <= 1:
                 assign[k][r] = list(range(len(costs)))
@@ -92,33 +100,33 @@ def plan_library(items: Sequence[Tuple[int, Sequence[int]]], world: int) -> Tupl
             else:
                 poured.append(k)
         for k in poured:
-            trunk, costs = items[k]
+            trunk, costs = trunks[k], costs_of[k]
             rest = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
             while rest:
                 r = min(range(world), key=lambda r: (loads[r], r))
-                if r not in assign[k]:
-                    loads[r] += trunk                     # a rank pays the schema's trunk once
                 mine = assign[k].setdefault(r, [])
                 took = False
                 for i in list(rest):                      # largest passes that still fit under the line
-                    if loads[r] + costs[i] <= line or not took:
+                    extra = trunk if (needs[k][i] and not holds_trunk(k, mine)) else 0     # the first trunk-dependent pass brings the trunk
+                    if loads[r] + extra + costs[i] <= line or not took:
                         mine.append(i)
-                        loads[r] += costs[i]
+                        loads[r] += extra + costs[i]
                         rest.remove(i)
                         took = True
         # local improvement: passes move from the most loaded rank to the least loaded one while that lowers the makespan
-        for _ in range(4 * sum(len(c) for _, c in items)):
+        for _ in range(4 * sum(len(c) for c in costs_of)):
             hi = max(range(world), key=lambda r: (loads[r], -r))
             lo = min(range(world), key=lambda r: (loads[r], r))
             move = None
             for k in range(K):
                 mine = assign[k].get(hi)
-                if not mine or len(items[k][1]) <= 1:
+                if not mine or len(costs_of[k]) <= 1:
                     continue
-                trunk, costs = items[k]
-                join = 0 if assign[k].get(lo) else trunk                 # a new member recomputes the trunk
-                leave = trunk if len(mine) == 1 else 0                   # the last pass of hi takes its trunk share along
+                trunk, costs = trunks[k], costs_of[k]
+                theirs = assign[k].get(lo, [])
                 for i in mine:
+                    join = trunk if (needs[k][i] and not holds_trunk(k, theirs)) else 0          # lo starts running the trunk
+                    leave = trunk if (needs[k][i] and not holds_trunk(k, [j for j in mine if j != i])) else 0   # hi stops
                     new_hi, new_lo = loads[hi] - costs[i] - leave, loads[lo] + costs[i] + join
                     gain = loads[hi] - max(new_hi, new_lo)
                     if gain > 1e-9 and (move is None or gain > move[0]):

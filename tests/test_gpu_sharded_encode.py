@@ -21,15 +21,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
+    """``backend="nccl"`` (= RCCL on ROCm): one device per rank (``cuda:{rank}``), the exchange over xGMI; ``"gloo"``: both ranks
+    on cuda:0 (RCCL wants one device per rank), the exchange through the host."""
     import torch.distributed as dist
+    dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
     from promptcache_amd import CacheEngine, Prompt, synth
     from promptcache_amd.model import Llama2
     from promptcache_amd.model.config import SHAPES
     from promptcache_amd.model.weights import make_weights_np
     try:
         shape = SHAPES["mid"]
-        lm = Llama2(name="mid", shape=shape, weights=make_weights_np(shape, 11, 0.05), device="cuda:0")
+        lm = Llama2(name="mid", shape=shape, weights=make_weights_np(shape, 11, 0.05), device=dev)
         fmt = lm.get_formatter()
         sp, pp = synth.persona_like("shard", system_len=60, intro_len=20,
                                     traits=(("age", (30, 25, 34)), ("home", (40, 32, 37)), ("job", (25, 30, 21))),
@@ -54,7 +58,7 @@ def _worker(rank, world, port, q):
 
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         eng = CacheEngine(1024, lm)
         eng.add_schema(fmt(sp))                                    # world == 2: sharded passes + slab exchange
         lib2, st2 = library(eng)
@@ -70,8 +74,9 @@ def _worker(rank, world, port, q):
         eng.add_schemas(texts)
         mine = torch.tensor([[eng.schemas[nm].encode_stats["passes"], eng.schemas[nm].encode_stats["computed_tokens"]] for nm in names],
                             dtype=torch.int64)
-        both = mine.clone()
+        both = mine.clone().to(dev if backend == "nccl" else "cpu")
         dist.all_reduce(both)
+        both = both.cpu()
         for k, nm in enumerate(names):
             assert int(both[k, 0]) == eng.schemas[nm].encode_stats["total_passes"], (nm, both)
         rows = [int(mine[:, 1].sum()), int(both[:, 1].sum()) - int(mine[:, 1].sum())]
@@ -102,11 +107,22 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_sharded_encode_on_one_gpu():
+    _two_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL wants one device per rank: needs >= 2 visible GPUs")
+def test_two_rank_sharded_encode_over_rccl():
+    """The same end-to-end run on the ``nccl`` backend (RCCL over xGMI), one device per rank: the first execution of
+    ``parallel.exchange_slabs``' grouped send / recv on real links happens HERE, not in a benchmark."""
+    _two_ranks("nccl")
+
+
+def _two_ranks(backend):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -115,6 +131,6 @@ def test_two_rank_sharded_encode_on_one_gpu():
     for r in res:
         assert r[1] == "ok", r[2]
     passes = sorted(r[2] for r in res)
-    print(f"[sharded encode, 2 ranks on one GPU] passes per rank {passes}, max|dKV| vs solo {max(r[3] for r in res):.2e}, "
+    print(f"[sharded encode, 2 ranks, {backend}] passes per rank {passes}, max|dKV| vs solo {max(r[3] for r in res):.2e}, "
           f"max|dlogit| {max(r[4] for r in res):.2e}")
     assert all(r[0] in (0, 1) for r in res) and all(p.exitcode == 0 for p in procs)

@@ -132,18 +132,22 @@ def test_library_schedule_levels_the_bench_library_at_pass_granularity():
     from promptcache_amd.cache_engine import CacheEngine
     caches = _bench_library_caches()
     items = [c.plan_items() for c in caches]
-    one = sum(t + sum(cs) for t, cs in items)
+    one = sum((t if any(nd) else 0) + sum(cs) for t, cs, nd in items)
     assert one == sum(c.plan_cost() for c in caches)            # world 1: exactly the rows a one-rank encode runs
     want = {2: 1.9, 4: 3.7, 8: 7.0}
     for world, floor in want.items():
         order, shards = CacheEngine.library_schedule(caches, world)
         assert sorted(order) == list(range(len(caches)))
         loads = [0] * world
-        for k, (trunk, costs) in enumerate(items):
+        for k, (trunk, costs, needs) in enumerate(items):
             assert sorted(i for r in range(world) for i in shards[k][r]) == list(range(len(costs)))
             for r in range(world):
                 if shards[k][r]:
-                    loads[r] += trunk + sum(costs[i] for i in shards[k][r])
+                    # a rank runs the trunk only when one of its passes builds on it (the root pass or a suffix pass)
+                    loads[r] += (trunk if any(needs[i] for i in shards[k][r]) else 0) + sum(costs[i] for i in shards[k][r])
+                    # ... and the forwards it would run add up to at least those rows (padding on top)
+                    assert sum(caches[k].plan_forwards(shards[k][r])) >= (trunk if any(needs[i] for i in shards[k][r]) else 0) + \
+                        sum(costs[i] for i in shards[k][r])
         assert one / max(loads) >= floor, (world, loads)
         # single-encoder schemas are walked first: their exchanges overlap the shared schemas' encodes
         members = [sum(1 for sh in shards[k] if sh) for k in order]
@@ -164,3 +168,9 @@ def test_plan_library_edge_cases():
     assert max(loads) <= 1700 + 4 * 250 and sum(1 for ld in loads if ld) == 8
     sh1, loads1 = parallel.plan_library([(300, [0, 200, 210, 190])], 1)
     assert sh1 == [[[0, 1, 2, 3]]] and loads1 == [900]
+    # a rank that holds only scaffolds encoded in full (needs_trunk False) is not charged the trunk
+    sh, loads = parallel.plan_library([(1000, [0, 400, 400, 900, 900], [True, True, True, False, False])], 2)
+    for r in range(2):
+        exp = sum([0, 400, 400, 900, 900][i] for i in sh[0][r]) + (1000 if any(i <= 2 for i in sh[0][r]) else 0)
+        assert loads[r] == exp, (sh, loads)
+    assert max(loads) == 1800 and sorted(sh[0][0] + sh[0][1]) == [0, 1, 2, 3, 4]      # {trunk + both suffixes} | {the two whole scaffolds}

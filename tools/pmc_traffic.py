@@ -54,8 +54,24 @@ tab = {
                         "source": src + " (average of o_proj = gemm_skinny_kernel<1,1,EPI_ADD> and down_proj = gemm_skinny_ks_kernel)"},
     "gemm_skinny_gate_up": {"signature": "T=12,hid=4096,inter=11008", "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 3, 2"), "source": src},
 }
-a, c = pick("attn_small_kernel"), pick("attn_combine_kernel")
-tab["attn_cached"] = {"signature": "H=32,Hkv=32,D=128,q=12,S=1725", "hbm_bytes_per_launch": (a + c) if a and c else None,
-                      "source": src + " (attn_small_kernel + attn_combine_kernel)"}
+c = pick("attn_combine_kernel")
+# the timed step's attention since round 4: the staging variant (module K/V read once, staged rows written as they pass)
+a = pick("attn_small_kernel<128, false, 0, true>")
+tab["attn_staging"] = {"signature": "H=32,Hkv=32,D=128,q=12,S=1725", "hbm_bytes_per_launch": (a + c) if a and c else None,
+                       "source": src + " (attn_small_kernel<128, false, 0, true> = pc_attn gather_rows + attn_combine_kernel)"}
+a = pick("attn_small_kernel<128, false, 0, false>")          # (only present when the run includes steps that stage by pc_kv_gather)
+if a and c:
+    tab["attn_cached"] = {"signature": "H=32,Hkv=32,D=128,q=12,S=1725", "hbm_bytes_per_launch": a + c,
+                          "source": src + " (attn_small_kernel + attn_combine_kernel)"}
+tab["gemm_skinny_qkv"] = {"signature": "T=12,hid=4096,inter=11008", "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 3, 3"),
+                          "source": src + " (q|k|v + RMSNorm + RoPE + KV append)"}
+# keep entries of earlier rounds that this run did not re-measure (e.g. attn_cached: the copy-first step)
+try:
+    old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for k_, v_ in old.items():
+        if k_ not in tab or not tab[k_].get("hbm_bytes_per_launch"):
+            tab[k_] = v_
+except (OSError, ValueError):
+    pass
 json.dump(tab, open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(tab, indent=1))

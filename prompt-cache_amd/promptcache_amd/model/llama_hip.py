@@ -255,6 +255,10 @@ class LlamaHIP:
         self._gather = None         # set per forward: the row table while the attention launches stage as they read
         self.stats = {"fused_gather": 0}     # forwards that carried out a pending staging inside their attention launches
         self._gather_ok_cache, self._nsplit_cache = {}, {}
+        # hipGraphs for the 65..512-row forward as well (B = 1, 16-row buckets): nine launches per layer from Python are host-bound
+        # at 7b and ~100 rows (PC_GRAPH_MID=0: launched eagerly, as in rounds 1-3)
+        self.graph_mid = os.environ.get("PC_GRAPH_MID", "1") != "0"
+        self.max_mid_graphs = 8
 
     # the many-row layer loop of THIS class hands the attention a shared key prefix (__call__'s ``shared_prefix``); a subclass
     # with its own loop says so itself
@@ -506,6 +510,9 @@ class LlamaHIP:
             not (many_rows and self.precise_dense and T > self.SKINNY_MAX_ROWS)   # (the streaming stacks have no kv_only exit)
         streaming = graphed or mid
         self._lo_mode = self._tail_mode(arena, q_len, past_len) if streaming else 0
+        if mid and not graphed and self.graph_mid and self.use_graphs and B == 1 and not many_rows and not self.llm_int8 and \
+                T > self.SKINNY_MAX_ROWS and (self._shared_prefix_loop or type(self)._forward_skinny is LlamaHIP._forward_skinny):
+            graphed = True                    # a long question over a staged cache: the row-split stack, captured per 16-row bucket
         if graphed:
             # Token ids and positions on the HOST (what GenerationEngine hands over) travel with the call's other words in one
             # pinned copy (_InputBlock); device tensors (the reference's calling convention, generation_engine.py:96-97) are
@@ -929,7 +936,7 @@ class LlamaHIP:
         if g <= 1 or B != 1 or q_len == 1 or last_token_only or self.llm_int8 or self.use_chain:
             return q_len          # (LLM.int8 picks its outlier columns over all rows of a call: no pad rows there)
         qb = (q_len + g - 1) // g * g
-        if qb > self.SKINNY_MAX_ROWS or past_len + qb > arena.cap:
+        if qb > (self.MID_MAX_ROWS if self.graph_mid else self.SKINNY_MAX_ROWS) or past_len + qb > arena.cap:
             return q_len
         if (qb + 15) // 16 != (q_len + 15) // 16 or (q_len <= 32) != (qb <= 32):
             return q_len          # never across a row-tile count or the residual-tail regime of the attention
@@ -965,10 +972,60 @@ class LlamaHIP:
             v = self._nsplit_cache[k] = _native.attn_workspace_bytes(B, self.H, self.D, q_len, kv_len)   # monotone in the split count
         return v
 
+    def _graph_key(self, arena, B, q_len, past_len, last_token_only, num_layers, gather):
+        mode = self._lo_mode
+        tail = arena.tail_lo if mode else None
+        return (B, q_len, arena.buf.data_ptr(), arena.cap, self._nsplit_key(B, q_len, past_len + q_len), bool(last_token_only), num_layers,
+                self.fuse_norm, self.use_chain, mode, tail.data_ptr() if mode else 0, tail.shape[4] if mode else 0, gather)
+
+    def _graph_entry(self, key, arena, B, q_len, past_len, last_token_only, num_layers, gather, eager_first=True):
+        """The captured forward for ``key`` -> ``[graph, input block, logits buffer]`` (captured now when it does not exist yet:
+        the block's host side must already hold valid inputs; ``eager_first`` runs the forward once before capturing)."""
+        ent = self._graphs.pop(key, None)
+        if ent is not None:
+            self._graphs[key] = ent                          # LRU: a hit moves the entry to the young end
+            return ent, False
+        n = _native
+        T = B * q_len
+        if len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))       # evict the least recently used
+        if T > self.SKINNY_MAX_ROWS:
+            # the captured 65..512-row forwards hold their slabs and planes in the graph's pool (a few hundred MB each): a handful
+            big = [k for k in self._graphs if isinstance(k[0], int) and k[0] * k[1] > self.SKINNY_MAX_ROWS]
+            if len(big) >= self.max_mid_graphs:
+                self._graphs.pop(big[0])
+        blk = _InputBlock(self.device, T, self.GATHER_MAX_SEG if gather else 0)
+        ent = [None, blk, None]
+        self._graphs[key] = ent
+        return ent, True
+
+    def _capture(self, ent, arena, B, q_len, past_len, last_token_only, num_layers, gather, eager_first=True):
+        n = _native
+        blk = ent[1]
+
+        def run():
+            blk.fetch()
+            if gather:
+                n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
+                               arena.row_table())
+                self._gather = arena.row_tab
+            try:
+                return self._forward_skinny(blk.ids, blk.pos, blk.words, arena, B, q_len, past_len, last_token_only, num_layers)
+            finally:
+                self._gather = None
+
+        if eager_first:
+            # one eager pass first (loads code objects / sizes the allocator), then capture
+            run()
+            torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = run()
+        ent[0], ent[2] = g, out
+
     def _graphed_skinny(self, ids, pos, arena, B, q_len, past_len, last_token_only, num_layers):
         """Replay (capturing on first use) the hipGraph of the small-q forward for this shape.  ``ids`` / ``pos``: flat integer
         tensors; host tensors are the fast path (device tensors -- the reference's calling convention -- are read back first)."""
-        n = _native
         q_real = q_len
         q_len = self._graph_rows(arena, B, q_len, past_len, last_token_only)
         if q_len != q_real:
@@ -978,17 +1035,9 @@ class LlamaHIP:
         if not gather:
             arena.materialize()
         mode = self._lo_mode
-        tail = arena.tail_lo if mode else None
-        key = (B, q_len, arena.buf.data_ptr(), arena.cap, self._nsplit_key(B, q_len, past_len + q_len), bool(last_token_only), num_layers,
-               self.fuse_norm, self.use_chain, mode, tail.data_ptr() if mode else 0, tail.shape[4] if mode else 0, gather)
-        ent = self._graphs.pop(key, None)
+        key = self._graph_key(arena, B, q_len, past_len, last_token_only, num_layers, gather)
+        ent, fresh = self._graph_entry(key, arena, B, q_len, past_len, last_token_only, num_layers, gather)
         T = B * q_len
-        fresh = ent is None
-        if fresh:
-            if len(self._graphs) >= self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))   # evict the least recently used
-            ent = [None, _InputBlock(self.device, T, self.GATHER_MAX_SEG if gather else 0), None]
-        self._graphs[key] = ent                              # LRU: a hit moves the entry to the young end
         blk = ent[1]
         # ---- this call's inputs: written into the pinned block the graph's first node fetches ----
         blk.acquire()
@@ -1008,33 +1057,47 @@ class LlamaHIP:
         if gather:
             w[3] = len(plan.segs)
             blk.h_segs[:len(plan.segs)] = plan.seg_array(_SEG_DTYPE)
-
         if fresh:
-            def run():
-                blk.fetch()
-                if gather:
-                    n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
-                                   arena.row_table())
-                    self._gather = arena.row_tab
-                try:
-                    return self._forward_skinny(blk.ids, blk.pos, blk.words, arena, B, q_len, past_len, last_token_only, num_layers)
-                finally:
-                    self._gather = None
-
-            # one eager pass first (loads code objects / sizes the allocator), then capture
-            run()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = run()
-            ent[0], ent[2] = g, out
+            self._capture(ent, arena, B, q_len, past_len, last_token_only, num_layers, gather)
         g, out = ent[0], ent[2]
         g.replay()
         blk.release()
         if gather:
             arena.pending = None                             # the staged rows are in the arena now
             self.stats["fused_gather"] += 1
-        return out[:, :q_real].clone() if q_len != q_real else out.clone()
+        res = out[:, :q_real].clone() if q_len != q_real else out.clone()
+        if fresh and self.prewarm_tiles and B == 1 and q_real > 1 and T <= self.SKINNY_MAX_ROWS and not last_token_only:
+            self._prewarm(arena, past_len + q_real, num_layers)
+        return res
+
+    # Capture the sibling row tiles of a prompt-sized forward as soon as the first one is captured: a question whose tile count
+    # (16 / 32 / 48 / 64 rows) is new then replays instead of paying an eager pass + capture on its own TTFT (cold-shape TTFT
+    # 14.7 ms against 4.7 ms warm in round 3).  Capture only -- nothing is executed, so the arena and the residual tail are not
+    # touched; the host spends ~5 ms per tile, once per arena, behind the replay of the request that triggered it.
+    prewarm_tiles = os.environ.get("PC_PREWARM_TILES", "1") != "0"
+
+    def _prewarm(self, arena, past_len: int, num_layers) -> None:
+        if self.llm_int8 or self.use_chain or self.graph_row_bucket != 16 or self.decode_tail:
+            return
+        saved = self._lo_mode
+        try:
+            for q in (16, 32, 48, 64):
+                if past_len + q > arena.cap:
+                    break
+                self._lo_mode = self._tail_mode(arena, q, past_len)
+                key = self._graph_key(arena, 1, q, past_len, False, num_layers, False)
+                if key in self._graphs:
+                    continue
+                ent, fresh = self._graph_entry(key, arena, 1, q, past_len, False, num_layers, False)
+                if fresh:
+                    try:
+                        self._capture(ent, arena, 1, q, past_len, False, num_layers, False, eager_first=False)
+                    except Exception:                           # a capture that cannot be taken cold is simply taken on first use
+                        self._graphs.pop(key, None)
+                        self.prewarm_tiles = False
+                        return
+        finally:
+            self._lo_mode = saved
 
     @torch.inference_mode()
     def _loop_state(self) -> dict:

@@ -879,3 +879,88 @@ def test_row_bucketed_graph_equals_the_exact_row_graph(q_words):
            use_cache=True)
         assert len(m._graphs) == before
     m.graph_row_bucket = type(m).graph_row_bucket
+
+
+@pytest.mark.parametrize("q_words", [70, 150, 310])
+def test_long_question_graph_equals_the_eager_row_split_forward(q_words):
+    """65..512 new rows over a staged cache (B = 1): the row-split stack captured per 16-row bucket (pad rows behind the question's
+    own, under the causal mask nothing reaches back from them) against the same stack launched eagerly at the exact row count --
+    logits of the prefill and of the decode steps on top, and the K/V rows the pass appended."""
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    shape = SHAPES["mid_gqa"]
+    lm = Llama2(name="x", shape=shape, weights=make_weights_np(shape, 9, 3.0), device="cuda:0")
+    m = lm.hf_model
+    fmt = lm.get_formatter()
+    eng = CacheEngine(1024, lm)
+    sp, pp = synth.flat_docs("lq", 12, (120, 90), q_words, seed=7)
+    eng.add_schema(fmt(sp))
+    prompt = Prompt(pp, [fmt])
+
+    def run(graph_mid):
+        m.graph_mid = graph_mid
+        eng.prompt_cache.reset()
+        ids, pos, _, cache = eng.process(prompt)
+        n0 = len(m._graphs)
+        out = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+        captured = len(m._graphs) - n0
+        logits = [out.logits.clone()]
+        past, tok, p0 = out.past_key_values, int(out.logits[0, -1].argmax()), max(pos) + 1
+        for i in range(3):
+            o = lm(input_ids=torch.tensor([[tok]]), position_ids=torch.tensor([[p0 + 1 + i]]), past_key_values=past, use_cache=True)
+            logits.append(o.logits.clone())
+            past, tok = o.past_key_values, int(o.logits[0, -1].argmax())
+        n = past.length
+        return len(ids), captured, logits, past.arena.buf[0, :, :, :, :n].clone()
+
+    q, cap_e, eager, kv_e = run(False)
+    q2, cap_g, graphed, kv_g = run(True)
+    assert q == q2 and 64 < q <= 512 and q % 16 != 0, q
+    assert cap_e == 0 and cap_g == 1                              # the eager stack captures nothing; the graphed one its bucket
+    assert eager[0].shape == graphed[0].shape == (1, q, shape.vocab_size)
+    # (not bit-identical: the many-row attention cuts its key range into KV splits by the total key count, which the pad rows
+    # change -- the partials merge in another order; everything else in the stack is row-independent)
+    for a, b in zip(eager, graphed):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
+    assert float((kv_e.float() - kv_g.float()).abs().max()) <= 4e-3 and float((kv_e != kv_g).float().mean()) < 0.01
+    # the same bucket again: a replay, no capture
+    _, cap_again, again, _ = run(True)
+    assert cap_again == 0 and torch.equal(again[0], graphed[0])
+    m.graph_mid = True
+
+
+def test_first_prompt_prewarms_the_other_row_tiles():
+    """The first prompt-sized forward over an arena also captures the graphs of the other row tiles (16 / 32 / 48 / 64 rows), so a
+    question with a new tile count replays: no capture on its own call, and the numbers of a model that captured it on demand."""
+    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import make_weights_np
+    shape = SHAPES["mid"]
+    res = {}
+    for prewarm in (True, False):
+        lm = Llama2(name="x", shape=shape, weights=make_weights_np(shape, 4, 0.05), device="cuda:0")
+        m = lm.hf_model
+        m.prewarm_tiles = prewarm
+        fmt = lm.get_formatter()
+        eng = CacheEngine(1024, lm)
+        sp, _ = synth.flat_docs("pw", 12, (150, 140), 8, seed=3)
+        eng.add_schema(fmt(sp))
+        outs, captured = [], []
+        for qw in (8, 20, 40, 55, 9):                              # tiles 1, 2, 3, 4, 1
+            _, pp = synth.flat_docs("pw", 12, (150, 140), qw, seed=3)
+            eng.prompt_cache.reset()
+            ids, pos, _, cache = eng.process(Prompt(pp, [fmt]))
+            n0 = len(m._graphs)
+            o = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+            captured.append(len(m._graphs) - n0)
+            outs.append((len(ids), o.logits.clone()))
+        res[prewarm] = (outs, captured)
+    tiles = [(n + 15) // 16 for n, _ in res[True][0]]
+    assert tiles == [1, 2, 3, 4, 1], tiles
+    assert res[False][1] == [1, 1, 1, 1, 0]                        # on demand: one capture per new tile count
+    assert res[True][1][0] >= 4 and res[True][1][1:] == [0, 0, 0, 0], res[True][1]   # prewarmed: everything behind the first call replays
+    for (na, a), (nb, b) in zip(res[True][0], res[False][0]):
+        assert na == nb and torch.equal(a, b)

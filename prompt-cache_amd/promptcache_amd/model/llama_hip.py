@@ -215,6 +215,19 @@ class LlamaHIP:
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops
         self.precise_dense = os.environ.get("PC_FAST_DENSE", "0") != "1"
+        # Many-row projections that run on the hi activation plane only (a tile pass of 1 plane instead of 2: half the MFMAs of that
+        # launch).  Measured at full depth against the numpy oracle (tests/test_gpu_fullsize.py, 32 layers at the 7b shape; plain
+        # init / six 60x outlier channels), max |dlogit| by which projection drops its lo plane: none 1.1e-3 / 7.0e-4, gate|up
+        # 3.4e-3 / 3.1e-3, down 2.7e-3 / 2.4e-3, o 2.9e-3 / 2.8e-3, gate|up + down 4.4e-3 / 3.9e-3, q|k|v 1.5e-2 / 7.5e-3 (FAILS:
+        # its outputs are the stored K / V and the attention's Q).  gate|up is 45 % of a layer's projection MACs: default.
+        # PC_DENSE_LO_SKIP= (empty): every projection on both planes, as in rounds 1-3.
+        # Depth matters (the error grows with every layer): the 40-layer 13b stack measured 7.2e-3 with gate|up on one plane against
+        # 1.7e-3 on two -- inside the bar, but with little room -- so the default applies up to 32 layers; deeper stacks keep both
+        # planes everywhere unless PC_DENSE_LO_SKIP says otherwise.
+        _skip = os.environ.get("PC_DENSE_LO_SKIP")
+        if _skip is None:
+            _skip = "gu" if getattr(shape, "num_hidden_layers", 99) <= 32 else ""
+        self.dense_lo_skip = tuple(t for t in _skip.split(",") if t)
         self.fused_dense_qkv = os.environ.get("PC_FUSED_DENSE_QKV", "1") != "0"   # RoPE + KV append in the many-row q|k|v epilogue
         self.encode_mid = os.environ.get("PC_ENC_MID", "1") != "0"    # encode passes of 65..512 rows on the row-split stack
         # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
@@ -617,8 +630,8 @@ class LlamaHIP:
         lo = (lambda t: t[1]) if two else (lambda t: None)
         layers = self.layers if num_layers is None else self.layers[:num_layers]
 
-        def norm(src, gain, rows):
-            if two:
+        def norm(src, gain, rows, want_lo=True):
+            if two and want_lo:
                 n.rmsnorm_split(src, gain, h2[0], h2[1], rows, hid, eps)
             else:
                 n.rmsnorm(src, gain, h2[0], rows, hid, eps, True)
@@ -627,16 +640,21 @@ class LlamaHIP:
         # otherwise the projection leaves fp32 [T, W] for pc_rope_append
         fused_qkv = D == 128 and len(layers) > 0 and layers[0].get("wqkv_ds") is None and self.fused_dense_qkv
         qkv = None if fused_qkv else torch.empty((T, W), dtype=f32, device=dev)
+        skip = self.dense_lo_skip                  # dev probe (PC_DENSE_LO_SKIP): projections that run on the hi plane only
+        lo_q = (lambda t: None) if "qkv" in skip else lo
+        lo_o = (lambda t: None) if "o" in skip else lo
+        lo_g = (lambda t: None) if "gu" in skip else lo
+        lo_d = (lambda t: None) if "down" in skip else lo
         for li, lw in enumerate(layers):
             norm(x, lw["ln1"], T)
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
             if fused_qkv:
-                n.gemm_dense_qkv_rope(h2[0], lo(h2), lw["wqkv"], hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                n.gemm_dense_qkv_rope(h2[0], lo_q(h2), lw["wqkv"], hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                                       arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, kv_lo=kv_lo,
                                       past_lens=self._past_lens)
             else:
-                self._proj(h2[0], lo(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)
+                self._proj(h2[0], lo_q(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)
                 n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,
                               kp, vp, arena.batch_stride, arena.head_stride, cs, B, H, Hkv, D, q_len, past_len, arena.cap, True,
                               q_out_lo=q16l, kv_lo=kv_lo, past_lens=self._past_lens)
@@ -646,10 +664,10 @@ class LlamaHIP:
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, attn2[0],
                        q_len * H * D, H * D, B, H, Hkv, D, q_len, pre_max, self.softmax_scale, ws, q_lo=q16l,
                        out_lo=lo(attn2), kv_lo=kv_lo, past_lens=pre_lens, prefix=prefix_of(li))
-            self._proj(attn2[0], lo(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)                    # x += attn @ Wo^T
-            norm(x, lw["ln2"], T)
-            self._proj(h2[0], lo(h2), lw, "wgu", T, 2 * inter, hid, n.EPI_SILU, out_hi=act2[0], out_lo=lo(act2))
-            self._proj(act2[0], lo(act2), lw, "wdown", T, hid, inter, n.EPI_ADD, y=x)                   # x += act @ Wd^T
+            self._proj(attn2[0], lo_o(attn2), lw, "wo", T, hid, H * D, n.EPI_ADD, y=x)                  # x += attn @ Wo^T
+            norm(x, lw["ln2"], T, want_lo="gu" not in skip)
+            self._proj(h2[0], lo_g(h2), lw, "wgu", T, 2 * inter, hid, n.EPI_SILU, out_hi=act2[0], out_lo=lo_d(act2))
+            self._proj(act2[0], lo_d(act2), lw, "wdown", T, hid, inter, n.EPI_ADD, y=x)                 # x += act @ Wd^T
         if full_lo:
             arena.lo_len = past_len + q_len
         if self._kv_only:
@@ -1240,7 +1258,9 @@ class LlamaHIP:
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wo_s"])                                                    # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm
-            n.gemm_skinny(lw["wgu_f"], xh, xl, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl, wscale=lw["wgu_s"])  # silu(g)*u
+            # (an encode pass on this stack follows the many-row stack's plane policy: dense_lo_skip)
+            gu_lo = None if (self._lo_mode == 3 and T > self.SKINNY_MAX_ROWS and "gu" in self.dense_lo_skip) else xl
+            n.gemm_skinny(lw["wgu_f"], xh, gu_lo, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl, wscale=lw["wgu_s"])  # silu(g)*u
             n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wdown_s"])                                                 # act @ Wd^T
             pending = KQ

@@ -660,6 +660,10 @@ def test_suffix_batches_over_the_trunk_in_place_store_the_module_kv_of_the_copie
     from promptcache_amd.model.weights import make_weights_np
     lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 5, 2.0), device="cuda:0")
     assert lm.hf_model.supports_shared_prefix
+    # two forms of the SAME arithmetic: compared on the all-projections-on-both-planes stack (with gate|up on one plane -- the
+    # default up to 32 layers -- an fp32 round-off difference in its input moves an fp16 ulp: ~3 % of the stored values then
+    # differ by one ulp instead of ~0.3 %; the default mode's accuracy is what the full-depth oracle tests measure)
+    lm.hf_model.dense_lo_skip = ()
     sp, _ = synth.persona_like("p", system_len=70, intro_len=20,
                                traits=(("age", (30, 26, 33)), ("home", (41, 37, 44, 35)), ("job", (25, 29, 22)), ("pet", (50, 12))), seed=4)
     text = lm.get_formatter()(sp)
@@ -696,6 +700,7 @@ def test_trunk_pass_on_the_row_split_stack_stores_the_module_kv_of_the_many_row_
     from promptcache_amd.model.config import SHAPES
     from promptcache_amd.model.weights import make_weights_np
     lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 5, 2.0), device="cuda:0")
+    lm.hf_model.dense_lo_skip = ()          # (same arithmetic in two tilings: see the in-place test above)
     sp, _ = synth.persona_like("p", system_len=90, intro_len=30,
                                traits=(("age", (30, 26, 33)), ("home", (41, 37, 44, 35)), ("job", (25, 29, 22))), seed=9)
     text = lm.get_formatter()(sp)

@@ -637,9 +637,12 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         lib_ok = bool(torch.equal(lo, hi))
     mcfg = lm.hf_model.config
-    planes = 2 if lm.hf_model.precise_dense else 1
-    macs_tok = (mcfg.hidden_size * (lm.hf_model.H + 2 * lm.hf_model.Hkv) * lm.hf_model.D + lm.hf_model.H * lm.hf_model.D * mcfg.hidden_size
-                + 3 * mcfg.hidden_size * mcfg.intermediate_size)          # projection MACs per token per layer
+    _hm = lm.hf_model
+    _macs = {"qkv": mcfg.hidden_size * (_hm.H + 2 * _hm.Hkv) * _hm.D, "o": _hm.H * _hm.D * mcfg.hidden_size,
+             "gu": 2 * mcfg.hidden_size * mcfg.intermediate_size, "down": mcfg.hidden_size * mcfg.intermediate_size}
+    macs_tok = sum(_macs.values())                                         # projection MACs per token per layer
+    # activation planes the MFMAs run, averaged over the projections (hi + lo, except the projections on the hi plane only)
+    planes = (sum(m_ * (1 if k_ in getattr(_hm, "dense_lo_skip", ()) else 2) for k_, m_ in _macs.items()) / macs_tok) if _hm.precise_dense else 1
     comp_tokens = int(sc.encode_stats["computed_tokens"])
     enc_flops_alg = 2.0 * macs_tok * mcfg.num_hidden_layers * comp_tokens          # 2 * P per token that runs
     enc_flops = planes * enc_flops_alg                                              # what the MFMAs execute (hi + lo planes)
@@ -666,7 +669,7 @@ def main():
                            "reference_work_TFLOPs": 2.0 * macs_tok * mcfg.num_hidden_layers * enc_tokens / t_enc / 1e12,
                            "what": "frac: ALGORITHMIC projection flops (2 x MACs x layers x the tokens that ran through the model; "
                                    "padding rows and attention not counted) / wall time of the whole add_schema call, against the dense "
-                                   f"fp16 MFMA peak; executed_*: the same x {planes} activation plane(s) (what the MFMAs run for the "
+                                   f"fp16 MFMA peak; executed_*: the same x {planes:.2f} activation plane(s) on average (what the MFMAs run for the "
                                    "split-precision parity); reference_work_*: 2 x MACs x every scaffold token as the reference encodes "
                                    "them (every scaffold in full) / the same wall time -- what trunk reuse and scaffold cutting buy; "
                                    "kernel-level rates: profiles/r02_encode_kernel_stats.txt"},

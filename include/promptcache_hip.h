@@ -480,6 +480,18 @@ int pc_gemm_dense_a8(const void* xq, int64_t ldx, const void* w_codes, int64_t l
  * replay that reads it has finished. */
 int pc_fetch_block(const void* host_src, void* dst, int32_t nbytes, void* stream);
 
+/* pc_prefill_prologue -- everything a captured small-q forward does before its first layer, as ONE launch reading the call's pinned
+ * host block (layout: int64 ids[n_tok] | int32 pos[n_tok] at o_pos | int32 words[8] at o_words = {past_len, tail base, live rows,
+ * segments, rows of the row table, ...} | pc_kv_seg[max_seg] at o_segs): the block copied to its device twin (pc_fetch_block), the
+ * embedding rows of the tokens as the fp32 residual stream x_out [n_tok][hidden] (embed_tokens, llama2.py:869), the (cos, sin)
+ * rows of the supplied positions cs_out [n_tok][head_dim/2][2] (pc_rope_table; llama2.py:129-147, :204-207) and -- when `rows` is
+ * given -- the staging plan expanded per staged row (pc_kv_row_table; words[3] segments, words[4] rows).  Replaces the uploads of
+ * generation_engine.py:96-97 and four small launches per forward. */
+int pc_prefill_prologue(const void* host_block, void* dev_block, int32_t nbytes, int32_t n_tok, int32_t o_pos, int32_t o_words,
+                        int32_t o_segs, int32_t max_seg, const void* embed_table, int32_t hidden, int32_t vocab, float* x_out,
+                        const float* inv_freq, int32_t head_dim, float* cs_out, pc_kv_row* rows, const void* dst, int32_t max_ctx,
+                        void* stream);
+
 /* Greedy decode without a host round trip per token (generation_engine.py:123-168, greedy branch :159): the tail of a
  * captured decode step.  token = argmax(logits[0..vocab)) (lowest index among equal maxima); ids[0] = token, pos[0] += 1,
  * past_len[0] += 1 -- the device words the NEXT replay of the same hipGraph reads its token id, position id and past

@@ -197,22 +197,11 @@ PC_EXPORT int pc_kv_slice_store(const void* src, int32_t src_cap, const int32_t*
 namespace {
 constexpr int kRowTabMaxSeg = 1024;   // descriptors one expansion handles (16 KiB of LDS)
 
-__global__ __launch_bounds__(256) void kv_row_table_kernel(const pc_kv_seg* __restrict__ segs, const int32_t* __restrict__ nseg_dev,
-                                                           int max_seg, const int32_t* __restrict__ total_dev, uint64_t dst,
-                                                           uint32_t row_bytes, uint32_t dst_plane_stride16, int max_ctx,
-                                                           pc_kv_row* __restrict__ rows) {
-    __shared__ pc_kv_seg s_seg[kRowTabMaxSeg];
-    int nseg = *nseg_dev;
-    nseg = nseg < 0 ? 0 : (nseg > max_seg ? max_seg : nseg);
-    for (int i = threadIdx.x; i < nseg; i += blockDim.x) s_seg[i] = segs[i];
-    __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    int total = *total_dev;
-    total = total > max_ctx ? max_ctx : total;
-    if (r >= total) return;
-    // last descriptor with dst_row <= r (descriptors are in staging order)
+// entry of staged row r given the plan's descriptors in LDS (staging order) -- shared by kv_row_table_kernel and the prologue
+__device__ __forceinline__ pc_kv_row row_entry(const pc_kv_seg* s_seg, int nseg, int r, uint64_t dst, uint32_t row_bytes,
+                                               uint32_t dst_plane_stride16) {
     int lo = 0, hi = nseg;
-    while (lo < hi) {
+    while (lo < hi) {                                       // last descriptor with dst_row <= r
         const int mid = (lo + hi) >> 1;
         if (s_seg[mid].dst_row <= r) lo = mid + 1; else hi = mid;
     }
@@ -228,8 +217,119 @@ __global__ __launch_bounds__(256) void kv_row_table_kernel(const pc_kv_seg* __re
             e.flags = 0;
         }
     }
-    rows[r] = e;
+    return e;
 }
+
+__global__ __launch_bounds__(256) void kv_row_table_kernel(const pc_kv_seg* __restrict__ segs, const int32_t* __restrict__ nseg_dev,
+                                                           int max_seg, const int32_t* __restrict__ total_dev, uint64_t dst,
+                                                           uint32_t row_bytes, uint32_t dst_plane_stride16, int max_ctx,
+                                                           pc_kv_row* __restrict__ rows) {
+    __shared__ pc_kv_seg s_seg[kRowTabMaxSeg];
+    int nseg = *nseg_dev;
+    nseg = nseg < 0 ? 0 : (nseg > max_seg ? max_seg : nseg);
+    for (int i = threadIdx.x; i < nseg; i += blockDim.x) s_seg[i] = segs[i];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = *total_dev;
+    total = total > max_ctx ? max_ctx : total;
+    if (r >= total) return;
+    rows[r] = row_entry(s_seg, nseg, r, dst, row_bytes, dst_plane_stride16);
+}
+
+// ---- pc_prefill_prologue: everything a captured small-q forward does before its first layer, in ONE launch ------------------
+// Block roles (all of them read the call's PINNED HOST block directly, with system-scope loads: no ordering inside the launch is
+// needed, and the host rewrites the block between replays):
+//   [0, n_tok)            embedding row of token t as the fp32 residual stream          (llama2.py:869; ids from the host block)
+//   n_tok                 the whole block -> its device twin (past length, live rows, ... for the layers' kernels) and the
+//                         (cos, sin) rows of the supplied positions                         (llama2.py:129-147, :204-207)
+//   n_tok + 1 ..          the staging plan expanded to one pc_kv_row per staged row (pc_kv_row_table), when `rows` is given
+typedef __attribute__((address_space(1))) unsigned long long g64;
+__device__ __forceinline__ unsigned long long host_ld8(const void* p) {
+    return __hip_atomic_load((g64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct PrologueArgs {
+    const char* host; char* dev; int32_t nbytes, n_tok, o_pos, o_words, o_segs, max_seg;
+    const _Float16* table; int32_t hidden, vocab; float* x;
+    const float* inv_freq; int32_t half_dim; float2* cs;
+    pc_kv_row* rows; uint64_t dst; uint32_t row_bytes, dst_plane_stride16; int32_t max_ctx;
+};
+
+typedef _Float16 h8g __attribute__((ext_vector_type(8)));
+typedef float f4g __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void prefill_prologue_kernel(const PrologueArgs a) {
+    __shared__ pc_kv_seg s_seg[kRowTabMaxSeg];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b < a.n_tok) {
+        long long id = (long long)host_ld8(a.host + 8 * b);
+        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+        for (int i = tid; i < (a.hidden >> 3); i += 256) {
+            const h8g v = *(const h8g*)(a.table + id * a.hidden + i * 8);
+            float* o = a.x + (int64_t)b * a.hidden + i * 8;
+            *(f4g*)o = f4g{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            *(f4g*)(o + 4) = f4g{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        }
+        return;
+    }
+    if (b == a.n_tok) {
+        for (int i = tid; i < a.nbytes / 8; i += 256) ((unsigned long long*)a.dev)[i] = host_ld8(a.host + 8 * i);
+        for (int i = tid; i < a.n_tok * a.half_dim; i += 256) {
+            const int t = i / a.half_dim, f = i - t * a.half_dim;
+            const unsigned long long w = host_ld8(a.host + a.o_pos + 8 * (t >> 1));      // two int32 positions per 8 bytes
+            const int pos = (int)((t & 1) ? (w >> 32) : (w & 0xffffffffu));
+            const float ang = __fmul_rn((float)pos, a.inv_freq[f]);                      // as rope_table_kernel (pc_rope.hip)
+            float sn, c;
+            sincosf(ang, &sn, &c);
+            a.cs[i] = make_float2(c, sn);
+        }
+        return;
+    }
+    if (!a.rows) return;
+    // words[3] = segments, words[4] = rows of the table (o_words is 4-byte aligned: read the two int32 words separately)
+    const unsigned long long w34a = host_ld8(a.host + ((a.o_words + 12) & ~7));
+    const unsigned long long w34b = host_ld8(a.host + ((a.o_words + 16) & ~7));
+    int nseg = (int)(((a.o_words + 12) & 7) ? (w34a >> 32) : (w34a & 0xffffffffu));
+    int total = (int)(((a.o_words + 16) & 7) ? (w34b >> 32) : (w34b & 0xffffffffu));
+    nseg = nseg < 0 ? 0 : (nseg > a.max_seg ? a.max_seg : nseg);
+    total = total > a.max_ctx ? a.max_ctx : total;
+    for (int i = tid; i < nseg; i += 256) {
+        const unsigned long long p0 = host_ld8(a.host + a.o_segs + 16 * i), p1 = host_ld8(a.host + a.o_segs + 16 * i + 8);
+        pc_kv_seg sg;
+        sg.src = (const void*)(uintptr_t)p0; sg.dst_row = (int32_t)(p1 & 0xffffffffu); sg.len = (int32_t)(p1 >> 32);
+        s_seg[i] = sg;
+    }
+    __syncthreads();
+    const int r = (b - a.n_tok - 1) * 256 + tid;
+    if (r < total) a.rows[r] = row_entry(s_seg, nseg, r, a.dst, a.row_bytes, a.dst_plane_stride16);
+}
+}  // namespace
+
+PC_EXPORT int pc_prefill_prologue(const void* host_block, void* dev_block, int32_t nbytes, int32_t n_tok, int32_t o_pos,
+                                  int32_t o_words, int32_t o_segs, int32_t max_seg, const void* embed_table, int32_t hidden,
+                                  int32_t vocab, float* x_out, const float* inv_freq, int32_t head_dim, float* cs_out,
+                                  pc_kv_row* rows, const void* dst, int32_t max_ctx, void* stream) {
+    PC_REQUIRE(host_block && dev_block && embed_table && x_out && inv_freq && cs_out, PC_ERR_ARG, "pc_prefill_prologue: null pointer");
+    PC_REQUIRE(nbytes > 0 && nbytes % 8 == 0 && nbytes <= (1 << 20) && n_tok > 0 && n_tok <= 512, PC_ERR_ARG,
+               "pc_prefill_prologue: need 8 | nbytes <= 1 MiB and 1 <= n_tok <= 512");
+    PC_REQUIRE(o_pos % 8 == 0 && o_words % 4 == 0 && o_segs % 8 == 0 && o_pos >= 8 * n_tok && o_words >= o_pos + 4 * n_tok &&
+               o_words + 32 <= nbytes && (!rows || o_segs + 16 * max_seg <= nbytes), PC_ERR_ARG,
+               "pc_prefill_prologue: block layout (ids | pos | words[8] | segs) does not fit nbytes");
+    PC_REQUIRE(hidden > 0 && hidden % 8 == 0 && vocab > 0 && head_dim > 0 && head_dim % 2 == 0, PC_ERR_ARG, "pc_prefill_prologue: bad sizes");
+    PC_REQUIRE(!rows || (dst && max_ctx > 0 && max_seg > 0 && max_seg <= kRowTabMaxSeg), PC_ERR_ARG,
+               "pc_prefill_prologue: the row table needs the staged buffer, max_ctx and 1 <= max_seg <= %d", kRowTabMaxSeg);
+    PrologueArgs a;
+    a.host = (const char*)host_block; a.dev = (char*)dev_block; a.nbytes = nbytes; a.n_tok = n_tok; a.o_pos = o_pos; a.o_words = o_words;
+    a.o_segs = o_segs; a.max_seg = max_seg; a.table = (const _Float16*)embed_table; a.hidden = hidden; a.vocab = vocab; a.x = x_out;
+    a.inv_freq = inv_freq; a.half_dim = head_dim / 2; a.cs = (float2*)cs_out; a.rows = rows; a.dst = (uint64_t)(uintptr_t)dst;
+    a.row_bytes = (uint32_t)head_dim * 2u; a.dst_plane_stride16 = rows ? (uint32_t)(((uint64_t)max_ctx * a.row_bytes) >> 4) : 0u;
+    a.max_ctx = max_ctx;
+    const int nblk = n_tok + 1 + (rows ? pc_ceil_div(max_ctx, 256) : 0);
+    hipLaunchKernelGGL(prefill_prologue_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    return pc_check_launch("prefill_prologue_kernel");
+}
+
+namespace {
 }  // namespace
 
 PC_EXPORT int pc_kv_row_table(const pc_kv_seg* segs, const int32_t* nseg_dev, int32_t max_seg, const int32_t* total_rows_dev,

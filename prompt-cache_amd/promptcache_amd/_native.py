@@ -112,6 +112,7 @@ SIGNATURES = {
     "pc_embed_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pc_probe_layouts": (C.c_int, [_vp, _vp, _vp]),
     "pc_fetch_block": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "pc_prefill_prologue": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "pc_rope_append_var": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
@@ -507,6 +508,16 @@ def fetch_block(host_pinned, dst, nbytes: int, stream: Optional[int] = None) -> 
     """Graph node: pull ``nbytes`` of a pinned host tensor into the device tensor ``dst`` (``pc_fetch_block``)."""
     rc = load().pc_fetch_block(host_pinned.data_ptr(), dst.data_ptr(), nbytes, current_stream() if stream is None else stream)
     check(rc, "pc_fetch_block")
+
+
+def prefill_prologue(host_pinned, dev_block, nbytes: int, n_tok: int, o_pos: int, o_words: int, o_segs: int, max_seg: int, embed_table,
+                     hidden: int, vocab: int, x_out, inv_freq, head_dim: int, cs_out, rows=None, dst=None, max_ctx: int = 0,
+                     stream: Optional[int] = None) -> None:
+    """Graph node: host block -> device block, embedding rows -> fp32 residual stream, (cos, sin) rows, row table (``pc_prefill_prologue``)."""
+    rc = load().pc_prefill_prologue(host_pinned.data_ptr(), dev_block.data_ptr(), nbytes, n_tok, o_pos, o_words, o_segs, max_seg,
+                                    embed_table.data_ptr(), hidden, vocab, x_out.data_ptr(), inv_freq.data_ptr(), head_dim,
+                                    cs_out.data_ptr(), _ptr(rows), _ptr(dst), max_ctx, current_stream() if stream is None else stream)
+    check(rc, "pc_prefill_prologue")
 
 
 def probe_layouts(out_mfma, out_tr, stream: Optional[int] = None) -> None:

@@ -266,6 +266,8 @@ class LlamaHIP:
         self.batch_invariant = True         # a row's result does not depend on the other rows of the forward (see llm_int8)
         self.tail_supported = True  # a subclass whose layer loops do not thread `_tail_for` through must switch this off
         self._gather = None         # set per forward: the row table while the attention launches stage as they read
+        self._pre = None            # set per captured forward: (fp32 residual stream, rotation table) from pc_prefill_prologue
+        self.fused_prologue = os.environ.get("PC_FUSED_PROLOGUE", "1") != "0"
         self.stats = {"fused_gather": 0}     # forwards that carried out a pending staging inside their attention launches
         self._gather_ok_cache, self._nsplit_cache = {}, {}
         # hipGraphs for the 65..512-row forward as well (B = 1, 16-row buckets): nine launches per layer from Python are host-bound
@@ -1021,16 +1023,31 @@ class LlamaHIP:
         n = _native
         blk = ent[1]
 
+        fused_pro = self.fused_prologue and type(self)._forward_skinny is LlamaHIP._forward_skinny and not self.llm_int8
+
         def run():
-            blk.fetch()
+            if fused_pro:
+                # ONE launch: block fetch + embedding rows (fp32 residual stream) + rotation table + row table
+                T = B * q_len
+                x = torch.empty((T, self.config.hidden_size), dtype=torch.float32, device=self.device)
+                cs = torch.empty((T, self.D // 2, 2), dtype=torch.float32, device=self.device)
+                n.prefill_prologue(blk.host, blk.dev, blk.nbytes, T, blk.o_pos, blk.o_words, blk.o_segs, blk.max_seg, self.embed,
+                                   self.config.hidden_size, self.config.vocab_size, x, self.inv_freq, self.D, cs,
+                                   rows=arena.row_table() if gather else None, dst=arena.buf if gather else None,
+                                   max_ctx=arena.cap if gather else 0)
+                self._pre = (x, cs)
+            else:
+                blk.fetch()
+                if gather:
+                    n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
+                                   arena.row_table())
             if gather:
-                n.kv_row_table(blk.segs, blk.words[3:4], self.GATHER_MAX_SEG, blk.words[4:5], arena.buf, self.Hkv, self.D, arena.cap,
-                               arena.row_table())
                 self._gather = arena.row_tab
             try:
                 return self._forward_skinny(blk.ids, blk.pos, blk.words, arena, B, q_len, past_len, last_token_only, num_layers)
             finally:
                 self._gather = None
+                self._pre = None
 
         if eager_first:
             # one eager pass first (loads code objects / sizes the allocator), then capture
@@ -1210,11 +1227,14 @@ class LlamaHIP:
         W = (H + 2 * Hkv) * D
         eps = c.rms_norm_eps
         mt = (T + 15) // 16
-        cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
-        n.rope_table(pos32, self.inv_freq, cs, T, D)
-        h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
-        n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
-        x = h16.float()  # fp32 residual stream
+        if self._pre is not None:                     # (captured forward: pc_prefill_prologue already produced both)
+            x, cs = self._pre
+        else:
+            cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=dev)
+            n.rope_table(pos32, self.inv_freq, cs, T, D)
+            h16 = torch.empty((T, hid), dtype=self.dtype, device=dev)
+            n.embed_gather(self.embed, ids, h16, T, hid, c.vocab_size)
+            x = h16.float()  # fp32 residual stream
         q16 = torch.empty((T, H * D), dtype=self.dtype, device=dev)
         q16l = torch.empty((T, H * D), dtype=self.dtype, device=dev)       # low-order plane of the split-precision q
         ws_bytes = n.attn_workspace_bytes(B, H, D, q_len, past_len + q_len)

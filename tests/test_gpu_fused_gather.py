@@ -240,3 +240,52 @@ def test_generate_through_the_deferred_staging_matches_the_copy_first_engine():
         texts[defer] = outs[-1].new_text
         assert lm.hf_model.stats["fused_gather"] == (1 if defer else 0)
     assert texts[True] == texts[False] and len(texts[True]) > 0
+
+
+@pytest.mark.parametrize("T,nseg_plan", [(12, True), (16, False), (1, False), (77, True)])
+def test_prefill_prologue_equals_the_separate_launches(T, nseg_plan):
+    """pc_prefill_prologue (block fetch + embedding rows as fp32 + rotation table + row table in ONE launch, every role reading
+    the pinned host block itself) against pc_fetch_block, pc_embed_gather + cast, pc_rope_table and pc_kv_row_table: bit for bit."""
+    n = _n()
+    rng = np.random.default_rng(3)
+    hid, vocab, D, Hkv, cap, max_seg = 512, 1000, 128, 2, 700, 64
+    table = _rand_half((vocab, hid), rng)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(DEV)
+    o_pos, o_words = 8 * T, 12 * T
+    o_segs = (o_words + 32 + 15) // 16 * 16
+    nbytes = o_segs + 16 * max_seg
+    host = torch.zeros(nbytes, dtype=torch.uint8, pin_memory=True)
+    h = host.numpy()
+    ids = rng.integers(-3, vocab + 5, size=T)                        # (out-of-range ids are clamped, as pc_embed_gather does)
+    pos = rng.integers(0, 9000, size=T).astype(np.int32)
+    h[:8 * T].view(np.int64)[:] = ids
+    h[o_pos:o_pos + 4 * T].view(np.int32)[:] = pos
+    words = h[o_words:o_words + 32].view(np.int32)
+    lens, offs = [40, 1, 300, 7], [10, 50, 51, 351]
+    stores = [torch.zeros((1, 2, Hkv, ln, D), dtype=torch.float16, device=DEV) for ln in lens]
+    words[:] = [500, 0, T, len(lens), 358 + T, 0, 0, 0]
+    sa = h[o_segs:].view(np.dtype([("src", "<u8"), ("dst_row", "<i4"), ("len", "<i4")]))
+    for i, (st, o, ln) in enumerate(zip(stores, offs, lens)):
+        sa[i] = (st.data_ptr(), o, ln)
+    arena = torch.zeros((1, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+    dev = torch.full((nbytes,), 0xEE, dtype=torch.uint8, device=DEV)
+    x = torch.full((T, hid), float("nan"), device=DEV)
+    cs = torch.full((T, D // 2, 2), float("nan"), device=DEV)
+    rows = torch.full((cap * 16,), 0xAB, dtype=torch.uint8, device=DEV) if nseg_plan else None
+    n.prefill_prologue(host, dev, nbytes, T, o_pos, o_words, o_segs, max_seg, table, hid, vocab, x, inv, D, cs,
+                       rows=rows, dst=arena if nseg_plan else None, max_ctx=cap if nseg_plan else 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dev.cpu(), host)
+    ids_d = torch.from_numpy(ids.astype(np.int64)).to(DEV)
+    h16 = torch.empty((T, hid), dtype=torch.float16, device=DEV)
+    n.embed_gather(table, ids_d, h16, T, hid, vocab)
+    assert torch.equal(x, h16.float())
+    cs2 = torch.empty_like(cs)
+    n.rope_table(torch.from_numpy(pos).to(DEV), inv, cs2, T, D)
+    assert torch.equal(cs.view(torch.int32), cs2.view(torch.int32))
+    if nseg_plan:
+        rows2 = torch.full((cap * 16,), 0xAB, dtype=torch.uint8, device=DEV)
+        blk = dev
+        n.kv_row_table(blk[o_segs:], blk[o_words + 12:o_words + 16].view(torch.int32), max_seg, blk[o_words + 16:o_words + 20].view(torch.int32),
+                       arena, Hkv, D, cap, rows2)
+        assert torch.equal(rows, rows2)

@@ -177,10 +177,20 @@ __device__ __forceinline__ void attn_tail_block(const AttnParams& p, float* __re
 // 2.5e-3, fp16 P: 1.7e-3 max |delta logit| on a 7b-shaped layer); K/V stay fp16 as staged.
 // PRE: the launch carries a shared key prefix (AttnParams::pre_k): its own instantiation, so that the others keep their
 // register allocation (the prefix walk costs the residual variant its second wave per SIMD).
-template <int D, bool HP, bool ALIBI, bool KVLO, bool PRE>
+// GATHER (pc_attn gather_rows; tail mode, one q-block, B = 1: prompts of 17..32 new tokens): stage while reading, as in
+// attn_small_kernel -- every staged key row is fetched from where its row-table entry says it lies and, unless it is in the arena
+// already, written there when the tile goes to LDS (the staging registers hold it anyway).  A (kv head, key row) belongs to exactly
+// one workgroup of the launch.  The tile's stores are waited for one tile later, behind a tile's worth of MFMAs.
+#ifdef PC_GATHER_STORE_PLAIN
+#define PC_GATHER_ST(v, p) (*(p) = (v))
+#else
+#define PC_GATHER_ST(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+template <int D, bool HP, bool ALIBI, bool KVLO, bool PRE, bool GATHER = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
     static_assert(!KVLO || HP, "K/V residual planes go with split-precision Q and P");
     static_assert(!PRE || !ALIBI, "a shared prefix excludes ALiBi");
+    static_assert(!GATHER || (HP && !KVLO && !PRE && !ALIBI), "the staging stream is the tail-mode instantiation");
     constexpr int KS = D / 32;   // MFMA k-steps across the head dim (QK^T)
     constexpr int DB = D / 16;   // 16-wide head-dim blocks of O^T
     constexpr int CPR = D / 8;   // 16-byte chunks per K/V row
@@ -300,6 +310,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
             if (p.pre_k_lo) { klb = p.pre_k_lo + (int64_t)hkv * p.pre_hs; vlb = p.pre_v_lo + (int64_t)hkv * p.pre_hs; }
         }
     }
+    [[maybe_unused]] uint32_t gflag[GATHER ? LPT : 1];
+    [[maybe_unused]] const bool g_writer = GATHER && (h % (p.H / p.Hkv)) == 0;
+    [[maybe_unused]] const uint64_t g_koff = GATHER ? (uint64_t)(uint32_t)(p.g_kplane + hkv) : 0;
+    [[maybe_unused]] const uint64_t g_voff = GATHER ? (uint64_t)(uint32_t)(p.g_vplane + hkv) : 0;
     auto issue_loads = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -309,6 +323,17 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
             u32x4 z = {0u, 0u, 0u, 0u};
             kr[i] = z; vr[i] = z;   // zero-fill rows at/after kend: a garbage V row would turn 0 * NaN into NaN
             if (KVLO) { krl[i] = z; vrl[i] = z; }
+            if constexpr (GATHER) {
+                gflag[i] = PC_KV_ROW_STAGED;
+                if (key < kend) {
+                    const u32x4 e = *(const u32x4*)(p.rows + key);
+                    const uint64_t base = ((uint64_t)e[1] << 32) | e[0];
+                    gflag[i] = e[3];
+                    kr[i] = __builtin_nontemporal_load((const u32x4*)(uintptr_t)(base + ((g_koff * e[2]) << 4) + col * 16));
+                    vr[i] = __builtin_nontemporal_load((const u32x4*)(uintptr_t)(base + ((g_voff * e[2]) << 4) + col * 16));
+                }
+                continue;
+            }
             if (key < kend) {
                 kr[i] = *(const u32x4*)(kbase + (int64_t)key * D + col * 8);
                 vr[i] = *(const u32x4*)(vbase + (int64_t)key * D + col * 8);
@@ -345,6 +370,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
             // touches then sit in 8 different 32-B windows of the 256-B bank row instead of the same one (the
             // unrotated tile measured SQ_LDS_BANK_CONFLICT = 68 % of SQ_LDS_IDX_ACTIVE: an 8-way conflict)
             *(u32x4*)(Vl + row * D + (((col + 2 * (row & 7)) & (CPR - 1)) << 3)) = vr[i];
+            if constexpr (GATHER) {
+                if (g_writer && !(gflag[i] & PC_KV_ROW_STAGED)) {      // (gflag is STAGED for rows at / behind kend)
+                    _Float16* kd = const_cast<_Float16*>(kbase) + (int64_t)(key0 + row) * D + col * 8;
+                    _Float16* vd = const_cast<_Float16*>(vbase) + (int64_t)(key0 + row) * D + col * 8;
+                    PC_GATHER_ST(kr[i], (u32x4*)kd);
+                    PC_GATHER_ST(vr[i], (u32x4*)vd);
+                }
+            }
             if (KVLO) {
                 if (tile_lo) {
                     *(u32x4*)(Kll + row * D + ((col ^ (row & (CPR - 1))) << 3)) = krl[i];
@@ -493,9 +526,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams p) {
     }
 }
 
-template <int D, bool HP, bool ALIBI = false, bool KVLO = false>
+template <int D, bool HP, bool ALIBI = false, bool KVLO = false, bool GATHER = false>
 __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnParams p) {
-    attn_fwd_body<D, HP, ALIBI, KVLO, false>(p);
+    attn_fwd_body<D, HP, ALIBI, KVLO, false, GATHER>(p);
 }
 
 // the shared-prefix walk for passes of <= 64 rows (longer ones: pc_attn_ring.hip); its residual variant runs one wave per SIMD
@@ -841,11 +874,6 @@ __device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, i
 // count in vmcnt with the loads, and a store in front of the V wait would put its write acknowledgement on the critical path.
 // (The launch is sized to ONE workgroup per CU -- small_nstream -- so the staging variant, which keeps the K fragments alive until
 // they are stored, takes the registers of a one-wave-per-SIMD kernel instead of spilling at 256.)
-#ifdef PC_GATHER_STORE_PLAIN
-#define PC_GATHER_ST(v, p) (*(p) = (v))
-#else
-#define PC_GATHER_ST(v, p) __builtin_nontemporal_store((v), (p))
-#endif
 template <int D, bool ALIBI, int NS, bool GATHER = false>
 __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(const AttnParams p) {
     constexpr bool FUSE = NS > 0;
@@ -1264,7 +1292,8 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     } else if (p.key_pos) {
         if (want_hp) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(kThreads), 0, stream, p);
-    } else if (want_hp) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
+    } else if (want_hp && p.rows) hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, false, true>), grid, dim3(kThreads), 0, stream, p);
+    else if (want_hp) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     int rc = pc_check_launch("attn_fwd_kernel");
     if (rc != PC_OK) return rc;
@@ -1361,11 +1390,13 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
         if (ns >= 2) p.nsplit = ns; else small = false;
     }
     p.small = small ? 1 : 0;
-    // staging while reading lives in attn_small_kernel's two-launch form, one batch row
-    const bool can_gather = small && !counters && B == 1 && past_len > 0;
+    // staging while reading lives in attn_small_kernel's two-launch form and in the tail-mode instantiation of the 64-row kernel
+    // (17..32 new rows: one q-block, the streaming splits cover staged keys only); one batch row
+    const bool mid_gather = !small && p.tail && !ring_first && !key_pos && !pre_k && q_len <= kQB;
+    const bool can_gather = (small || mid_gather) && (small ? !counters : true) && B == 1 && past_len > 0;
     if (gather_ok) { *gather_ok = can_gather ? 1 : 0; return PC_OK; }
     PC_REQUIRE(!gather_rows || can_gather, PC_ERR_ARG,
-               "pc_attn: gather_rows needs B = 1, <= %d query rows over >= 256 keys and no counters (ask pc_attn_gather_ok)", kSmallQ);
+               "pc_attn: gather_rows needs B = 1 and a launch of <= %d query rows in tail mode or <= %d rows over >= 256 keys without counters (ask pc_attn_gather_ok)", kTailMax, kSmallQ);
     PC_REQUIRE(!gather_rows || (((uintptr_t)gather_rows & 15) == 0 && g_kplane >= 0 && g_vplane >= 0), PC_ERR_ARG,
                "pc_attn: gather_rows must be 16-byte aligned, planes non-negative");
     p.rows = gather_rows; p.g_kplane = g_kplane; p.g_vplane = g_vplane;

@@ -967,8 +967,12 @@ class LlamaHIP:
         library itself (pc_attn_gather_ok) with the arguments _forward_skinny passes; the answer only depends on the row count,
         the residual mode and whether the key range reaches the streaming kernel's minimum, so it is remembered."""
         plan = arena.pending
-        if plan is None or not self.supports_fused_gather or self.llm_int8 or B != 1 or plan.total != past_len or \
-                len(plan.segs) > self.GATHER_MAX_SEG or self.use_chain:
+        if plan is None or plan.total != past_len or len(plan.segs) > self.GATHER_MAX_SEG:
+            return False
+        return self._gather_shape_ok(arena, B, q_len, past_len)
+
+    def _gather_shape_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
+        if not self.supports_fused_gather or self.llm_int8 or B != 1 or self.use_chain or past_len <= 0:
             return False
         ck = (q_len, self._lo_mode, past_len + q_len >= 256, self._attn_counters is None)
         ok = self._gather_ok_cache.get(ck)
@@ -1120,17 +1124,19 @@ class LlamaHIP:
                 if past_len + q > arena.cap:
                     break
                 self._lo_mode = self._tail_mode(arena, q, past_len)
-                key = self._graph_key(arena, 1, q, past_len, False, num_layers, False)
-                if key in self._graphs:
-                    continue
-                ent, fresh = self._graph_entry(key, arena, 1, q, past_len, False, num_layers, False)
-                if fresh:
-                    try:
-                        self._capture(ent, arena, 1, q, past_len, False, num_layers, False, eager_first=False)
-                    except Exception:                           # a capture that cannot be taken cold is simply taken on first use
-                        self._graphs.pop(key, None)
-                        self.prewarm_tiles = False
-                        return
+                # both ways a prompt of this tile may arrive: rows already staged, or a staging plan for the attention to carry out
+                for gather in ((False, True) if self._gather_shape_ok(arena, 1, q, past_len) else (False,)):
+                    key = self._graph_key(arena, 1, q, past_len, False, num_layers, gather)
+                    if key in self._graphs:
+                        continue
+                    ent, fresh = self._graph_entry(key, arena, 1, q, past_len, False, num_layers, gather)
+                    if fresh:
+                        try:
+                            self._capture(ent, arena, 1, q, past_len, False, num_layers, gather, eager_first=False)
+                        except Exception:                       # a capture that cannot be taken cold is simply taken on first use
+                            self._graphs.pop(key, None)
+                            self.prewarm_tiles = False
+                            return
         finally:
             self._lo_mode = saved
 

@@ -65,6 +65,11 @@ GATHER_CASES = [
     (16, 16, 64, 3, [100, 1, 1, 250], 0, True),                                        # D = 64
     (4, 4, 32, 12, [64, 64, 1, 200], 0, False),                                        # D = 32
     (32, 32, 128, 1, [500, 1, 120], 0, False),                                         # one row (a decode-shaped first call)
+    # 17..32 new rows: the tail-mode instantiation of the 64-row kernel (attn_fwd_kernel<D, true, false, false, GATHER>)
+    (32, 32, 128, 26, [275, 1, 1, 1, 1, 1, 84, 1, 1, 174, 1, 1, 256, 1, 1, 155, 1, 1, 267, 1, 1, 265, 1, 1, 232], 0, True),
+    (8, 2, 128, 32, [40, 1, 300, 7, 129], 41, True),                                   # GQA, kept prefix, a full 32-row tile pair
+    (16, 16, 64, 20, [100, 1, 1, 250], 0, True),                                       # D = 64
+    (4, 4, 32, 17, [64, 64, 1, 90], 0, True),                                          # D = 32, short cache (< 256 keys)
 ]
 
 

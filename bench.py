@@ -571,6 +571,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("PC_BENCH_FAULT_S"):          # dev: dump every thread's stack and exit if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PC_BENCH_FAULT_S"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -228,6 +228,7 @@ class LlamaHIP:
         if _skip is None:
             _skip = "gu" if getattr(shape, "num_hidden_layers", 99) <= 32 else ""
         self.dense_lo_skip = tuple(t for t in _skip.split(",") if t)
+        self.mid_lo_skip = tuple(t for t in os.environ.get("PC_MID_LO_SKIP", "").split(",") if t)
         self.fused_dense_qkv = os.environ.get("PC_FUSED_DENSE_QKV", "1") != "0"   # RoPE + KV append in the many-row q|k|v epilogue
         self.encode_mid = os.environ.get("PC_ENC_MID", "1") != "0"    # encode passes of 65..512 rows on the row-split stack
         # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
@@ -1284,8 +1285,10 @@ class LlamaHIP:
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wo_s"])                                                    # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm
-            # (an encode pass on this stack follows the many-row stack's plane policy: dense_lo_skip)
-            gu_lo = None if (self._lo_mode == 3 and T > self.SKINNY_MAX_ROWS and "gu" in self.dense_lo_skip) else xl
+            # (an encode pass on this stack follows the many-row stack's plane policy: dense_lo_skip; PC_MID_LO_SKIP=gu extends it to
+            # the long-question forward)
+            gu_lo = None if (T > self.SKINNY_MAX_ROWS and ((self._lo_mode == 3 and "gu" in self.dense_lo_skip) or
+                                                           (self._lo_mode != 3 and "gu" in self.mid_lo_skip))) else xl
             n.gemm_skinny(lw["wgu_f"], xh, gu_lo, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl, wscale=lw["wgu_s"])  # silu(g)*u
             n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wdown_s"])                                                 # act @ Wd^T

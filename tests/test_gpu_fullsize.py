@@ -275,6 +275,16 @@ def test_full_depth_7b_end_to_end_vs_numpy_oracle():
 
 
 @_skip_full
+def test_full_depth_7b_long_question_vs_numpy_oracle():
+    """All 32 layers at the 7b shape with a question of ~100 new tokens: the 65..512-row stack (row-split projections, ring
+    attention, hipGraph per 16-row bucket) end to end against the numpy oracle -- the regime of BASELINE config 4's questions."""
+    from promptcache_amd.model.config import SHAPES
+    shape = dataclasses.replace(SHAPES["llama2-7b"], vocab_size=8192)
+    _full_depth_llama("plq", shape, 15, dict(system_len=110, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57))),
+                                             question_len=96, seed=16))
+
+
+@_skip_full
 def test_full_depth_13b_40_layers_vs_numpy_oracle():
     """BASELINE config 4's model: all 40 layers at the llama2-13b layer shape (small vocabulary: the oracle's lm_head / embedding
     are not what depth tests), a short schema -- hidden 5120 / 40 heads take the two-tile N = hidden launches and 320-tile grids."""

@@ -1393,10 +1393,12 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     // staging while reading lives in attn_small_kernel's two-launch form and in the tail-mode instantiation of the 64-row kernel
     // (17..32 new rows: one q-block, the streaming splits cover staged keys only); one batch row
     const bool mid_gather = !small && p.tail && !ring_first && !key_pos && !pre_k && q_len <= kQB;
-    const bool can_gather = (small || mid_gather) && (small ? !counters : true) && B == 1 && past_len > 0;
+    // ... and in the ring kernel (more than 32 split-precision rows at head_dim 128, no shared prefix, one past length)
+    const bool ring_gather = !small && ring_eligible(p, D) && !pre_k && !past_lens;
+    const bool can_gather = (small || mid_gather || ring_gather) && (small ? !counters : true) && B == 1 && past_len > 0;
     if (gather_ok) { *gather_ok = can_gather ? 1 : 0; return PC_OK; }
     PC_REQUIRE(!gather_rows || can_gather, PC_ERR_ARG,
-               "pc_attn: gather_rows needs B = 1 and a launch of <= %d query rows in tail mode or <= %d rows over >= 256 keys without counters (ask pc_attn_gather_ok)", kTailMax, kSmallQ);
+               "pc_attn: gather_rows needs B = 1 and a launch of <= %d query rows in tail mode, <= %d rows over >= 256 keys without counters, or a split-precision launch of >= %d rows at head_dim 128 (ask pc_attn_gather_ok)", kTailMax, kSmallQ, ring_min_rows());
     PC_REQUIRE(!gather_rows || (((uintptr_t)gather_rows & 15) == 0 && g_kplane >= 0 && g_vplane >= 0), PC_ERR_ARG,
                "pc_attn: gather_rows must be 16-byte aligned, planes non-negative");
     p.rows = gather_rows; p.g_kplane = g_kplane; p.g_vplane = g_vplane;

@@ -70,8 +70,16 @@ __device__ __forceinline__ void glds16_raw(const _Float16* g, uint32_t lds_addr)
 
 struct Region { const _Float16* k; const _Float16* v; const _Float16* kl; const _Float16* vl; int a, e, lo; };
 
-template <bool KVLO, bool PRE>
+// GATHER (pc_attn gather_rows; B = 1, no shared prefix): STAGE WHILE READING, as attn_small_kernel does for short prompts.  Keys of
+// the PLAIN region are fetched from where their row-table entries say they lie (module stores for rows a fresh prompt stages, the
+// arena itself for the rest); the workgroups of q-block 0 -- one per (kv head, KV split): together they walk every staged key once
+// -- write the rows that are not in the arena yet, from the ring stage they just waited for (each wave stores the 8 KiB it
+// DMA'd: its own lane-linear chunks, back through the swizzle).  Entries are fetched one stage ahead of the DMA that uses them
+// (right behind the previous issue, consumed behind the loop's vmcnt(0)), so the ring's timing does not see the extra load level;
+// the stores are waited for at the end of the stage, a stage's worth of MFMAs later.
+template <bool KVLO, bool PRE, bool GATHER = false>
 __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParams p) {
+    static_assert(!(GATHER && PRE), "the staging stream has no shared prefix");
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
     constexpr int D = RD, KS = RKS, DB = RDB, CPR = RCPR;
     constexpr int NREG = (PRE || KVLO) ? 2 : 1;      // [prefix | own rows]  or  [own rows, plain | own rows, with residuals]
@@ -192,14 +200,25 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
 
     // ---- staging: lane -> (row of the plane, chunk position), source chunk by the tile's swizzle ----
     // wave-instruction j of a plane covers rows 4 * (8 j + wave) .. + 4 (1 KiB); lane l: row + (l >> 4), position l & 15
-    int srow[2], skoff[2], svoff[2];
+    // (GATHER: recomputed from the lane id at each use -- six registers the arithmetic phase needs more)
+    struct LaneSlot { int srow[2], skoff[2], svoff[2]; };
+    auto lane_slots = [&](int l) {
+        LaneSlot z;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 4 * (8 * j + wave) + (lane >> 4), c = lane & 15;
-        srow[j] = r;
-        skoff[j] = (c ^ (r & 15)) << 3;                       // K: position c holds chunk c ^ (row & 15)
-        svoff[j] = ((c - 2 * (r & 7)) & 15) << 3;             // V: position c holds chunk (c - 2 (row & 7)) mod 16
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int r = 4 * (8 * j + wave) + (l >> 4), c = l & 15;
+            z.srow[j] = r;
+            z.skoff[j] = (c ^ (r & 15)) << 3;                 // K: position c holds chunk c ^ (row & 15)
+            z.svoff[j] = ((c - 2 * (r & 7)) & 15) << 3;       // V: position c holds chunk (c - 2 (row & 7)) mod 16
+        }
+        return z;
+    };
+    auto fresh_slots = [&]() {
+        int l = lane;
+        if constexpr (GATHER) asm volatile("" : "+v"(l));
+        return lane_slots(l);
+    };
+    [[maybe_unused]] const LaneSlot slots0 = lane_slots(lane);
     // stage s of the walk -> its region and first key (workgroup-uniform; NREG <= 4, unrolled selects)
     auto locate = [&](int s, Region& x, int& key0) {
         x = reg[0];
@@ -215,16 +234,66 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
         }
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    // GATHER: the row-table entries of this lane's four DMA slots of the NEXT stage to issue are themselves fetched by LDS-DMA
+    // (4 x 1 KiB per wave and stage, right behind the previous stage's tile DMA; landed by the loop's next vmcnt(0)): no register
+    // holds them across a stage's arithmetic and hipcc sees no load it would wait for in the wrong place.  128 KiB of ring +
+    // 32 KiB of entries = all of the CU's LDS, one workgroup per CU as before.  g_nost: do-not-store lane masks (ballots, in SGPRs) of the
+    // three stages in flight: [0] the stage being multiplied, [1] the one landing, [2] the one just issued.
+    __shared__ __attribute__((aligned(16))) char gtab[GATHER ? kRingThreads * 64 : 16];
+    [[maybe_unused]] const uint32_t gtab0 = GATHER ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)gtab + wave * 4096 : 0;
+    [[maybe_unused]] uint64_t g_nost[3][4] = {{~0ull, ~0ull, ~0ull, ~0ull}, {~0ull, ~0ull, ~0ull, ~0ull}, {~0ull, ~0ull, ~0ull, ~0ull}};
+    [[maybe_unused]] auto g_rotate = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g_nost[0][k] = g_nost[1][k]; g_nost[1][k] = g_nost[2][k]; }
+    };
+    [[maybe_unused]] const bool g_writer = GATHER && qblk == 0 && (h % (p.H / p.Hkv)) == 0;
+    [[maybe_unused]] auto fetch_entries = [&](int stage) {
+        if constexpr (GATHER) {
+            if (stage >= nst) return;
+            Region x;
+            int skey0;
+            locate(stage, x, skey0);
+            if (x.lo) return;                                  // (workgroup-uniform) the pass's own rows are read from the arena as always
+            const int last = x.e - 1;
+            const LaneSlot z = fresh_slots();
+            const int* srow = z.srow;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int key = skey0 + t * kTK + srow[j];
+                    glds16_raw((const _Float16*)(p.rows + (key < last ? key : last)), gtab0 + (2 * t + j) * 1024);
+                }
+        }
+    };
     auto issue = [&](int stage, uint32_t buf) {
         Region x;
         int skey0;
         locate(stage, x, skey0);
         const int last = x.e - 1;
+        const LaneSlot z = GATHER ? fresh_slots() : slots0;
+        const int *srow = z.srow, *skoff = z.skoff, *svoff = z.svoff;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t dst = buf + (8 * j + wave) * 1024;
+                if constexpr (GATHER) {
+                    if (!x.lo) {
+                        const u32x4 e = *(const u32x4*)(gtab + wave * 4096 + (2 * t + j) * 1024 + lane * 16);
+                        const uint64_t base = ((uint64_t)e[1] << 32) | e[0];
+                        const uint64_t ka = base + (((uint64_t)(uint32_t)(p.g_kplane + hkv) * e[2]) << 4) + (uint32_t)(skoff[j] * 2);
+                        const uint64_t va = base + (((uint64_t)(uint32_t)(p.g_vplane + hkv) * e[2]) << 4) + (uint32_t)(svoff[j] * 2);
+                        const int key = skey0 + t * kTK + srow[j];
+                        const uint32_t nostore = (key <= last && !(e[3] & PC_KV_ROW_STAGED)) ? 0u : 1u;
+                        g_nost[2][2 * t + j] = __ballot(nostore);
+                        glds16_raw((const _Float16*)(uintptr_t)ka, dst + (2 * t) * kPlane);
+                        glds16_raw((const _Float16*)(uintptr_t)va, dst + (2 * t + 1) * kPlane);
+                        __builtin_amdgcn_sched_barrier(0);         // one slot's entry and addresses in registers at a time
+                        continue;
+                    }
+                    g_nost[2][2 * t + j] = ~0ull;              // (the pass's own rows: nothing to store)
+                }
                 if (x.lo) {
                     // one tile with residuals: planes K V Klo Vlo (t = 0: K, V; t = 1: Klo, Vlo)
                     int key = skey0 + srow[j];
@@ -509,10 +578,20 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
     if (nst > 0) {
+        if constexpr (GATHER) { fetch_entries(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         issue(0, lds0);
+        if constexpr (GATHER) { g_rotate(); g_rotate(); }                       // stage 0's masks -> [0]
         if (nst > 1) {
+            if constexpr (GATHER) { fetch_entries(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             issue(1, lds0 + kStage);
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");      // stage 0 landed, everyone's
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g_nost[1][k] = g_nost[2][k];          // stage 1's masks -> [1]
+                fetch_entries(2);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // (the entry DMA sits behind the tile DMA in the queue: drain)
+            } else {
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // stage 0 landed, everyone's
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -525,6 +604,29 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             Region x;
             int key0;
             locate(i, x, key0);
+            if constexpr (GATHER) {
+                // ---- stage i has landed: the rows of it that are not in the arena yet leave for it ----
+                if (g_writer && !x.lo) {
+                    _Float16* kd = const_cast<_Float16*>(p.k) + (int64_t)hkv * p.kv_hs;
+                    _Float16* vd = const_cast<_Float16*>(p.v) + (int64_t)hkv * p.kv_hs;
+                    const LaneSlot z = fresh_slots();
+                    const int *srow = z.srow, *skoff = z.skoff, *svoff = z.svoff;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (!((g_nost[0][2 * t + j] >> lane) & 1ull)) {
+                                const char* src = buf + (8 * j + wave) * 1024 + lane * 16;
+                                const u32x4 kc = *(const u32x4*)(src + (2 * t) * kPlane);
+                                const u32x4 vc = *(const u32x4*)(src + (2 * t + 1) * kPlane);
+                                const int64_t key = key0 + t * kTK + srow[j];
+                                __builtin_nontemporal_store(kc, (u32x4*)(kd + key * D + skoff[j]));
+                                __builtin_nontemporal_store(vc, (u32x4*)(vd + key * D + svoff[j]));
+                            }
+                            __builtin_amdgcn_sched_barrier(0);     // one row pair at a time: eight chunks in registers at once cost a spill
+                        }
+                }
+            }
             if (wave_active && key0 < wave_vis_end) {
                 if (KVLO && x.lo) {
                     run_tile((const _Float16*)buf, (const _Float16*)(buf + kPlane), (const _Float16*)(buf + 2 * kPlane),
@@ -549,6 +651,7 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
 #if PC_RING_EXP != 2      // (2: dev probe without the ring's synchronisation and refills)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (i + 2 < nst) issue(i + 2, lds0 + (i & 1) * kStage);
+                if constexpr (GATHER) { g_rotate(); fetch_entries(i + 3); }
 #endif
             }
         }
@@ -640,6 +743,9 @@ int launch_attn_ring(const AttnParams& p0, int B, hipStream_t stream) {
     if (p.pre_k) {
         if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((attn_ring_kernel<false, true>), grid, block, 0, stream, p);
+    } else if (p.rows) {         // stage while reading (pc_attn gather_rows)
+        if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_ring_kernel<false, false, true>), grid, block, 0, stream, p);
     } else if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_ring_kernel<false, false>), grid, block, 0, stream, p);
     return pc_check_launch("attn_ring_kernel");

@@ -28,7 +28,7 @@ from .llama_hip import LlamaHIP
 
 class FalconHIP(LlamaHIP):
     _shared_prefix_loop = False     # (its many-row loop keeps a copy of the trunk per batch row)
-    supports_fused_gather = False   # (its layer loops read staged rows from the arena: PromptCache.update copies at once)
+    supports_fused_gather = True    # (the weight-streaming loop hands pc_attn the row table: the first forward stages, as in LlamaHIP)
 
     def __init__(self, shape: FalconShape, weights: Dict[str, torch.Tensor], device="cuda:0", decode_headroom: int = 256,
                  skinny: bool = True, int8_weights: bool = False):
@@ -181,7 +181,8 @@ class FalconHIP(LlamaHIP):
                             lo_base=lo_base, wscale=lw["wqkv_s"])
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, 1, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo)
+                       q_lo=q16l, kv_lo=kvlo,
+                       gather=None if self._gather is None else (self._gather, li * 2, li * 2 + 1))     # (one K/V head: planes 2 li, 2 li + 1)
             n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs[:KQ], ldy=hid, kslices=KQ, wscale=lw["wo_s"])
             n.gemm_skinny(lw["w1_f"], xh, xl, T, inter, hid, n.EPI_GELU, of_hi=ch, of_lo=cl, wscale=lw["w1_s"])
             n.gemm_skinny(lw["w2_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs[KQ:], ldy=hid, kslices=KQ, wscale=lw["w2_s"])

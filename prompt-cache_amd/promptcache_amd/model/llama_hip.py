@@ -764,7 +764,8 @@ class LlamaHIP:
                                     arena.cap, past_dev, kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
                 n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                            B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                           q_lo=q16l, kv_lo=kvlo)
+                           q_lo=q16l, kv_lo=kvlo,
+                           gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
                 cd, xs = quant(1, ah, H * D, bufs[1])
                 n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
                 cd, xs = quant(2, xh, hid, bufs[2], norm=(x, lw["ln2"]))
@@ -783,7 +784,8 @@ class LlamaHIP:
                                kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H))
+                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
+                       gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
             cd, xs, corr, hs = self._i8_lin_frag(1, ah, H * D, lw, "wo", None, T, hid, bufs[1])
             n.gemm_skinny_a8(lw["wo_f"], lw["wo_s"], cd, zero, xs, corr, hs, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
             cd, xs, corr, hs = self._i8_lin_frag(2, xh, hid, lw, "wgu", None, T, 2 * inter, bufs[2], norm=(x, lw["ln2"], eps))
@@ -973,7 +975,7 @@ class LlamaHIP:
         return self._gather_shape_ok(arena, B, q_len, past_len)
 
     def _gather_shape_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
-        if not self.supports_fused_gather or self.llm_int8 or B != 1 or self.use_chain or past_len <= 0:
+        if not self.supports_fused_gather or B != 1 or self.use_chain or past_len <= 0:
             return False
         ck = (q_len, self._lo_mode, past_len + q_len >= 256, self._attn_counters is None)
         ok = self._gather_ok_cache.get(ck)

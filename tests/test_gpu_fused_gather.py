@@ -70,6 +70,15 @@ GATHER_CASES = [
     (8, 2, 128, 32, [40, 1, 300, 7, 129], 41, True),                                   # GQA, kept prefix, a full 32-row tile pair
     (16, 16, 64, 20, [100, 1, 1, 250], 0, True),                                       # D = 64
     (4, 4, 32, 17, [64, 64, 1, 90], 0, True),                                          # D = 32, short cache (< 256 keys)
+    # more than 32 new rows at head_dim 128: the ring kernel (attn_ring_kernel<KVLO, false, GATHER>): the q-block-0 workgroup of
+    # each kv head stores every landed stage; the row-table entries travel by LDS-DMA one stage ahead of the tiles
+    (32, 32, 128, 100, [275, 1, 1, 1, 1, 1, 84, 1, 1, 174, 1, 1, 256, 1, 1, 155, 1, 1, 267, 1, 1, 265, 1, 1, 232], 0, True),
+    (40, 40, 128, 259, [8000], 0, True),                                               # config 4: three q-blocks, XCD remap, no KV splits
+    (8, 2, 128, 130, [40, 1, 300, 7, 129], 41, True),                                  # GQA, kept prefix, two q-blocks, KV splits
+    (32, 32, 128, 64, [500, 1, 120], 0, False),                                        # no residual planes for the pass's own rows
+    (4, 4, 128, 40, [30], 0, True),                                                    # less than one stage of staged keys
+    (4, 4, 128, 33, [127, 1, 128, 1, 255], 0, True),                                   # segment ends at and next to stage boundaries
+    (16, 16, 128, 300, [1, 1, 1, 3000, 1, 1], 0, True),
 ]
 
 

@@ -246,7 +246,17 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
 #pragma unroll
         for (int k = 0; k < 4; ++k) { g_nost[0][k] = g_nost[1][k]; g_nost[1][k] = g_nost[2][k]; }
     };
-    [[maybe_unused]] const bool g_writer = GATHER && qblk == 0 && (h % (p.H / p.Hkv)) == 0;
+    // Who stores: every workgroup of a kv head's group streams the same staged keys (they lie in front of every query row), so
+    // the landed stages are dealt out over all of them -- stage i leaves with writer i mod g_nw.  The stores are issued in front
+    // of the stage's arithmetic, which hides their completion; a light last q-block (config 4's 259 rows = 128 + 128 + 3) has no
+    // arithmetic to hide it behind but is one memory round trip per stage ahead of the others anyway.  (One writer per kv head:
+    // +47 us per launch at config 4, all stages to the light block: +43 us, dealt out: see profiles/r04_variants.txt.)
+    [[maybe_unused]] int g_w = -1, g_nw = 1;
+    if constexpr (GATHER) {
+        const int group = p.H / p.Hkv, nqb = p.nqblk;
+        g_nw = group * nqb;
+        g_w = (h % group) * nqb + qblk;
+    }
     [[maybe_unused]] auto fetch_entries = [&](int stage) {
         if constexpr (GATHER) {
             if (stage >= nst) return;
@@ -254,6 +264,9 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             int skey0;
             locate(stage, x, skey0);
             if (x.lo) return;                                  // (workgroup-uniform) the pass's own rows are read from the arena as always
+#ifdef PC_RING_G_NOFETCH
+            return;
+#endif
             const int last = x.e - 1;
             const LaneSlot z = fresh_slots();
             const int* srow = z.srow;
@@ -273,14 +286,24 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
         const int last = x.e - 1;
         const LaneSlot z = GATHER ? fresh_slots() : slots0;
         const int *srow = z.srow, *skoff = z.skoff, *svoff = z.svoff;
+        // (GATHER: the four entries of the stage come out of LDS in one batch -- one LDS round trip in front of the eight DMA
+        // instructions, not one per slot: 0.4 us per stage otherwise, tools/ring_gather_micro.py)
+        [[maybe_unused]] u32x4 ent[GATHER ? 4 : 1];
+        if constexpr (GATHER) {
+            if (!x.lo) {
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) ent[sl] = *(const u32x4*)(gtab + wave * 4096 + sl * 1024 + lane * 16);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t dst = buf + (8 * j + wave) * 1024;
+#ifndef PC_RING_G_PLAINADDR     // (dev probe: the staging instantiation with the plain launch's addressing -- all rows must be staged)
                 if constexpr (GATHER) {
                     if (!x.lo) {
-                        const u32x4 e = *(const u32x4*)(gtab + wave * 4096 + (2 * t + j) * 1024 + lane * 16);
+                        const u32x4 e = ent[2 * t + j];
                         const uint64_t base = ((uint64_t)e[1] << 32) | e[0];
                         const uint64_t ka = base + (((uint64_t)(uint32_t)(p.g_kplane + hkv) * e[2]) << 4) + (uint32_t)(skoff[j] * 2);
                         const uint64_t va = base + (((uint64_t)(uint32_t)(p.g_vplane + hkv) * e[2]) << 4) + (uint32_t)(svoff[j] * 2);
@@ -289,11 +312,11 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
                         g_nost[2][2 * t + j] = __ballot(nostore);
                         glds16_raw((const _Float16*)(uintptr_t)ka, dst + (2 * t) * kPlane);
                         glds16_raw((const _Float16*)(uintptr_t)va, dst + (2 * t + 1) * kPlane);
-                        __builtin_amdgcn_sched_barrier(0);         // one slot's entry and addresses in registers at a time
                         continue;
                     }
                     g_nost[2][2 * t + j] = ~0ull;              // (the pass's own rows: nothing to store)
                 }
+#endif
                 if (x.lo) {
                     // one tile with residuals: planes K V Klo Vlo (t = 0: K, V; t = 1: Klo, Vlo)
                     int key = skey0 + srow[j];
@@ -606,7 +629,7 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
             locate(i, x, key0);
             if constexpr (GATHER) {
                 // ---- stage i has landed: the rows of it that are not in the arena yet leave for it ----
-                if (g_writer && !x.lo) {
+                if (!x.lo && i % g_nw == g_w) {
                     _Float16* kd = const_cast<_Float16*>(p.k) + (int64_t)hkv * p.kv_hs;
                     _Float16* vd = const_cast<_Float16*>(p.v) + (int64_t)hkv * p.kv_hs;
                     const LaneSlot z = fresh_slots();
@@ -623,7 +646,6 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
                                 __builtin_nontemporal_store(kc, (u32x4*)(kd + key * D + skoff[j]));
                                 __builtin_nontemporal_store(vc, (u32x4*)(vd + key * D + svoff[j]));
                             }
-                            __builtin_amdgcn_sched_barrier(0);     // one row pair at a time: eight chunks in registers at once cost a spill
                         }
                 }
             }

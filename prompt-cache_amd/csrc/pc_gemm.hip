@@ -254,9 +254,9 @@ PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
     const bool norm = a->x != nullptr;
     PC_REQUIRE(a->wf && (norm ? (a->norm_weight && !a->xf_hi) : (a->xf_hi != nullptr)), PC_ERR_ARG,
                "pc_gemm: pass the weight image and either the activation planes or (x, norm_weight)");
-    PC_REQUIRE(!norm || (M <= 16 && K <= 32 * kGamSteps * kWaves &&
+    PC_REQUIRE(!norm || (M <= (a->w_scale ? 16 : 32) && K <= 32 * kGamSteps * kWaves &&
                          (epi == PC_GEMM_EPI_STORE || epi == PC_GEMM_EPI_SILU || qkv) && a->kslices <= 1), PC_ERR_ARG,
-               "pc_gemm: the fused-RMSNorm source needs M <= 16, K <= 16384, no K-slicing, epilogue store / SiLU / q|k|v");
+               "pc_gemm: the fused-RMSNorm source needs M <= 32 (16 with int8 weights), K <= 16384, no K-slicing, epilogue store / SiLU / q|k|v");
     const int kslices = a->kslices < 1 ? 1 : a->kslices;
     const bool fused = a->flags != nullptr;                       // in-launch LLM.int8 outlier correction
     PC_REQUIRE(!a->w_scale || (M <= 64 && (norm || a->xf_lo) && ((uintptr_t)a->w_scale & 15) == 0 && K % 64 == 0), PC_ERR_ARG,

@@ -93,7 +93,7 @@ constexpr int kSyncWave = kWaves - 1;          // the wave that arrives / polls 
 template <int T, int EPI, int U, bool NORM, bool HAVE_PRE, class PF>
 __device__ __forceinline__ void chain_phase(const GemmParams& p, int nblk, const GridSync& gs, uint32_t seam, bool last_seam,
                                             const h8 (*pre)[(EPI == EPI_SILU) ? 2 * T : T], PF prefetch_next,
-                                            float* red, float (*ssl)[16], _Float16* gam_lds) {
+                                            float* red, float (*ssl)[32], _Float16* gam_lds) {
     static_assert(T <= 4, "one reduction round, and the sync wave never stores");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool storing = wave < T;                        // single-round launches (MT = 1): output item w is wave w's
@@ -141,7 +141,7 @@ __device__ __forceinline__ void chain_phase(const GemmParams& p, int nblk, const
 template <int TO, int TG, int TD, int TQ, int UO, int UG, int UD, int UQ>
 __global__ __launch_bounds__(kThreads) void gemm_chain_kernel(const ChainParams c) {
     __shared__ __attribute__((aligned(16))) float red[kWaves * 8 * 64 * 4];      // 64 KiB: the widest phase's reduction buffer
-    __shared__ float ssl[kWaves][16];
+    __shared__ float ssl[kWaves][32];
     __shared__ __attribute__((aligned(16))) _Float16 gam_lds[kWaves * kGamHalfs];
     GridSync gs;
     gs.init(c.sync);

@@ -264,16 +264,16 @@ struct GammaStage {
     }
 };
 
-template <int TT, int U, bool TAIL, bool W8 = false, bool PRE = false>
-__device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT], const float* xrow, const _Float16* gam,
-                                             int ks, int nvalid, bool row_ok, f4 (&acc)[1][TT], float& ss,
+template <int MT, int TT, int U, bool TAIL, bool W8 = false, bool PRE = false>
+__device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT], const float* const (&xrow)[MT], const _Float16* gam,
+                                             int ks, int nvalid, const bool (&row_ok)[MT], f4 (&acc)[MT][TT], float (&ss)[MT],
                                              GammaStage& gst, const h8 (*wpre)[TT] = nullptr) {
     static_assert(!PRE || (!TAIL && !W8), "prefetched first blocks are full fp16 blocks");
     constexpr int NW = W8 ? U / 2 : U;                   // W8: k-step pairs per 16-byte load, see k_block
     static_assert(!W8 || U % 2 == 0, "int8 weights come in k-step pairs");
     h8 w[W8 ? 1 : U][TT], gw[U];
     u32x4 raw[W8 ? NW : 1][TT];
-    f4 xa[U][2];
+    f4 xa[MT][U][2];
 #pragma unroll
     for (int u = 0; u < NW; ++u)
 #pragma unroll
@@ -289,17 +289,19 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
             }
         }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
-        f4 z = {0.f, 0.f, 0.f, 0.f};
-        xa[u][0] = z; xa[u][1] = z;
-    }
-    if (row_ok) {
+    for (int a = 0; a < MT; ++a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
-            xa[u][0] = *(const f4*)(xrow + (ks + uu) * 32);
-            xa[u][1] = *(const f4*)(xrow + (ks + uu) * 32 + 4);
+            f4 z = {0.f, 0.f, 0.f, 0.f};
+            xa[a][u][0] = z; xa[a][u][1] = z;
+        }
+        if (row_ok[a]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int uu = (TAIL && u >= nvalid) ? nvalid - 1 : u;
+                xa[a][u][0] = *(const f4*)(xrow[a] + (ks + uu) * 32);
+                xa[a][u][1] = *(const f4*)(xrow[a] + (ks + uu) * 32 + 4);
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -312,23 +314,28 @@ __device__ __forceinline__ void k_block_norm(const _Float16* const (&wbase)[TT],
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (TAIL && u >= nvalid) continue;              // the re-read k-step contributes nothing
-        h8 hi, lo;
+        h8 hi[MT], lo[MT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xv = e < 4 ? xa[u][0][e] : xa[u][1][e - 4];
-            ss += xv * xv;
-            const float v = xv * (float)gw[u][e];
-            _Float16 vh, vl;
-            pc_split(v, vh, vl);
-            hi[e] = vh; lo[e] = vl;
-        }
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xv = e < 4 ? xa[a][u][0][e] : xa[a][u][1][e - 4];
+                ss[a] += xv * xv;
+                const float v = xv * (float)gw[u][e];
+                _Float16 vh, vl;
+                pc_split(v, vh, vl);
+                hi[a][e] = vh; lo[a][e] = vl;
+            }
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             h8 wv;
             if constexpr (W8) wv = (u & 1) ? cvt_w8(raw[u >> 1][t][2], raw[u >> 1][t][3]) : cvt_w8(raw[u >> 1][t][0], raw[u >> 1][t][1]);
             else wv = w[u][t];
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, hi, acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, lo, acc[0][t], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, hi[a], acc[a][t], 0, 0, 0);
+                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, lo[a], acc[a][t], 0, 0, 0);
+            }
         }
     }
 }
@@ -540,10 +547,10 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // after_k() runs between the K loop and the reduction (pc_gemm_chain: the early prefetch of the next phase's weights).
 template <int MT, int T, int EPI, bool TWO, int U, bool NORM = false, bool W8 = false, bool PRE = false, class AfterK = NoHook>
 __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int bx, const int by,
-                                                 float* red_raw, float (*ssl)[16],
+                                                 float* red_raw, float (*ssl)[32],
                                                  const h8 (*wpre)[(EPI == EPI_SILU) ? 2 * T : T] = nullptr,
                                                  AfterK after_k = AfterK(), _Float16* gam_lds = nullptr) {
-    static_assert(!NORM || (MT == 1 && TWO), "the fused-RMSNorm source is for one row tile");
+    static_assert(!NORM || (MT <= 2 && TWO), "the fused-RMSNorm source is for one or two row tiles");
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;   // weight tiles reduced per workgroup
     constexpr int TPI = (EPI == EPI_SILU) ? 2 : 1;                 // tiles per output item
     constexpr int kRT = (MT * TT < 8) ? MT * TT : 8;               // tiles per wave in the reduction buffer (<= 64 KiB)
@@ -590,25 +597,32 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
 #pragma unroll
     for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < rows_live;
     int ks = ks0;
-    [[maybe_unused]] float ss = 0.f;
+    [[maybe_unused]] float ss[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) ss[a] = 0.f;
     if constexpr (NORM) {
-        const float* xrow = p.xn + (int64_t)m * (KS * 32) + g * 8;
+        const float* xrow[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) xrow[a] = p.xn + (int64_t)(a * 16 + m) * (KS * 32) + g * 8;   // (rows behind rows_live are never read)
         // the RMSNorm gain of this wave's K range through its LDS slice (GammaStage; the launcher guarantees <= kGamSteps k-steps)
         _Float16* gslice = gam_lds + wave * kGamHalfs;
         GammaStage gst;
         gst.issue(p.gamma + (int64_t)ks0 * 32, gslice, (ks1 - ks0) * 32, lane);
         const _Float16* gam = gslice + g * 8 - ks0 * 32;
         if constexpr (PRE) {
-            k_block_norm<TT, U, false, W8, true>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss, gst, wpre);
+            k_block_norm<MT, TT, U, false, W8, true>(wbase, xrow, gam, ks, U, row_ok, acc, ss, gst, wpre);
             ks += U;
         }
         int blk = 0;
-        for (; ks + U <= ks1; ks += U) { alt_prio(p, wave, blk); k_block_norm<TT, U, false, W8>(wbase, xrow, gam, ks, U, row_ok[0], acc, ss, gst); }
-        if (ks < ks1) { alt_prio(p, wave, blk); k_block_norm<TT, U, true, W8>(wbase, xrow, gam, ks, ks1 - ks, row_ok[0], acc, ss, gst); }
+        for (; ks + U <= ks1; ks += U) { alt_prio(p, wave, blk); k_block_norm<MT, TT, U, false, W8>(wbase, xrow, gam, ks, U, row_ok, acc, ss, gst); }
+        if (ks < ks1) { alt_prio(p, wave, blk); k_block_norm<MT, TT, U, true, W8>(wbase, xrow, gam, ks, ks1 - ks, row_ok, acc, ss, gst); }
         if (p.prio_alt) __builtin_amdgcn_s_setprio(0);
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        if (g == 0) ssl[wave][m] = ss;                   // this wave's share of sum(x^2) of row m
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            ss[a] += __shfl_xor(ss[a], 16);
+            ss[a] += __shfl_xor(ss[a], 32);
+            if (g == 0) ssl[wave][a * 16 + m] = ss[a];   // this wave's share of sum(x^2) of row 16 a + m
+        }
     } else {
         if constexpr (PRE) {
             k_block<MT, TT, TWO, U, false, W8, true>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc, wpre);
@@ -802,7 +816,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
         if constexpr (NORM) {
             float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) tot += ssl[w][m];
+            for (int w = 0; w < kWaves; ++w) tot += ssl[w][a * 16 + m];
             const float rs = rsqrtf(tot / (float)(KS * 32) + p.eps);
             v[0] *= rs; v[1] *= rs; v[2] *= rs; v[3] *= rs;
             u[0] *= rs; u[1] *= rs; u[2] *= rs; u[3] *= rs;
@@ -821,7 +835,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
     constexpr int kRT = (MT * TT < 8) ? MT * TT : 8;
     __shared__ __attribute__((aligned(16))) float red[kWaves * kRT * 64 * 4];
-    __shared__ float ssl[kWaves][16];
+    __shared__ float ssl[kWaves][32];
     __shared__ __attribute__((aligned(16))) _Float16 gam_lds[NORM ? kWaves * kGamHalfs : 8];
     gemm_skinny_body<MT, T, EPI, TWO, U, NORM, W8>(p, (int)blockIdx.x, (int)blockIdx.y, red, ssl, nullptr, NoHook(), gam_lds);
 }
@@ -860,9 +874,10 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
             launch_w8<MT, T, EPI, UW>(p, grid, block, s);                                             \
             break;                                                                                    \
         }                                                                                             \
-        if constexpr (MT == 1 && EPI != EPI_ADD) {                                                    \
-            if (p.xn) {                                                                               \
-                hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UV, true>), grid, block, 0, s, p); \
+        if constexpr (MT <= 2 && EPI != EPI_ADD) {                                                    \
+            if (p.xn) {   /* (two row tiles of fp32 rows: eight k-steps of them in flight spill) */       \
+                constexpr int UN = (MT == 2 && (UV) > 4) ? 4 : (UV);                                  \
+                hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UN, true>), grid, block, 0, s, p); \
                 break;                                                                                \
             }                                                                                         \
         }                                                                                             \

@@ -185,7 +185,10 @@ class LlamaHIP:
     gate|up projections so each is one GEMM."""
 
     SKINNY_MAX_ROWS = 64   # B*q_len at or below this: split-precision weight-streaming kernels inside one hipGraph
-    NORM_FUSED_MAX_ROWS = 16   # ... and at or below this the RMSNorms are folded into the projections
+    # ... and at or below this the RMSNorms are folded into the projections.  The kernels take two row tiles as well
+    # (PC_NORM_FUSED_MAX=32), but at 17..32 rows the six-launch loop measured SLOWER than slabs + pc_rmsnorm_frag (7b, 24 rows:
+    # 110 vs 107 us of projections per layer -- o_proj / down_proj lose their K slices; profiles/r04_variants.txt)
+    NORM_FUSED_MAX_ROWS = int(os.environ.get("PC_NORM_FUSED_MAX", "16"))
     # ... and up to here: the row-split weight-streaming kernel (gemm_rows_kernel, pc_gemm.hip), launched eagerly; above,
     # pc_gemm_dense.  Crossover against pc_gemm_dense_ws (tools/dense_vs_rows.py, profiles/r02_dense_splitk.txt, 7b layer,
     # split-precision planes on both sides): 259 rows 322 vs 402 us per layer, 512 rows 455 vs 441 us -- the streaming
@@ -882,7 +885,7 @@ class LlamaHIP:
     # ------------------------------------------------------------------------------------------
     def _layers_norm_fused(self, x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
                            last_token_only, tail=None):
-        """T <= 16 rows: six launches per layer.  Both RMSNorms are folded into the projections that consume them
+        """T <= 32 rows (NORM_FUSED_MAX_ROWS): six launches per layer.  Both RMSNorms are folded into the projections that consume them
         (pc_gemm_*_norm read the fp32 residual stream directly) and both residual adds into the o_proj / down_proj
         epilogues, so x is the only activation that round-trips through memory in fp32."""
         n = _native
@@ -893,7 +896,7 @@ class LlamaHIP:
         # one persistent launch (pc_gemm_chain: the same four bodies, bit-identical, but the weight stream runs through
         # the seams); three launches per layer instead of six.  Shapes without an instantiation fall back here.
         rows_dev = past_dev[2:3] if (past_dev is not None and past_dev.numel() > 2 and B == 1) else None
-        chain = self.use_chain and layers and layers[0]["wqkv_s"] is None
+        chain = self.use_chain and layers and layers[0]["wqkv_s"] is None and T <= 16
         if chain and self._chain_sync is None:
             self._chain_sync = n.chain_sync_state(self.device)
         qkv_done = False
@@ -925,14 +928,14 @@ class LlamaHIP:
                     continue
                 except RuntimeError:
                     chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
-            if self.ks_o and lw["wo_s"] is None and T >= self.ks_min_rows:
+            if self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 16:      # (the in-launch K reduction: one row tile)
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr, rows_dev=rows_dev)
             else:
                 n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"], rows_dev=rows_dev)  # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
                                wscale=lw["wgu_s"], rows_dev=rows_dev)
-            if self.ks_down and lw["wdown_s"] is None and T >= self.ks_min_rows and inter >= 2 * hid:
+            if self.ks_down and lw["wdown_s"] is None and self.ks_min_rows <= T <= 16 and inter >= 2 * hid:
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, x, hid, self.ks_down[1], self.ks_down[0], sc, ctr, rows_dev=rows_dev)
             else:
@@ -1267,7 +1270,7 @@ class LlamaHIP:
         qkv_slabs = torch.empty((QS, T, W), dtype=torch.float32, device=dev) if QS > 1 else None
         pending = 0                                   # slabs waiting to be added to x
         layers = self.layers if num_layers is None else self.layers[:num_layers]
-        if T <= self.NORM_FUSED_MAX_ROWS and self.fuse_norm:
+        if T <= (16 if self.int8_weights else self.NORM_FUSED_MAX_ROWS) and self.fuse_norm:   # (int8 weight images: one row tile)
             return self._layers_norm_fused(x, cs, q16, q16l, ws, ah, al, ch, cl, arena, layers, B, q_len, past_len, past_dev,
                                            last_token_only, tail)
         for li, lw in enumerate(layers):

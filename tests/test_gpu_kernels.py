@@ -773,10 +773,11 @@ def test_gemm_rows_qkv_rope_with_k_slices_equals_the_single_launch(B, H, Hkv, q_
 
 
 # ---------------------------------------------------------------------------------------------------
-# RMSNorm folded into the projection (M <= 16)
+# RMSNorm folded into the projection (M <= 32: one or two row tiles)
 # ---------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("M,N,K", [(12, 12288, 4096), (1, 4096, 4096), (16, 32000, 4096), (5, 48, 32), (14, 15360, 5120), (3, 64, 96)])
+@pytest.mark.parametrize("M,N,K", [(12, 12288, 4096), (1, 4096, 4096), (16, 32000, 4096), (5, 48, 32), (14, 15360, 5120), (3, 64, 96),
+                                   (17, 4096, 4096), (26, 32000, 4096), (32, 12288, 4096), (20, 48, 32), (29, 15360, 5120), (31, 64, 96)])
 def test_gemm_skinny_norm_store(M, N, K):
     n = _n()
     rng = np.random.default_rng(31)
@@ -803,7 +804,8 @@ def test_gemm_skinny_norm_store(M, N, K):
     assert torch.equal(y, y3)
 
 
-@pytest.mark.parametrize("M,inter,K", [(12, 11008, 4096), (3, 64, 32), (16, 13824, 5120), (1, 1376, 512)])
+@pytest.mark.parametrize("M,inter,K", [(12, 11008, 4096), (3, 64, 32), (16, 13824, 5120), (1, 1376, 512),
+                                       (26, 11008, 4096), (17, 64, 32), (32, 13824, 5120), (21, 1376, 512)])
 def test_gemm_skinny_norm_silu(M, inter, K):
     n = _n()
     rng = np.random.default_rng(32)
@@ -811,7 +813,7 @@ def test_gemm_skinny_norm_silu(M, inter, K):
     x = torch.from_numpy((2.0 * rng.standard_normal((M, K), dtype=np.float32))).to(DEV)
     gam = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(K, dtype=np.float32)).astype(np.float16)).to(DEV)
     eps = 1e-6
-    oh = torch.zeros((1, inter // 32, 64, 8), dtype=torch.float16, device=DEV)
+    oh = torch.zeros(((M + 15) // 16, inter // 32, 64, 8), dtype=torch.float16, device=DEV)
     ol = torch.zeros_like(oh)
     n.gemm_skinny_norm(n.to_weight_frags(w), x, gam, eps, M, 2 * inter, K, n.EPI_SILU, of_hi=oh, of_lo=ol)
     xd = x.double()
@@ -823,7 +825,9 @@ def test_gemm_skinny_norm_silu(M, inter, K):
     assert (got - ref).abs().max().item() < 2e-4 * float(ref.abs().max()) + 1e-5
 
 
-@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 7, 512), (1, 2, 2, 64, 1, 30, 256)])
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past,hid", [(1, 32, 32, 128, 12, 100, 4096), (2, 4, 2, 128, 5, 7, 512), (1, 2, 2, 64, 1, 30, 256),
+                                                       (1, 32, 32, 128, 26, 100, 4096), (2, 4, 2, 128, 11, 7, 512), (1, 2, 2, 64, 32, 30, 256),
+                                                       (1, 40, 40, 128, 17, 9, 5120)])
 def test_gemm_qkv_rope_norm_equals_two_launches(B, H, Hkv, D, q_len, past, hid):
     n = _n()
     rng = np.random.default_rng(33)

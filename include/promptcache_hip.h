@@ -260,6 +260,9 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
  *              row-bucketed hipGraph: their results are unspecified and their activations are not loaded
  *   x_scale, corr, ldc, corr_has   LLM.int8 activations (pc_quant_act_i8): the planes hold int8 CODES, x_scale[m] = SCA[m] / 127;
  *              y = (sum_k code_w code_x) * w_scale[n] * x_scale[m] (+ corr[m][n] when *corr_has: pc_outlier_corr); OR
+ *              The products run on the int8 MFMA (v_mfma_i32_16x16x64_i8, int32 sums: igemmlt's arithmetic, exact for any K).
+ *   x_codes8   (optional, with x_scale, M <= 64) the codes as the int8 operand image pc_quant_act_i8 / pc_rmsnorm_quant_i8 write
+ *              next to the fp16 codes plane: the K loop then reads it instead of xf_hi (half the activation bytes, no packing)
  *   flags, x_raw, w_codes_t, ldt, row_perm   the outlier correction computed INSIDE the launch (M <= 64): the flag bytes of
  *              pc_quant_act_i8 (>= 16384 bytes, zero behind K), the fp16 activations (fragment plane), the transposed int8 weight
  *              codes [K][ldt] (original row order) and, for q|k|v, the image-row -> original-row permutation
@@ -286,6 +289,7 @@ typedef struct pc_gemm_args {
     int64_t arena_batch_stride, arena_head_stride;
     int32_t B, H, Hkv, D, q_len, past_len, cap;
     const int32_t* past_len_dev; void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_base;
+    const void* x_codes8;
 } pc_gemm_args;
 int pc_gemm(const pc_gemm_args* args, void* stream);
 int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
@@ -455,7 +459,10 @@ int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* attn_lo, in
  *   y = (sum_k w_code[n][k] * x_code[m][k]) * w_scale[n] * x_scale[m] + (*corr_has ? corr[m][n] : 0), then the epilogue
  *   (same epilogue codes and outputs as with fp16 operands). */
 int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale, void* flags_set,
-                    void* flags_clear, int32_t clear_len, float threshold, void* stream);
+                    void* flags_clear, int32_t clear_len, float threshold, void* codes8, void* stream);
+/* codes8 (optional; K % 64 == 0, 16-byte aligned, ceil(T/16) * K * 16 bytes): the same codes as the int8 MFMA's operand image
+ * [T/16][K/64][64][16] -- a lane's 16 signed bytes = its eight codes of k-step 2s, then of 2s + 1, the byte order of the int8
+ * weight image -- for pc_gemm's x_codes8: the projection then loads half the activation bytes and converts nothing. */
 /* (pc_gemm with `flags` computes the outlier correction INSIDE the projection launch, M <= 64: every workgroup compacts the flags
  * and its eight waves share the outlier columns; equal to pc_outlier_corr + the corr form up to the fp32 summation order over the
  * outlier columns.  Saves one launch per projection, ~4 us even when no column is flagged.) */
@@ -464,7 +471,8 @@ int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t
  * x: fp32 residual stream [T][hidden]; x_hi: the normalised fp16 activations (read by pc_outlier_corr), codes / x_scale / flags as
  * pc_quant_act_i8. */
 int pc_rmsnorm_quant_i8(const float* x, const void* norm_weight, float eps, int32_t T, int32_t hidden, void* x_hi, void* codes,
-                        float* x_scale, void* flags_set, void* flags_clear, int32_t clear_len, float threshold, void* stream);
+                        float* x_scale, void* flags_set, void* flags_clear, int32_t clear_len, float threshold, void* codes8,
+                        void* stream);
 int pc_outlier_corr(const void* flags, int32_t K, const void* x, const void* codes, int64_t ldx, int32_t frag,
                     const float* x_scale, const void* w_codes_t, int64_t ldt, const float* w_scale, const int32_t* row_perm,
                     int32_t T, int32_t N, float* corr, int64_t ldc, int32_t* has, void* stream);

@@ -268,6 +268,8 @@ PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
                           ((uintptr_t)a->flags & 15) == 0 && (!qkv || a->row_perm)), PC_ERR_ARG,
                "pc_gemm: the fused correction needs x_scale, w_scale, 16-byte aligned flags (>= 16384 bytes), x_raw, w_codes_t "
                "(ldt >= N), K <= 16384 (and row_perm for q|k|v)");
+    PC_REQUIRE(!a->x_codes8 || (a->x_scale && M <= 64 && ((uintptr_t)a->x_codes8 & 15) == 0), PC_ERR_ARG,
+               "pc_gemm: x_codes8 goes with x_scale (LLM.int8 activations), M <= 64, 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
 
     // ---- residual add with K split across workgroups and the reduction inside the launch (pc_gemm_ks.hip) ----
@@ -284,6 +286,7 @@ PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
     p.xn = a->x; p.gamma = (const _Float16*)a->norm_weight; p.eps = a->eps;
     p.wscale = a->w_scale; p.w8 = a->w_scale ? 1 : 0;
     p.xscale = a->x_scale; p.corr = a->corr; p.ldc = a->ldc; p.corr_has = a->corr_has;
+    p.xq8 = (const signed char*)a->x_codes8;
     if (fused) {
         p.oflags = (const unsigned char*)a->flags; p.xraw = (const _Float16*)a->x_raw; p.cbt = (const signed char*)a->w_codes_t;
         p.ldt = a->ldt; p.row_perm = a->row_perm;

@@ -88,6 +88,7 @@ struct GemmParams {
     // corr[m][n] (row stride ldc, output-feature index in the image's row order) is added before the epilogue's
     // nonlinearity when *corr_has != 0 (the fp16 outlier part of the decomposition)
     const float* xscale; const float* corr; int64_t ldc; const int32_t* corr_has;
+    const signed char* xq8;            // (optional) the codes as the int8 MFMA's operand image, [M/16][KS/2][64][16] (pc_quant_act_i8 codes8)
     // ... or the correction is computed INSIDE the launch (pc_gemm_*_a8c): oflags = the K outlier-column flag bytes of
     // pc_quant_act_i8 (buffer of >= 16384 bytes, zero behind K), xraw = the fp16 activations (fragment plane, same layout as the
     // code plane xf_hi), cbt = the int8 weight codes transposed [K][ldt] in ORIGINAL row order, row_perm = image row -> original
@@ -134,6 +135,23 @@ __device__ __forceinline__ h8 cvt_w8(uint32_t d0, uint32_t d1) {
     return out;
 }
 
+// LLM.int8 activations on the int8 MFMA: the codes plane holds integers in [-127, 127] as fp16 values (pc_quant_act_i8); the
+// eight of k-step 2s and the eight of 2s + 1 of a lane become the 16 signed bytes of one v_mfma_i32_16x16x64_i8 operand, in the
+// byte order of the weight image's 16 bytes (so the lanes of the two operands agree on which k sits where; the sum over k does
+// not care which).  Exactly: the code goes under the exponent of 1024.0 as an offset-binary byte (code + 1152 = 0x6400 | (code +
+// 128)), v_perm_b32 collects the low bytes, the XOR turns offset binary into two's complement.  6 VALU ops per k-step of a row
+// tile -- once per ROW tile; the weight fragments, which are what cost eight conversions per tile and k-step on the fp16 MFMA,
+// need one XOR per dword.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 pack_codes8(h8 c) {
+    const h2v bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+    const h2v p0 = h2v{c[0], c[1]} + bias, p1 = h2v{c[2], c[3]} + bias, p2 = h2v{c[4], c[5]} + bias, p3 = h2v{c[6], c[7]} + bias;
+    u32x2 r;
+    r[0] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p1), __builtin_bit_cast(uint32_t, p0), 0x06040200u) ^ 0x80808080u;
+    r[1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p3), __builtin_bit_cast(uint32_t, p2), 0x06040200u) ^ 0x80808080u;
+    return r;
+}
+
 // position of element (row m, feature k) in a fragment-major plane with KS k-steps
 __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
     return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
@@ -151,15 +169,18 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
 template <int MT, int TT, bool TWO, int U, bool TAIL, bool W8 = false, bool PRE = false>
 __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], const _Float16* xh_base,
                                         const _Float16* xl_base, int KS, int ks, int nvalid, const bool (&row_ok)[MT],
-                                        f4 (&acc)[MT][TT], const h8 (*wpre)[TT] = nullptr) {
+                                        f4 (&acc)[MT][TT], const h8 (*wpre)[TT] = nullptr, const signed char* x8_base = nullptr) {
     static_assert(!PRE || (!TAIL && !W8), "prefetched first blocks are full fp16 blocks");
     // W8: the image holds k-step PAIRS -- a lane's 16 bytes are its 8 values of k-step 2s and of 2s + 1 -- so one
     // global_load_dwordx4 feeds four MFMAs; ks, nvalid and U are even (the K ranges are cut on pair boundaries).  The
     // raw bytes wait in registers (half of what fp16 fragments take) and are converted right before their MFMAs.
     constexpr int NW = W8 ? U / 2 : U;
     static_assert(!W8 || U % 2 == 0, "int8 weights come in k-step pairs");
+    constexpr bool A8 = W8 && !TWO;                      // LLM.int8 codes on both sides
     h8 w[W8 ? 1 : U][TT], xh[U][MT], xl[U][MT];
     u32x4 raw[W8 ? NW : 1][TT];
+    [[maybe_unused]] u32x4 xq[A8 ? NW : 1][MT];          // x8_base: the activations' int8 operand image, one load per k-step pair
+    const bool img = A8 && x8_base != nullptr;           // (wave-uniform)
 #pragma unroll
     for (int u = 0; u < NW; ++u)
 #pragma unroll
@@ -182,6 +203,20 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
             xh[u][a] = z;
             if (TWO) xl[u][a] = z;
         }
+        if constexpr (A8) {
+#pragma unroll
+            for (int u = 0; u < NW; ++u) xq[u][a] = u32x4{0u, 0u, 0u, 0u};
+            if (img) {
+                if (row_ok[a]) {
+#pragma unroll
+                    for (int u = 0; u < NW; ++u) {
+                        const int uu = (TAIL && 2 * u >= nvalid) ? nvalid / 2 - 1 : u;
+                        xq[u][a] = *(const u32x4*)(x8_base + ((int64_t)a * (KS >> 1) + (ks >> 1) + uu) * 1024);
+                    }
+                }
+                continue;
+            }
+        }
         if (row_ok[a]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -203,6 +238,34 @@ __device__ __forceinline__ void k_block(const _Float16* const (&wbase)[TT], cons
 #pragma unroll
                 for (int t = 0; t < TT; ++t) w[u][t] = z;
             }
+    }
+    if constexpr (A8) {
+        // int8 codes on both sides (LLM.int8; launch_w8 instantiates TWO = false for x_scale launches only): one
+        // v_mfma_i32_16x16x64_i8 per weight tile and k-step PAIR, int32 accumulators kept in acc's registers (the caller converts
+        // them once, behind the K loop) -- the arithmetic Linear8bitLt's igemmlt does, exact for any K
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            if (TAIL && 2 * u >= nvalid) continue;        // (wave-uniform) the re-read pair contributes nothing
+            i32x4 xa[MT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                if (img) {
+                    xa[a] = i32x4{(int)xq[u][a][0], (int)xq[u][a][1], (int)xq[u][a][2], (int)xq[u][a][3]};
+                } else {
+                    const u32x2 lo = pack_codes8(xh[2 * u][a]), hi = pack_codes8(xh[2 * u + 1][a]);
+                    xa[a] = i32x4{(int)lo[0], (int)lo[1], (int)hi[0], (int)hi[1]};
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const u32x4 wq = raw[u][t] ^ 0x80808080u;
+                const i32x4 wv = {(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+                    acc[a][t] = __builtin_bit_cast(f4, __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, xa[a], __builtin_bit_cast(i32x4, acc[a][t]), 0, 0, 0));
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -591,6 +654,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
     for (int t = 0; t < TT; ++t) wbase[t] = p.wf + ((int64_t)tile[t] * (W8 ? KS / 2 : KS) * 64 + lane) * 8;
     const _Float16* xh_base = p.xf_hi + lane * 8;
     const _Float16* xl_base = TWO ? p.xf_lo + lane * 8 : nullptr;
+    [[maybe_unused]] const signed char* x8_base = (W8 && !TWO && p.xq8) ? p.xq8 + lane * 16 : nullptr;
 
     bool row_ok[MT];
     const int rows_live = p.m_dev ? (*p.m_dev < p.M ? *p.m_dev : p.M) : p.M;
@@ -625,13 +689,22 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmParams& p, const int 
         }
     } else {
         if constexpr (PRE) {
-            k_block<MT, TT, TWO, U, false, W8, true>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc, wpre);
+            k_block<MT, TT, TWO, U, false, W8, true>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc, wpre, x8_base);
             ks += U;
         }
         int blk = 0;
-        for (; ks + U <= ks1; ks += U) { alt_prio(p, wave, blk); k_block<MT, TT, TWO, U, false, W8>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc); }
-        if (ks < ks1) { alt_prio(p, wave, blk); k_block<MT, TT, TWO, U, true, W8>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc); }
+        for (; ks + U <= ks1; ks += U) { alt_prio(p, wave, blk); k_block<MT, TT, TWO, U, false, W8>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc, nullptr, x8_base); }
+        if (ks < ks1) { alt_prio(p, wave, blk); k_block<MT, TT, TWO, U, true, W8>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc, nullptr, x8_base); }
         if (p.prio_alt) __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (W8 && !TWO) {                      // the int8 MFMA left int32 sums in acc's registers (k_block)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const i32x4 c = __builtin_bit_cast(i32x4, acc[a][t]);
+                acc[a][t] = f4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
+            }
     }
     after_k();
     trace_stamp(p, bx, by, wave, 1);
@@ -842,7 +915,9 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmParams 
 
 // int8 weight images (W8): more than 8 accumulator tiles next to the dequantised k-step pairs spill (36 .. 716 B per lane at
 // 12 .. 16 tiles), so those shapes are not instantiated -- launch_T keeps int8 launches at or below 8.
-template <int MT, int T, int EPI, int UW>
+// UA: k-steps per block of the LLM.int8 instantiation (codes on both sides: a k-step PAIR is one 16-byte load per operand, so
+// the one-tile launches can keep sixteen k-steps in flight where the fp16-activation form stops at eight)
+template <int MT, int T, int EPI, int UW, int UA = UW>
 void launch_w8(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
     if constexpr (MT * TT <= 8) {
@@ -853,7 +928,7 @@ void launch_w8(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s) {
             }
         }
         if (p.xscale)     // LLM.int8 codes: ONE activation plane (the "lo" plane of the a8 calls is all zeros)
-            hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UW, false, true>), grid, block, 0, s, p);
+            hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, false, UA, false, true>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((gemm_skinny_kernel<MT, T, EPI, true, UW, false, true>), grid, block, 0, s, p);
     }
@@ -871,7 +946,8 @@ int launch_one(const GemmParams& p, int units, hipStream_t s) {
         if (p.w8) {   /* int8 weights: split-precision activations only.  Same k-steps per block as fp16 (half the   */ \
                       /* bytes in flight): doubling them measured slower, 23.4 vs 21.6 us on the 7b gate|up launch */ \
             constexpr int UW = ((UV) < 2) ? 2 : (((UV) > 8) ? 8 : (UV));                              \
-            launch_w8<MT, T, EPI, UW>(p, grid, block, s);                                             \
+            constexpr int UA = (MT * TT <= 2 && (UV) >= 16) ? 16 : UW;                                \
+            launch_w8<MT, T, EPI, UW, UA>(p, grid, block, s);                                         \
             break;                                                                                    \
         }                                                                                             \
         if constexpr (MT <= 2 && EPI != EPI_ADD) {                                                    \

@@ -35,10 +35,27 @@ __device__ __forceinline__ int64_t frag_off(int m, int k, int KS) {
     return ((((int64_t)(m >> 4) * KS + (k >> 5)) * 64) + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
 }
 
+// The int8 operand image of the codes (pc_gemm x_codes8): [T/16][K/64][64 lanes][16 bytes], lane (row & 15, g) holding its eight
+// codes of k-step 2s (k = 64 s + 8 g + e) and then of 2s + 1 (k = 64 s + 32 + 8 g + e) as signed bytes -- the byte order of the
+// int8 weight image, i.e. one v_mfma_i32_16x16x64_i8 operand per 16-byte load.  r[e]: the rounded, clamped codes of chunk c.
+__device__ __forceinline__ void store_codes8(signed char* __restrict__ codes8, int row, int c, int KS, const float (&r)[8]) {
+    const int s = c >> 2, g = c & 3;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        lo |= ((uint32_t)(int)r[e] & 0xffu) << (8 * e);
+        hi |= ((uint32_t)(int)r[4 + e] & 0xffu) << (8 * e);
+    }
+    const int64_t off = ((((int64_t)(row >> 4) * (KS >> 1) + (s >> 1)) * 64 + g * 16 + (row & 15)) << 4) + ((s & 1) << 3);
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    *(u2v*)(codes8 + off) = u2v{lo, hi};
+}
+
 template <int G, bool FRAG>
 __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restrict__ x, int64_t ld, int K, _Float16* __restrict__ codes,
                                                         float* __restrict__ x_scale, unsigned char* __restrict__ flags_set,
-                                                        unsigned char* __restrict__ flags_clear, int clear_len, float threshold) {
+                                                        unsigned char* __restrict__ flags_clear, int clear_len, float threshold,
+                                                        signed char* __restrict__ codes8) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x, nchunk = K >> 3, KS = K >> 5;
     // the flag bytes of the NEXT activation slot are cleared here (its quantiser runs after this launch, its last reader ran
@@ -77,14 +94,17 @@ __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restri
         const int c = tid + i * 256;
         if (c < nchunk) {
             h8 q;
+            float rr[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float r = rintf(a[i][e] * inv);
                 r = fminf(fmaxf(r, -127.f), 127.f);
                 q[e] = (_Float16)r;
+                rr[e] = r;
             }
             const int64_t off = FRAG ? frag_off(row, c * 8, KS) : (int64_t)row * ld + c * 8;
             *(h8*)(codes + off) = q;
+            if (codes8) store_codes8(codes8, row, c, KS, rr);
         }
     }
 }
@@ -100,7 +120,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float* __restr
                                                             _Float16* __restrict__ of_hi, _Float16* __restrict__ codes,
                                                             float* __restrict__ x_scale, unsigned char* __restrict__ flags_set,
                                                             unsigned char* __restrict__ flags_clear, int clear_len, float threshold,
-                                                            int hidden, float eps) {
+                                                            int hidden, float eps, signed char* __restrict__ codes8) {
     __shared__ float red[4];
     __shared__ float redq[4];
     const int row = blockIdx.x, tid = threadIdx.x, nv = hidden >> 3, KS = hidden >> 5;
@@ -165,13 +185,16 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float* __restr
         const int i = tid + k * 256;
         if (i < nv) {
             h8 q;
+            float rr[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float r = rintf(a[k][e] * inv);
                 r = fminf(fmaxf(r, -127.f), 127.f);
                 q[e] = (_Float16)r;
+                rr[e] = r;
             }
             *(h8*)(codes + frag_off(row, i * 8, KS)) = q;
+            if (codes8) store_codes8(codes8, row, i, KS, rr);
         }
     }
 }
@@ -289,7 +312,9 @@ __global__ __launch_bounds__(256) void outlier_corr_kernel(const unsigned char* 
 }  // namespace
 
 PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t T, int32_t K, void* codes, float* x_scale,
-                              void* flags_set, void* flags_clear, int32_t clear_len, float threshold, void* stream) {
+                              void* flags_set, void* flags_clear, int32_t clear_len, float threshold, void* codes8, void* stream) {
+    PC_REQUIRE(!codes8 || (K % 64 == 0 && ((uintptr_t)codes8 & 15) == 0), PC_ERR_ARG,
+               "pc_quant_act_i8: the int8 operand image needs K %% 64 == 0 and a 16-byte aligned buffer");
     PC_REQUIRE(T > 0 && K > 0 && K % 32 == 0 && K <= 16384, PC_ERR_ARG, "pc_quant_act_i8: need T > 0, K %% 32 == 0, K <= 16384");
     PC_REQUIRE(x && codes && x_scale && flags_set, PC_ERR_ARG, "pc_quant_act_i8: null pointer");
     PC_REQUIRE(frag || (ldx >= K && ldx % 8 == 0), PC_ERR_ARG, "pc_quant_act_i8: row-major planes need ldx >= K, ldx %% 8 == 0");
@@ -298,9 +323,9 @@ PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t 
 #define PC_Q(GV)                                                                                                          \
     do {                                                                                                                  \
         if (frag) hipLaunchKernelGGL((quant_act_kernel<GV, true>), dim3(T), dim3(256), 0, s, (const _Float16*)x, ldx, K,  \
-                                     (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold); \
+                                     (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold, (signed char*)codes8); \
         else hipLaunchKernelGGL((quant_act_kernel<GV, false>), dim3(T), dim3(256), 0, s, (const _Float16*)x, ldx, K,       \
-                                (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold); \
+                                (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold, (signed char*)codes8); \
     } while (0)
     if (groups <= 1) PC_Q(1); else if (groups <= 2) PC_Q(2); else if (groups <= 4) PC_Q(4); else PC_Q(8);
 #undef PC_Q
@@ -309,7 +334,9 @@ PC_EXPORT int pc_quant_act_i8(const void* x, int64_t ldx, int32_t frag, int32_t 
 
 PC_EXPORT int pc_rmsnorm_quant_i8(const float* x, const void* norm_weight, float eps, int32_t T, int32_t hidden, void* x_hi,
                                   void* codes, float* x_scale, void* flags_set, void* flags_clear, int32_t clear_len,
-                                  float threshold, void* stream) {
+                                  float threshold, void* codes8, void* stream) {
+    PC_REQUIRE(!codes8 || (hidden % 64 == 0 && ((uintptr_t)codes8 & 15) == 0), PC_ERR_ARG,
+               "pc_rmsnorm_quant_i8: the int8 operand image needs hidden %% 64 == 0 and a 16-byte aligned buffer");
     PC_REQUIRE(T > 0 && T <= 64 && hidden > 0 && hidden % 32 == 0 && hidden <= 16384, PC_ERR_ARG,
                "pc_rmsnorm_quant_i8: need 1 <= T <= 64, hidden %% 32 == 0, hidden <= 16384");
     PC_REQUIRE(x && norm_weight && x_hi && codes && x_scale && flags_set, PC_ERR_ARG, "pc_rmsnorm_quant_i8: null pointer");
@@ -318,7 +345,7 @@ PC_EXPORT int pc_rmsnorm_quant_i8(const float* x, const void* norm_weight, float
 #define PC_RQ(GV)                                                                                                          \
     hipLaunchKernelGGL(rmsnorm_quant_kernel<GV>, dim3(T), dim3(256), 0, s, x, (const _Float16*)norm_weight, (_Float16*)x_hi,  \
                        (_Float16*)codes, x_scale, (unsigned char*)flags_set, (unsigned char*)flags_clear, clear_len, threshold, \
-                       hidden, eps)
+                       hidden, eps, (signed char*)codes8)
     if (groups <= 1) PC_RQ(1); else if (groups <= 2) PC_RQ(2); else if (groups <= 4) PC_RQ(4); else PC_RQ(8);
 #undef PC_RQ
     return pc_check_launch("rmsnorm_quant_kernel");

@@ -76,7 +76,7 @@ class GemmArgs(C.Structure):
                 ("arena_batch_stride", _i64), ("arena_head_stride", _i64),
                 ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
                 ("past_len_dev", _vp), ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64),
-                ("lo_base", _i32)]
+                ("lo_base", _i32), ("x_codes8", _vp)]
 
 
 # name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one
@@ -116,8 +116,8 @@ SIGNATURES = {
     "pc_rope_append_var": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp,
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "pc_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
-    "pc_rmsnorm_quant_i8": (C.c_int, [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
+    "pc_quant_act_i8": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
+    "pc_rmsnorm_quant_i8": (C.c_int, [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
     "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_dense_a8": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
@@ -605,37 +605,38 @@ LLM_INT8_THRESHOLD = 6.0        # transformers' llm_int8_threshold default, what
 
 
 def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags_clear=None, threshold: float = LLM_INT8_THRESHOLD,
-                 ldx: Optional[int] = None, stream: Optional[int] = None) -> None:
+                 ldx: Optional[int] = None, stream: Optional[int] = None, codes8=None) -> None:
     """LLM.int8 activation quantiser: fp16 ``x`` (row-major [T, ld] or a fragment plane) -> ``codes`` (fp16, same layout),
-    ``x_scale`` [T] fp32, outlier-column flag bytes."""
+    ``x_scale`` [T] fp32, outlier-column flag bytes; ``codes8`` (optional, int8 [ceil(T/16), K/64, 64, 16]): the int8 MFMA's
+    operand image of the same codes (``pc_gemm`` ``x_codes8``)."""
     rc = load().pc_quant_act_i8(x.data_ptr(), (0 if frag else x.stride(-2)) if ldx is None else ldx, int(frag), T, K, codes.data_ptr(),
                                 x_scale.data_ptr(), flags_set.data_ptr(), _ptr(flags_clear),
-                                0 if flags_clear is None else flags_clear.numel(), threshold,
+                                0 if flags_clear is None else flags_clear.numel(), threshold, _ptr(codes8),
                                 current_stream() if stream is None else stream)
     check(rc, "pc_quant_act_i8")
 
 
 def gemm_skinny_a8c(wf8, w_scale, xq, zeros, x_scale, flags, x_raw, w_codes_t, M: int, N: int, K: int, epilogue: int, y=None,
-                    ldy: int = 0, of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
+                    ldy: int = 0, of_hi=None, of_lo=None, stream: Optional[int] = None, codes8=None) -> None:
     """LLM.int8 projection over the code plane ``xq`` with the outlier correction inside the launch (``flags``: >= 16384 bytes)."""
-    _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, flags=flags, x_raw=x_raw,
+    _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, flags=flags, x_raw=x_raw,
           w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi, of_lo=of_lo)
 
 
 def gemm_qkv_rope_a8c(wf8_perm, w_scale_perm, xq, zeros, x_scale, flags, x_raw, w_codes_t, row_perm, M, K, cs, q_hi, q_lo, q_ts,
                       k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev=None, kv_lo=None,
-                      lo_base: int = -1, stream: Optional[int] = None) -> None:
-    _gemm(stream, wf=wf8_perm, w_scale=w_scale_perm, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, flags=flags, x_raw=x_raw,
+                      lo_base: int = -1, stream: Optional[int] = None, codes8=None) -> None:
+    _gemm(stream, wf=wf8_perm, w_scale=w_scale_perm, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, flags=flags, x_raw=x_raw,
           w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), row_perm=row_perm, M=M, K=K,
           **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
 
 
 def rmsnorm_quant_i8(x, norm_weight, eps: float, T: int, hidden: int, x_hi, codes, x_scale, flags_set, flags_clear=None,
-                     threshold: float = LLM_INT8_THRESHOLD, stream: Optional[int] = None) -> None:
+                     threshold: float = LLM_INT8_THRESHOLD, stream: Optional[int] = None, codes8=None) -> None:
     """RMSNorm + LLM.int8 activation quantiser in one launch (fragment planes, T <= 64): pc_rmsnorm_frag + pc_quant_act_i8."""
     rc = load().pc_rmsnorm_quant_i8(x.data_ptr(), norm_weight.data_ptr(), eps, T, hidden, x_hi.data_ptr(), codes.data_ptr(),
                                     x_scale.data_ptr(), flags_set.data_ptr(), _ptr(flags_clear),
-                                    0 if flags_clear is None else flags_clear.numel(), threshold,
+                                    0 if flags_clear is None else flags_clear.numel(), threshold, _ptr(codes8),
                                     current_stream() if stream is None else stream)
     check(rc, "pc_rmsnorm_quant_i8")
 
@@ -651,15 +652,15 @@ def outlier_corr(flags, K: int, x, codes, frag: bool, x_scale, w_codes_t, w_scal
 
 
 def gemm_skinny_a8(wf8, w_scale, xq, zeros, x_scale, corr, has, M: int, N: int, K: int, epilogue: int, y=None, ldy: int = 0,
-                   of_hi=None, of_lo=None, stream: Optional[int] = None) -> None:
-    _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, corr=corr, ldc=corr.stride(-2),
+                   of_hi=None, of_lo=None, stream: Optional[int] = None, codes8=None) -> None:
+    _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, corr=corr, ldc=corr.stride(-2),
           corr_has=has, M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi, of_lo=of_lo)
 
 
 def gemm_qkv_rope_a8(wf8, w_scale, xq, zeros, x_scale, corr, has, M: int, K: int, cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs,
                      B, H, Hkv, D, q_len, past_len, cap, past_len_dev=None, kv_lo=None, lo_base: int = -1,
-                     stream: Optional[int] = None) -> None:
-    _gemm(stream, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, corr=corr, ldc=corr.stride(-2), corr_has=has, M=M, K=K,
+                     stream: Optional[int] = None, codes8=None) -> None:
+    _gemm(stream, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, corr=corr, ldc=corr.stride(-2), corr_has=has, M=M, K=K,
           **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev,
                         kv_lo[:4] if kv_lo else None, lo_base))
 

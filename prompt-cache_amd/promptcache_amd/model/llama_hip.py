@@ -701,11 +701,12 @@ class LlamaHIP:
         correction for projection ``key``: -> (codes, x_scale, corr, has).  ``norm=(x_f32, gain, eps)``: the activation is
         RMSNorm(x) -- normalised, written to ``act_hi`` and quantised in ONE launch (pc_rmsnorm_quant_i8)."""
         n = _native
-        codes, xs, corr, has = bufs
+        codes, xs, corr, has, c8 = bufs
         if norm is not None:
-            n.rmsnorm_quant_i8(norm[0], norm[1], norm[2], T, K, act_hi, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
+            n.rmsnorm_quant_i8(norm[0], norm[1], norm[2], T, K, act_hi, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4],
+                               codes8=c8)
         else:
-            n.quant_act_i8(act_hi, True, T, K, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4])
+            n.quant_act_i8(act_hi, True, T, K, codes, xs, self._i8_flags[slot], self._i8_flags[(slot + 1) % 4], codes8=c8)
         n.outlier_corr(self._i8_flags[slot], K, act_hi, codes, True, xs, lw[key + "_t8"], lw[key + "_ds"], perm, T, N, corr, has)
         return codes, xs, corr, has
 
@@ -737,10 +738,15 @@ class LlamaHIP:
         ch, cl, cq = planes(inter, 3)
         zero = self._i8_zero
         has = torch.zeros(4, dtype=torch.int32, device=dev)
-        bufs = [(xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, W), dtype=f32, device=dev), has[0:1]),
-                (aq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[1:2]),
-                (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3]),
-                (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4])]
+
+        def image8(k):        # the int8 MFMA's operand image of a code plane (pc_quant_act_i8 codes8; K % 64 == 0 with int8 weights)
+            return torch.empty((mt, k // 64, 64, 16), dtype=torch.int8, device=dev)
+
+        x8, a8, c8 = image8(hid), image8(H * D), image8(inter)
+        bufs = [(xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, W), dtype=f32, device=dev), has[0:1], x8),
+                (aq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[1:2], a8),
+                (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3], x8),
+                (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4], c8)]
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         # Outlier flags are set-only and slot s is cleared by the quantiser of slot s - 1: a pass that stopped behind a
         # layer's q|k|v (kv_only encodes) left slot 0 set, and this pass's first quantiser would OR onto it -- results would
@@ -753,9 +759,9 @@ class LlamaHIP:
             def quant(slot, act_hi, K, buf, norm=None):
                 codes, xs = buf[0], buf[1]
                 if norm is not None:
-                    n.rmsnorm_quant_i8(norm[0], norm[1], eps, T, K, act_hi, codes, xs, fl[slot], fl[(slot + 1) % 4])
+                    n.rmsnorm_quant_i8(norm[0], norm[1], eps, T, K, act_hi, codes, xs, fl[slot], fl[(slot + 1) % 4], codes8=buf[4])
                 else:
-                    n.quant_act_i8(act_hi, True, T, K, codes, xs, fl[slot], fl[(slot + 1) % 4])
+                    n.quant_act_i8(act_hi, True, T, K, codes, xs, fl[slot], fl[(slot + 1) % 4], codes8=buf[4])
                 return codes, xs
 
             for li, lw in enumerate(layers):
@@ -764,19 +770,20 @@ class LlamaHIP:
                 cd, xs = quant(0, xh, hid, bufs[0], norm=(x, lw["ln1"]))
                 n.gemm_qkv_rope_a8c(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, fl[0], xh, lw["wqkv_t8"], self._qkv_perm_i32, T, hid, cs,
                                     q16, q16l, H * D, kp, vp, arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len,
-                                    arena.cap, past_dev, kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
+                                    arena.cap, past_dev, kv_lo=kvlo and kvlo[:4], lo_base=lo_base, codes8=x8)
                 n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                            B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                            q_lo=q16l, kv_lo=kvlo,
                            gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
                 cd, xs = quant(1, ah, H * D, bufs[1])
-                n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
+                n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid,
+                                  codes8=a8)
                 cd, xs = quant(2, xh, hid, bufs[2], norm=(x, lw["ln2"]))
                 n.gemm_skinny_a8c(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, fl[2], xh, lw["wgu_t8"], T, 2 * inter, hid, n.EPI_SILU,
-                                  of_hi=ch, of_lo=cl)
+                                  of_hi=ch, of_lo=cl, codes8=x8)
                 cd, xs = quant(3, ch, inter, bufs[3])
                 n.gemm_skinny_a8c(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, fl[3], ch, lw["wdown_t8"], T, hid, inter, n.EPI_ADD,
-                                  y=x, ldy=hid)
+                                  y=x, ldy=hid, codes8=c8)
             layers = []
         for li, lw in enumerate(layers):
             kp, vp = arena.k_plane(li), arena.v_plane(li)
@@ -784,17 +791,17 @@ class LlamaHIP:
             cd, xs, corr, hs = self._i8_lin_frag(0, xh, hid, lw, "wqkv", self._qkv_perm_i32, T, W, bufs[0], norm=(x, lw["ln1"], eps))
             n.gemm_qkv_rope_a8(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, corr, hs, T, hid, cs, q16, q16l, H * D, kp, vp,
                                arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
-                               kv_lo=kvlo and kvlo[:4], lo_base=lo_base)
+                               kv_lo=kvlo and kvlo[:4], lo_base=lo_base, codes8=x8)
             n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
                        gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
             cd, xs, corr, hs = self._i8_lin_frag(1, ah, H * D, lw, "wo", None, T, hid, bufs[1])
-            n.gemm_skinny_a8(lw["wo_f"], lw["wo_s"], cd, zero, xs, corr, hs, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid)
+            n.gemm_skinny_a8(lw["wo_f"], lw["wo_s"], cd, zero, xs, corr, hs, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, codes8=a8)
             cd, xs, corr, hs = self._i8_lin_frag(2, xh, hid, lw, "wgu", None, T, 2 * inter, bufs[2], norm=(x, lw["ln2"], eps))
-            n.gemm_skinny_a8(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, corr, hs, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl)
+            n.gemm_skinny_a8(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, corr, hs, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl, codes8=x8)
             cd, xs, corr, hs = self._i8_lin_frag(3, ch, inter, lw, "wdown", None, T, hid, bufs[3])
-            n.gemm_skinny_a8(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, corr, hs, T, hid, inter, n.EPI_ADD, y=x, ldy=hid)
+            n.gemm_skinny_a8(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, corr, hs, T, hid, inter, n.EPI_ADD, y=x, ldy=hid, codes8=c8)
         V = c.vocab_size
         if last_token_only:
             xlast = x.view(B, q_len, hid)[:, -1, :].contiguous()

@@ -252,3 +252,83 @@ def test_fused_outlier_correction_silu_and_qkv_rope_equal_the_two_launch_forms()
     for a, b in zip(outs[0], outs[1]):
         assert float((a - b).abs().max()) < 2e-3 * max(1.0, float(a.abs().max()))      # (the arena holds fp16: one ulp)
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-5 * max(1.0, float(outs[0][0].abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the codes as the int8 MFMA's operand image (pc_quant_act_i8 / pc_rmsnorm_quant_i8 codes8 -> pc_gemm x_codes8)
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _image_to_rows(img, T, K):
+    """[mt][K/64][64 lanes = g*16 + m][16 bytes = k-step 2s (8), 2s+1 (8)] -> codes [T][K]: k = 64 P + 32 half + 8 g + e."""
+    mt = img.shape[0]
+    v = img.view(mt, K // 64, 4, 16, 2, 8)                    # P, g, m, half, e
+    return v.permute(0, 3, 1, 4, 2, 5).reshape(mt * 16, K)[:T]
+
+
+@pytest.mark.parametrize("T,K", [(12, 4096), (1, 64), (37, 11008), (64, 512), (17, 5120)])
+def test_quantisers_write_the_int8_operand_image_of_the_same_codes(T, K):
+    n = _n()
+    x = _acts(T, K, seed=3 * T + K, outliers=[(0, 3, 9.0), (T - 1, K - 1, -6.5)])
+    mt = (T + 15) // 16
+    hi, _ = n.to_act_frags(torch.from_numpy(x).to(DEV).half().float())
+    codes = torch.empty_like(hi)
+    img = torch.full((mt, K // 64, 64, 16), 99, dtype=torch.int8, device=DEV)
+    xs = torch.empty(T, dtype=torch.float32, device=DEV)
+    flags = torch.zeros(K, dtype=torch.uint8, device=DEV)
+    n.quant_act_i8(hi, True, T, K, codes, xs, flags, None, codes8=img)
+    torch.cuda.synchronize()
+    rows = n.from_act_frags(codes, T)
+    assert torch.equal(_image_to_rows(img, T, K).to(torch.float16), rows)
+    # ... and from the fused RMSNorm + quantiser
+    xf = torch.from_numpy(x).to(DEV)
+    gam = torch.from_numpy((1.0 + 0.1 * np.random.default_rng(0).standard_normal(K)).astype(np.float16)).to(DEV)
+    xh = torch.empty_like(hi); codes2 = torch.empty_like(hi)
+    img2 = torch.full_like(img, 99)
+    n.rmsnorm_quant_i8(xf, gam, 1e-5, T, K, xh, codes2, xs, flags, None, codes8=img2)
+    torch.cuda.synchronize()
+    assert torch.equal(_image_to_rows(img2, T, K).to(torch.float16), n.from_act_frags(codes2, T))
+    with pytest.raises(RuntimeError, match="operand image"):
+        n.quant_act_i8(hi[:, :1].contiguous(), True, T, 32, codes, xs, flags, None, codes8=img)
+
+
+@pytest.mark.parametrize("T,K,N,epi", [(12, 4096, 512, 0), (12, 11008, 4096, 1), (1, 4096, 4096, 1), (16, 4096, 2 * 1024, 2), (29, 1024, 256, 0),
+                                       (50, 4096, 12288, 0), (7, 192, 64, 1), (12, 5120, 5120, 1)])
+def test_a8_projection_reads_the_image_and_agrees_with_the_code_plane_bit_for_bit(T, K, N, epi):
+    """int32 sums on the int8 MFMA either way: operands packed from the fp16 code plane in the kernel, or loaded from the image."""
+    n = _n()
+    rng = np.random.default_rng(T + K + N)
+    x = _acts(T, K, seed=T + N)
+    x = np.clip(x, -5.9, 5.9)
+    w = (0.03 * rng.standard_normal((N, K))).astype(np.float32)
+    q, sc = n.quantize_rows_int8(torch.from_numpy(w).to(DEV))
+    wf8 = n.to_weight_frags_i8(q)
+    mt = (T + 15) // 16
+    hi, _ = n.to_act_frags(torch.from_numpy(x).to(DEV).half().float())
+    codes = torch.empty_like(hi)
+    img = torch.empty((mt, K // 64, 64, 16), dtype=torch.int8, device=DEV)
+    xs = torch.empty(T, dtype=torch.float32, device=DEV)
+    flags = torch.zeros(max(K, 16384), dtype=torch.uint8, device=DEV)
+    n.quant_act_i8(hi, True, T, K, codes, xs, flags, None, codes8=img)
+    corr = torch.zeros((T, N), dtype=torch.float32, device=DEV)
+    has = torch.zeros(1, dtype=torch.int32, device=DEV)
+    zero = torch.zeros_like(hi)
+    out = []
+    for c8 in (None, img):
+        if epi == 2:
+            oh = torch.zeros((mt, N // 2 // 32, 64, 8), dtype=torch.float16, device=DEV); ol = torch.zeros_like(oh)
+            n.gemm_skinny_a8(wf8, sc, codes, zero, xs, corr, has, T, N, K, n.EPI_SILU, of_hi=oh, of_lo=ol, codes8=c8)
+            out.append(torch.stack([oh, ol]))
+        else:
+            y = torch.full((T, N), 0.25, dtype=torch.float32, device=DEV)
+            n.gemm_skinny_a8(wf8, sc, codes, zero, xs, corr, has, T, N, K, epi, y=y, ldy=N, codes8=c8)
+            out.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0].view(torch.int32) if out[0].dtype == torch.float32 else out[0].view(torch.int16),
+                       out[1].view(torch.int32) if out[1].dtype == torch.float32 else out[1].view(torch.int16))
+    if epi != 2:
+        # exact integer sums: y = (sum_k cw cx) * w_scale * x_scale (+ 0.25 for the residual add), one fp32 rounding per factor
+        cx = n.from_act_frags(codes, T).double().cpu().numpy()
+        isum = cx @ q.double().cpu().numpy().T
+        ref = isum.astype(np.float32) * (xs.cpu().numpy()[:, None] * sc.cpu().numpy()[None, :]) + (0.25 if epi == 1 else 0.0)
+        got = out[1].cpu().numpy()
+        assert np.abs(got - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max())

@@ -987,7 +987,7 @@ class LlamaHIP:
     def _gather_shape_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
         if not self.supports_fused_gather or B != 1 or self.use_chain or past_len <= 0:
             return False
-        ck = (q_len, self._lo_mode, past_len + q_len >= 256, self._attn_counters is None)
+        ck = (q_len, self._lo_mode, past_len + q_len >= 256)
         ok = self._gather_ok_cache.get(ck)
         if ok is None:
             buf = arena.buf
@@ -995,8 +995,7 @@ class LlamaHIP:
             H, D = self.H, self.D
             ok = _native.attn_gather_ok(buf, q_len * H * D, H * D, arena.k_plane(0), arena.v_plane(0), arena.batch_stride,
                                         arena.head_stride, None, 0, 0, B, H, self.Hkv, D, q_len, past_len, self.softmax_scale,
-                                        None, past_len_dev=buf, out_frag=(buf, buf), q_lo=buf, kv_lo=kvlo,
-                                        counters=self._counters_for(B, H))
+                                        None, past_len_dev=buf, out_frag=(buf, buf), q_lo=buf, kv_lo=kvlo)
             self._gather_ok_cache[ck] = ok
         return ok
 
@@ -1218,8 +1217,10 @@ class LlamaHIP:
         return self._ks_state
 
     def _counters_for(self, B: int, H: int):
+        """Arrival counters for the in-launch split merge (PC_ATTN_FUSED=1) -- not for a forward that stages while it reads: that
+        one runs the two-launch form of the streaming kernel (pc_attn_gather_ok)."""
         c = self._attn_counters
-        return c if c is not None and B * H <= c.numel() else None
+        return c if c is not None and self._gather is None and B * H <= c.numel() else None
 
     def _tail_for(self, arena, past_dev):
         """Per-layer ``((k_lo, v_lo, batch_stride, head_stride, lo_row0) | None, lo_base)`` for the current tail mode."""

@@ -1245,6 +1245,25 @@ int choose_nsplit(int B, int H, int q_len, int kv_len, bool hp) {
     return ns;
 }
 
+// Streaming splits of a tail-mode launch of the 64-row kernel (<= 32 new rows, their own keys in the tail workgroup's fp32 pass):
+// the merge launch runs anyway, the streams cover the staged keys only, and what a short question over a SHORT cache pays is the
+// serial walk of one workgroup over its key tiles -- choose_nsplit's "two tiles per split at least" left 5 tiles to one workgroup
+// at 300 staged keys.  Here: as many streams as there are tiles while the grid stays within two workgroups per CU, then the
+// fewest streams with the same tiles per stream.  7b, 22 / 30 new rows: 300 staged keys 4.50 -> 4.24 ms, 1 727: 4.57 -> 4.50 ms
+// (profiles/r04_variants.txt).
+int tail_stream_splits(int B, int H, int past_len) {
+    static const int forced = [] { const char* e = getenv("PC_ATTN_NSPLIT"); return e ? atoi(e) : 0; }();
+    const int T = pc_ceil_div(past_len > 0 ? past_len : 1, kTK);
+    int cmax = 512 / (B * H > 0 ? B * H : 1) - 1;
+    if (cmax > kMaxSplit - 1) cmax = kMaxSplit - 1;
+    if (cmax < 1) cmax = 1;
+    if (forced > 0) return forced < cmax ? forced : cmax;
+    int c = T < cmax ? T : cmax;
+    const int per = pc_ceil_div(T, c);
+    while (c > 1 && pc_ceil_div(T, c - 1) == per) --c;
+    return c;
+}
+
 template <int D>
 int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     AttnParams p = p0;
@@ -1325,7 +1344,11 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     const int ns_a = choose_nsplit(B, H, q_len, kv_len_max, false), ns_b = choose_nsplit(B, H, q_len, kv_len_max, true);
     int ns = ns_a > ns_b ? ns_a : ns_b;
     // passes of <= kTailMax rows may run in tail mode (pc_attn_fwd_ex with lo_row0 = -1): one more split, always merged
-    if (q_len <= kTailMax) ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
+    if (q_len <= kTailMax) {
+        const int nt = tail_stream_splits(B, H, kv_len_max);
+        ns = ns > nt ? ns : nt;
+        ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
+    }
     // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
     if (q_len <= kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;
     if (D == 128 && q_len >= ring_min_rows()) { const int nr = ring_nsplit(B, H, q_len, kv_len_max); ns = ns > nr ? ns : nr; }   // (pc_attn_ring.hip)
@@ -1404,6 +1427,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.rows = gather_rows; p.g_kplane = g_kplane; p.g_vplane = g_vplane;
     if (ring_eligible(p, D)) p.nsplit = ring_nsplit(B, H, q_len, past_len + q_len);
     if (p.tail && !small) {
+        p.nsplit = tail_stream_splits(B, H, past_len);
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the
         // next instantiation of the merge kernel (4 / 8 / 16 / 32 partials per row)
         int ms = p.nsplit;

@@ -1,5 +1,5 @@
 """TTFT of the cached prefill as the number of new tokens q grows (7b shape, S = 1725 staged): shows where the
-weight-streaming path (q <= 64) hands over to the dense path."""
+weight-streaming path (q <= 64) hands over to the dense path.  python tools/ttft_vs_q.py [q,q,...] [document tokens]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ lm = Llama2("llama2-7b", random_init=True)
 fmt = lm.get_formatter()
 qs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "4,12,16,17,24,32,33,48,64,65,96,128,192,256").split(",")]
 for q in qs:
-    sp, pp = synth.flat_docs(f"s{q}", 4, (1700,), max(q - 2, 1))
+    sp, pp = synth.flat_docs(f"s{q}", 4, (int(sys.argv[2]) if len(sys.argv) > 2 else 1700,), max(q - 2, 1))
     eng = CacheEngine(4096, lm)
     eng.add_schema(fmt(sp))
     prompt = Prompt(pp, [fmt])

@@ -287,13 +287,18 @@ def attn_roofline(lm, staged, q_len: int):
 def attn_many_roofline(lm, q_len: int, S: int):
     """Event-time the many-row attention (> 64 new rows over S staged keys: pc_attn_ring.hip + the split-KV merge) on synthetic
     operands of the model's shape, called as the forward calls it (split-precision Q, residual rows of the pass, fragment output
-    up to 512 rows).  MFMA-bound: algorithmic flops = 4 H D q (S + (q + 1) / 2) per launch; the kernel executes
-    twice that (Q and P enter as hi + lo pairs)."""
+    up to 512 rows) -- in the form the step runs: STAGING (every key row read from a module store through the row table and written
+    to the arena as its stage lands) when the forward fuses the gather, and the plain launch over a staged arena beside it.  The
+    launches walk over Lr layers of K/V (~2 GB: nothing is found in the MALL, as inside a forward) and the two forms alternate.
+    MFMA-bound: algorithmic flops = 4 H D q (S + (q + 1) / 2) per launch; the kernel executes twice that (Q and
+    P enter as hi + lo pairs)."""
+    import numpy as np
     import torch
     from promptcache_amd import _native as n
     m = lm.hf_model
     H, Hkv, D, dev = m.H, m.Hkv, m.D, m.device
-    cap, Lr = S + q_len + 64, 4
+    cap = S + q_len + 64
+    Lr = max(2, min(12, int(2.2e9 / (2 * Hkv * cap * D * 2))))
     arena = torch.randn((Lr, 2, Hkv, cap, D), device=dev).half()
     q16 = torch.randn((q_len, H * D), device=dev).half()
     q16l = (torch.randn((q_len, H * D), device=dev) * 2 ** -11).half()
@@ -305,31 +310,57 @@ def attn_many_roofline(lm, q_len: int, S: int):
     out = torch.empty((q_len, H * D), dtype=torch.float16, device=dev)
     ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, S + q_len), 4) // 4, dtype=torch.float32, device=dev)
     kvlo = (lo[0], lo[1], Hkv * (q_len + 64) * D, (q_len + 64) * D, -1)
-    evs = []
-    for i in range(3 * m.L):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        li = i % Lr
+    staging = bool(getattr(m, "supports_fused_gather", False)) and frag and D == 128 and os.environ.get("PC_DEFER_GATHER", "1") != "0"
+    rows = None
+    if staging:
+        store = torch.randn((Lr, 2, Hkv, S, D), device=dev).half()
+        seg = np.zeros(1, dtype=np.dtype([("src", "<u8"), ("dst_row", "<i4"), ("len", "<i4")]))
+        seg[0] = (store.data_ptr(), 0, S)
+        segs = torch.from_numpy(seg.view(np.uint8).copy()).to(dev)
+        words = torch.tensor([1, S + q_len], dtype=torch.int32, device=dev)
+        rows = torch.zeros(cap * 16, dtype=torch.uint8, device=dev)
+        n.kv_row_table(segs, words[0:1], 64, words[1:2], arena, Hkv, D, cap, rows)
+        staging = bool(n.attn_gather_ok(q16, q_len * H * D, H * D, arena[0, 0], arena[0, 1], 2 * Hkv * cap * D, cap * D, None, 0, 0, 1, H,
+                                        Hkv, D, q_len, S, m.softmax_scale, ws, out_frag=(ah, al), q_lo=q16l, kv_lo=kvlo))
+
+    def one(li, gather):
         if frag:
             n.attn_fwd(q16, q_len * H * D, H * D, arena[li, 0], arena[li, 1], 2 * Hkv * cap * D, cap * D, None, 0, 0, 1, H, Hkv, D, q_len,
-                       S, m.softmax_scale, ws, out_frag=(ah, al), q_lo=q16l, kv_lo=kvlo)
+                       S, m.softmax_scale, ws, out_frag=(ah, al), q_lo=q16l, kv_lo=kvlo,
+                       gather=(rows, li * 2 * Hkv, (li * 2 + 1) * Hkv) if gather else None)
         else:
             n.attn_fwd(q16, q_len * H * D, H * D, arena[li, 0], arena[li, 1], 2 * Hkv * cap * D, cap * D, out, q_len * H * D, H * D, 1, H,
                        Hkv, D, q_len, S, m.softmax_scale, ws, q_lo=q16l, out_lo=torch.empty_like(out), kv_lo=kvlo)
-        e1.record()
-        if i >= m.L:
-            evs.append((e0, e1))
+
+    forms = [False, True] if staging else [False]
+    evs = {f: [] for f in forms}
+    for i in range(3 * m.L):
+        for vi, f in enumerate(forms):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            one((len(forms) * i + vi) % Lr, f)
+            e1.record()
+            if i >= m.L:
+                evs[f].append((e0, e1))
     torch.cuda.synchronize()
-    us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-    avg = sum(us) / len(us)
+    us = {f: sorted(a.elapsed_time(b) * 1e3 for a, b in evs[f]) for f in forms}
+    avg = sum(us[staging]) / len(us[staging])
     flops = 4.0 * H * D * q_len * (S + (q_len + 1) / 2)
-    return {"kernel": "attn_ring_kernel<KVLO> + attn_combine_kernel (pc_attn, > 64 split-precision rows; pc_attn_ring.hip)",
-            "bound": "mfma", "achieved": flops / (avg * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "executed_frac": 2 * flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
-            "traffic": None, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg, "min_launch_us": us[0],
-            "launches_timed": len(us), "launches_per_step": m.L, "q_len": q_len, "staged_keys": S,
-            "how": "HIP events around eager pc_attn calls (ring kernel + split-KV merge) on synthetic K/V of the model's shape; frac = "
-                   "algorithmic flops (one plane) / 2.5 PFLOP/s, executed_frac counts the hi + lo planes of Q and P"}
+    kv_bytes = 2 * Hkv * S * D * 2
+    res = {"kernel": ("attn_ring_kernel<KVLO, GATHER> (stages while it reads: pc_attn gather_rows)" if staging else "attn_ring_kernel<KVLO>") +
+                     " + attn_combine_kernel (pc_attn, > 64 split-precision rows; pc_attn_ring.hip)",
+           "staging": staging, "bound": "mfma", "achieved": flops / (avg * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "executed_frac": 2 * flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+           "traffic": None, "algorithmic_flops_per_launch": flops, "avg_launch_us": avg, "min_launch_us": us[staging][0],
+           "launches_timed": len(us[staging]), "launches_per_step": m.L, "q_len": q_len, "staged_keys": S,
+           "hbm_bytes_per_launch_algorithmic": (2 if staging else 1) * kv_bytes,
+           "hbm_GBps": (2 if staging else 1) * kv_bytes / (avg * 1e-6) / 1e9,
+           "how": "HIP events around eager pc_attn calls (ring kernel + split-KV merge) on synthetic K/V of the model's shape, "
+                  f"{Lr} layers of K/V cycled (cache-cold); frac = algorithmic flops (one plane) / 2.5 PFLOP/s, executed_frac counts the "
+                  "hi + lo planes of Q and P; hbm_*: module K/V read once (+ written once when staging)"}
+    if staging:
+        res["plain_launch_us"] = sum(us[False]) / len(us[False])
+    return res
 
 
 def config_workload(cfg: int):

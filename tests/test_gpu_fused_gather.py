@@ -303,3 +303,50 @@ def test_prefill_prologue_equals_the_separate_launches(T, nseg_plan):
         n.kv_row_table(blk[o_segs:], blk[o_words + 12:o_words + 16].view(torch.int32), max_seg, blk[o_words + 16:o_words + 20].view(torch.int32),
                        arena, Hkv, D, cap, rows2)
         assert torch.equal(rows, rows2)
+
+
+@pytest.mark.parametrize("q_len,stage", [(22, False), (22, True), (9, False), (30, True)])
+def test_tail_mode_streams_sized_for_a_longer_cache_run_empty_without_harm(q_len, stage):
+    """tail_stream_splits sizes the streams of a <= 32-row tail-mode launch from the HOST past length (one per key tile); a captured
+    forward replays that grid for any shorter cache in its bucket (the kernels read the length from the device word).  Launch with a
+    host length of 900 keys (15 streams) over 130 real ones -- 12 streams find no keys -- and compare with the launch sized for 130:
+    same result up to the merge's fp32 order, same staged bytes when the launch stages."""
+    n = _n()
+    rng = np.random.default_rng(5)
+    H = Hkv = 8
+    D, L, li, S, S_host = 128, 2, 1, 130, 900
+    cap = S_host + q_len + 8
+    store = _rand_half((L, 2, Hkv, S, D), rng)
+    q32 = rng.standard_normal((1, q_len, H, D), dtype=np.float32)
+    q = torch.from_numpy(q32.astype(np.float16)).to(DEV)
+    ql = torch.from_numpy((q32 - q.float().cpu().numpy()).astype(np.float16)).to(DEV)
+    new_kv = _rand_half((L, 2, Hkv, q_len, D), rng)
+    klo, vlo = _rand_half((1, Hkv, q_len, D), rng, 1e-4), _rand_half((1, Hkv, q_len, D), rng, 1e-4)
+    kv_lo = (klo, vlo, Hkv * q_len * D, q_len * D, -1)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, S_host + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+    mt = (q_len + 15) // 16
+    past_dev = torch.tensor([S, 0, q_len, 0], dtype=torch.int32, device=DEV)
+    outs, arenas = [], []
+    for host_len in (S, S_host):
+        a = torch.full((L, 2, Hkv, cap, D), float("nan"), dtype=torch.float16, device=DEV)
+        a[:, :, :, S:S + q_len] = new_kv
+        gather = None
+        if stage:
+            segs, words = _plan_block(n, [store.data_ptr()], [S], [0], S + q_len)
+            rows = torch.zeros(cap * 16, dtype=torch.uint8, device=DEV)
+            n.kv_row_table(segs, words[0:1], 64, words[1:2], a, Hkv, D, cap, rows)
+            gather = (rows, li * 2 * Hkv, (li * 2 + 1) * Hkv)
+        else:
+            n.kv_gather([store.data_ptr()], [S], [0], a, L, Hkv, D, cap)
+        oh = torch.full((mt, H * D // 32, 64, 8), float("nan"), dtype=torch.float16, device=DEV)
+        ol = torch.full_like(oh, float("nan"))
+        n.attn_fwd(q, q_len * H * D, H * D, a[li, 0].unsqueeze(0), a[li, 1].unsqueeze(0), L * 2 * Hkv * cap * D, cap * D, None, 0, 0,
+                   1, H, Hkv, D, q_len, host_len, 1.0 / np.sqrt(D), ws, past_len_dev=past_dev, out_frag=(oh, ol), q_lo=ql, kv_lo=kv_lo,
+                   gather=gather)
+        torch.cuda.synchronize()
+        outs.append(n.from_act_frags(oh, q_len).float() + n.from_act_frags(ol, q_len).float())
+        arenas.append(a[li, :, :, :S].clone())
+    assert torch.isfinite(outs[1]).all()
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-6 * max(1.0, float(outs[0].abs().max()))
+    assert torch.equal(arenas[0].view(torch.int16), arenas[1].view(torch.int16))
+    assert torch.equal(arenas[1].view(torch.int16), store[li].view(torch.int16))

@@ -874,15 +874,21 @@ __device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, i
 // count in vmcnt with the loads, and a store in front of the V wait would put its write acknowledgement on the critical path.
 // (The launch is sized to ONE workgroup per CU -- small_nstream -- so the staging variant, which keeps the K fragments alive until
 // they are stored, takes the registers of a one-wave-per-SIMD kernel instead of spilling at 256.)
-template <int D, bool ALIBI, int NS, bool GATHER = false>
-__global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(const AttnParams p) {
+// RT: 16-row tiles of query rows per wave (1: <= 16 new rows; 2: 17..32 -- every K fragment and V tile read serves both tiles;
+// one workgroup per CU, as the staging variant).
+template <int D, bool ALIBI, int NS, bool GATHER = false, int RT = 1>
+__global__ __launch_bounds__(kThreads, (GATHER || RT > 1) ? 1 : 2) void attn_small_kernel(const AttnParams p) {
     constexpr bool FUSE = NS > 0;
     static_assert(!(FUSE && GATHER), "the in-launch merge and the staging stream are separate instantiations");
+    static_assert(RT == 1 || (RT == 2 && !FUSE && 16 * RT <= kTailMax), "two row tiles: the two-launch form");
     constexpr int KS = D / 32, DB = D / 16, CPR = D / 8;
     constexpr int LPW = kTK * CPR / 64;              // 16-byte V chunks per lane per tile
     constexpr int kTileHalfs = kTK * D;
-    constexpr int kTailBytes = (2 * 16 * D + 16 * D + 16 * 16) * 4;
-    constexpr int kLdsBytes = 4 * kTileHalfs * 2 > kTailBytes ? 4 * kTileHalfs * 2 : kTailBytes;
+    constexpr int kTailRows = 16 * RT;
+    constexpr int kTailBytes = (2 * kTailRows * D + kTailRows * D + kTailRows * kTailRows) * 4;
+    constexpr int kMergeBytes = RT * (4 * (D / 16) * 64 * 4 + 4 * 16 * 2) * 4;      // the four waves' (O, m, l) per row tile
+    constexpr int kLds0 = 4 * kTileHalfs * 2 > kTailBytes ? 4 * kTileHalfs * 2 : kTailBytes;
+    constexpr int kLdsBytes = kLds0 > kMergeBytes ? kLds0 : kMergeBytes;
     constexpr int kTabBytes = GATHER ? 4 * kTK * 16 : 0;           // row-table entries of the four waves' tiles
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes + 16 + kTabBytes];
     int* s_last = (int*)(smem + kLdsBytes);
@@ -902,7 +908,7 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
     stamp(0);
     if (p.tail && split == nstream) {                 // workgroup-uniform: the pass's own rows, fp32
         float* f = (float*)smem;
-        attn_tail_block<D, 16, ALIBI, FUSE>(p, f, f + 16 * D, f + 2 * 16 * D, f + 3 * 16 * D, b, h, split);
+        attn_tail_block<D, kTailRows, ALIBI, FUSE>(p, f, f + kTailRows * D, f + 2 * kTailRows * D, f + 3 * kTailRows * D, b, h, split);
         if constexpr (FUSE) small_arrive_merge<D, NS>(p, b, h, s_last);
         return;
     }
@@ -911,31 +917,40 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
     cpw = (cpw + 15) & ~15;
     const int k0 = (split * 4 + wave) * cpw;
     const int k1 = (k0 + cpw < kv_len) ? k0 + cpw : kv_len;
-    const int qi = n;                                              // this lane's query row
-    const int row_vis_end = qi < q_len ? (p.tail ? past_len : past_len + qi + 1) : 0;
+    int qi[RT], row_vis_end[RT];                                   // this lane's query row of each row tile
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        qi[rt] = rt * 16 + n;
+        row_vis_end[rt] = qi[rt] < q_len ? (p.tail ? past_len : past_len + qi[rt] + 1) : 0;
+    }
 
     // Every load below is unconditional (rows / keys past the end are clamped to the last valid one and masked later): a load
     // under a branch makes hipcc's vmcnt bookkeeping wait for the NEWEST loads at the first use, which would put the whole
     // V stream behind the K round trip.
-    h8 qf[KS], qfl[KS];
-    {
-        const int qc = qi < q_len ? qi : q_len - 1;
+    h8 qf[RT][KS], qfl[RT][KS];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int qc = qi[rt] < q_len ? qi[rt] : q_len - 1;
         const _Float16* qlo = p.q_lo ? p.q_lo : p.q;          // (no lo plane: a finite stand-in, multiplied by zero below)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int64_t off = b * p.q_bs + (int64_t)qc * p.q_ts + (int64_t)h * D + ks * 32 + g * 8;
-            qf[ks] = *(const h8*)(p.q + off);
-            qfl[ks] = *(const h8*)(qlo + off);
+            qf[rt][ks] = *(const h8*)(p.q + off);
+            qfl[rt][ks] = *(const h8*)(qlo + off);
         }
         if (!p.q_lo) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { h8 z = {0, 0, 0, 0, 0, 0, 0, 0}; qfl[ks] = z; }
+            for (int ks = 0; ks < KS; ++ks) { h8 z = {0, 0, 0, 0, 0, 0, 0, 0}; qfl[rt][ks] = z; }
         }
     }
-    f4 o[DB];
+    f4 o[RT][DB];
+    float m_run[RT], l_run[RT];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) { f4 z = {0.f, 0.f, 0.f, 0.f}; o[db] = z; }
-    float m_run = kNegBig, l_run = 0.f;
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { f4 z = {0.f, 0.f, 0.f, 0.f}; o[rt][db] = z; }
+        m_run[rt] = kNegBig; l_run[rt] = 0.f;
+    }
     const _Float16* kbase = p.k + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
     const _Float16* vbase = p.v + b * p.kv_bs + (int64_t)hkv * p.kv_hs;
     [[maybe_unused]] const float slope = ALIBI ? p.slopes[h] : 0.f;
@@ -1003,53 +1018,56 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
             }
         }
         __builtin_amdgcn_sched_barrier(0);               // the whole tile is in flight before the first wait
-        // ---- S^T = K . Q^T ----
-        float sv[4][4];
-        float mx = -INFINITY;
+        // ---- S^T = K . Q^T, online softmax: per row tile, on the same K fragments ----
+        h8 pb[RT][2], pbl[RT][2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) {
+            float sv[4][4];
+            float mx = -INFINITY;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const h8 a = __builtin_bit_cast(h8, kr[kb][ks]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qfl[ks], acc, 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const h8 a = __builtin_bit_cast(h8, kr[kb][ks]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[rt][ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qfl[rt][ks], acc, 0, 0, 0);
+                }
+                f4 kb4 = {0.f, 0.f, 0.f, 0.f};
+                if (ALIBI) kb4 = *(const f4*)(kpos + key0 + kb * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kb * 16 + g * 4 + r;
+                    float sc = acc[r] * p.scale_log2;
+                    if (ALIBI) sc += slope * kb4[r];
+                    const float s = (key < row_vis_end[rt] && key < k1) ? sc : -INFINITY;
+                    sv[kb][r] = s;
+                    mx = fmaxf(mx, s);
+                }
             }
-            f4 kb4 = {0.f, 0.f, 0.f, 0.f};
-            if (ALIBI) kb4 = *(const f4*)(kpos + key0 + kb * 16 + g * 4);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[rt], mx);
+            const float alpha = fast_exp2(m_run[rt] - m_new);
+            float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + kb * 16 + g * 4 + r;
-                float sc = acc[r] * p.scale_log2;
-                if (ALIBI) sc += slope * kb4[r];
-                const float s = (key < row_vis_end && key < k1) ? sc : -INFINITY;
-                sv[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp2(sv[kb][r] - m_new);
+                    rs += e;
+                    const _Float16 eh = (_Float16)e;
+                    pb[rt][kb >> 1][(kb & 1) * 4 + r] = eh;
+                    pbl[rt][kb >> 1][(kb & 1) * 4 + r] = (_Float16)(e - (float)eh);
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            if (rt == 0 && key0 == k0) stamp(1);         // K arrived, scores + softmax of the first tile done
+            l_run[rt] = l_run[rt] * alpha + rs;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) { o[rt][db][0] *= alpha; o[rt][db][1] *= alpha; o[rt][db][2] *= alpha; o[rt][db][3] *= alpha; }
+            m_run[rt] = m_new;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2(m_run - m_new);
-        float rs = 0.f;
-        h8 pb[2], pbl[2];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = fast_exp2(sv[kb][r] - m_new);
-                rs += e;
-                const _Float16 eh = (_Float16)e;
-                pb[kb >> 1][(kb & 1) * 4 + r] = eh;
-                pbl[kb >> 1][(kb & 1) * 4 + r] = (_Float16)(e - (float)eh);
-            }
-        rs += __shfl_xor(rs, 16);
-        rs += __shfl_xor(rs, 32);
-        if (key0 == k0) stamp(1);                        // K arrived, scores + softmax of the first tile done
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int db = 0; db < DB; ++db) { o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha; }
-        m_run = m_new;
         // ---- the V tile has landed (this wave's own DMA: vmcnt covers it, no barrier), back transposed ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1061,8 +1079,11 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
                 const h4 lo = lds_tr_read(vp);
                 const h4 hi = lds_tr_read(vp + 16 * D);
                 const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[t], o[db], 0, 0, 0);
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[t], o[db], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    o[rt][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[rt][t], o[rt][db], 0, 0, 0);
+                    o[rt][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbl[rt][t], o[rt][db], 0, 0, 0);
+                }
             }
         }
         if constexpr (GATHER) {
@@ -1095,42 +1116,48 @@ __global__ __launch_bounds__(kThreads, GATHER ? 1 : 2) void attn_small_kernel(co
     stamp(2);                                            // the wave's key slice is done
     // ---- merge the four waves' partials through LDS: one (m, l, O) partial per workgroup ----
     __syncthreads();                                     // every wave is done with its V tile
-    float* mo = (float*)smem;                            // [4][DB][64][4]
-    float* mml = mo + 4 * DB * 64 * 4;                   // [4][16][2]
+    float* mo = (float*)smem;                            // [RT][4][DB][64][4]
+    float* mml = mo + RT * 4 * DB * 64 * 4;              // [RT][4][16][2]
 #pragma unroll
-    for (int db = 0; db < DB; ++db) *(f4*)(mo + ((wave * DB + db) * 64 + lane) * 4) = o[db];
-    if (g == 0) { mml[(wave * 16 + n) * 2] = m_run; mml[(wave * 16 + n) * 2 + 1] = l_run; }
-    __syncthreads();
-    float mw[4], lw[4], mstar = kNegBig;
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        mw[w] = mml[(w * 16 + n) * 2]; lw[w] = mml[(w * 16 + n) * 2 + 1];
-        mstar = fmaxf(mstar, mw[w]);
+        for (int db = 0; db < DB; ++db) *(f4*)(mo + (((rt * 4 + wave) * DB + db) * 64 + lane) * 4) = o[rt][db];
+        if (g == 0) { mml[((rt * 4 + wave) * 16 + n) * 2] = m_run[rt]; mml[((rt * 4 + wave) * 16 + n) * 2 + 1] = l_run[rt]; }
     }
-    float wt[4], lsum = 0.f;
+    __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { wt[w] = fast_exp2(mw[w] - mstar); lsum += wt[w] * lw[w]; }
-    if (qi < q_len) {
-        const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi;
-        constexpr int DPW = (DB + 3) / 4;                // head-dim blocks merged by one wave
+    for (int rt = 0; rt < RT; ++rt) {
+        float mw[4], lw[4], mstar = kNegBig;
 #pragma unroll
-        for (int j = 0; j < DPW; ++j) {
-            const int db = wave * DPW + j;
-            if (db < DB) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const f4 x = *(const f4*)(mo + ((w * DB + db) * 64 + lane) * 4);
-                    acc[0] += wt[w] * x[0]; acc[1] += wt[w] * x[1]; acc[2] += wt[w] * x[2]; acc[3] += wt[w] * x[3];
-                }
-                float* dst = p.part_o + slot * D + db * 16 + g * 4;
-                if constexpr (FUSE) { st_wt2(dst, acc[0], acc[1]); st_wt2(dst + 2, acc[2], acc[3]); }
-                else *(f4*)dst = acc;
-            }
+        for (int w = 0; w < 4; ++w) {
+            mw[w] = mml[((rt * 4 + w) * 16 + n) * 2]; lw[w] = mml[((rt * 4 + w) * 16 + n) * 2 + 1];
+            mstar = fmaxf(mstar, mw[w]);
         }
-        if (wave == 0 && g == 0) {
-            if constexpr (FUSE) st_wt2(p.part_ml + slot * 2, mstar, lsum);
-            else { p.part_ml[slot * 2] = mstar; p.part_ml[slot * 2 + 1] = lsum; }
+        float wt[4], lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { wt[w] = fast_exp2(mw[w] - mstar); lsum += wt[w] * lw[w]; }
+        if (qi[rt] < q_len) {
+            const int64_t slot = (((int64_t)b * p.H + h) * p.nsplit + split) * q_len + qi[rt];
+            constexpr int DPW = (DB + 3) / 4;                // head-dim blocks merged by one wave
+#pragma unroll
+            for (int j = 0; j < DPW; ++j) {
+                const int db = wave * DPW + j;
+                if (db < DB) {
+                    f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const f4 x = *(const f4*)(mo + (((rt * 4 + w) * DB + db) * 64 + lane) * 4);
+                        acc[0] += wt[w] * x[0]; acc[1] += wt[w] * x[1]; acc[2] += wt[w] * x[2]; acc[3] += wt[w] * x[3];
+                    }
+                    float* dst = p.part_o + slot * D + db * 16 + g * 4;
+                    if constexpr (FUSE) { st_wt2(dst, acc[0], acc[1]); st_wt2(dst + 2, acc[2], acc[3]); }
+                    else *(f4*)dst = acc;
+                }
+            }
+            if (wave == 0 && g == 0) {
+                if constexpr (FUSE) st_wt2(p.part_ml + slot * 2, mstar, lsum);
+                else { p.part_ml[slot * 2] = mstar; p.part_ml[slot * 2 + 1] = lsum; }
+            }
         }
     }
     if (p.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
@@ -1294,9 +1321,11 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
         if (rrc != PC_OK) return rrc;
     } else if (p.small && p.rows) {       // stage while reading (pc_attn gather_rows)
         if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0, true>), grid, dim3(kThreads), 0, stream, p);
+        else if (p.q_len > kSmallQ) hipLaunchKernelGGL((attn_small_kernel<D, false, 0, true, 2>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_small_kernel<D, false, 0, true>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.small) {
         if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0>), grid, dim3(kThreads), 0, stream, p);
+        else if (p.q_len > kSmallQ) hipLaunchKernelGGL((attn_small_kernel<D, false, 0, false, 2>), grid, dim3(kThreads), 0, stream, p);
         else hipLaunchKernelGGL((attn_small_kernel<D, false, 0>), grid, dim3(kThreads), 0, stream, p);
     } else if (rows32) {
         if (p.key_pos) hipLaunchKernelGGL((attn_fwd32_kernel<D, true>), grid, dim3(kThreads), 0, stream, p);
@@ -1350,7 +1379,7 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
         ns = (ns < kMaxSplit ? ns : kMaxSplit - 1) + 1;
     }
     // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
-    if (q_len <= kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;
+    if (q_len <= 2 * kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;   // (17..32 rows: two row tiles per wave)
     if (D == 128 && q_len >= ring_min_rows()) { const int nr = ring_nsplit(B, H, q_len, kv_len_max); ns = ns > nr ? ns : nr; }   // (pc_attn_ring.hip)
     if (ns <= 1) return 0;
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
@@ -1407,7 +1436,11 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     // <= 16 rows over a long cache: one key slice per WAVE, partials merged per workgroup (attn_small_kernel).  Not for
     // launches that carry residual tiles in the stream (decode over a residual tail, lo_row0 != -1).
     static const bool small_off = [] { const char* e = getenv("PC_ATTN_NO_SMALL"); return e && e[0] == '1'; }();
-    bool small = !small_off && q_len <= kSmallQ && !past_lens && (!k_lo || p.tail) && past_len + q_len >= 256;
+    // 17..32 rows in tail mode take the same kernel with two row tiles per wave (every K fragment and V tile serves both;
+    // two-launch form, no ALiBi instantiation); PC_ATTN_SMALL2=0: the 64-row kernel, as in rounds 1-3
+    static const bool small2_off = [] { const char* e = getenv("PC_ATTN_SMALL2"); return e && e[0] == '0'; }();
+    const bool small2 = !small2_off && q_len > kSmallQ && q_len <= 2 * kSmallQ && p.tail && !key_pos && !counters;
+    bool small = !small_off && (q_len <= kSmallQ || small2) && !past_lens && (!k_lo || p.tail) && past_len + q_len >= 256;
     if (small) {
         const int ns = small_nstream(B, H, p.tail) + p.tail;
         if (ns >= 2) p.nsplit = ns; else small = false;

@@ -56,10 +56,10 @@ tab = {
 }
 c = pick("attn_combine_kernel")
 # the timed step's attention since round 4: the staging variant (module K/V read once, staged rows written as they pass)
-a = pick("attn_small_kernel<128, false, 0, true>")
+a = pick("attn_small_kernel<128, false, 0, true, 1>")
 tab["attn_staging"] = {"signature": "H=32,Hkv=32,D=128,q=12,S=1725", "hbm_bytes_per_launch": (a + c) if a and c else None,
                        "source": src + " (attn_small_kernel<128, false, 0, true> = pc_attn gather_rows + attn_combine_kernel)"}
-a = pick("attn_small_kernel<128, false, 0, false>")          # (only present when the run includes steps that stage by pc_kv_gather)
+a = pick("attn_small_kernel<128, false, 0, false, 1>")          # (only present when the run includes steps that stage by pc_kv_gather)
 if a and c:
     tab["attn_cached"] = {"signature": "H=32,Hkv=32,D=128,q=12,S=1725", "hbm_bytes_per_launch": a + c,
                           "source": src + " (attn_small_kernel + attn_combine_kernel)"}

@@ -741,11 +741,14 @@ bool ring_eligible(const AttnParams& p, int D) {
 int ring_nsplit(int B, int H, int q_len, int kv_len) {
     const int units = B * H * pc_ceil_div(q_len, kRingQB);
     if (units >= 256) return 1;             // the grid fills the chip by itself: splits only add partials to merge
+    // (rounds 3-4 kept >= 4 stages per split; for 33..128 rows over a 1.7 k cache that left half of the CUs idle: 7b q = 36 / 50 /
+    // 66 / 102: 5.10 / 5.41 / 6.05 / 6.65 -> 4.91 / 5.27 / 5.85 / 6.48 ms without the floor, profiles/r04_variants.txt)
+    static const int min_stages = [] { const char* e = getenv("PC_RING_MIN_STAGES"); return e ? atoi(e) : 1; }();
     int best = 1;
     double best_cost = 1e30;
     for (int s = 1; s <= 16; ++s) {
         const int stages = pc_ceil_div(pc_ceil_div(kv_len, s), 2 * kTK);
-        if (s > 1 && stages < 4) break;
+        if (s > 1 && stages < min_stages) break;
         const int rounds = pc_ceil_div(units * s, 256);
         const double cost = rounds * (stages + 1.0) + (s > 1 ? 2.0 + 0.25 * s : 0.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }

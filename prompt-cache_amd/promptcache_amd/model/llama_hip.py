@@ -577,7 +577,9 @@ class LlamaHIP:
             return int(forced)
         if self.SKINNY_MAX_ROWS < T <= 512 and os.environ.get("PC_ROWS_WIDE", "1") != "0":
             blocks = 1 if T <= 288 else 2                     # (289..512 rows: two row blocks per column panel)
-            return max(1, min(8, 256 // (blocks * -(-N // 128))))
+            # (above 128 rows six slices beat eight at the 7b shape -- 192 workgroups, fewer slabs for the norm to fold:
+            # q = 130 / 194 / 258 / 288: 7.56 / 9.31 / 11.49 / 12.53 -> 7.45 / 9.09 / 10.97 / 11.92 ms; profiles/r04_variants.txt)
+            return max(1, min(8 if T <= 128 else 6, 256 // (blocks * -(-N // 128))))
         return self.kslices
 
     def _proj(self, a_hi, a_lo, lw: dict, key: str, M: int, N: int, K: int, epi: int, **out) -> None:

@@ -362,6 +362,51 @@ def test_attn_single_launch_merge_equals_two_launch_merge_and_oracle(B, H, Hkv, 
         np.testing.assert_allclose(got, ref, atol=2e-4, rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,Hkv,D,q_len,past", [(1, 32, 32, 128, 26, 1725), (2, 8, 2, 128, 17, 300), (1, 16, 16, 64, 32, 777), (1, 4, 4, 32, 21, 400),
+                                                   (1, 40, 40, 128, 31, 250)])
+@pytest.mark.parametrize("frag", [False, True])
+def test_attn_17_to_32_rows_over_a_long_cache_matches_the_oracle(B, H, Hkv, D, q_len, past, frag):
+    """17..32 new rows in tail mode over >= 256 keys: attn_small_kernel with two row tiles per wave (+ the 32-row fp32 tail
+    workgroup, + attn_combine_kernel) against oracle.attention_core on the split-precision operands."""
+    n = _n()
+    rng = np.random.default_rng(23)
+    cap = past + q_len + 3
+    f16 = lambda a: torch.from_numpy(a.astype(np.float16)).to(DEV)             # noqa: E731
+    q32 = rng.standard_normal((B, q_len, H, D), dtype=np.float32)
+    q = f16(q32)
+    ql = f16(q32 - q.float().cpu().numpy())
+    k = f16(rng.standard_normal((B, Hkv, cap, D), dtype=np.float32))
+    v = f16(rng.standard_normal((B, Hkv, cap, D), dtype=np.float32))
+    k[:, :, past + q_len:] = float("nan")
+    v[:, :, past + q_len:] = float("nan")
+    klo = f16(1e-4 * rng.standard_normal((B, Hkv, q_len, D), dtype=np.float32))
+    vlo = f16(1e-4 * rng.standard_normal((B, Hkv, q_len, D), dtype=np.float32))
+    kv_lo = (klo, vlo, Hkv * q_len * D, q_len * D, -1)
+    ws = torch.full((max(n.attn_workspace_bytes(B, H, D, q_len, past + q_len), 4) // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    scale = 1.0 / np.sqrt(D)
+    if frag:
+        mt = (B * q_len + 15) // 16
+        oh = torch.full((mt, H * D // 32, 64, 8), float("nan"), dtype=torch.float16, device=DEV)
+        ol = torch.full_like(oh, float("nan"))
+        n.attn_fwd(q, q_len * H * D, H * D, k, v, Hkv * cap * D, cap * D, None, 0, 0, B, H, Hkv, D, q_len, past, scale, ws,
+                   out_frag=(oh, ol), q_lo=ql, kv_lo=kv_lo)
+        got = (n.from_act_frags(oh, B * q_len).float() + n.from_act_frags(ol, B * q_len).float()).view(B, q_len, H * D).cpu().numpy()
+    else:
+        oh = torch.full((B, q_len, H * D), float("nan"), dtype=torch.float16, device=DEV)
+        ol = torch.full_like(oh, float("nan"))
+        n.attn_fwd(q, q_len * H * D, H * D, k, v, Hkv * cap * D, cap * D, oh, q_len * H * D, H * D, B, H, Hkv, D, q_len, past, scale, ws,
+                   q_lo=ql, out_lo=ol, kv_lo=kv_lo)
+        got = (oh.float() + ol.float()).cpu().numpy()
+    torch.cuda.synchronize()
+    kf = k.float().clone(); vf = v.float().clone()
+    kf[:, :, past:past + q_len] += klo.float(); vf[:, :, past:past + q_len] += vlo.float()
+    qn = (q.float() + ql.float()).cpu().numpy().transpose(0, 2, 1, 3)
+    ref = orc.attention_core(qn, kf[:, :, :past + q_len].cpu().numpy(), vf[:, :, :past + q_len].cpu().numpy(), past, H // Hkv)
+    ref = ref.transpose(0, 2, 1, 3).reshape(B, q_len, H * D)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-4)
+
+
 def test_attn_softmax_rescale_with_key_spike():
     """Force the running max to jump late in the KV stream (online-softmax rescale path) and early
     (later tiles contribute ~0): a spike row in K aligned with one query."""

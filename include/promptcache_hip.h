@@ -173,7 +173,8 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *              lies -- plane gather_k_plane + kv_head for K, gather_v_plane + kv_head for V: (layer * 2 + 0|1) * Hkv of this
  *              layer -- and, unless the entry carries PC_KV_ROW_STAGED, written to row r of `k` / `v`.  After the launch
  *              rows [0, past_len) of `k` / `v` hold exactly what pc_kv_gather would have left there.  Rows from past_len on
- *              (this pass's own) are read from `k` / `v` as always
+ *              (this pass's own) are read from `k` / `v` as always.  Implemented by the streaming kernel of <= 32-row passes
+ *              (tail mode or >= 256 keys), the tail-mode 64-row kernel, and the ring kernel (33..512 split-precision rows, D = 128)
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
 

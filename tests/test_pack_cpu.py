@@ -102,12 +102,13 @@ def test_union_member_equal_to_or_prefixing_the_default_member_still_runs_one_ro
 
 def test_rows_kslices_fills_the_chip_with_k_slices_for_wide_panels():
     """LlamaHIP.rows_kslices: 65..288 rows -> 256 // (N / 128) slices (wide panels), 289..512 -> half of that (two row blocks per
-    panel), clamped to 1..8; other row counts keep the model's default."""
+    panel), clamped to 1..8 up to 128 rows and to 1..6 above (measured: profiles/r04_variants.txt); other row counts keep the
+    model's default."""
     import types
     from promptcache_amd.model.llama_hip import LlamaHIP
     m = types.SimpleNamespace(SKINNY_MAX_ROWS=64, kslices=4)
     f = lambda T, N: LlamaHIP.rows_kslices(m, T, N)       # noqa: E731
-    assert f(259, 5120) == 6 and f(259, 4096) == 8 and f(100, 8192) == 4 and f(70, 64) == 8
+    assert f(259, 5120) == 6 and f(259, 4096) == 6 and f(128, 4096) == 8 and f(129, 4096) == 6 and f(100, 8192) == 4 and f(70, 64) == 8
     assert f(402, 5120) == 3 and f(512, 4096) == 4
     assert f(12, 4096) == 4 and f(64, 4096) == 4 and f(600, 4096) == 4
     assert f(259, 128 * 300) == 1

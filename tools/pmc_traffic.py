@@ -65,6 +65,22 @@ if a and c:
                           "source": src + " (attn_small_kernel + attn_combine_kernel)"}
 tab["gemm_skinny_qkv"] = {"signature": "T=12,hid=4096,inter=11008", "hbm_bytes_per_launch": pick("gemm_skinny_kernel<1, 3, 3"),
                           "source": src + " (q|k|v + RMSNorm + RoPE + KV append)"}
+# --config4: one more pair of passes over bench.py --config 4 for the ring attention of its step (13b, 259 rows over 8 258 keys)
+if "--config4" in sys.argv:
+    v4 = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(OUT, "c4_" + ctr)
+        subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable,
+                        os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+        xs = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "attn_ring_kernel<true, false, true>" in r["Kernel_Name"]]
+        v4[ctr] = sum(xs) / len(xs) if xs else None
+    if v4["FETCH_SIZE"] is not None and v4["WRITE_SIZE"] is not None:
+        tab["attn_ring_staging"] = {"signature": "H=40,Hkv=40,D=128,q=259,S=8258",
+                                    "hbm_bytes_per_launch": int((2 * v4["FETCH_SIZE"] + v4["WRITE_SIZE"]) * 1024),
+                                    "source": src.replace("bench.py --no-context", "bench.py --config 4") +
+                                    " (attn_ring_kernel<true, false, true> = pc_attn gather_rows at > 32 rows; the split merge not included)"}
 # keep entries of earlier rounds that this run did not re-measure (e.g. attn_cached: the copy-first step)
 try:
     old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

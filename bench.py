@@ -384,15 +384,25 @@ def config_workload(cfg: int):
 
 
 def run_config(args, device, world, rank, barrier):
+    result = measure_config(args.config, args.steps, args.warmup, device, world, rank, barrier)
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def measure_config(cfg, steps, warmup, device, world, rank, barrier, lm=None, repeats: int = 3, attention_leg: bool = True):
     """BASELINE.json configs 2-4 with the reference's latency recipe (eval.py:172-219, eval_sys.py:29): for every entry
-    add_schema -> process -> first lm() call, the cached run and the no_cache run, 3 repeats each.  The driver-timed region
-    is K cached steps (one step = CacheEngine.process + first forward of the next entry, entries cycled, schemas resident)."""
+    add_schema -> process -> first lm() call, the cached run and the no_cache run, ``repeats`` repeats each.  The timed region
+    is K cached steps (one step = CacheEngine.process + first forward of the next entry, entries cycled, schemas resident).
+    ``lm``: a resident model of the config's shape to reuse (the default run's ``configs`` leg reuses the headline 7b model for
+    config 2)."""
     import torch
     import torch.distributed as dist
     from promptcache_amd import CacheEngine, Prompt
     from promptcache_amd.model import Llama2
+    args = argparse.Namespace(config=cfg, steps=steps, warmup=warmup)
     name, max_ctx, max_tokens, entries, label = config_workload(args.config)
-    lm = Llama2(name, device=device, random_init=True, seed=0)
+    if lm is None:
+        lm = Llama2(name, device=device, random_init=True, seed=0)
     eng = CacheEngine(max_ctx, lm)
     fmt = lm.get_formatter()
     t0 = time.perf_counter()
@@ -418,7 +428,7 @@ def run_config(args, device, world, rank, barrier):
     for pr in prompts:                                     # the reference's per-entry numbers (3 repeats, eval_sys.py:29)
         ent = {}
         for mode, nc in (("cached", False), ("no_cache", True)):
-            runs = [one(pr, nc) for _ in range(4)][1:]     # first run of a shape pays hipGraph capture / code-object load
+            runs = [one(pr, nc) for _ in range(repeats + 1)][1:]     # first run of a shape pays hipGraph capture / code-object load
             ent[mode] = {"new_tokens": runs[0][0], "staged_tokens": runs[0][1],
                          "cache_time_ms": [r[2] for r in runs], "response_time_ms": [r[3] for r in runs],
                          "ttft_ms": min(r[2] + r[3] for r in runs)}
@@ -458,12 +468,42 @@ def run_config(args, device, world, rank, barrier):
                            "algorithmic_bytes_per_step": step_bytes,
                            "note": "q > 64 rows (config 4) leaves the weight-streaming regime; per-kernel figures: bench.py --config 1"},
               "encode_seconds": t_enc, "entries": per_entry,
-              "recipe": "reference eval.py:172-219: per entry cache_time + response_time, cached and no_cache, best of 3"}
+              "recipe": f"reference eval.py:172-219: per entry cache_time + response_time, cached and no_cache, best of {repeats}"}
     q0, S0 = per_entry[0]["cached"]["new_tokens"], per_entry[0]["cached"]["staged_tokens"]
-    if rank == 0 and q0 > 64 and lm.hf_model.D == 128:
+    if rank == 0 and q0 > 64 and lm.hf_model.D == 128 and attention_leg:
         result["roofline_attention"] = attn_many_roofline(lm, q0, S0)
-    if rank == 0:
-        print(json.dumps(result))
+    for nm in list(eng.schemas):
+        eng.remove_schema(nm)
+    return result
+
+
+def configs_leg(device, world, rank, barrier, lm7b):
+    """The other single-GPU BASELINE configs, compact, on the DEFAULT run's JSON line (the driver only runs
+    ``bench.py`` with default arguments, so configs 2-4 were builder-run claims): per config the cached step (ms, whole-step HBM
+    roofline fraction), staged / new tokens of the first entry, and the no_cache TTFT beside it.  Fewer steps and one repeat less
+    than ``--config N`` (which stays the full per-entry recipe)."""
+    import torch
+    out = {}
+    for cfg, steps, warm in ((2, 30, 5), (3, 48, 8), (4, 12, 3)):
+        t0 = time.perf_counter()
+        r = measure_config(cfg, steps, warm, device, world, rank, barrier, lm=lm7b if cfg == 2 else None, repeats=2,
+                           attention_leg=(cfg == 4))
+        e0 = r["entries"][0]
+        out[str(cfg)] = {"ms_per_step": r["ms_per_step"], "frac": r["roofline"]["frac"], "tokens_per_s": r["value"],
+                         "S": e0["cached"]["staged_tokens"], "q": e0["cached"]["new_tokens"], "entries": len(r["entries"]),
+                         "steps": steps, "no_cache_ttft_ms": sum(e["no_cache"]["ttft_ms"] for e in r["entries"]) / len(r["entries"]),
+                         "cached_ttft_ms_entries": [round(e["cached"]["ttft_ms"], 3) for e in r["entries"]],
+                         "workload": r["config"]["workload"], "leg_seconds": None}
+        if "roofline_attention" in r:
+            ra = r["roofline_attention"]
+            out[str(cfg)]["roofline_attention"] = {k: ra[k] for k in ("frac", "achieved", "unit", "avg_launch_us", "bound") if k in ra}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        out[str(cfg)]["leg_seconds"] = round(time.perf_counter() - t0, 2)
+    out["what"] = ("BASELINE configs 2-4 inside the default run: ms_per_step = K cached steps (CacheEngine.process + first lm() call, "
+                   "entries cycled), frac = (weights once + gather read/write + staged K/V once) / ms_per_step / 8 TB/s; "
+                   "`python bench.py --config N` prints the full per-entry recipe")
+    return out
 
 
 def plan_only(args):
@@ -554,8 +594,14 @@ def plan_only(args):
                 extra = {"seconds_compute_by_measured_curve": round(max(t_curve), 4),
                          "predicted_speedup_by_measured_curve": round(t_one_curve / (max(t_curve) + t_rx_last), 2),
                          "predicted_speedup_by_measured_curve_exchange_exposed": round(t_one_curve / (max(t_curve) + t_rx_all), 2)}
+            lib_bytes = sum(len(tc) for c in caches for j in c._plan_with_prefix()[0] for tc in j["owned"]) * kvb
             rows.append({"ranks": world, "per_rank_computed_rows": loads, "compute_speedup": round(one / max(loads), 2), **extra,
                          "exchange_rx_bytes_per_rank_max": int(max(rx)),
+                         # what a rank ALLOCATES for the exchange: one receive slab per peer and schema at its exact size
+                         # (parallel.exchange_slabs; the received segments are used in place) -- next to its own slabs that makes
+                         # the whole library resident on every rank, as the reference keeps it on its one device
+                         "receive_buffer_bytes_per_rank": [int(b) for b in rx],
+                         "library_bytes_resident_per_rank": int(lib_bytes),
                          "seconds_compute": round(t_comp, 4), "seconds_exchange_if_fully_exposed": round(t_rx_all, 4),
                          "seconds_exchange_last_schema": round(t_rx_last, 4),
                          "predicted_speedup_overlapped": round((one / row_rate) / (t_comp + t_rx_last), 2),
@@ -565,6 +611,9 @@ def plan_only(args):
     out["measured_curve"] = None if not curve else {"file": os.path.relpath(cpath, ROOT), "points": len(curve),
                                                      "what": "seconds of ONE encode forward (many_rows, kv_only) by its row count, 1 GPU; "
                                                              "*_by_measured_curve price every forward of every rank on it instead of one rate"}
+    out["memory_note"] = ("every rank ends with the whole module library resident (own slabs + receive slabs = "
+                          "library_bytes_resident_per_rank, independent of the rank count): fine at 288 GB of HBM per GPU, and what "
+                          "CacheEngine.process needs -- any prompt may name any module")
     out["note"] = ("compute_speedup = rows of a one-rank encode / rows of the most loaded rank (a rank that takes passes of a schema "
                    "re-runs its trunk); seconds_* price rows at the assumed scaffold-token rate (computed rows cost "
                    "scaffold_tokens / computed_rows of a scaffold token each) and the exchange at (ranks - 1) links of the "
@@ -589,6 +638,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-library", action="store_true", help="skip the schema-library encode leg (BASELINE config 5)")
     ap.add_argument("--no-int8", action="store_true", help="skip the int8-weight context leg (builds a second model)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the compact BASELINE config 2-4 legs of the default run")
     ap.add_argument("--no-context", action="store_true", help="skip the extra (untimed) no-cache / decode / GEMM-roofline runs")
     ap.add_argument("--plan-only", action="store_true",
                     help="CPU only: print the predicted 1/2/4/8-GPU schedule of the schema-library encode and exit")
@@ -1015,6 +1065,10 @@ def main():
         base, parity = cpu_baseline_and_parity(lm, eng, prompt, ids, pos, args.cpu_layers, parity_layers=args.parity_layers)
         result["cpu_baseline"] = base
         result["parity"] = parity
+    if rank == 0 and world == 1 and not args.no_context and not args.no_configs:
+        eng.remove_all_schemas()
+        torch.cuda.empty_cache()
+        result["configs"] = configs_leg(device, world, rank, barrier, lm)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

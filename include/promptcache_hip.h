@@ -130,8 +130,8 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *   sees every staged key j < past_len and new keys past_len + i' with i' <= i.  fp32 softmax and
  *   accumulation, MFMA fp16 x fp16 -> fp32 for both contractions, flash-style (scores are never
  *   materialised), split over the KV axis when (heads x q-blocks) cannot fill the chip.
- *   ONE struct-taking entry point (rounds 1-2 exported pc_attn_fwd / _alibi / _ex / _var: C callers find them as inline
- *   wrappers over this one in promptcache_hip_compat.h).  Optional pointers are NULL when unused.
+ *   ONE struct-taking entry point (rounds 1-2 exported pc_attn_fwd / _alibi / _ex / _var; they had no caller left and are
+ *   gone since round 4).  Optional pointers are NULL when unused.
  *
  *   struct_bytes  sizeof(pc_attn_args) of the caller's header (ABI check)
  *   q, q_lo    fp16 [B][q_len][H][D], RoPE applied; q_lo: optional low-order plane (q = q_hi + q_lo: split precision)
@@ -494,8 +494,10 @@ int pc_fetch_block(const void* host_src, void* dst, int32_t nbytes, void* stream
  * segments, rows of the row table, ...} | pc_kv_seg[max_seg] at o_segs): the block copied to its device twin (pc_fetch_block), the
  * embedding rows of the tokens as the fp32 residual stream x_out [n_tok][hidden] (embed_tokens, llama2.py:869), the (cos, sin)
  * rows of the supplied positions cs_out [n_tok][head_dim/2][2] (pc_rope_table; llama2.py:129-147, :204-207) and -- when `rows` is
- * given -- the staging plan expanded per staged row (pc_kv_row_table; words[3] segments, words[4] rows).  Replaces the uploads of
- * generation_engine.py:96-97 and four small launches per forward. */
+ * given -- the staging plan expanded per staged row (pc_kv_row_table; words[3] segments, words[4] rows).  words[5] != 0: the
+ * caller's ids / positions are DEVICE tensors (the reference's convention, generation_engine.py:96-97) that it copied into the
+ * ids | pos region of dev_block on `stream` before this launch -- they are read there and that region is not overwritten (no
+ * host read-back of device inputs).  Replaces the uploads of generation_engine.py:96-97 and four small launches per forward. */
 int pc_prefill_prologue(const void* host_block, void* dev_block, int32_t nbytes, int32_t n_tok, int32_t o_pos, int32_t o_words,
                         int32_t o_segs, int32_t max_seg, const void* embed_table, int32_t hidden, int32_t vocab, float* x_out,
                         const float* inv_freq, int32_t head_dim, float* cs_out, pc_kv_row* rows, const void* dst, int32_t max_ctx,

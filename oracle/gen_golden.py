@@ -2,6 +2,7 @@
 /root/reference via ``oracle/ref_shim.py``) in the build container.
 
     python oracle/gen_golden.py            # rewrites tests/golden/*
+    python oracle/gen_golden.py --layout-only   # only pml_layout.json / pml_recover.json / pml/*.xml
 
 TEST INFRASTRUCTURE.  The reference never ships to the GPU box: only these fixtures (data: inputs and
 expected outputs) and this script are committed.  Inputs are reproducible without the reference:
@@ -89,6 +90,30 @@ SYN_FLAT = """<schema name="doc">
 </schema>
 """
 SYN_FLAT_PROMPT = """<prompt schema='doc'><a/><b/><c/><user>When does the committee meet?</user></prompt>"""
+
+# Children the reference serialises as text (schema.py:362-363): XML comments (under lxml a comment is a child node whose tag is not
+# a string) and unknown elements go through ``lxml.etree.tostring`` -- which returns BYTES -- into ``lm.encode``; a comment inside a
+# union fails the union's tag check (schema.py:207-208).  Authored here; what the reference does with them is recorded.
+SYN_COMMENT_MODULE = """<schema name="c1">
+    <module name="a">Alpha text. <!-- a note for the schema author --> Beta text.</module>
+</schema>
+"""
+SYN_COMMENT_UNION = """<schema name="c2">
+    <module name="m"><union><!-- pick one --><module name="x">X.</module><module name="y">Y.</module></union></module>
+</schema>
+"""
+SYN_UNKNOWN_TAG = """<schema name="c3">
+    <module name="a">Some <b>bold</b> words.</module>
+</schema>
+"""
+SYN_COMMENT_OUTSIDE = """<!-- scenario: 1 -->
+<schema name="c4">
+    <module name="a">Alpha text.</module>
+</schema>
+<!-- trailing -->
+"""
+SYN_EXTRA = {"syn:comment_module": ("comment_module.xml", SYN_COMMENT_MODULE), "syn:comment_union": ("comment_union.xml", SYN_COMMENT_UNION),
+             "syn:unknown_tag": ("unknown_tag.xml", SYN_UNKNOWN_TAG), "syn:comment_outside": ("comment_outside.xml", SYN_COMMENT_OUTSIDE)}
 
 PERSONA_PROMPT = """<prompt schema='persona'>
     <age><young-adult/></age>
@@ -220,11 +245,13 @@ def layout_goldens(pc):
              ("examples/personalization-education.xml", None), ("benchmark/schema/test/schema_mbti.xml", None),
              ("benchmark/schema/test/schema_mbti_short.xml", None), ("benchmark/schema/test/schema_persona.xml", None),
              ("benchmark/schema/test/schema_persona_long.xml", None), ("benchmark/schema/test/empty.xml", None),
-             ("syn:trip", None), ("syn:doc", None), ("syn:trip", 12)]
+             # the two reference schemas that carry XML comments among module children (schema.py:362-363)
+             ("benchmark/schema/test/schema_code_generation.xml", None), ("benchmark/schema/test/schema_long_task_1.xml", None),
+             ("syn:trip", None), ("syn:doc", None), ("syn:trip", 12)] + [(k, None) for k in SYN_EXTRA]
     out = {}
     for fn, max_tokens in files:
         if fn.startswith("syn:"):
-            text = fmt({"syn:trip": SYN_UNION, "syn:doc": SYN_FLAT}[fn])
+            text = fmt({"syn:trip": SYN_UNION, "syn:doc": SYN_FLAT, **{k: v[1] for k, v in SYN_EXTRA.items()}}[fn])
         else:
             text = rp.read_file(os.path.join(REF, fn), [fmt])
         key = fn + (f"@{max_tokens}" if max_tokens else "")
@@ -428,9 +455,11 @@ def main():
     with open(os.path.join(GOLD, "pml_recover.json"), "w") as f:
         json.dump(recover_goldens(), f, indent=0)
     os.makedirs(os.path.join(GOLD, "pml"), exist_ok=True)
-    for name, text in (("trip.xml", SYN_UNION), ("doc.xml", SYN_FLAT)):
+    for name, text in (("trip.xml", SYN_UNION), ("doc.xml", SYN_FLAT), *SYN_EXTRA.values()):
         with open(os.path.join(GOLD, "pml", name), "w") as f:
             f.write(text)
+    if "--layout-only" in sys.argv:          # the integer-layout fixtures alone (seconds; the model fixtures take minutes)
+        return
     model_golden(pc, "tiny_trip", "tiny", seed=0, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT, max_ctx=256)
     model_golden(pc, "tiny_trip2", "tiny", seed=0, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT2, max_ctx=256)
     model_golden(pc, "mid_trip", "mid", seed=1, scale=2.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT, max_ctx=300)

@@ -6,9 +6,10 @@ TEST INFRASTRUCTURE (used by ``oracle/gen_golden.py`` to produce the committed f
 ``bench.py`` imports this module.
 
 Shims:
-  * ``lxml`` / ``lxml.etree`` -> stdlib ElementTree; ``XMLParser(recover=True)`` is emulated by a
-    pre-pass through the system libxml2 (``xmlReadMemory`` with XML_PARSE_RECOVER), the same library
-    lxml wraps, then a strict ElementTree parse of the repaired dump;
+  * ``lxml`` / ``lxml.etree`` -> stdlib ElementTree with comments kept as child nodes (as lxml keeps them);
+    ``XMLParser(recover=True)`` is emulated by a pre-pass through the system libxml2 (``xmlReadMemory`` with
+    XML_PARSE_RECOVER), the same library lxml wraps, then a strict ElementTree parse of the repaired dump;
+    ``tostring`` returns bytes with the tail, like lxml's;
   * ``termcolor`` -> identity ``colored``;
   * ``transformers.utils.is_flash_attn_available`` -> ``False`` (needed by the falcon import chain);
   * ``torch.cuda.Event`` / ``torch.cuda.synchronize`` -> perf_counter based fakes (no GPU here).
@@ -55,18 +56,30 @@ class _XMLParser:
         self.recover = recover
 
 
+def _et_parse(text: str):
+    """ElementTree parse that KEEPS comments as child nodes, as lxml does (its XMLParser has remove_comments=False): a comment is
+    an element whose ``tag`` is the ``ET.Comment`` factory -- not a string, exactly like ``lxml.etree.Comment`` -- so the
+    reference's ``match e.tag`` falls through to ``case _`` (schema.py:362-363) and ``e.tag != "module"`` is true in a union
+    (schema.py:207-208).  Comments outside the root element are dropped by the tree builder, as ``lxml.etree.fromstring`` returns
+    the root element only."""
+    return ET.fromstring(text, parser=ET.XMLParser(target=ET.TreeBuilder(insert_comments=True)))
+
+
 def _fromstring(text, parser=None):
     if isinstance(text, bytes):
         text = text.decode("utf-8")
     try:
-        return ET.fromstring(text)
+        return _et_parse(text)
     except ET.ParseError:
         if parser is not None and getattr(parser, "recover", False):
-            return ET.fromstring(libxml2_recover(text))
+            return _et_parse(libxml2_recover(text))
         raise
 
 
 def _tostring(e, **_kw):
+    """``lxml.etree.tostring(e)`` with default arguments: BYTES (ASCII, character references for the rest), no declaration, the
+    element's tail included; a comment renders as ``<!--text-->`` + tail.  ``ET.tostring`` does all of that for both node kinds
+    (its serialiser writes ``<!--%s-->`` for ``ET.Comment`` nodes and appends the tail of the node it is given)."""
     return ET.tostring(e)
 
 

@@ -258,11 +258,20 @@ struct PrologueArgs {
 typedef _Float16 h8g __attribute__((ext_vector_type(8)));
 typedef float f4g __attribute__((ext_vector_type(4)));
 
+typedef __attribute__((address_space(1))) unsigned int g32;
+__device__ __forceinline__ unsigned int host_ld4(const void* p) {
+    return __hip_atomic_load((g32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void prefill_prologue_kernel(const PrologueArgs a) {
     __shared__ pc_kv_seg s_seg[kRowTabMaxSeg];
     const int b = blockIdx.x, tid = threadIdx.x;
+    // words[5] != 0: the caller's token ids and position ids are DEVICE tensors (the reference's calling convention,
+    // generation_engine.py:96-97) that it copied into the device twin's ids | pos region on this stream before the launch:
+    // read them there, and leave that region alone when the block is fetched
+    const bool dev_in = host_ld4(a.host + a.o_words + 20) != 0u;
     if (b < a.n_tok) {
-        long long id = (long long)host_ld8(a.host + 8 * b);
+        long long id = dev_in ? ((const long long*)a.dev)[b] : (long long)host_ld8(a.host + 8 * b);
         id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
         for (int i = tid; i < (a.hidden >> 3); i += 256) {
             const h8g v = *(const h8g*)(a.table + id * a.hidden + i * 8);
@@ -273,11 +282,20 @@ __global__ __launch_bounds__(256) void prefill_prologue_kernel(const PrologueArg
         return;
     }
     if (b == a.n_tok) {
-        for (int i = tid; i < a.nbytes / 8; i += 256) ((unsigned long long*)a.dev)[i] = host_ld8(a.host + 8 * i);
+        if (!dev_in) {
+            for (int i = tid; i < a.nbytes / 8; i += 256) ((unsigned long long*)a.dev)[i] = host_ld8(a.host + 8 * i);
+        } else {          // (o_words is only 4-byte aligned: the words and the plan go over in 4-byte pieces)
+            for (int i = a.o_words / 4 + tid; i < a.nbytes / 4; i += 256) ((unsigned int*)a.dev)[i] = host_ld4(a.host + 4 * i);
+        }
         for (int i = tid; i < a.n_tok * a.half_dim; i += 256) {
             const int t = i / a.half_dim, f = i - t * a.half_dim;
-            const unsigned long long w = host_ld8(a.host + a.o_pos + 8 * (t >> 1));      // two int32 positions per 8 bytes
-            const int pos = (int)((t & 1) ? (w >> 32) : (w & 0xffffffffu));
+            int pos;
+            if (dev_in) {
+                pos = ((const int*)(a.dev + a.o_pos))[t];
+            } else {
+                const unsigned long long w = host_ld8(a.host + a.o_pos + 8 * (t >> 1));  // two int32 positions per 8 bytes
+                pos = (int)((t & 1) ? (w >> 32) : (w & 0xffffffffu));
+            }
             const float ang = __fmul_rn((float)pos, a.inv_freq[f]);                      // as rope_table_kernel (pc_rope.hip)
             float sn, c;
             sincosf(ang, &sn, &c);

@@ -582,7 +582,11 @@ class SchemaCache:
                 torch.cuda.synchronize()
             blocking_s = 0.0 if async_exchange else time.perf_counter() - t_x      # a blocking exchange is exposed in full
             self._pending.extend(handles)
-            self._exchange = dict(slab=my_slab, sizes=sizes_by_rank, bytes_rx=parallel.exchange_bytes(sizes_by_rank)[rank])
+            # bytes_rx: the planner's figure (parallel.exchange_bytes, from the token layout); bytes_rx_buffers: what the receive
+            # slabs this rank really allocated and posted irecvs for hold (tests assert the two agree)
+            self._exchange = dict(slab=my_slab, sizes=sizes_by_rank, bytes_rx=parallel.exchange_bytes(sizes_by_rank)[rank],
+                                  bytes_rx_buffers=sum(v.numel() * v.element_size() for r, vs in enumerate(views_by_rank)
+                                                       if r != rank for v in vs))
             for r, idxs in enumerate(shards):
                 vit = iter(views_by_rank[r])
                 for i in idxs:
@@ -595,7 +599,9 @@ class SchemaCache:
         self.encode_stats = dict(passes=len(mine), total_passes=len(jobs), encoded_tokens=encoded_tokens,
                                  computed_tokens=computed_tokens, trunk_shared_passes=len(shared), owner_rank=owner_rank,
                                  cached_tokens=sum(len(c) for c in self.cache_l1.values()),
+                                 owned_cached_tokens=sum(len(tc) for i in mine for tc in jobs[i]["owned"]),   # ... this rank encoded
                                  exchange_bytes_rx=(self._exchange["bytes_rx"] if world > 1 else 0),
+                                 exchange_bytes_rx_buffers=(self._exchange["bytes_rx_buffers"] if world > 1 else 0),
                                  exchange_exposed_s=(blocking_s if world > 1 else 0.0))
         gc.collect()
 

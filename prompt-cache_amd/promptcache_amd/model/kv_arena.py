@@ -13,6 +13,7 @@ past in every layer of every call, ``promptcache/model/llama2.py:361-364``).
 from __future__ import annotations
 
 import weakref
+from collections.abc import Sequence
 from typing import List, Optional, Tuple
 
 import torch
@@ -138,50 +139,72 @@ class KVArena:
         return a
 
 
-class StagedKV(list):
+class StagedKV(Sequence):
     """``past_key_values`` as the reference's callers index it (``[layer][0|1]``), plus the arena it
     aliases so the model can append in place.  Entries are ``[B, Hkv, length, D]`` views (``[Hkv, length, D]`` for the
     unbatched form ``CacheEngine.process`` returns).
 
-    The 2 x n_layers views are built when somebody first LOOKS at them -- indexing, iterating, assigning -- which is what a
-    caller that inspects or rebuilds the list does (the reference's GenerationEngine, generation_engine.py:101-102); at that
-    moment a staging the arena still owes (``KVArena.pending``) is carried out too.  Handing the object itself to the model
-    does neither: the model finds the arena through ``.arena`` and may stage inside its first attention launches -- and the
-    engines' own hot path never pays for 64 tensor views per call."""
+    The 2 x n_layers views are built when somebody first LOOKS at them -- indexing, iterating, comparing, copying -- which is
+    what a caller that inspects or rebuilds the list does (the reference's GenerationEngine, generation_engine.py:101-102); at
+    that moment a staging the arena still owes (``KVArena.pending``) is carried out too.  Handing the object itself to the
+    model does neither: the model finds the arena through ``.arena`` and may stage inside its first attention launches -- and
+    the engines' own hot path never pays for 64 tensor views per call.
+
+    A ``collections.abc.Sequence`` (not a ``list`` subclass: a list's C fast paths -- ``copy()``, ``+``, ``==``, pickling,
+    ``PySequence_Fast`` consumers -- read the underlying storage directly and would see an empty list without carrying out a
+    pending staging); every read accessor, inherited mixins included, goes through ``__getitem__`` / ``__iter__``."""
 
     def __init__(self, arena: KVArena, length: int, batched: bool = True):
-        super().__init__()
         self.arena = arena
         self.length = length
         self._batched = batched
-        self._built = False
+        self._items: Optional[list] = None
 
-    def _look(self) -> None:
+    def _look(self) -> list:
         a = self.arena
         if a.pending is not None:
             a.materialize()
-        if not self._built:
-            self._built = True
+        if self._items is None:
             n, buf = self.length, a.buf
             if self._batched:
-                list.extend(self, ((buf[:, i, 0, :, :n], buf[:, i, 1, :, :n]) for i in range(a.L)))
+                self._items = [(buf[:, i, 0, :, :n], buf[:, i, 1, :, :n]) for i in range(a.L)]
             else:
-                list.extend(self, ((buf[0, i, 0, :, :n], buf[0, i, 1, :, :n]) for i in range(a.L)))
+                self._items = [(buf[0, i, 0, :, :n], buf[0, i, 1, :, :n]) for i in range(a.L)]
+        return self._items
 
     def __len__(self):
         return self.arena.L
 
     def __getitem__(self, i):
-        self._look()
-        return list.__getitem__(self, i)
+        return self._look()[i]
 
     def __setitem__(self, i, v):
-        self._look()
-        list.__setitem__(self, i, v)
+        self._look()[i] = v
 
     def __iter__(self):
-        self._look()
-        return list.__iter__(self)
+        return iter(self._look())
+
+    def __eq__(self, other):
+        if isinstance(other, StagedKV):
+            other = other._look()
+        return self._look() == other
+
+    __hash__ = None
+
+    def __add__(self, other):
+        return self._look() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self._look()
+
+    def copy(self) -> list:
+        return list(self._look())
+
+    def __reduce__(self):
+        return (list, (self._look(),))       # pickles as the plain list of views it stands for
+
+    def __repr__(self):
+        return f"StagedKV(layers={self.arena.L}, length={self.length}, pending={self.arena.pending is not None})"
 
     def unbatched(self) -> "StagedKV":
         """``[Hkv, length, D]`` views: what ``CacheEngine.process`` returns (``cache_engine.py:161-165``)."""

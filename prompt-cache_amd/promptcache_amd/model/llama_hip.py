@@ -45,7 +45,8 @@ class _InputBlock:
     (``pc_fetch_block``) pulls into its device twin:
 
         ids   int64 [T] | pos int32 [T] | words int32 [8] = {past_len, residual-tail base, live rows, segments, rows of the row
-        table, -, -, -} | pc_kv_seg [max_seg]  (the staging plan, when the forward stages while it reads)
+        table, ids / pos already on the device (0 | 1), -, -} | pc_kv_seg [max_seg]  (the staging plan, when the forward stages
+        while it reads)
 
     Per call the host writes the block (numpy views) and replays the graph: no copy is enqueued, no fill kernel launched.  The
     block may be rewritten once the replay that read it has finished (``acquire`` waits for the event ``release`` records)."""
@@ -504,7 +505,7 @@ class LlamaHIP:
         if many_rows and self.precise_dense and past_key_values is None:
             arena.with_lo()           # a schema-encode pass: keep the residuals of every row it appends
         if position_ids is None:  # llama2.py:859-864
-            position_ids = torch.arange(past_len, past_len + q_len, device=dev).unsqueeze(0).expand(B, q_len)
+            position_ids = torch.arange(past_len, past_len + q_len, device=input_ids.device).unsqueeze(0).expand(B, q_len)
         position_ids = position_ids.view(-1, q_len)
         if attention_mask is not None:
             am = attention_mask.to(dev)
@@ -977,13 +978,15 @@ class LlamaHIP:
             return q_len          # never across a row-tile count or the residual-tail regime of the attention
         return qb
 
-    def _gather_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
+    def _gather_ok(self, arena, B: int, q_len: int, past_len: int, num_layers: Optional[int] = None) -> bool:
         """Will the attention launches of this (bucketed) forward run on the kernel that stages while it reads?  Asked of the
         library itself (pc_attn_gather_ok) with the arguments _forward_skinny passes; the answer only depends on the row count,
         the residual mode and whether the key range reaches the streaming kernel's minimum, so it is remembered."""
         plan = arena.pending
         if plan is None or plan.total != past_len or len(plan.segs) > self.GATHER_MAX_SEG:
             return False
+        if num_layers is not None and num_layers < self.L:
+            return False      # a partial-depth forward would stage only its own layers' planes: materialise the whole plan instead
         return self._gather_shape_ok(arena, B, q_len, past_len)
 
     def _gather_shape_ok(self, arena, B: int, q_len: int, past_len: int) -> bool:
@@ -1013,8 +1016,11 @@ class LlamaHIP:
     def _graph_key(self, arena, B, q_len, past_len, last_token_only, num_layers, gather):
         mode = self._lo_mode
         tail = arena.tail_lo if mode else None
+        # (a staging forward captures the address of the arena's row table as well: a NEW arena that happens to land on the freed
+        # buffer address of an old one must not replay a graph that writes through the old arena's freed row table)
         return (B, q_len, arena.buf.data_ptr(), arena.cap, self._nsplit_key(B, q_len, past_len + q_len), bool(last_token_only), num_layers,
-                self.fuse_norm, self.use_chain, mode, tail.data_ptr() if mode else 0, tail.shape[4] if mode else 0, gather)
+                self.fuse_norm, self.use_chain, mode, tail.data_ptr() if mode else 0, tail.shape[4] if mode else 0,
+                arena.row_table().data_ptr() if gather else 0)
 
     def _graph_entry(self, key, arena, B, q_len, past_len, last_token_only, num_layers, gather, eager_first=True):
         """The captured forward for ``key`` -> ``[graph, input block, logits buffer]`` (captured now when it does not exist yet:
@@ -1037,11 +1043,16 @@ class LlamaHIP:
         self._graphs[key] = ent
         return ent, True
 
+    def _fused_pro(self) -> bool:
+        """Does a captured forward of this model start with pc_prefill_prologue (one launch: block fetch, embedding, rotation
+        table, row table)?"""
+        return self.fused_prologue and type(self)._forward_skinny is LlamaHIP._forward_skinny and not self.llm_int8
+
     def _capture(self, ent, arena, B, q_len, past_len, last_token_only, num_layers, gather, eager_first=True):
         n = _native
         blk = ent[1]
 
-        fused_pro = self.fused_prologue and type(self)._forward_skinny is LlamaHIP._forward_skinny and not self.llm_int8
+        fused_pro = self._fused_pro()
 
         def run():
             if fused_pro:
@@ -1083,7 +1094,7 @@ class LlamaHIP:
         q_len = self._graph_rows(arena, B, q_len, past_len, last_token_only)
         if q_len != q_real:
             self._lo_mode = self._tail_mode(arena, q_len, past_len)
-        gather = self._gather_ok(arena, B, q_len, past_len)
+        gather = self._gather_ok(arena, B, q_len, past_len, num_layers)
         plan = arena.pending if gather else None
         if not gather:
             arena.materialize()
@@ -1095,14 +1106,26 @@ class LlamaHIP:
         # ---- this call's inputs: written into the pinned block the graph's first node fetches ----
         blk.acquire()
         n_real = q_real * B
-        if ids.is_cuda or pos.is_cuda:
-            ids, pos = ids.cpu(), pos.cpu()
-        blk.h_ids[:n_real] = ids.numpy()
-        blk.h_pos[:n_real] = pos.numpy()
-        if q_len != q_real:                                  # pad rows BEHIND the prompt's own (see _graph_rows)
-            blk.h_ids[n_real:] = 0
-            blk.h_pos[n_real:] = int(blk.h_pos[n_real - 1]) + np.arange(1, T - n_real + 1, dtype=np.int32)
         w = blk.h_words
+        dev_in = ids.is_cuda or pos.is_cuda
+        if dev_in and self._fused_pro():
+            # device inputs (the reference's calling convention, generation_engine.py:96-97): copied into the device twin's
+            # ids | pos region on this stream; the prologue reads them there (words[5]) -- no read-back, no host sync
+            blk.ids[:n_real].copy_(ids, non_blocking=True)
+            blk.pos[:n_real].copy_(pos, non_blocking=True)
+            if q_len != q_real:                              # pad rows BEHIND the prompt's own (see _graph_rows)
+                blk.ids[n_real:].zero_()
+                blk.pos[n_real:] = blk.pos[n_real - 1] + torch.arange(1, T - n_real + 1, dtype=torch.int32, device=self.device)
+            w[5] = 1
+        else:
+            if dev_in:                                       # (stacks without the fused prologue: correct, one read-back)
+                ids, pos = ids.cpu(), pos.cpu()
+            blk.h_ids[:n_real] = ids.numpy()
+            blk.h_pos[:n_real] = pos.numpy()
+            if q_len != q_real:                              # pad rows BEHIND the prompt's own (see _graph_rows)
+                blk.h_ids[n_real:] = 0
+                blk.h_pos[n_real:] = int(blk.h_pos[n_real - 1]) + np.arange(1, T - n_real + 1, dtype=np.int32)
+            w[5] = 0
         w[0] = past_len
         w[1] = arena.tail_base if mode == 2 else 0
         w[2] = n_real                                        # rows that carry tokens: the projections do not load the pad rows' activations
@@ -1111,7 +1134,11 @@ class LlamaHIP:
             w[3] = len(plan.segs)
             blk.h_segs[:len(plan.segs)] = plan.seg_array(_SEG_DTYPE)
         if fresh:
-            self._capture(ent, arena, B, q_len, past_len, last_token_only, num_layers, gather)
+            try:
+                self._capture(ent, arena, B, q_len, past_len, last_token_only, num_layers, gather)
+            except BaseException:
+                self._graphs.pop(key, None)                  # no half-built entry: the next call captures again
+                raise
         g, out = ent[0], ent[2]
         g.replay()
         blk.release()

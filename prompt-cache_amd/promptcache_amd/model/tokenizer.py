@@ -53,6 +53,12 @@ class StandInTokenizer:
         return tid
 
     def encode(self, text: str, add_special_tokens: bool = False) -> List[int]:
+        if not isinstance(text, str):
+            # the contract of the HF (Python) tokenizers the reference loads (LlamaTokenizer / CodeLlamaTokenizer,
+            # promptcache/model/__init__.py:167,188; transformers 4.34 PreTrainedTokenizer._encode_plus.get_input_ids): anything
+            # that is not a string or a list of strings / ints is refused -- the reference reaches this with the BYTES that
+            # lxml.etree.tostring returns for an XML comment or unknown tag among a module's children (schema.py:362-363)
+            raise ValueError(f"Input {text} is not valid. Should be a string, a list/tuple of strings or a list/tuple of integers.")
         ids: List[int] = [1] if add_special_tokens else []
         n = self.max_piece_chars
         for m in _PIECE.finditer(text):

@@ -1,12 +1,14 @@
 """Where does the full-depth (32-layer, 7b-shape) logit error come from?  Diagnostic, run by hand on the GPU box:
-    python -m tests.debug_full_depth [layers]
+    python -m tests.probes.full_depth [layers]
 Compares, against the numpy oracle: (a) the module KV the GPU encode stored, per layer; (b) the cached prefill run on
 the ORACLE's staged KV (isolates the prefill); (c) the end-to-end logits."""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prompt-cache_amd"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "prompt-cache_amd"))
 
 import numpy as np
 import torch

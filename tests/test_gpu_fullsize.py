@@ -216,72 +216,107 @@ def test_mpt_7b_shape_alibi_cached_equals_nocache_and_oracle():
 _skip_full = pytest.mark.skipif(os.environ.get("PC_SKIP_FULL_PARITY", "0") == "1", reason="PC_SKIP_FULL_PARITY=1")
 
 
-def _full_depth_llama(tag, shape, seed, schema, outlier_channels=None):
-    """Every layer of a Llama-family shape, end to end: schema encode (trunk reuse, dense + weight-streaming paths), gather,
-    cached prefill -- against the numpy oracle doing the reference's full per-scaffold encode in fp32 on the host.
-    ``outlier_channels``: scale these hidden channels of the embedding by 60x, so the residual stream carries a handful of
-    massive channels through every layer the way a trained Llama's does (after RMSNorm: ~24 against ~0.4 for the rest) --
-    the regime the split-precision planes, the fp16 K/V stores and the LLM.int8 outlier columns exist for; N(0, 0.02)
-    init alone never produces it."""
+_FULL = {}      # state shared by consecutive full-depth tests on ONE model: (lm, engine, oracle, oracle's module library, schema kwargs)
+
+
+def _full_depth_state(tag, shape, seed, schema, outlier_channels=None):
+    """Model + engine with the schema encoded on the GPU, and the numpy oracle with the SAME schema encoded the reference's way
+    (every scaffold in full, fp32, on the host) -- built once per ``tag`` and shared by the tests that only differ in the prompt
+    (the oracle's schema encode is where a full-depth test spends its time)."""
     import time
     from oracle import engine_oracle as eo
     from oracle.llama_oracle import LlamaOracle, OracleConfig
-    from promptcache_amd import CacheEngine, Prompt, synth
+    from promptcache_amd import CacheEngine, synth
     from promptcache_amd.model import Llama2
     from promptcache_amd.model.weights import random_weights_device
+    if tag in _FULL:
+        return _FULL[tag]
+    _FULL.clear()                        # one full-depth model (device images + fp32 host copy) resident at a time
+    t0 = time.perf_counter()
     w = random_weights_device(shape, "cuda:0", torch.float16, seed=seed)
     if outlier_channels:
         w["embed"][:, list(outlier_channels)] *= 60.0
     lm = Llama2(name=tag, shape=shape, weights=w, device="cuda:0")
-    sp, pp = synth.persona_like(tag, **schema)
+    sp, _ = synth.persona_like(tag, **schema)
     fmt = lm.get_formatter()
     eng = CacheEngine(2048, lm)
     eng.add_schema(fmt(sp))
-    prompt = Prompt(pp, [fmt])
-    ids, pos, _, cache = eng.process(prompt)
-    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
-             past_key_values=cache, use_cache=True)
-    got = out.logits[0].cpu().numpy()
-    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
     cfg = OracleConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, intermediate_size=shape.intermediate_size,
                        num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
                        num_key_value_heads=shape.num_key_value_heads, rms_norm_eps=shape.rms_norm_eps,
                        rope_theta=shape.rope_theta, inv_freq=lm.hf_model.inv_freq_cpu.numpy())
     model = LlamaOracle(cfg, {k: v.float().cpu().numpy() for k, v in w.items()})
+    del w
+    t2 = time.perf_counter()
     sc = eng.get_schema(tag)
     jobs = []
     for p in sc.encode_paths():
         sf = sc.get_scaffold(p)
         jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
     lib = eo.encode_schema(model, jobs)
+    t3 = time.perf_counter()
+    print(f"[full depth {tag}] build + GPU encode {t1 - t0:.1f} s, weights to the host oracle {t2 - t1:.1f} s, oracle encode of "
+          f"{len(jobs)} scaffolds / {sum(len(j['token_ids']) for j in jobs)} tokens {t3 - t2:.1f} s")
+    _FULL[tag] = (lm, eng, model, lib, schema)
+    return _FULL[tag]
+
+
+def _full_depth_llama(tag, shape, seed, schema, outlier_channels=None, question_len=None):
+    """Every layer of a Llama-family shape, end to end: schema encode (trunk reuse, dense + weight-streaming paths), gather,
+    cached prefill -- against the numpy oracle doing the reference's full per-scaffold encode in fp32 on the host.
+    ``outlier_channels``: scale these hidden channels of the embedding by 60x, so the residual stream carries a handful of
+    massive channels through every layer the way a trained Llama's does (after RMSNorm: ~24 against ~0.4 for the rest) --
+    the regime the split-precision planes, the fp16 K/V stores and the LLM.int8 outlier columns exist for; N(0, 0.02)
+    init alone never produces it.  ``question_len``: new tokens of the prompt (default: the schema kwargs')."""
+    import time
+    from oracle import engine_oracle as eo
+    from promptcache_amd import Prompt, synth
+    lm, eng, model, lib, schema = _full_depth_state(tag, shape, seed, schema, outlier_channels)
+    kw = dict(schema)
+    if question_len is not None:
+        kw["question_len"] = question_len
+    _, pp = synth.persona_like(tag, **kw)
+    fmt = lm.get_formatter()
+    prompt = Prompt(pp, [fmt])
+    eng.prompt_cache.reset()
+    ids, pos, _, cache = eng.process(prompt)
+    out = lm(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"),
+             past_key_values=cache, use_cache=True)
+    got = out.logits[0].cpu().numpy()
+    t0 = time.perf_counter()
     used = [m.token_sequence for m in eng.prompt_cache.staged]
     _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
     err = np.abs(got - logits[0]).max()
     st = eng.schemas[tag].encode_stats
     print(f"[full depth {tag}] L={shape.num_hidden_layers} S={S} q={len(ids)} passes={st['total_passes']} (trunk-shared "
           f"{st['trunk_shared_passes']}) max|dlogit| vs numpy oracle = {err:.2e}  (max|logit| {np.abs(logits).max():.2f}; "
-          f"oracle {time.perf_counter() - t0:.0f} s)")
+          f"oracle prefill {time.perf_counter() - t0:.0f} s)")
     assert err < TOL
     return err
+
+
+_P7 = dict(system_len=120, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))),
+           question_len=8, seed=9)
 
 
 @_skip_full
 def test_full_depth_7b_end_to_end_vs_numpy_oracle():
     """All 32 layers at the true llama2-7b shape.  Small persona-structured schema so the oracle finishes in minutes."""
     from promptcache_amd.model.config import SHAPES
-    _full_depth_llama("p7", SHAPES["llama2-7b"], 5,
-                      dict(system_len=120, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57)), ("job", (45, 50, 41))),
-                           question_len=8, seed=9))
+    _full_depth_llama("p7", SHAPES["llama2-7b"], 5, _P7)
 
 
 @_skip_full
 def test_full_depth_7b_long_question_vs_numpy_oracle():
     """All 32 layers at the 7b shape with a question of ~100 new tokens: the 65..512-row stack (row-split projections, ring
-    attention, hipGraph per 16-row bucket) end to end against the numpy oracle -- the regime of BASELINE config 4's questions."""
+    attention, hipGraph per 16-row bucket) end to end against the numpy oracle -- the regime of BASELINE config 4's questions.
+    Same model, same encoded schema and same oracle library as the test above (run right after it, the state is shared: the
+    oracle's schema encode is paid once); only the prompt differs."""
     from promptcache_amd.model.config import SHAPES
-    shape = dataclasses.replace(SHAPES["llama2-7b"], vocab_size=8192)
-    _full_depth_llama("plq", shape, 15, dict(system_len=110, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57))),
-                                             question_len=96, seed=16))
+    _full_depth_llama("p7", SHAPES["llama2-7b"], 5, _P7, question_len=96)
+    _FULL.clear()
 
 
 @_skip_full
@@ -323,22 +358,27 @@ def test_full_depth_falcon_mpt_end_to_end_vs_numpy_oracle(family):
     from promptcache_amd import CacheEngine, Prompt, synth
     from promptcache_amd.model import Falcon, Mpt
     from promptcache_amd.model.config import FalconShape, MptShape
-    from promptcache_amd.model.weights import make_falcon_weights_np, make_mpt_weights_np
+    # weights are drawn on the device (seeded) and copied to the host oracle: drawing 7e9 normals with numpy takes about as long
+    # as the whole oracle run
+    from promptcache_amd.model.weights import random_falcon_weights_device, random_mpt_weights_device
+    t_start = time.perf_counter()
     if family == "falcon":
         from oracle.falcon_oracle import FalconOracle, FalconOracleConfig
         shape = FalconShape(vocab_size=4096, hidden_size=4544, num_hidden_layers=32, num_attention_heads=71, name="falcon-7b-32l")
-        w16 = make_falcon_weights_np(shape, 21, 1.0)
+        w16 = random_falcon_weights_device(shape, "cuda:0", torch.float16, seed=21)
         lm = Falcon(name=shape.name, shape=shape, weights=w16, device="cuda:0")
         model = FalconOracle(FalconOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
                                                 shape.layer_norm_epsilon, shape.rope_theta, lm.hf_model.inv_freq_cpu.numpy()),
-                             {k: v.astype(np.float32) for k, v in w16.items()})
+                             {k: v.float().cpu().numpy() for k, v in w16.items()})
     else:
         from oracle.mpt_oracle import MptOracle, MptOracleConfig
         shape = MptShape(vocab_size=4096, hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, name="mpt-7b-32l")
-        w16 = make_mpt_weights_np(shape, 22, 1.0)
+        w16 = random_mpt_weights_device(shape, "cuda:0", torch.float16, seed=22)
         lm = Mpt(name=shape.name, shape=shape, weights=w16, device="cuda:0")
         model = MptOracle(MptOracleConfig(shape.vocab_size, shape.hidden_size, shape.num_hidden_layers, shape.num_attention_heads,
-                                          shape.layer_norm_epsilon, shape.alibi_bias_max), {k: v.astype(np.float32) for k, v in w16.items()})
+                                          shape.layer_norm_epsilon, shape.alibi_bias_max), {k: v.float().cpu().numpy() for k, v in w16.items()})
+    del w16
+    print(f"[full depth {family}] weights, model build, host copy for the oracle: {time.perf_counter() - t_start:.1f} s")
     sp, pp = synth.persona_like("pf", system_len=100, intro_len=30, traits=(("age", (40, 35, 44)), ("home", (60, 52, 57))),
                                 question_len=8, seed=10)
     fmt = lm.get_formatter()

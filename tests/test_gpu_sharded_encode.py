@@ -63,6 +63,16 @@ def _worker(rank, world, port, q, backend="gloo"):
         eng.add_schema(fmt(sp))                                    # world == 2: sharded passes + slab exchange
         lib2, st2 = library(eng)
         logits2 = serve(eng)
+        # the exchange moved exactly what the plan said it would: the receive slabs this rank posted hold the bytes
+        # parallel.exchange_bytes predicts from the segment sizes, and both equal the module KV of the passes the OTHER rank encoded
+        # (cached tokens it owns x KV bytes per token) -- on RCCL this is the first check of the grouped send / recv's sizes on real links
+        L_, Hkv_, D_ = lm.get_cache_shape()
+        kvb = 2 * L_ * Hkv_ * D_ * 2
+        own_tok = torch.tensor([float(st2["owned_cached_tokens"])], dtype=torch.float64)
+        tot_tok = own_tok.clone().to(dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tot_tok)
+        other = int(tot_tok.item()) - int(own_tok.item())
+        assert st2["exchange_bytes_rx"] == st2["exchange_bytes_rx_buffers"] == other * kvb > 0, (st2, other, kvb)
         # a LIBRARY of three schemas through add_schemas: whole schemas dealt by LPT, the residual imbalance levelled pass by
         # pass (CacheEngine.library_schedule); every pass has exactly one encoder, both ranks carry about half of the rows,
         # and every rank ends with every schema, equal to the solo encode

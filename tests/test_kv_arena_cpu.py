@@ -16,3 +16,30 @@ def test_plain_views_resolve_to_the_live_arena():
     assert got_b is b
     foreign = [(torch.zeros(1, 4, 10, 32, dtype=torch.float16), torch.zeros(1, 4, 10, 32, dtype=torch.float16)) for _ in range(2)]
     assert arena_from_past(foreign, 2, 4, 32) is None
+
+
+def test_staged_views_answer_every_read_accessor():
+    """``StagedKV`` builds its views lazily; every way of LOOKING at it -- not only indexing and iterating -- must see
+    all layers (a ``list`` subclass would have shown ``copy()``, ``+``, ``==``, ``in``, ``reversed``, pickling and
+    ``PySequence_Fast`` consumers an empty list)."""
+    import copy
+    import pickle
+    from promptcache_amd.model.kv_arena import KVArena, StagedKV
+    a = KVArena(1, 3, 2, 16, 8, "cpu")
+    a.buf.copy_(torch.arange(a.buf.numel(), dtype=torch.float32).reshape(a.buf.shape).to(torch.float16))
+    v = a.views(5)
+    assert isinstance(v, StagedKV) and len(v) == 3
+    fresh = lambda: a.views(5)
+    assert len(fresh().copy()) == 3 and len(fresh() + []) == 3 and len([] + fresh()) == 3
+    assert len(list(reversed(fresh()))) == 3 and len(tuple(fresh())) == 3 and len([*fresh()]) == 3
+    k2 = fresh()[2][0]
+    assert k2.shape == (1, 2, 5, 8) and torch.equal(k2, a.buf[:, 2, 0, :, :5])
+    assert fresh().unbatched()[1][1].shape == (2, 5, 8)
+    assert len(copy.copy(fresh())) == 3
+    restored = pickle.loads(pickle.dumps(fresh()))
+    assert isinstance(restored, list) and len(restored) == 3 and torch.equal(restored[1][0], a.buf[:, 1, 0, :, :5])
+    w = fresh()
+    w[0] = ("k", "v")
+    assert w[0] == ("k", "v") and len(w) == 3
+    # a sequence consumer that is not written for this class
+    assert len(torch.nn.utils.rnn.pad_sequence([t[0][0, 0] for t in fresh()], batch_first=True)) == 3

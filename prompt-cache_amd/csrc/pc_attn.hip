@@ -796,12 +796,10 @@ __device__ __forceinline__ void small_arrive_merge(const AttnParams& p, int b, i
     __syncthreads();
     if (tid == 0) {
         gu32* c = (gu32*)(p.counters + b * p.H + h);
-        // (same hand-off contract as gemm_skinny_ks_kernel, pc_gemm_ks.hip: gfx9 vmcnt semantics; -DPC_FORMAL_HANDOFF = acq_rel)
-#ifdef PC_FORMAL_HANDOFF
-        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+        // (same hand-off contract as gemm_skinny_ks_kernel, pc_gemm_ks.hip: gfx9 vmcnt semantics; PC_FORMAL_HANDOFF=1 in the
+        // environment selects the acq_rel arrival at launch time -- both forms live in the one binary, the suite runs both)
+        const uint32_t old = p.formal_handoff ? __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                              : __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (old + 1u == (uint32_t)p.nsplit) ? 1 : 0;
         if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last = last;
@@ -1421,6 +1419,7 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.past_len_dev = past_len_dev;
     p.past_lens = past_lens;
     p.counters = counters;
+    p.formal_handoff = pc_formal_handoff();
     p.pre_k = (const _Float16*)pre_k; p.pre_v = (const _Float16*)pre_v;
     p.pre_k_lo = (const _Float16*)pre_k_lo; p.pre_v_lo = (const _Float16*)pre_v_lo; p.pre_hs = pre_hs;
     p.trace = g_attn_trace;

@@ -53,6 +53,7 @@ struct AttnParams {
     // the rows this pass appended in fp32 (attn_tail_block) and leaves it as one more partial for the merge kernel.
     int32_t tail;
     int32_t small;          // attn_small_kernel launch (host-side dispatch flag)
+    int32_t formal_handoff; // fused merge: acq_rel arrival (the C++-memory-model form, env PC_FORMAL_HANDOFF=1) instead of relaxed + vmcnt(0)
     int32_t xcd_remap, nqblk, nbatch;
     float scale_log2;
 };

@@ -744,6 +744,10 @@ int ring_nsplit(int B, int H, int q_len, int kv_len) {
     // (rounds 3-4 kept >= 4 stages per split; for 33..128 rows over a 1.7 k cache that left half of the CUs idle: 7b q = 36 / 50 /
     // 66 / 102: 5.10 / 5.41 / 6.05 / 6.65 -> 4.91 / 5.27 / 5.85 / 6.48 ms without the floor, profiles/r04_variants.txt)
     static const int min_stages = [] { const char* e = getenv("PC_RING_MIN_STAGES"); return e ? atoi(e) : 1; }();
+    // (Round 5 tried pricing a THIN last q-block -- 259 = 128 + 128 + 3 rows, BASELINE config 4: seven of its eight waves only help
+    // with the DMA -- at a third of a full block so that 259 rows take the 3 splits 256 rows take: 360 workgroups instead of 240,
+    // the attention launch 155 -> 202 us and the step 21.3 -> 22.8 ms on one box (profiles/r05_variants.txt): the second round of
+    // workgroups costs more than the shorter key ranges save.  The count below stands.)
     int best = 1;
     double best_cost = 1e30;
     for (int s = 1; s <= 16; ++s) {

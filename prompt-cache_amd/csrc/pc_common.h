@@ -31,6 +31,15 @@ static inline int pc_check_launch(const char* what) {
 
 static inline int pc_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// PC_FORMAL_HANDOFF=1 (environment, read at every launch that has an in-launch hand-off; captured graphs keep what their capture
+// read): the arrival of gemm_skinny_ks_kernel / the fused split-KV merge as an acq_rel fetch-add -- the C++-memory-model form --
+// instead of relaxed + s_waitcnt vmcnt(0).  Default off: +1.7 us per launch (buffer_wbl2 + buffer_inv on the critical path).
+#include <stdlib.h>
+static inline int pc_formal_handoff(void) {
+    const char* e = getenv("PC_FORMAL_HANDOFF");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+
 #ifdef __HIPCC__
 // fp32 -> split-precision fp16 pair (hi = fp16(s), lo = fp16(s - hi)).  The value is pinned in a register first:
 // under -ffp-contract=fast hipcc may fuse the multiply that produced s into the conversion (v_fma_mix*_f16) for one

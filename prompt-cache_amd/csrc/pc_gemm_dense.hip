@@ -77,7 +77,7 @@ __device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int WM, int EPI, bool TWO>
+template <int WM, int EPI, bool TWO, bool PP>
 __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
     constexpr int WN = 8 / WM, MT = BM / (32 * WM), NT = 2, BN = 64 * WN;
     constexpr int kWT = BN * BK * 2;             // bytes of the weight tile
@@ -215,6 +215,158 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
             else if (2 * k < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // (an odd one left)
         }
     };
+    if constexpr (PP) {
+        // ---- ping-pong main loop (round 5; the guide's two-waves-per-SIMD regime).  MEASURED SLOWER than the lockstep loop below
+        // on this kernel (0.87-0.90 x with both planes, profiles/r05_dense_pp_ab.txt) in all three forms tried -- fragment reads
+        // waited for inside their load segment; read one phase ahead with hipcc's waits (lgkmcnt(0) every other phase: its
+        // scoreboard merges conservatively at the group branches); read ahead as raw ds_read_b128 with explicit counted waits
+        // (this form) -- kept for A/B behind -DPC_DEV_SWEEPS.  Eight barriers per K-step and one wave per SIMD feeding the
+        // matrix pipe at a time lose to two waves per SIMD interleaving their MFMAs with one barrier per K-step; what is left
+        // between the lockstep loop (1.09-1.15 PFLOP/s executed on random data) and the ~1.3 the guide's 8-phase template
+        // reaches at 4096^3 is not in the wave pairing. ----
+        // The loop above keeps the two waves of a SIMD in lockstep: both issue MFMAs at once (54 % of wave time were issue stalls
+        // behind the shared pipe, profiles/r02_pmc_gemm_dense.txt) and both sit out the barrier and the first fragment reads of
+        // the next K-step together (MFMA pipes busy 63 % of the kernel's cycles).  Here the workgroup's eight waves are two GROUPS
+        // of four (one wave of each group per SIMD) that run the same program ONE BARRIER APART: a K-step is four phases (one
+        // 16-deep slab each), a phase is a LOAD segment (the slab's 6 fragment reads, waited for) and a COMPUTE segment (its 8
+        // MFMAs = 256 matrix-pipe cycles), every segment ends in a raw s_barrier -- so while group 0 is in its compute segment
+        // group 1 is in its load segment and vice versa: the SIMD's matrix pipe always has exactly one wave feeding it, and the
+        // LDS reads, the waits and the barrier latency of one wave pass under the MFMAs of the other.  One fragment register
+        // set instead of two.
+        //   barrier n separates interval n from n + 1.  Group 0: load (t, s) in interval 8t + 2s, compute in 8t + 2s + 1; group 1
+        //   one interval later.  A load segment only ISSUES the fragment reads of the NEXT slab (two register sets); they are
+        //   consumed one phase later, so the segment is a few dozen issue cycles and the LDS latency never sits in front of a
+        //   barrier (first version: reads waited for inside their load segment -- the load segment then took longer than the
+        //   partner's 256-cycle compute segment and the loop ran at ITS pace: 0.81-0.93 x the lockstep loop).
+        //   Slab 0 of K-step t + 1 is read in load (t, 3): group 0 in interval 8t + 6, so K-step t + 1 must have landed, for all
+        //   waves, by barrier 8t + 6: the LDS-DMA goes out in two pieces between MFMAs -- group 0 in compute (t, 0), (t, 1), waited
+        //   for at the end of compute (t, 2); group 1 in load (t, 0) and compute (t, 0), waited for at the end of load (t, 2) -- at
+        //   least two intervals of flight for the last piece.  The buffer it lands in held K-step t - 1, whose last reads (group
+        //   1, issued in its load (t - 1, 2)) are complete at the start of interval 8t: every issue point above lies behind
+        //   barrier 8t + 1.
+        // Same MFMA order per accumulator as the loop above: bit-identical results.
+        constexpr int NI = NXI * (TWO ? 2 : 1) + NWI;          // LDS-DMA instructions per wave and K-step
+        auto stage_piece = [&](int tl, char* buf, int piece) {
+            const int t = t0 + tl;
+            const bool tail = ktail && t == nkt - 1;
+            const int64_t ko = (int64_t)t * BK;
+            const int kchunks = tail ? (K - t * BK) / 8 : 8;
+            const int q0 = piece * NI / 2, q1 = (piece + 1) * NI / 2;
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) {
+                const bool ok = !tail || cx[j] < kchunks;
+                if (q >= q0 && q < q1) glds16(ok ? gx[j] + ko : p.zeros, buf + (wave * 16 + j * 8) * 128);
+                ++q;
+                if (TWO) {
+                    if (q >= q0 && q < q1) glds16(ok ? gx[j] + lo_delta + ko : p.zeros, buf + kXT + (wave * 16 + j * 8) * 128);
+                    ++q;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NWI; ++j) {
+                if (q >= q0 && q < q1)
+                    glds16((!tail || cw[j] < kchunks) ? gw[j] + ko : gw[j] - cw[j] * 8, buf + 2 * kXT + (wave * (BN / 8) + j * 8) * 128);
+                ++q;
+            }
+        };
+        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+        Frags fr2[2];                                           // slab s lives in set s & 1: read one phase ahead of its MFMAs
+        // The fragment reads of the ping-pong loop are raw ds_read_b128 statements hipcc does not count: a read issued in load
+        // segment s is consumed in compute segment s + 1 behind an explicit `s_waitcnt lgkmcnt(R)` (R = reads per slab: only
+        // the NEWER slab's reads may still be in flight).  Left to hipcc, the uniform `if (group)` branches between a read and
+        // its use make the waitcnt pass merge its scoreboards conservatively: lgkmcnt(0) in every other phase, i.e. the LDS
+        // latency of the just-issued reads in front of the MFMAs -- what the read-ahead is there to hide.  The loop holds no
+        // other LDS or scalar-memory instruction (checked in the ISA: lgkmcnt counts in order only without SMEM in flight).
+        constexpr int NR = MT * (TWO ? 2 : 1) + NT;
+        const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+        auto load_frags_raw = [&](Frags& f, uint32_t buf_off, int ks) {
+            const uint32_t aa = lds32 + buf_off + a_base + foff[ks], ab = lds32 + buf_off + b_base + foff[ks];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ah[i]) : "v"(aa), "i"(i * 32 * 128));
+                if (TWO) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.al[i]) : "v"(aa), "i"(kXT + i * 32 * 128));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.bw[j]) : "v"(ab), "i"(j * 32 * 128));
+        };
+        stage(0, lds);
+        stage(nk > 1 ? 1 : 0, lds + kStage);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // both K-steps (the prologue is not where the time goes)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags_raw(fr2[0], 0, 0);
+        if (grp) {                                              // group 1 runs one interval behind
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto half_a = [&](const Frags& f) {                     // first half of a slab's MFMAs (hi plane; without a lo plane: the first row block)
+#pragma unroll
+            for (int i = 0; i < (TWO ? MT : (MT + 1) / 2); ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bw[j], acc[i][j], 0, 0, 0);
+        };
+        auto half_b = [&](const Frags& f) {
+            if (TWO) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bw[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = (MT + 1) / 2; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bw[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        for (int t = 0; t < nk; ++t) {
+            char* cur = lds + (t & 1) * kStage;
+            char* nxt = lds + ((t + 1) & 1) * kStage;
+            const int u1 = t + 1 < nk ? t + 1 : nk - 1;         // (clamped: past the end the last K-step goes into the idle buffer again)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                // ---- load segment: only ISSUES the next slab's fragment reads (slab 0 of K-step t + 1 behind slab 3: its DMA was
+                // waited for two barriers ago); they complete under the partner group's MFMAs and this group's own ----
+                if (sl < 3) load_frags_raw(fr2[(sl + 1) & 1], (t & 1) * kStage, sl + 1);
+                else load_frags_raw(fr2[0], ((t + 1) & 1) * kStage, 0);     // (past the last K-step: the clamped re-load of it, never multiplied)
+                if (grp) {
+                    if (sl == 0) stage_piece(u1, nxt, 0);
+                    if (sl == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- compute segment: the slab read one phase ago; the newer slab's NR reads stay in flight ----
+                static_assert(NR == 6 || NR == 4 || NR == 3, "reads per slab");
+                if constexpr (NR == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else if constexpr (NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                half_a(fr2[sl & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!grp) {
+                    if (sl < 2) stage_piece(u1, nxt, sl);
+                } else {
+                    if (sl == 0) stage_piece(u1, nxt, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                half_b(fr2[sl & 1]);
+                __builtin_amdgcn_s_setprio(0);
+                if (sl == 2 && !grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the read-ahead behind the last slab: landed before its registers die)
+        if (!grp) {                                             // group 0 waits for group 1's last compute segment
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     Frags fa, fb;
     stage(0, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -257,6 +409,7 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         mfmas(fa);
         interleave();
         mfmas(fb);
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the clamped re-load of the last K-step)
 
@@ -438,8 +591,19 @@ int launch_dense(DenseParams& p, hipStream_t s, int kslices = 1) {
     const int nkt = pc_ceil_div(p.K, BK);
     p.kper = pc_ceil_div(nkt, kslices);
     const dim3 grid(8 * p.mb * pc_ceil_div(p.nb, 8), pc_ceil_div(nkt, p.kper)), block(512);
-    if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false>), grid, block, 0, s, p);
+#ifdef PC_DEV_SWEEPS
+    // The ping-pong main loop (PP = true) is a MEASURED NEGATIVE RESULT and only built for A/B (PC_BUILD_FLAGS=-DPC_DEV_SWEEPS,
+    // then PC_DENSE_PP=1; tools/dense_pp_ab.py): bit-identical to the lockstep loop and 0.87-0.90 x its speed at the encode's
+    // shapes with both planes, 0.66-0.83 x on one plane (profiles/r05_dense_pp_ab.txt).
+    const char* e = getenv("PC_DENSE_PP");
+    if (e && e[0] == '1') {
+        if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false, true>), grid, block, 0, s, p);
+        return pc_check_launch("gemm_dense_kernel");
+    }
+#endif
+    if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false, false>), grid, block, 0, s, p);
     return pc_check_launch("gemm_dense_kernel");
 }
 

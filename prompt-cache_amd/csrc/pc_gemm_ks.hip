@@ -35,6 +35,7 @@ struct KsParams {
     GemmParams g;            // wf, xf_hi, xf_lo, y, ldy, M, ntiles, KS, kslices
     float* slabs;            // [kslices][ntiles][64][4] fp32 partial tiles (MFMA C layout, lane-linear)
     uint32_t* counters;      // [ceil(ntiles / T)] arrival counters, zero between launches
+    int32_t formal;          // acq_rel arrival (PC_FORMAL_HANDOFF=1) instead of relaxed + vmcnt(0)
 };
 
 template <int T, int U>
@@ -99,18 +100,16 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
 #if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
 #error "gemm_skinny_ks_kernel's in-launch hand-off relies on gfx9 vmcnt semantics (stores counted in vmcnt); re-derive it for this target"
 #endif
-    // -DPC_FORMAL_HANDOFF: the C++-memory-model form (release on the arrival, acquire in the last arriver) for A/B: +1.7 us per
-    // launch on MI355X (buffer_wbl2 + buffer_inv on the critical path; profiles/r04_variants.txt).  tests/test_gpu_handoff.py
-    // hammers the default form: 1e5 launches under uneven load, every word compared.
+    // PC_FORMAL_HANDOFF=1 (environment, read at launch: kp.formal): the C++-memory-model form (release on the arrival, acquire in
+    // the last arriver) for A/B: +1.7 us per launch on MI355X (buffer_wbl2 + buffer_inv on the critical path;
+    // profiles/r04_variants.txt).  tests/test_gpu_handoff.py hammers the default form (launches under uneven load, every word
+    // compared) and runs the formal form through the same stress.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave: its stores are acknowledged
     __syncthreads();
     if (tid == 0) {
         gu32* c = (gu32*)(kp.counters + bx);
-#ifdef PC_FORMAL_HANDOFF
-        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        const uint32_t old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+        const uint32_t old = kp.formal ? __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                       : __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (old + 1u == (uint32_t)S) ? 1 : 0;
         if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = last;
@@ -165,7 +164,7 @@ int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M
     memset(&kp, 0, sizeof(kp));
     kp.g.wf = (const _Float16*)wf; kp.g.xf_hi = (const _Float16*)xf_hi; kp.g.xf_lo = (const _Float16*)xf_lo;
     kp.g.y = y; kp.g.ldy = ldy; kp.g.M = M; kp.g.m_dev = rows_dev; kp.g.ntiles = N / 16; kp.g.KS = K / 32; kp.g.kslices = kslices;
-    kp.slabs = (float*)scratch; kp.counters = (uint32_t*)counters;
+    kp.slabs = (float*)scratch; kp.counters = (uint32_t*)counters; kp.formal = pc_formal_handoff();
     // k-steps per block: a wave's K share is K / 32 / (8 kslices) k-steps -- keep the whole share in flight where it fits
     const int share = pc_ceil_div(pc_ceil_div(K / 32, kslices), kWaves);
     switch (tiles_per_wg) {

@@ -85,6 +85,28 @@ class _InputBlock:
         self._busy = True
 
 
+_GRAPH_RNG_PRIMED = False
+
+
+def prime_graph_capture(device) -> None:
+    """torch allocates the CUDA generator's graph-capture state (seed / offset words) at the FIRST capture of the process and
+    updates it in place at every later one.  The forwards of this package capture under ``torch.inference_mode()``; if theirs is
+    the first capture, those words are inference tensors and any capture the CALLER later takes outside inference mode dies in
+    ``capture_begin`` ("Inplace update to inference tensor outside InferenceMode").  So the first capture of the process is a
+    trivial one taken with inference mode switched off (once, ~1 ms) -- and KEPT: torch frees those words again when the last
+    registered graph dies and would re-allocate them under whatever mode the next capture runs in."""
+    global _GRAPH_RNG_PRIMED
+    if _GRAPH_RNG_PRIMED is not False:
+        return
+    with torch.inference_mode(False):
+        t = torch.zeros(8, device=device)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            t.add_(1.0)
+    _GRAPH_RNG_PRIMED = (g, t)
+
+
 def lw0_fp16(layers) -> bool:
     """fp16 weight images (no int8 scales) in the layer stack."""
     return len(layers) > 0 and layers[0].get("wqkv_s") is None
@@ -1082,6 +1104,7 @@ class LlamaHIP:
             # one eager pass first (loads code objects / sizes the allocator), then capture
             run()
             torch.cuda.synchronize()
+        prime_graph_capture(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = run()
@@ -1217,6 +1240,7 @@ class LlamaHIP:
         # writes again and does not touch the loop state
         self._forward_skinny(st["ids"], st["pos"], st["past"], arena, 1, 1, past_len, False, None)
         torch.cuda.synchronize()
+        prime_graph_capture(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = self._forward_skinny(st["ids"], st["pos"], st["past"], arena, 1, 1, past_len, False, None)

@@ -21,7 +21,7 @@ import torch
 
 from .. import _native
 from .config import MptShape
-from .llama_hip import CausalLMOutput, LlamaHIP
+from .llama_hip import CausalLMOutput, LlamaHIP, prime_graph_capture
 
 _LOG2E = 1.4426950408889634
 
@@ -162,6 +162,7 @@ class MptHIP(LlamaHIP):
         if fresh:
             self._forward_skinny(st_ids, st_kpos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)
             torch.cuda.synchronize()
+            prime_graph_capture(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._forward_skinny(st_ids, st_kpos, st_past, arena, B, q_len, past_len, last_token_only, num_layers)

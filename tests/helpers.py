@@ -122,3 +122,12 @@ def oracle_for_case(g, shape):
                        num_attention_heads=shape.num_attention_heads, num_key_value_heads=shape.num_key_value_heads,
                        rms_norm_eps=shape.rms_norm_eps, rope_theta=shape.rope_theta, inv_freq=g["inv_freq"])
     return LlamaOracle(cfg, {k: v.astype(np.float32) for k, v in w16.items()}), w16
+
+
+def oracle_blas():
+    """Context manager: the BLAS pool at the width the host oracle runs fastest at.  numpy's OpenBLAS defaults to 64 threads on
+    the 256-CPU GPU boxes, where an sgemm of a few hundred rows runs 4-5x SLOWER than on 16 (tools/blas_probe.py: 0.54 vs 2.6
+    TFLOP/s at 130 rows) -- the full-depth parity tests spend their time exactly there."""
+    import os
+    from threadpoolctl import threadpool_limits
+    return threadpool_limits(limits=min(16, os.cpu_count() or 16), user_api="blas")

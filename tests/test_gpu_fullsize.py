@@ -255,7 +255,9 @@ def _full_depth_state(tag, shape, seed, schema, outlier_channels=None):
     for p in sc.encode_paths():
         sf = sc.get_scaffold(p)
         jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
-    lib = eo.encode_schema(model, jobs)
+    from tests.helpers import oracle_blas
+    with oracle_blas():
+        lib = eo.encode_schema(model, jobs)
     t3 = time.perf_counter()
     print(f"[full depth {tag}] build + GPU encode {t1 - t0:.1f} s, weights to the host oracle {t2 - t1:.1f} s, oracle encode of "
           f"{len(jobs)} scaffolds / {sum(len(j['token_ids']) for j in jobs)} tokens {t3 - t2:.1f} s")
@@ -287,7 +289,9 @@ def _full_depth_llama(tag, shape, seed, schema, outlier_channels=None, question_
     got = out.logits[0].cpu().numpy()
     t0 = time.perf_counter()
     used = [m.token_sequence for m in eng.prompt_cache.staged]
-    _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
+    from tests.helpers import oracle_blas
+    with oracle_blas():
+        _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
     err = np.abs(got - logits[0]).max()
     st = eng.schemas[tag].encode_stats
     print(f"[full depth {tag}] L={shape.num_hidden_layers} S={S} q={len(ids)} passes={st['total_passes']} (trunk-shared "
@@ -395,9 +399,11 @@ def test_full_depth_falcon_mpt_end_to_end_vs_numpy_oracle(family):
     for p in sc.encode_paths():
         sf = sc.get_scaffold(p)
         jobs.append(dict(token_ids=sf.token_ids(), position_ids=sf.position_ids(), targets=sf.select(p).all_token_sequences()))
-    lib = eo.encode_schema(model, jobs)
-    used = [m.token_sequence for m in eng.prompt_cache.staged]
-    _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
+    from tests.helpers import oracle_blas
+    with oracle_blas():
+        lib = eo.encode_schema(model, jobs)
+        used = [m.token_sequence for m in eng.prompt_cache.staged]
+        _, S, (logits, _) = eo.cached_prefill(model, lib, used, ids, pos, 2048)
     err = np.abs(out.logits[0].cpu().numpy() - logits[0]).max()
     print(f"[full depth {family}] L=32 S={S} q={len(ids)} max|dlogit| vs numpy oracle = {err:.2e} "
           f"(max|logit| {np.abs(logits).max():.2f}; oracle {time.perf_counter() - t0:.0f} s)")

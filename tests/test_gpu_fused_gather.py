@@ -256,6 +256,87 @@ def test_generate_through_the_deferred_staging_matches_the_copy_first_engine():
     assert texts[True] == texts[False] and len(texts[True]) > 0
 
 
+def test_device_ids_and_positions_take_the_staging_forward_without_a_read_back():
+    """the reference hands the model DEVICE tensors (generation_engine.py:96-97).  With the StagedKV object as the
+    cache they take the same captured, staging forward as host tensors do -- copied into the graph's input block on the stream,
+    read there by pc_prefill_prologue (words[5]) -- and give the same bits; also with the default position ids and through the
+    row-bucket padding (q not a multiple of 16), prefill and decode."""
+    from promptcache_amd import Prompt
+    res = {}
+    for where in ("host", "device"):
+        lm, eng, prompt_pml = _engine(True)
+        ids, pos, _, cache = eng.process(Prompt(prompt_pml, [lm.get_formatter()]))
+        arena = eng.prompt_cache.arena
+        arena.buf.fill_(float("nan"))
+        kw = dict(device=DEV) if where == "device" else {}
+        o = lm(input_ids=torch.tensor([ids], **kw), position_ids=torch.tensor([pos], **kw), past_key_values=cache, use_cache=True)
+        assert lm.hf_model.stats["fused_gather"] == 1 and arena.pending is None
+        o2 = lm(input_ids=torch.tensor([[7]], **kw), position_ids=torch.tensor([[max(pos) + 2]], **kw), past_key_values=o.past_key_values,
+                use_cache=True)
+        o3 = lm(input_ids=torch.tensor([[9, 11, 13]], **kw), past_key_values=o2.past_key_values, use_cache=True)   # default positions
+        S = len(eng.prompt_cache)
+        res[where] = (o.logits.clone(), o2.logits.clone(), o3.logits.clone(), arena.buf[0, :, :, :, :S + len(ids) + 4].clone())
+    for a, b in zip(res["host"], res["device"]):
+        assert torch.isfinite(a.float()).all() and torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a,
+                                                              b.view(torch.int16) if b.dtype == torch.float16 else b)
+
+
+def test_a_partial_depth_forward_does_not_consume_the_staging_plan():
+    """``num_layers`` < L over an arena with a pending plan would stage only those layers' planes inside the attention
+    launches while the plan is dropped: such a forward materialises the whole plan first, and the full-depth forward that
+    follows reads every layer's staged rows."""
+    from promptcache_amd import Prompt
+    lm, eng, prompt_pml = _engine(True)
+    lm2, eng2, _ = _engine(False)
+    prompt = Prompt(prompt_pml, [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    ids2, pos2, _, cache2 = eng2.process(prompt)
+    arena = eng.prompt_cache.arena
+    arena.buf.fill_(float("nan"))
+    S = len(eng.prompt_cache)
+    lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True, num_layers=1)
+    assert arena.pending is None and lm.hf_model.stats["fused_gather"] == 0
+    assert torch.equal(arena.buf[0, :, :, :, :S].view(torch.int16), eng2.prompt_cache.arena.buf[0, :, :, :, :S].view(torch.int16))
+    o = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=eng.prompt_cache.cache, use_cache=True)
+    o2 = lm2(input_ids=torch.tensor([ids2]), position_ids=torch.tensor([pos2]), past_key_values=cache2, use_cache=True)
+    assert torch.equal(o.logits, o2.logits)
+
+
+def test_staging_graphs_are_keyed_on_the_row_table_and_a_failed_capture_leaves_no_entry():
+    """(i) a staging forward captures the address of the arena's row table, so that address is part of the graph key
+    (a new arena on a recycled buffer address must not replay a graph that writes through the old arena's freed table);
+    (ii) a capture that raises leaves no half-built entry behind -- the next call captures again instead of replaying None."""
+    from promptcache_amd import Prompt
+    lm, eng, prompt_pml = _engine(True)
+    m = lm.hf_model
+    prompt = Prompt(prompt_pml, [lm.get_formatter()])
+    ids, pos, _, cache = eng.process(prompt)
+    arena = eng.prompt_cache.arena
+    m._lo_mode = m._tail_mode(arena, 16, len(eng.prompt_cache))
+    k_plain = m._graph_key(arena, 1, 16, len(eng.prompt_cache), False, None, False)
+    k_stage = m._graph_key(arena, 1, 16, len(eng.prompt_cache), False, None, True)
+    assert k_plain[-1] == 0 and k_stage[-1] == arena.row_table().data_ptr() != 0
+    old = arena.row_tab
+    arena.row_tab = None                                          # what a fresh arena on the same buffer address would hold
+    assert m._graph_key(arena, 1, 16, len(eng.prompt_cache), False, None, True) != k_stage
+    del old
+    real, calls = m._capture, []
+
+    def failing(*a, **k):
+        calls.append(1)
+        raise RuntimeError("capture failed (test)")
+    m._capture = failing
+    n_before = len(m._graphs)
+    with pytest.raises(RuntimeError, match="capture failed"):
+        lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+    assert len(m._graphs) == n_before and calls
+    m._capture = real
+    eng.prompt_cache.reset()
+    ids, pos, _, cache = eng.process(prompt)
+    o = lm(input_ids=torch.tensor([ids]), position_ids=torch.tensor([pos]), past_key_values=cache, use_cache=True)
+    assert torch.isfinite(o.logits).all() and m.stats["fused_gather"] == 1
+
+
 @pytest.mark.parametrize("T,nseg_plan", [(12, True), (16, False), (1, False), (77, True)])
 def test_prefill_prologue_equals_the_separate_launches(T, nseg_plan):
     """pc_prefill_prologue (block fetch + embedding rows as fp32 + rotation table + row table in ONE launch, every role reading

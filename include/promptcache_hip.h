@@ -403,6 +403,10 @@ typedef struct pc_dense_qkv_args {
     void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_row0;
     int32_t B, H, Hkv, D, q_len, past_len, cap;
     const int32_t* past_lens;
+    /* optional (round 5, instead of x_lo): the residual plane as int8 codes + row scales against an int8 weight image + row
+     * scales -- see pc_gemm_dense_lo8 */
+    const void* x_lo8; const float* x_lo8_scale; int64_t ldx8;
+    const void* w8; const float* w8_scale; int64_t ldw8;
 } pc_dense_qkv_args;
 int pc_gemm_dense_qkv_rope(const pc_dense_qkv_args* args, void* stream);
 
@@ -414,6 +418,25 @@ int pc_gemm_dense_qkv_rope(const pc_dense_qkv_args* args, void* stream);
 int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw, const float* w_scale,
                      int32_t M, int32_t N, int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo,
                      int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* pc_gemm_dense_lo8 / pc_quant_rows_i8 -- the many-row projections with the RESIDUAL activation plane on the int8 MFMA (round 5).
+ * The split-precision path multiplies every weight fragment twice (x_hi and x_lo = fp16(x - x_hi)) so that a projection sees
+ * ~22-bit activations, as the reference's fp32 CPU path does (llama2.py:345-347, :405, :242).  The residual
+ * plane only has to be good to a few bits: pc_quant_rows_i8 turns x_lo [M][K] into int8 codes with one scale per row
+ * (code = round_half_even(x_lo * 127 / max_k |x_lo|), scale = max / 127), the weights exist a second time as row-wise absmax
+ * int8 codes [N][K] + scales (the LLM.int8 weight quantiser, promptcache_amd._native.quantize_rows_int8), and
+ *     y = x_hi . W^T  (fp16 MFMA, fp32 sums)  +  (x_lo8 . W8^T as exact int32 sums on v_mfma_i32_32x32x32_i8) * x_lo8_scale[m] * w8_scale[n]
+ * -- 24 matrix-pipe slots per K-step instead of 32, and half the residual plane's LDS / L2 traffic.  What it costs in accuracy:
+ * the residual is carried to 2^-8 of its row maximum (|x_lo| <= 2^-11 |x|: ~19 bits of the row's largest activation) and the
+ * weights of the residual term to 2^-8 of their row maximum (on a term that is 2^-11 of the product).  Same epilogues, tiles and
+ * split-K workspace as pc_gemm_dense_ws; K % 64 == 0; x_lo8 / w8 16-byte aligned, ldx8 / ldw8 (bytes per row) % 16 == 0.
+ * No reference counterpart (the reference multiplies in fp32); parity: tests/test_gpu_dense.py, tests/test_gpu_fullsize.py. */
+int pc_quant_rows_i8(const void* x /* fp16 [M][ldx] */, int64_t ldx, int32_t M, int32_t K, void* codes /* int8 [M][ld8] */,
+                     int64_t ld8, float* scale /* [M] */, void* stream);
+int pc_gemm_dense_lo8(const void* x_hi, int64_t ldx, const void* x_lo8, const float* x_lo8_scale, int64_t ldx8, const void* w,
+                      int64_t ldw, const void* w8, const float* w8_scale, int64_t ldw8, int32_t M, int32_t N, int32_t K,
+                      int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* ---- pc_gemm_chain: the projections between two attention calls of a <= 16-row forward as ONE persistent launch --------
  *   phase 0  x += attn @ Wo^T                                   o_proj + residual        llama2.py:405, :638

@@ -37,6 +37,8 @@
 #include <hip/hip_fp16.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "pc_common.h"
 
 namespace {
@@ -57,6 +59,11 @@ struct DenseParams {
     // LLM.int8 (pc_int8.hip): xh holds activation CODES, xscale[m] = SCA[m] / 127; corr[m][n] (global weight-row index n) is
     // added before the epilogue's nonlinearity when *corr_has != 0
     const float* xscale; const float* corr; int64_t ldc; const int32_t* corr_has;
+    // LO8 (round 5): the lo activation plane as INT8 codes [M][K] with one scale per row (lo ~ code * xl8_scale[m]) against an int8
+    // image of the weights [N][K] with one scale per row (W ~ code * w8_scale[n]): the residual product runs on
+    // v_mfma_i32_32x32x32_i8 -- twice the fp16 MFMA rate, exact integer sums -- and joins the fp32 accumulator in the epilogue
+    const signed char* xl8; const float* xl8_scale; int64_t ldx8;
+    const signed char* w8; const float* w8_scale; int64_t ldw8;
     const _Float16* zeros;                                 // >= 16 B of zeros: source of activation chunks past K
     float* y; int64_t ldy;                                 // EPI_STORE / EPI_ADD
     _Float16* oh; _Float16* ol; int64_t ldo;               // EPI_SILU / EPI_GELU output planes
@@ -77,12 +84,20 @@ __device__ __forceinline__ void glds16(const _Float16* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int WM, int EPI, bool TWO, bool PP>
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
+
+template <int WM, int EPI, bool TWO, bool PP, bool LO8 = false>
 __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
+    static_assert(!(LO8 && (TWO || PP)), "LO8 replaces the fp16 lo plane; lockstep main loop only");
     constexpr int WN = 8 / WM, MT = BM / (32 * WM), NT = 2, BN = 64 * WN;
     constexpr int kWT = BN * BK * 2;             // bytes of the weight tile
-    constexpr int kStage = 2 * kXT + kWT;        // Xhi | Xlo | W
+    // stage image: Xhi | Xlo | W   (LO8: Xhi | Xlo8 (64-byte rows) | W | W8 (64-byte rows))
+    constexpr int oW = LO8 ? kXT + kXT / 2 : 2 * kXT;
+    constexpr int oW8 = oW + kWT;
+    constexpr int kStage = LO8 ? oW8 + kWT / 2 : 2 * kXT + kWT;
     constexpr int NXI = 2, NWI = BN / 64;        // staging instructions per wave: 2 per activation plane, BN/64 for W
+    constexpr int NW8 = BN / 128;                // ... and for the int8 weight tile (16 rows x 64 B per instruction); Xlo8: one
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +152,23 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         cw[j] = scp ^ ((r >> 1) & 7);
         gw[j] = p.w + (int64_t)gr * p.ldw + cw[j] * 8;
     }
+    // LO8: one instruction of 16 rows x 64 B per wave for the activation codes, NW8 for the weight codes; lane -> (row, chunk
+    // POSITION); position c of row r holds source chunk c ^ ((r >> 2) & 3): the 16 lanes of every ds_read_b128 group then fall
+    // into 16 distinct 16-byte bank slots (64-byte rows: slot = 4 (r & 3) + position)
+    [[maybe_unused]] const signed char* gx8 = nullptr;
+    [[maybe_unused]] const signed char* gw8[NW8 > 0 ? NW8 : 1];
+    if constexpr (LO8) {
+        const int r = wave * 16 + (lane >> 2);
+        const int gm = (m0 + r < p.M) ? m0 + r : p.M - 1;
+        gx8 = p.xl8 + (int64_t)gm * p.ldx8 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+#pragma unroll
+        for (int j = 0; j < NW8; ++j) {
+            const int rw = wave * (BN / 8) + j * 16 + (lane >> 2);
+            int gr = wrow(rw);
+            gr = gr < 0 ? 0 : gr;
+            gw8[j] = p.w8 + (int64_t)gr * p.ldw8 + (((lane & 3) ^ ((rw >> 2) & 3)) << 4);
+        }
+    }
     const bool ktail = (K % BK) != 0;
     auto stage = [&](int tl, char* buf) {
         const int t = t0 + tl;
@@ -154,7 +186,12 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         for (int j = 0; j < NWI; ++j) {
             // chunks past K pair with zero activations: any finite weight bytes do (the row's first chunk)
             const _Float16* sw = (!tail || cw[j] < kchunks) ? gw[j] + ko : gw[j] - cw[j] * 8;
-            glds16(sw, buf + 2 * kXT + (wave * (BN / 8) + j * 8) * 128);
+            glds16(sw, buf + oW + (wave * (BN / 8) + j * 8) * 128);
+        }
+        if constexpr (LO8) {                           // (K % 64 == 0 with LO8: no tail)
+            glds16((const _Float16*)(gx8 + ko), buf + kXT + wave * 1024);
+#pragma unroll
+            for (int j = 0; j < NW8; ++j) glds16((const _Float16*)(gw8[j] + ko), buf + oW8 + (wave * (BN / 8) + j * 16) * 64);
         }
     };
 
@@ -164,7 +201,22 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) foff[ks] = fr * 128 + (((2 * ks + fh) ^ ((fr >> 1) & 7)) << 4);
     const int a_base = (wm * 32 * MT) * 128;              // + 32*i rows, + kXT for the lo plane
-    const int b_base = 2 * kXT + (wn * 64) * 128;         // + 32*j rows
+    const int b_base = oW + (wn * 64) * 128;              // + 32*j rows
+    // LO8: a lane's 16 codes of a 32-deep block kb are chunk 2 kb + fh of its row (A and B pair slot by slot, so which sixteen k
+    // of the block a lane holds is free as long as both sides agree)
+    [[maybe_unused]] int foff8[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) foff8[kb] = fr * 64 + (((2 * kb + fh) ^ ((fr >> 2) & 3)) << 4);
+    [[maybe_unused]] const int a8_base = kXT + (wm * 32 * MT) * 64, b8_base = oW8 + (wn * 64) * 64;
+    [[maybe_unused]] i16v iacc[LO8 ? MT : 1][LO8 ? NT : 1];
+    if constexpr (LO8) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) iacc[i][j][r] = 0;
+    }
 
     f16v acc[MT][NT];
 #pragma unroll
@@ -213,6 +265,65 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
             if (2 * k + 1 < R) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // two DS reads
             else if (2 * k < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // (an odd one left)
+        }
+    };
+    // The slab multiplied right behind the K-step barrier also carries the LDS-DMA issue of K-step t + 2 (its buffer was just
+    // freed).  Rounds 2-4 issued the 8 (LO8: 11) DMA instructions in one burst in front of that slab's MFMAs: both waves of a SIMD
+    // spend ~60-100 issue cycles per instruction there while the matrix pipe, drained by the barrier, has nothing to do (seen in
+    // the ISA: barrier, 8 x global_load_lds, then the first MFMA).  Round 5 spreads them BETWEEN that slab's MFMAs: one MFMA, two
+    // fragment reads (until they run out), the slab's share of the DMA instructions, next MFMA -- for launches with two fp16 planes
+    // (-0.6 ... -2.6 % per layer at 800 ... 6000 rows); one-plane and int8-residual launches measured 1-5 % SLOWER that way and keep
+    // the burst (profiles/r05_variants.txt).  -DPC_DENSE_SPREAD_DMA=0: the burst everywhere.
+#ifndef PC_DENSE_SPREAD_DMA
+#define PC_DENSE_SPREAD_DMA 1
+#endif
+    // one MFMA / one fragment read / a range of the DMA instructions of a K-step, by index (compile-time after unrolling)
+    auto mfma_one = [&](const Frags& f, int idx) {
+        const int pl = idx / (MT * NT), i = (idx / NT) % MT, j = idx % NT;
+        if (TWO && pl == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bw[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bw[j], acc[i][j], 0, 0, 0);
+    };
+    auto read_one = [&](Frags& f, const char* buf, int ks, int idx) {
+        constexpr int NA = MT * (TWO ? 2 : 1);
+        if (idx < NA) {
+            const int i = TWO ? idx >> 1 : idx;
+            if (TWO && (idx & 1)) f.al[i] = *(const h8*)(buf + kXT + a_base + i * 32 * 128 + foff[ks]);
+            else f.ah[i] = *(const h8*)(buf + a_base + i * 32 * 128 + foff[ks]);
+        } else {
+            const int j = idx - NA;
+            f.bw[j] = *(const h8*)(buf + b_base + j * 32 * 128 + foff[ks]);
+        }
+    };
+    auto stage_range = [&](int tl, char* buf, int q0, int q1) {
+        const int t = t0 + tl;
+        const bool tail = ktail && t == nkt - 1;
+        const int64_t ko = (int64_t)t * BK;
+        const int kchunks = tail ? (K - t * BK) / 8 : 8;
+        int q = 0;
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const bool ok = !tail || cx[j] < kchunks;
+            if (q >= q0 && q < q1) glds16(ok ? gx[j] + ko : p.zeros, buf + (wave * 16 + j * 8) * 128);
+            ++q;
+            if (TWO) {
+                if (q >= q0 && q < q1) glds16(ok ? gx[j] + lo_delta + ko : p.zeros, buf + kXT + (wave * 16 + j * 8) * 128);
+                ++q;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+            if (q >= q0 && q < q1)
+                glds16((!tail || cw[j] < kchunks) ? gw[j] + ko : gw[j] - cw[j] * 8, buf + oW + (wave * (BN / 8) + j * 8) * 128);
+            ++q;
+        }
+        if constexpr (LO8) {
+            if (q >= q0 && q < q1) glds16((const _Float16*)(gx8 + ko), buf + kXT + wave * 1024);
+            ++q;
+#pragma unroll
+            for (int j = 0; j < NW8; ++j) {
+                if (q >= q0 && q < q1) glds16((const _Float16*)(gw8[j] + ko), buf + oW8 + (wave * (BN / 8) + j * 16) * 64);
+                ++q;
+            }
         }
     };
     if constexpr (PP) {
@@ -366,6 +477,106 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if constexpr (LO8) {
+        // ---- lockstep main loop with the lo plane on the int8 MFMA (round 5) ----
+        // Per K-step: 16 fp16 MFMAs for the hi plane (as without a lo plane) + 8 v_mfma_i32_32x32x32_i8 for the residual plane
+        // (two 32-deep blocks x MT x NT) instead of 16 more fp16 ones: 24 matrix-pipe slots instead of 32.  One int8 fragment set:
+        // block kb is read one slab ahead of its MFMAs like the fp16 fragments (kb 0 next to slab 0, kb 1 next to slab 2).
+        struct F8 { i4v a[MT], b[NT]; };
+        F8 f8;
+        auto load8 = [&](const char* buf, int kb) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) f8.a[i] = *(const i4v*)(buf + a8_base + i * 32 * 64 + foff8[kb]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) f8.b[j] = *(const i4v*)(buf + b8_base + j * 32 * 64 + foff8[kb]);
+        };
+        auto imfmas = [&]() {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) iacc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f8.a[i], f8.b[j], iacc[i][j], 0, 0, 0);
+        };
+        // (reads of the next slab, MFMAs of this one): one MFMA, then two reads, until the reads run out
+        auto pin = [&](auto r_, auto mf_) {
+            constexpr int R = decltype(r_)::value, MF = decltype(mf_)::value;
+#pragma unroll
+            for (int k = 0; k < MF; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (2 * k + 1 < R) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (2 * k < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        using RH = std::integral_constant<int, MT + NT>;             // reads of one fp16 slab
+        using RB = std::integral_constant<int, 2 * (MT + NT)>;       // ... plus one int8 block
+        using MH = std::integral_constant<int, MT * NT>;             // MFMAs of one fp16 slab
+        using MB = std::integral_constant<int, 2 * MT * NT>;         // ... plus one int8 block
+        Frags fa, fb;
+        stage(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nk > 1) stage(1, lds + kStage);
+        load_frags(fa, lds, 0);
+        load8(lds, 0);
+        for (int t = 0; t + 1 < nk; ++t) {
+            const char* cur = lds + (t & 1) * kStage;
+            load_frags(fb, cur, 1);
+            mfmas(fa);
+            imfmas();
+            pin(RH{}, MB{});
+            load_frags(fa, cur, 2);
+            load8(cur, 1);
+            mfmas(fb);
+            pin(RB{}, MH{});
+            load_frags(fb, cur, 3);
+            mfmas(fa);
+            imfmas();
+            pin(RH{}, MB{});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int tn = t + 2 < nk ? t + 2 : nk - 1;
+            // (the DMA issue spread between this slab's MFMAs -- see the fp16 loop below -- measured SLOWER here: 4177 vs 4136 us per
+            // layer at 6000 rows, profiles/r05_variants.txt)
+            stage(tn, lds + (t & 1) * kStage);
+            load_frags(fa, lds + ((t + 1) & 1) * kStage, 0);
+            load8(lds + ((t + 1) & 1) * kStage, 0);
+            mfmas(fb);
+            pin(RB{}, MH{});
+        }
+        {
+            const char* cur = lds + ((nk - 1) & 1) * kStage;
+            load_frags(fb, cur, 1);
+            mfmas(fa);
+            imfmas();
+            pin(RH{}, MB{});
+            load_frags(fa, cur, 2);
+            load8(cur, 1);
+            mfmas(fb);
+            pin(RB{}, MH{});
+            load_frags(fb, cur, 3);
+            mfmas(fa);
+            imfmas();
+            pin(RH{}, MB{});
+            mfmas(fb);
+        }
+        // the residual product joins the fp32 accumulator: y += int_sum * xl8_scale[row] * w8_scale[col]
+        {
+            float wsc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int gr = wrow(wn * 64 + 32 * j + fr);
+                wsc[j] = p.w8_scale[gr < 0 ? 0 : gr];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 * MT + 32 * i + 8 * (r >> 2) + 4 * fh + (r & 3);
+                    const float xs = p.xl8_scale[m < p.M ? m : p.M - 1];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][r] = __builtin_fmaf((float)iacc[i][j][r], xs * wsc[j], acc[i][j][r]);
+                }
+        }
     } else {
     Frags fa, fb;
     stage(0, lds);
@@ -392,10 +603,24 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tn = t + 2 < nk ? t + 2 : nk - 1;
-        stage(tn, lds + (t & 1) * kStage);
-        load_frags(fa, lds + ((t + 1) & 1) * kStage, 0);
-        mfmas(fb);
-        interleave();
+        if constexpr (PC_DENSE_SPREAD_DMA && TWO) {
+            constexpr int MF = MT * NT * (TWO ? 2 : 1), R = MT * (TWO ? 2 : 1) + NT, V = NXI * (TWO ? 2 : 1) + NWI;
+            const char* nb = lds + ((t + 1) & 1) * kStage;
+#pragma unroll
+            for (int k = 0; k < MF; ++k) {
+                mfma_one(fb, k);
+                __builtin_amdgcn_sched_barrier(0);
+                if (2 * k < R) read_one(fa, nb, 0, 2 * k);
+                if (2 * k + 1 < R) read_one(fa, nb, 0, 2 * k + 1);
+                stage_range(tn, lds + (t & 1) * kStage, k * V / MF, (k + 1) * V / MF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            stage(tn, lds + (t & 1) * kStage);
+            load_frags(fa, lds + ((t + 1) & 1) * kStage, 0);
+            mfmas(fb);
+            interleave();
+        }
     }
     {
         const char* cur = lds + ((nk - 1) & 1) * kStage;
@@ -602,7 +827,14 @@ int launch_dense(DenseParams& p, hipStream_t s, int kslices = 1) {
         return pc_check_launch("gemm_dense_kernel");
     }
 #endif
-    if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true, false>), grid, block, 0, s, p);
+    if (p.xl8) {
+        if constexpr (EPI == EPI_GELU) {               // (no caller: the Falcon / MPT stacks keep the fp16 residual plane)
+            pc_set_error("pc_gemm_dense_lo8: no GELU instantiation");
+            return PC_ERR_ARG;
+        } else {
+            hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false, false, true>), grid, block, 0, s, p);
+        }
+    } else if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false, false>), grid, block, 0, s, p);
     return pc_check_launch("gemm_dense_kernel");
 }
@@ -655,10 +887,11 @@ int launch_dense_tile(DenseParams& p, hipStream_t s) {
 }  // namespace
 
 namespace {
+struct Lo8Operands { const void* x_lo8; const float* x_lo8_scale; int64_t ldx8; const void* w8; const float* w8_scale; int64_t ldw8; };
 int gemm_dense_impl(const void* x_hi, const void* x_lo, int64_t ldx, const void* w, int64_t ldw, const float* w_scale,
                     const float* x_scale, const float* corr, int64_t ldc, const int32_t* corr_has, int32_t M, int32_t N,
                     int32_t K, int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* stream,
-                    void* workspace = nullptr, int64_t ws_bytes = 0) {
+                    void* workspace = nullptr, int64_t ws_bytes = 0, const Lo8Operands* lo8 = nullptr) {
     PC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0, PC_ERR_ARG, "pc_gemm_dense: need M, N, K > 0, K%%8==0, N%%4==0");
     PC_REQUIRE(x_hi && w, PC_ERR_ARG, "pc_gemm_dense: null pointer");
     PC_REQUIRE(ldx >= K && ldw >= K && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w & 15) == 0 &&
@@ -672,6 +905,16 @@ int gemm_dense_impl(const void* x_hi, const void* x_lo, int64_t ldx, const void*
                "pc_gemm_dense_a8: int8 activations need w_scale, no lo plane, corr (16-byte aligned, ldc >= N) and corr_has");
     p.xscale = x_scale; p.corr = corr; p.ldc = ldc; p.corr_has = corr_has;
     p.M = M; p.N = N; p.K = K;
+    if (lo8) {
+        PC_REQUIRE(lo8->x_lo8 && lo8->x_lo8_scale && lo8->w8 && lo8->w8_scale && !x_lo && !x_scale && !w_scale, PC_ERR_ARG,
+                   "pc_gemm_dense_lo8: needs the int8 residual plane, its row scales, the int8 weight image and its row scales (and no "
+                   "fp16 lo plane / LLM.int8 operands)");
+        PC_REQUIRE(K % 64 == 0 && lo8->ldx8 >= K && lo8->ldw8 >= K && lo8->ldx8 % 16 == 0 && lo8->ldw8 % 16 == 0 &&
+                   (((uintptr_t)lo8->x_lo8 | (uintptr_t)lo8->w8) & 15) == 0, PC_ERR_ARG,
+                   "pc_gemm_dense_lo8: K %% 64 == 0, int8 planes 16-byte aligned with row strides %% 16 == 0");
+        p.xl8 = (const signed char*)lo8->x_lo8; p.xl8_scale = lo8->x_lo8_scale; p.ldx8 = lo8->ldx8;
+        p.w8 = (const signed char*)lo8->w8; p.w8_scale = lo8->w8_scale; p.ldw8 = lo8->ldw8;
+    }
     void* z = nullptr;
     if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero_chunk)) != hipSuccess || !z) {
         pc_set_error("pc_gemm_dense: hipGetSymbolAddress failed");
@@ -722,6 +965,17 @@ PC_EXPORT int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, 
                            out_lo, ldo, stream, workspace, ws_bytes);
 }
 
+// pc_gemm_dense with the residual activation plane as int8 codes (pc_quant_rows_i8) against an int8 image of the weights: the
+// second plane's product runs on v_mfma_i32_32x32x32_i8 at twice the fp16 MFMA rate (include/promptcache_hip.h).
+PC_EXPORT int pc_gemm_dense_lo8(const void* x_hi, int64_t ldx, const void* x_lo8, const float* x_lo8_scale, int64_t ldx8, const void* w,
+                                int64_t ldw, const void* w8, const float* w8_scale, int64_t ldw8, int32_t M, int32_t N, int32_t K,
+                                int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* workspace,
+                                int64_t ws_bytes, void* stream) {
+    const Lo8Operands lo8{x_lo8, x_lo8_scale, ldx8, w8, w8_scale, ldw8};
+    return gemm_dense_impl(x_hi, nullptr, ldx, w, ldw, nullptr, nullptr, nullptr, 0, nullptr, M, N, K, epilogue, y, ldy, out_hi, out_lo,
+                           ldo, stream, workspace, ws_bytes, &lo8);
+}
+
 // The fused q|k|v projection of a many-row pass at head_dim 128 (include/promptcache_hip.h: pc_dense_qkv_args): projection,
 // RoPE at the supplied positions, rotated q as hi / lo planes, rotated k and v appended to the arena (+ residual planes) -- the
 // [M][(H + 2 Hkv) D] fp32 intermediate and the separate pc_rope_append launch of the round-2 encode are gone.
@@ -748,6 +1002,13 @@ PC_EXPORT int pc_gemm_dense_qkv_rope(const pc_dense_qkv_args* a, void* stream) {
     p.xh = (const _Float16*)a->x_hi; p.xl = (const _Float16*)a->x_lo; p.ldx = a->ldx;
     p.w = (const _Float16*)a->w; p.ldw = a->ldw;
     p.M = a->B * a->q_len; p.N = (a->H + 2 * a->Hkv) * 128; p.K = a->K;
+    if (a->x_lo8) {
+        PC_REQUIRE(!a->x_lo && a->x_lo8_scale && a->w8 && a->w8_scale && a->K % 64 == 0 && a->ldx8 >= a->K && a->ldw8 >= a->K &&
+                   a->ldx8 % 16 == 0 && a->ldw8 % 16 == 0 && (((uintptr_t)a->x_lo8 | (uintptr_t)a->w8) & 15) == 0, PC_ERR_ARG,
+                   "pc_gemm_dense_qkv_rope: the int8 residual plane replaces x_lo; K %% 64 == 0; int8 planes 16-byte aligned, row strides %% 16 == 0");
+        p.xl8 = (const signed char*)a->x_lo8; p.xl8_scale = a->x_lo8_scale; p.ldx8 = a->ldx8;
+        p.w8 = (const signed char*)a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
+    }
     void* z = nullptr;
     if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero_chunk)) != hipSuccess || !z) {
         pc_set_error("pc_gemm_dense_qkv_rope: hipGetSymbolAddress failed");

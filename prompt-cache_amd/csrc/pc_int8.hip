@@ -109,6 +109,51 @@ __global__ __launch_bounds__(256) void quant_act_kernel(const _Float16* __restri
     }
 }
 
+// pc_quant_rows_i8 (round 5): a residual activation plane x_lo fp16 [M][K] as row-wise absmax int8 codes [M][K] + scale[M] for the
+// int8 MFMA of pc_gemm_dense_lo8.  One workgroup per row; no outlier logic (this is not LLM.int8: the plane is a rounding residual).
+template <int G>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const _Float16* __restrict__ x, int64_t ldx, int K, signed char* __restrict__ codes,
+                                                         int64_t ld8, float* __restrict__ scale) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, nchunk = K >> 3;
+    float a[G][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int c = tid + i * 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[i][e] = 0.f;
+        if (c < nchunk) {
+            const h8 v = *(const h8*)(x + (int64_t)row * ldx + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[i][e] = (float)v[e]; mx = fmaxf(mx, fabsf(a[i][e])); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    const float amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float inv = amax > 0.f ? 127.0f / amax : 0.f;
+    if (tid == 0) scale[row] = amax / 127.0f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int c = tid + i * 256;
+        if (c < nchunk) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r0 = fminf(fmaxf(rintf(a[i][e] * inv), -127.f), 127.f);
+                const float r1 = fminf(fmaxf(rintf(a[i][4 + e] * inv), -127.f), 127.f);
+                lo |= ((uint32_t)(int)r0 & 0xffu) << (8 * e);
+                hi |= ((uint32_t)(int)r1 & 0xffu) << (8 * e);
+            }
+            typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+            *(u2v*)(codes + (int64_t)row * ld8 + c * 8) = u2v{lo, hi};
+        }
+    }
+}
+
 // RMSNorm + quantiser in one launch for the two projection inputs that come out of a norm (q|k|v, gate|up; <= 64-row path):
 // exactly rmsnorm_frag_kernel's arithmetic (pc_gemm.hip: same per-thread partial sums, same reduction order, v = g * (x * rs),
 // hi = fp16(v)) followed by quant_act_kernel's on the hi values, so the pair of launches and this one are bit-identical.
@@ -367,4 +412,22 @@ PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const
         hipLaunchKernelGGL((outlier_corr_kernel<false>), grid, dim3(256), 0, s, (const unsigned char*)flags, K, (const _Float16*)x,
                            (const _Float16*)codes, ldx, x_scale, (const signed char*)w_codes_t, ldt, w_scale, row_perm, T, N, corr, ldc, has);
     return pc_check_launch("outlier_corr_kernel");
+}
+
+PC_EXPORT int pc_quant_rows_i8(const void* x, int64_t ldx, int32_t M, int32_t K, void* codes, int64_t ld8, float* scale, void* stream) {
+    PC_REQUIRE(x && codes && scale && M > 0 && K > 0 && K % 8 == 0 && ldx >= K && ldx % 8 == 0 && ld8 >= K && ld8 % 8 == 0 &&
+               ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 7) == 0, PC_ERR_ARG,
+               "pc_quant_rows_i8: K %% 8 == 0, fp16 rows 16-byte aligned, code rows 8-byte aligned");
+    const int g = pc_ceil_div(K >> 3, 256);
+    PC_REQUIRE(g <= 8, PC_ERR_ARG, "pc_quant_rows_i8: K up to 16384");
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16* xp = (const _Float16*)x;
+    signed char* cp = (signed char*)codes;
+    switch (g) {
+        case 1: hipLaunchKernelGGL((quant_rows_kernel<1>), dim3(M), dim3(256), 0, s, xp, ldx, K, cp, ld8, scale); break;
+        case 2: hipLaunchKernelGGL((quant_rows_kernel<2>), dim3(M), dim3(256), 0, s, xp, ldx, K, cp, ld8, scale); break;
+        case 3: case 4: hipLaunchKernelGGL((quant_rows_kernel<4>), dim3(M), dim3(256), 0, s, xp, ldx, K, cp, ld8, scale); break;
+        default: hipLaunchKernelGGL((quant_rows_kernel<8>), dim3(M), dim3(256), 0, s, xp, ldx, K, cp, ld8, scale); break;
+    }
+    return pc_check_launch("quant_rows_kernel");
 }

@@ -59,7 +59,8 @@ class DenseQkvArgs(C.Structure):
                 ("k_arena", _vp), ("v_arena", _vp), ("arena_batch_stride", _i64), ("arena_head_stride", _i64),
                 ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64), ("lo_row0", _i32),
                 ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
-                ("past_lens", _vp)]
+                ("past_lens", _vp),
+                ("x_lo8", _vp), ("x_lo8_scale", _vp), ("ldx8", _i64), ("w8", _vp), ("w8_scale", _vp), ("ldw8", _i64)]
 
 
 class GemmArgs(C.Structure):
@@ -127,6 +128,9 @@ SIGNATURES = {
                                 _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64,
                                 _i32, _vp, _vp]),
     "pc_gemm_dense_qkv_rope": (C.c_int, [_vp, _vp]),
+    "pc_quant_rows_i8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "pc_gemm_dense_lo8": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp,
+                                    _i64, _vp, _i64, _vp]),
     "pc_gemm_dense_ws": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
@@ -550,16 +554,40 @@ def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out
     check(rc, "pc_gemm_dense")
 
 
+def quant_rows_i8(x_lo, M: int, K: int, codes, scale, stream: Optional[int] = None) -> None:
+    """A residual activation plane fp16 ``[M, K]`` -> row-wise absmax int8 codes ``codes [M, K]`` + ``scale [M]`` fp32
+    (``pc_quant_rows_i8``): the second operand plane of ``gemm_dense(..., lo8=...)``."""
+    rc = load().pc_quant_rows_i8(x_lo.data_ptr(), x_lo.stride(-2), M, K, codes.data_ptr(), codes.stride(-2), scale.data_ptr(),
+                                 current_stream() if stream is None else stream)
+    check(rc, "pc_quant_rows_i8")
+
+
+def gemm_dense_lo8(x_hi, x_lo8, x_lo8_scale, w, w8, w8_scale, M: int, N: int, K: int, epilogue: int, y=None, out_hi=None, out_lo=None,
+                   workspace=None, stream: Optional[int] = None) -> None:
+    """``gemm_dense`` with the residual activation plane on the int8 MFMA (``pc_gemm_dense_lo8``): ``x_lo8`` int8 ``[M, K]`` +
+    ``x_lo8_scale [M]`` from ``quant_rows_i8``, ``w8`` int8 ``[N, K]`` + ``w8_scale [N]`` from ``quantize_rows_int8(w)``."""
+    rc = load().pc_gemm_dense_lo8(x_hi.data_ptr(), x_hi.stride(-2), x_lo8.data_ptr(), x_lo8_scale.data_ptr(), x_lo8.stride(-2),
+                                  w.data_ptr(), w.stride(-2), w8.data_ptr(), w8_scale.data_ptr(), w8.stride(-2), M, N, K, epilogue,
+                                  _ptr(y), 0 if y is None else y.stride(-2), _ptr(out_hi), _ptr(out_lo),
+                                  0 if out_hi is None else out_hi.stride(-2), _ptr(workspace),
+                                  0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                  current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_dense_lo8")
+
+
 def gemm_dense_qkv_rope(x_hi, x_lo, w, K: int, cs, q_hi, q_lo, q_ts: int, k_arena, v_arena, a_bs: int, a_hs: int, B: int, H: int,
                         Hkv: int, D: int, q_len: int, past_len: int, cap: int, kv_lo=None, past_lens=None,
-                        stream: Optional[int] = None) -> None:
+                        stream: Optional[int] = None, lo8=None) -> None:
     """The fused many-row q|k|v projection (``pc_gemm_dense_qkv_rope``): ``(x_hi + x_lo) @ [q; k; v]^T``, RoPE from the table
     ``cs``, rotated q into ``q_hi`` / ``q_lo``, rotated k and v into the arena planes behind each batch row's past (and their
-    residuals into ``kv_lo = (k_lo, v_lo, batch_stride, head_stride, row0)``)."""
+    residuals into ``kv_lo = (k_lo, v_lo, batch_stride, head_stride, row0)``).  ``lo8 = (x_lo8, x_lo8_scale, w8, w8_scale)``
+    instead of ``x_lo``: the residual plane on the int8 MFMA (``pc_gemm_dense_lo8``)."""
     lo = (None, None, 0, 0, 0) if kv_lo is None else kv_lo
+    l8 = (None, None, 0, None, None, 0) if lo8 is None else (lo8[0], lo8[1], lo8[0].stride(-2), lo8[2], lo8[3], lo8[2].stride(-2))
     a = DenseQkvArgs(C.sizeof(DenseQkvArgs), x_hi.data_ptr(), _ptr(x_lo), x_hi.stride(-2), w.data_ptr(), w.stride(-2), K,
                      cs.data_ptr(), q_hi.data_ptr(), _ptr(q_lo), q_ts, k_arena.data_ptr(), v_arena.data_ptr(), a_bs, a_hs,
-                     _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4], B, H, Hkv, D, q_len, past_len, cap, _ptr(past_lens))
+                     _ptr(lo[0]), _ptr(lo[1]), lo[2], lo[3], lo[4], B, H, Hkv, D, q_len, past_len, cap, _ptr(past_lens),
+                     _ptr(l8[0]), _ptr(l8[1]), l8[2], _ptr(l8[3]), _ptr(l8[4]), l8[5])
     rc = load().pc_gemm_dense_qkv_rope(C.byref(a), current_stream() if stream is None else stream)
     check(rc, "pc_gemm_dense_qkv_rope")
 

@@ -256,6 +256,15 @@ class LlamaHIP:
         self.dense_lo_skip = tuple(t for t in _skip.split(",") if t)
         self.mid_lo_skip = tuple(t for t in os.environ.get("PC_MID_LO_SKIP", "").split(",") if t)
         self.fused_dense_qkv = os.environ.get("PC_FUSED_DENSE_QKV", "1") != "0"   # RoPE + KV append in the many-row q|k|v epilogue
+        # Round 5: the many-row projections that keep their residual activation plane run it on the INT8 MFMA (pc_gemm_dense_lo8:
+        # x_lo as row-wise absmax int8 codes against an int8 image of the weights, exact int32 sums at twice the fp16 MFMA rate:
+        # 24 matrix-pipe slots per K-step instead of 32).  The residual only has to be good to a few bits -- it is 2^-11 of the
+        # activation -- and is carried to 2^-8 of its row maximum.  MEASURED (profiles/r05_variants.txt): the launches are 3-8 %
+        # faster than with the fp16 residual plane (not the 25 % the slot count promises: at ~1.15 PFLOP/s executed the kernel sits at
+        # ~75 % of the matrix peak at the clock the chip holds under this load), the persona encode 101.9 -> 104.2 k tok/s, full-depth
+        # parity unchanged at 7b (5.1e-3) and 3.3e-3 instead of 2.0e-3 at 13b -- for 6.7 GB of int8 weight images at 7b.  Not worth a
+        # second weight image by default: OPT-IN (PC_DENSE_LO8=1).
+        self.dense_lo8 = os.environ.get("PC_DENSE_LO8", "0") == "1"
         self.encode_mid = os.environ.get("PC_ENC_MID", "1") != "0"    # encode passes of 65..512 rows on the row-split stack
         # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
         # decoded token -- in the arena's residual tail and feed them to the attention (the reference keeps those rows in
@@ -376,7 +385,13 @@ class LlamaHIP:
             wo, wo_f, wo_s = prep(wo); t_o = self._last_qt
             wgu, wgu_f, wgu_s = prep(wgu); t_gu = self._last_qt
             wdown, wdown_f, wdown_s = prep(wdown); t_d = self._last_qt
-            self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown,
+            q8 = {}
+            if self.dense_lo8 and self.precise_dense and not self.int8_weights:
+                # int8 images (+ row scales) of the projections whose many-row launches keep the residual plane (dense_lo_skip)
+                for key, wt, tag in (("wqkv", wqkv, "qkv"), ("wo", wo, "o"), ("wgu", wgu, "gu"), ("wdown", wdown, "down")):
+                    if tag not in self.dense_lo_skip and wt.shape[1] % 64 == 0:
+                        q8[key + "_q8"], q8[key + "_q8s"] = _native.quantize_rows_int8(wt)
+            self.layers.append(dict(ln1=w(f"l{i}.ln1"), ln2=w(f"l{i}.ln2"), wqkv=wqkv, wo=wo, wgu=wgu, wdown=wdown, **q8,
                                     wqkv_t8=t_qkv, wo_t8=t_o, wgu_t8=t_gu, wdown_t8=t_d,
                                     wqkv_f=wqkv_f, wo_f=wo_f, wgu_f=wgu_f, wdown_f=wdown_f,
                                     wqkv_s=wqkv_s[0], wo_s=wo_s[0], wgu_s=wgu_s[0], wdown_s=wdown_s[0],
@@ -617,7 +632,20 @@ class LlamaHIP:
             ws = getattr(self, "_dense_ws", None)
             if ws is None:
                 ws = self._dense_ws = torch.empty(34 << 20, dtype=torch.uint8, device=self.device)
+        w8 = lw.get(key + "_q8") if (a_lo is not None and self.dense_lo8) else None
+        if w8 is not None:
+            # the residual plane on the int8 MFMA: one quantiser launch (M x K x 3 bytes of traffic), then the projection
+            codes, sc = self._lo8_codes(a_lo, M, K)
+            _native.gemm_dense_lo8(a_hi, codes, sc, lw[key], w8, lw[key + "_q8s"], M, N, K, epi, workspace=ws, **out)
+            return
         _native.gemm_dense(a_hi, a_lo, lw[key], M, N, K, epi, wscale=lw.get(key + "_ds"), workspace=ws, **out)
+
+    def _lo8_codes(self, a_lo, M: int, K: int):
+        """Row-wise absmax int8 codes + scales of a residual activation plane (pc_quant_rows_i8)."""
+        codes = torch.empty((M, K), dtype=torch.int8, device=self.device)
+        sc = torch.empty(M, dtype=torch.float32, device=self.device)
+        _native.quant_rows_i8(a_lo, M, K, codes, sc)
+        return codes, sc
 
     def _forward_dense(self, ids, pos32, arena, B, q_len, past_len, last_token_only, num_layers):
         """Layer stack for many rows (schema encode, no-cache prefill): every projection is a pc_gemm_dense launch with
@@ -681,9 +709,13 @@ class LlamaHIP:
             kp, vp = arena.k_plane(li), arena.v_plane(li)
             kv_lo = lo_for(li)
             if fused_qkv:
-                n.gemm_dense_qkv_rope(h2[0], lo_q(h2), lw["wqkv"], hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
+                xlo, lo8 = lo_q(h2), None
+                if xlo is not None and self.dense_lo8 and lw.get("wqkv_q8") is not None:
+                    codes, sc = self._lo8_codes(xlo, T, hid)
+                    xlo, lo8 = None, (codes, sc, lw["wqkv_q8"], lw["wqkv_q8s"])
+                n.gemm_dense_qkv_rope(h2[0], xlo, lw["wqkv"], hid, cs, q16, q16l, H * D, kp, vp, arena.batch_stride,
                                       arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, kv_lo=kv_lo,
-                                      past_lens=self._past_lens)
+                                      past_lens=self._past_lens, lo8=lo8)
             else:
                 self._proj(h2[0], lo_q(h2), lw, "wqkv", T, W, hid, n.EPI_STORE, y=qkv)
                 n.rope_append(qkv, q_len * W, W, q16, q_len * H * D, H * D, qkv[:, H * D:], qkv[:, (H + Hkv) * D:], q_len * W, W,

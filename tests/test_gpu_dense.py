@@ -166,3 +166,118 @@ def test_dense_strided_views_and_argument_errors():
     assert lib.pc_gemm_dense(None, None, 8, None, 8, None, 1, 4, 8, 0, None, 4, None, None, 0, None) < 0
     assert lib.pc_gemm_dense(buf.data_ptr(), None, K, wb.data_ptr(), K, None, M, N, 12, 0, y.data_ptr(), N, None, None, 0, None) < 0
     assert b"K%8" in lib.pc_last_error_string()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 5: the residual activation plane on the int8 MFMA (pc_quant_rows_i8 + pc_gemm_dense_lo8)
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _q8_rows(a):
+    """numpy restatement of the row-wise absmax quantiser: codes = rint(a * (127 / max|a|)) (fp32 arithmetic), scale = max / 127."""
+    a = a.astype(np.float32)
+    amax = np.abs(a).max(axis=1)
+    inv = np.where(amax > 0, np.float32(127.0) / amax, np.float32(0.0)).astype(np.float32)
+    codes = np.clip(np.rint(a * inv[:, None]), -127, 127).astype(np.int8)
+    return codes, (amax / np.float32(127.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,K", [(1, 64), (130, 4096), (300, 11008), (77, 13824), (5, 5120)])
+def test_quant_rows_i8_matches_numpy(M, K):
+    n = _n()
+    rng = np.random.default_rng(M + K)
+    lo = (rng.standard_normal((M, K)) * 2.0 ** -12 * rng.uniform(0.1, 30.0, size=(M, 1))).astype(np.float16)
+    lo[M // 2] = 0                                                        # an all-zero row: codes 0, scale 0
+    t = torch.from_numpy(lo).to(DEV)
+    codes = torch.full((M, K), 99, dtype=torch.int8, device=DEV)
+    sc = torch.full((M,), float("nan"), dtype=torch.float32, device=DEV)
+    n.quant_rows_i8(t, M, K, codes, sc)
+    torch.cuda.synchronize()
+    ref_c, ref_s = _q8_rows(lo)
+    got_c, got_s = codes.cpu().numpy(), sc.cpu().numpy()
+    assert np.array_equal(got_s, ref_s)
+    # (the device multiplies by 127 / max formed in fp32 division, numpy the same: identical codes up to ties broken by a last-bit
+    # difference of the quotient -- none expected, one code step tolerated)
+    assert np.abs(got_c.astype(np.int32) - ref_c.astype(np.int32)).max() <= 1
+    assert (got_c != ref_c).mean() < 1e-4
+
+
+LO8_SHAPES = [(128, 256, 64), (130, 260, 128), (300, 4096, 4096), (1000, 12288, 4096), (640, 4096, 11008), (257, 5120, 13824),
+              (2050, 1024, 128), (1, 4096, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", LO8_SHAPES)
+def test_dense_lo8_store_add_and_split_k(M, N, K):
+    """(x_hi + x_lo) @ W^T with the residual plane as int8 codes against the int8 weight image: (i) EXACT against the float64
+    evaluation of what the kernel is specified to compute -- x_hi . W^T + (codes_x . codes_w^T) * scale_x * scale_w -- up to fp32
+    accumulation; (ii) within the residual plane's quantisation of the true split-precision product (x_hi + x_lo) . W^T: an
+    error of 2^-8 of the row's largest residual per element, i.e. far below one fp16 ulp of the activations."""
+    n = _n()
+    x, w = _inputs(M, N, K, seed=3 * M + N + K)
+    hi, lo = _split(x)
+    cx, sx = _q8_rows(lo)
+    tw = torch.from_numpy(w).to(DEV)
+    w8, w8s = n.quantize_rows_int8(tw)
+    cw, sw = w8.cpu().numpy(), w8s.cpu().numpy()
+    spec = hi.astype(np.float64) @ w.astype(np.float64).T + \
+        (cx.astype(np.float64) @ cw.astype(np.float64).T) * sx.astype(np.float64)[:, None] * sw.astype(np.float64)[None, :]
+    true = (hi.astype(np.float64) + lo.astype(np.float64)) @ w.astype(np.float64).T
+    th, tl = torch.from_numpy(hi).to(DEV), torch.from_numpy(lo).to(DEV)
+    codes = torch.empty((M, K), dtype=torch.int8, device=DEV)
+    sc = torch.empty(M, dtype=torch.float32, device=DEV)
+    n.quant_rows_i8(tl, M, K, codes, sc)
+    assert np.array_equal(sc.cpu().numpy(), sx)
+    cx_dev = codes.cpu().numpy()
+    if not np.array_equal(cx_dev, cx):                                  # (a tie broken the other way: follow the device's codes)
+        spec = hi.astype(np.float64) @ w.astype(np.float64).T + \
+            (cx_dev.astype(np.float64) @ cw.astype(np.float64).T) * sx.astype(np.float64)[:, None] * sw.astype(np.float64)[None, :]
+    tol = 2e-6 * np.sqrt(K) * np.abs(hi).max() * 0.05 * 8 + 1e-6          # fp32 accumulation, as for pc_gemm_dense
+    ws = torch.full((34 << 20,), 0xFF, dtype=torch.uint8, device=DEV)
+    for workspace in (None, ws):
+        y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        n.gemm_dense_lo8(th, codes, sc, tw, w8, w8s, M, N, K, n.EPI_STORE, y=y, workspace=workspace)
+        base = torch.from_numpy(np.random.default_rng(1).standard_normal((M, N)).astype(np.float32)).to(DEV)
+        y2 = base.clone()
+        n.gemm_dense_lo8(th, codes, sc, tw, w8, w8s, M, N, K, n.EPI_ADD, y=y2, workspace=workspace)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        assert np.abs(got - spec).max() < tol, (np.abs(got - spec).max(), tol)
+        assert np.abs(y2.cpu().numpy().astype(np.float64) - (base.cpu().numpy().astype(np.float64) + spec)).max() < tol
+        # the residual plane's own error: |lo - codes * scale| <= scale / 2 per element and |w - cw * sw| <= sw / 2, summed over K at
+        # random sign; bound it by 4 sigma of that sum, and compare with what dropping the plane would cost
+        q_err = np.abs(got - true).max()
+        drop_err = np.abs(hi.astype(np.float64) @ w.astype(np.float64).T - true).max()
+        bound = 4.0 * np.sqrt(K) * (sx.max() / 2 * np.abs(w).max() + np.abs(lo).max() * sw.max() / 2) + tol
+        assert q_err < bound, (q_err, bound)
+        assert q_err < 0.05 * drop_err + tol, (q_err, drop_err)
+        # ... and it agrees with the fp16 residual plane's launch far inside an fp16 ulp of the outputs
+        y3 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        n.gemm_dense(th, tl, tw, M, N, K, n.EPI_STORE, y=y3)
+        assert float((y3 - y).abs().max()) < 2.0 ** -13 * max(float(y3.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("M,inter,K", [(300, 11008, 4096), (513, 13824, 5120), (130, 192, 128)])
+def test_dense_lo8_silu_epilogue(M, inter, K):
+    n = _n()
+    x, w = _inputs(M, 2 * inter, K, seed=M + inter)
+    hi, lo = _split(x)
+    th, tl, tw = torch.from_numpy(hi).to(DEV), torch.from_numpy(lo).to(DEV), torch.from_numpy(w).to(DEV)
+    w8, w8s = n.quantize_rows_int8(tw)
+    codes = torch.empty((M, K), dtype=torch.int8, device=DEV)
+    sc = torch.empty(M, dtype=torch.float32, device=DEV)
+    n.quant_rows_i8(tl, M, K, codes, sc)
+    oh = torch.empty((M, inter), dtype=torch.float16, device=DEV)
+    ol = torch.empty_like(oh)
+    n.gemm_dense_lo8(th, codes, sc, tw, w8, w8s, M, 2 * inter, K, n.EPI_SILU, out_hi=oh, out_lo=ol)
+    rh, rl = torch.empty_like(oh), torch.empty_like(oh)
+    n.gemm_dense(th, tl, tw, M, 2 * inter, K, n.EPI_SILU, out_hi=rh, out_lo=rl)
+    torch.cuda.synchronize()
+    got = oh.float() + ol.float()
+    ref = rh.float() + rl.float()
+    xs = hi.astype(np.float64) + lo.astype(np.float64)
+    g = xs @ w[:inter].astype(np.float64).T
+    u = xs @ w[inter:].astype(np.float64).T
+    exact = torch.from_numpy((g / (1.0 + np.exp(-g)) * u)).to(DEV)
+    scale = float(exact.abs().max())
+    assert float((got.double() - exact).abs().max()) < 2.0 ** -13 * scale
+    assert float((got - ref).abs().max()) < 2.0 ** -13 * scale

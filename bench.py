@@ -644,7 +644,7 @@ def main():
                          "2-4 follow the reference's latency recipe (eval.py:172-219): every entry, cached and no_cache")
     ap.add_argument("--model", default="llama2-7b")
     ap.add_argument("--max-ctx", type=int, default=4096)        # config/llm_config_llama2_7b.json of the reference
-    ap.add_argument("--cpu-layers", type=int, default=4, help="layers the cpu_baseline TIMING runs (scaled by L/k)")
+    ap.add_argument("--cpu-layers", type=int, default=8, help="layers the cpu_baseline TIMING runs (scaled by L/k)")
     ap.add_argument("--parity-layers", type=int, default=0, help="layers of the parity leg (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-library", action="store_true", help="skip the schema-library encode leg (BASELINE config 5)")

@@ -603,7 +603,8 @@ class SchemaCache:
                                  exchange_bytes_rx=(self._exchange["bytes_rx"] if world > 1 else 0),
                                  exchange_bytes_rx_buffers=(self._exchange["bytes_rx_buffers"] if world > 1 else 0),
                                  exchange_exposed_s=(blocking_s if world > 1 else 0.0))
-        gc.collect()
+        if os.environ.get("PC_ENCODE_GC", "1") != "0":          # (dev knob: what the collection costs the encode's wall time)
+            gc.collect()
 
     # tokens (padding included) one encode forward may carry when scaffolds are packed into a batch
     encode_token_budget = 8192

@@ -329,6 +329,186 @@ def layout_goldens(pc):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# PML fuzz: random schemas + prompts (generated HERE, seeded), laid out by the imported reference
+# ---------------------------------------------------------------------------------------------------
+
+_FWORDS = ("alpha beta gamma delta kilo lima mike echo seven eleven 42 x y zebra quick brown fox jumps over the lazy dog "
+           "if a <= b: return c&d \"quoted\" it's 3.14 [INST] </s> résumé naïve <- -> != ==").split()
+
+
+def _fuzz_text(rnd, lo=1, hi=12):
+    ws = rnd.choice(["", " ", "  ", "\n", "\n    ", " \n\t "])
+    we = rnd.choice(["", " ", "\n", "\n  ", "   "])
+    words = [rnd.choice(_FWORDS) for _ in range(rnd.randint(lo, hi))]
+    sep = rnd.choice([" ", " ", "  ", "\n"])
+    txt = sep.join(words)
+    if rnd.random() < 0.7:                       # mostly well-formed text; sometimes raw '<' / '&' for the recovering parser
+        txt = txt.replace("&", "&amp;").replace("<", "&lt;").replace(">", "&gt;")
+    return ws + txt + we
+
+
+def _fuzz_module(rnd, names, depth, allow_param=True):
+    name = rnd.choice(["m", "mod", "Doc", "a_b", "x-1", "p.q", "_u"]) + str(len(names))
+    names.append(name)
+    attrs = f' name="{name}"' + (rnd.choice(["", ' cache="false"', ' cache="true"']) if rnd.random() < 0.2 else "")
+    parts, kids, params = [], [], []
+    for _ in range(rnd.randint(0, 3 if depth < 2 else 1)):
+        r = rnd.random()
+        if r < 0.45:
+            parts.append(_fuzz_text(rnd))
+        elif r < 0.65 and allow_param:
+            pn = "arg" + str(len(names)) + str(len(params))
+            params.append((pn, rnd.randint(1, 8)))
+            sc = rnd.choice(["", f' scaffold="{rnd.choice(_FWORDS[:8])}"', ' scaffold="one two three four five six seven eight nine"'])
+            parts.append(f'<parameter name="{pn}" length="{params[-1][1]}"{sc}/>')
+        elif r < 0.85 and depth < 3:
+            sub, info = _fuzz_module(rnd, names, depth + 1)
+            parts.append(sub)
+            kids.append(info)
+        elif depth < 3:
+            members = []
+            minfo = []
+            for _ in range(rnd.randint(1, 3)):
+                sub, info = _fuzz_module(rnd, names, depth + 1)
+                members.append(sub)
+                minfo.append(info)
+            sc = f' scaffold="{minfo[rnd.randrange(len(minfo))]["name"]}"' if rnd.random() < 0.5 else ""
+            gap = rnd.choice(["", "\n", " "])
+            parts.append(f"<union{sc}>{gap}" + gap.join(members) + f"{gap}</union>")
+            kids.append({"union": minfo})
+        parts.append(rnd.choice(["", "", " ", "\n    ", _fuzz_text(rnd, 1, 4)]))
+    return f"<module{attrs}>" + "".join(parts) + "</module>", {"name": name, "kids": kids, "params": params}
+
+
+def _fuzz_prompt(rnd, schema_name, tops):
+    """A prompt over the schema: picks some top-level modules (one member per union), fills some parameters, trailing text."""
+    def ref(info):
+        args = "".join(f' {pn}="{rnd.choice(_FWORDS[:14])}{" more words here" if rnd.random() < 0.15 else ""}"'
+                       for pn, _ in info["params"] if rnd.random() < 0.7)
+        inner = ""
+        for k in info["kids"]:
+            if "union" in k:
+                if rnd.random() < 0.8:
+                    inner += ref(rnd.choice(k["union"]))
+            elif rnd.random() < 0.6:
+                inner += ref(k)
+        return f"<{info['name']}{args}>{inner}</{info['name']}>" if inner else f"<{info['name']}{args}/>"
+    body = ""
+    for t in tops:
+        if "union" in t:
+            if rnd.random() < 0.8:
+                body += ref(rnd.choice(t["union"]))
+        elif rnd.random() < 0.75:
+            body += ref(t)
+        body += rnd.choice(["", "\n", "  "])
+    tail = rnd.choice(["", " What now? ", "\n  <user>Please answer.</user>\n", " tail text "])
+    if not body and not tail.strip():
+        tail = " only text "
+    return f"<prompt schema='{schema_name}'>{body}{tail}</prompt>"
+
+
+def fuzz_goldens(pc, count=80, seed=20260929):
+    """``count`` random PML schemas (nested modules, unions with / without scaffold, parameters, raw whitespace, escapes and the odd
+    malformed character) each with two random prompts, laid out by the REFERENCE: schema length, encode paths, per-scaffold CRCs,
+    prompt assembly -- or the exception the reference raises.  The texts are generated here (seeded), not reference text."""
+    import importlib
+    import random
+    rm = importlib.import_module("promptcache.model")
+    rs = importlib.import_module("promptcache.schema")
+    rp = importlib.import_module("promptcache.prompt")
+    rce = importlib.import_module("promptcache.cache_engine")
+    fmt = rm.FormatConversation(system=("<s> [INST] <<SYS>>\n", "<</SYS>>\n\n", "<s> [INST] "),
+                                user=("", "[/INST]"), assistant=("", "</s><s> [INST] "))
+
+    class NoModelLM(TokOnlyLM):
+        device = "cpu"
+
+        def get_cache_shape(self):
+            return 1, 1, 8
+
+    rnd = random.Random(seed)
+    cases = []
+    for ci in range(count):
+        names, tops, parts = [], [], []
+        parts.append(rnd.choice(["", "\n", "<system>You are a helpful assistant.</system>", "  <system/>  "]))
+        wrap_user = rnd.random() < 0.5
+        if wrap_user:
+            parts.append("<user>")
+        for _ in range(rnd.randint(1, 4)):
+            r = rnd.random()
+            if r < 0.25:
+                parts.append(_fuzz_text(rnd))
+            elif r < 0.8:
+                sub, info = _fuzz_module(rnd, names, 1)
+                parts.append(sub)
+                tops.append(info)
+            else:
+                members, minfo = [], []
+                for _ in range(rnd.randint(1, 3)):
+                    sub, info = _fuzz_module(rnd, names, 1)
+                    members.append(sub)
+                    minfo.append(info)
+                sc = f' scaffold="{minfo[0]["name"]}"' if rnd.random() < 0.5 else ""
+                parts.append(f"<union{sc}>" + "\n".join(members) + "</union>")
+                tops.append({"union": minfo})
+            parts.append(rnd.choice(["", "\n", "    "]))
+        if wrap_user:
+            parts.append("</user>")
+        if rnd.random() < 0.3:
+            parts.append("<assistant>Sure.</assistant>")
+        sname = f"fz{ci}"
+        schema_text = f'<schema name="{sname}">' + "".join(parts) + "</schema>"
+        max_tokens = rnd.choice([None, None, None, 6, 20])
+        rec = {"schema": schema_text, "max_tokens": max_tokens, "prompts": []}
+        lm = TokOnlyLM()
+        try:
+            sc = rs.Schema(fmt(schema_text), lm, max_tokens=max_tokens)
+        except Exception as e:  # noqa: BLE001
+            rec["error"] = {"type": type(e).__name__, "message": str(e)}
+            cases.append(rec)
+            continue
+        stack, paths = [], [rs.Path()]
+        if sc.contains_union():
+            stack.append((list(), True, sc))
+        while stack:
+            path, is_default_parent, u = stack.pop()
+            for e in u.children:
+                if type(e) == rs.Module and e.contains_union():
+                    stack.append((path + [u.name], is_default_parent, e))
+                elif type(e) == rs.UnionModule:
+                    for n in e.modules:
+                        is_default = e.scaffold_name == n.name and is_default_parent
+                        if n.contains_union():
+                            stack.append((path + [u.name], is_default, n))
+                        if not is_default:
+                            paths.append(rs.Path(path + [u.name, n.name]).next)
+        rec["length"] = len(sc)
+        rec["paths"] = []
+        for p in paths:
+            sf = sc.get_scaffold(p)
+            sel = sf.select(p)
+            # (select() returning None makes the reference's SchemaCache._process die with AttributeError at cache_engine.py:268:
+            # recorded as targets = None)
+            rec["paths"].append({"path": str(p), "n": len(sf.token_ids()), "ids_crc": crc(sf.token_ids()), "pos_crc": crc(sf.position_ids()),
+                                 "targets": None if sel is None else [[t.offset, len(t)] for t in sel.all_token_sequences()]})
+        for _ in range(2):
+            ptxt = _fuzz_prompt(rnd, sname, tops)
+            pr = {"prompt": ptxt}
+            try:
+                nlm = NoModelLM()
+                eng = rce.CacheEngine(64, nlm, target_device="cpu")
+                eng.add_schema(fmt(schema_text), max_tokens=max_tokens, no_cache=True)
+                prompt = rp.Prompt(ptxt, [fmt])
+                ids, pos, _, _ = eng.process(prompt, no_cache=True)
+                pr.update(text=prompt.text, nocache_n=len(ids), nocache_ids_crc=crc(ids), nocache_pos_crc=crc(pos))
+            except Exception as e:  # noqa: BLE001
+                pr["error"] = {"type": type(e).__name__, "message": str(e)}
+            rec["prompts"].append(pr)
+        cases.append(rec)
+    return cases
+
+
 def recover_goldens():
     import xml.etree.ElementTree as ET
     snippets = ["<a>x < y</a>", "<a>x <= y</a>", "<a>1 <2 3</a>", "<a>p & q</a>", "<a>p &foo; q</a>", "<a>x <b>y</a>",
@@ -339,11 +519,34 @@ def recover_goldens():
                 "<a>x < y &lt;b&gt; z &amp; w &quot;q&quot;</a>", "<a>&lt;b&gt; x < y &lt;b&gt;</a>",
                 "<a><m>x < y</m><n>&lt;/s&gt;&lt;s&gt; [INST] &amp;</n></a>", "<a>x < y &#60;k&#62; &#x3c;</a>",
                 "<a>if a <= b: &gt; &lt; x</a>", "<a>p &foo; q &lt; r</a>", "<a>p & q &gt; r</a>",
+                # round 5 (found by the PML fuzz): unterminated references are dropped with the name / digits libxml2 had read
+                "<a>c&d e</a>", "<a>R&D dept, AT&T</a>", "<a>c&d</a>", "<a>x&1y z</a>", "<a>x&#y z</a>", "<a>x&#12y z</a>", "<a>x&;y</a>",
+                "<a>x &amp y</a>", "<a>x&lt y</a>", "<a>c&d-e.f:g_h i</a>", "<a>&d</a>", "<a>x&#x4g;</a>", "<a>x&#;y</a>", "<a>x&#x;y</a>",
+                "<a>x&\u00e9 y</a>", "<a b='c&d e'>t</a>", "<a>x&d<b/>y</a>", "<a>x&a&b;c</a>",
+                # ... ANY end tag closes the innermost element; what follows the root's end is ignored
+                "<a>1</c>;</a>", "<a><b>x</c>y</b>z</a>", "<a><b>x</a>y", "<a><b><c>x</b>y</c>z</a>w", "<r><a>1</c>;</a>t<d/></r>",
+                "<r>p<a>x</b>y</a>z<e/>q</r>", "<a>_<b/>x</</c>a</a>", "<a><d x='1'>:</&#65;& y='2';</a>", "<a><c>t</>u</a>",
+                "<a><e>t</ y='2'<c/>u</a>", "<a><c>t</c x>u</a>",
+                # ... and a start tag that cannot be finished is closed where it breaks
+                "<a><_ x>t</_>u</a>", "<a><_ =>t</a>", "<a><_ <b/>t</a>", "<a><_ x='1' <b/>t</a>", "<a><_ x='1' y>t</_>u</a>",
+                "<a><_ x='1'y='2'>t</_>u</a>", "<a><_ x=1>t</_>u</a>", "<a>q<_ x</a>", "<a><b/ >t</a>", "<a><b / >t</a>",
+                "<r><a b=\"x<y\">t</a>u</r>", "<a><\u00e9<_>&lt;</c></a>", "<a b='1' c=\"2\"  d = '3' >t</a>",
                 ]
 
     def dump(e):
         return {"tag": e.tag, "attrib": dict(e.attrib), "text": e.text, "tail": e.tail, "children": [dump(c) for c in e]}
 
+    import random
+    rnd = random.Random(20260929)                 # + 150 random malformed snippets (seeded; generated here)
+    alphabet = ["word ", " ", "\n  ", "&amp;", "&lt;=", "R&D ", "a<b ", "x > y ", "<module name=\"m\">", "</module>", "<union>", "</union>",
+                "<parameter name='p' length=\"3\"/>", "\"q\" ", "it's ", "</x>", "<m n=v>", "\u00e9 ", "&#233;", "&nbsp;", "</>", "<b/ >", "&#12", "&x"]
+    while len(snippets) < 64 + 150:
+        cand = "<schema name='s'>" + "".join(rnd.choice(alphabet) for _ in range(rnd.randint(2, 10))) + "</schema>"
+        try:
+            ET.fromstring(ref_shim.libxml2_recover(cand))
+        except Exception:  # noqa: BLE001  (libxml2 kept a duplicate attribute or produced nothing: not a tree to compare)
+            continue
+        snippets.append(cand)
     return [{"src": s, "tree": dump(ET.fromstring(ref_shim.libxml2_recover(s)))} for s in snippets]
 
 
@@ -458,6 +661,8 @@ def main():
     for name, text in (("trip.xml", SYN_UNION), ("doc.xml", SYN_FLAT), *SYN_EXTRA.values()):
         with open(os.path.join(GOLD, "pml", name), "w") as f:
             f.write(text)
+    with open(os.path.join(GOLD, "pml_fuzz.json"), "w") as f:
+        json.dump(fuzz_goldens(pc), f, indent=0)
     if "--layout-only" in sys.argv:          # the integer-layout fixtures alone (seconds; the model fixtures take minutes)
         return
     model_golden(pc, "tiny_trip", "tiny", seed=0, scale=4.0, schema_text=SYN_UNION, prompt_text=SYN_UNION_PROMPT, max_ctx=256)

@@ -487,7 +487,7 @@ class SchemaCache:
             pos_pad, _ = pad_batch([jobs[i]["position_ids"][:need[i]] for i in idxs], 0)
             out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                      position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
-                     attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
+                     attention_mask=torch.tensor(mask, dtype=torch.float16),     # (host: the HIP path only checks it is right-padded)
                      use_cache=True, many_rows=True, kv_only=True)
             arena: KVArena = out.past_key_values.arena
             for row, i in enumerate(idxs):
@@ -532,7 +532,7 @@ class SchemaCache:
                 pos_pad, _ = pad_batch([jobs[i]["position_ids"][prefix[i]:need[i]] for i in idxs], 0)
                 out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                          position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
-                         attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
+                         attention_mask=torch.tensor(mask, dtype=torch.float16),     # (host: the HIP path only checks it is right-padded)
                          use_cache=True, many_rows=True, kv_only=True, shared_prefix=(trunk_arena, pre))
                 arena = out.past_key_values.arena
                 for row, i in enumerate(idxs):
@@ -564,7 +564,7 @@ class SchemaCache:
             extra = {} if n_same is not None else {"past_lens": torch.tensor(pre, device=dev, dtype=torch.int32)}
             out = lm(input_ids=torch.tensor(ids_pad, device=dev, dtype=torch.long),
                      position_ids=torch.tensor(pos_pad, device=dev, dtype=torch.long),
-                     attention_mask=torch.tensor(mask, device=dev, dtype=torch.float16),
+                     attention_mask=torch.tensor(mask, dtype=torch.float16),     # (host: the HIP path only checks it is right-padded)
                      past_key_values=arena.views(), use_cache=True, many_rows=True, kv_only=True, **extra)
             arena = out.past_key_values.arena
             for row, i in enumerate(idxs):
@@ -772,8 +772,9 @@ class CacheEngine:
         (module reference, schema module) pairs, arguments fill the first positions of their
         parameter, trailing text continues after the schema."""
         # cache_time: the reference brackets request assembly + PromptCache.update with device events (:391-394, :507-509).
-        # When the staging is left to the first forward there is no device work in here to bracket: host wall-clock then.
-        host_timed = self.prompt_cache.defer_gather and not no_cache
+        # When the staging is left to the first forward, or nothing is staged at all (no_cache: pure host assembly), there
+        # is no device work in here to bracket: host wall-clock then.
+        host_timed = self.prompt_cache.defer_gather or no_cache
         t_host = time.perf_counter()
         if not host_timed:
             start = torch.cuda.Event(enable_timing=True)
@@ -822,10 +823,8 @@ class CacheEngine:
             # everything re-ordered by position, positions re-packed to range(N) (:476-493)
             pairs = sorted(zip([p for s in used for p in s.position_ids()] + position_ids,
                                [t for s in used for t in s.token_ids()] + input_ids))
-            end.record()
-            torch.cuda.synchronize()
             ids_sorted = tuple(t for _, t in pairs)
-            return ids_sorted, list(range(len(pairs))), start.elapsed_time(end), None
+            return ids_sorted, list(range(len(pairs))), (time.perf_counter() - t_host) * 1e3, None
 
         seq_caches = []
         for s in used:

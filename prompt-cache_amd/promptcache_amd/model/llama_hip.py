@@ -545,7 +545,10 @@ class LlamaHIP:
             position_ids = torch.arange(past_len, past_len + q_len, device=input_ids.device).unsqueeze(0).expand(B, q_len)
         position_ids = position_ids.view(-1, q_len)
         if attention_mask is not None:
-            am = attention_mask.to(dev)
+            # (checked where the mask LIVES: a host mask -- what CacheEngine passes since round 5 -- costs no upload and no
+            # device sync; a device mask, the reference's convention (cache_engine.py:246), is read back for the test: one
+            # pipeline drain per forward, which is what made 10 % of the schema encode's wall time idle in rounds 1-4)
+            am = attention_mask
             # only right padding is expressible without an explicit mask (cache_engine.py:38-47 pads right)
             if am.dim() == 2 and am.shape[1] == q_len and bool((am[:, 1:] > am[:, :-1]).any()):
                 raise NotImplementedError("left / interior padding masks are not supported by the HIP path")

@@ -107,7 +107,10 @@ class MptHIP(LlamaHIP):
             raise ValueError(f"MPT got {position_ids.shape[1]} position ids for {kv_len} keys: pass the full position ids "
                              "(CacheEngine.process(..., return_full_position_ids=True), mpt.py:172)")
         if attention_mask is not None:
-            am = attention_mask.to(dev)
+            # (checked where the mask LIVES: a host mask -- what CacheEngine passes since round 5 -- costs no upload and no
+            # device sync; a device mask, the reference's convention (cache_engine.py:246), is read back for the test: one
+            # pipeline drain per forward, which is what made 10 % of the schema encode's wall time idle in rounds 1-4)
+            am = attention_mask
             if am.dim() == 2 and am.shape[1] == q_len and bool((am[:, 1:] > am[:, :-1]).any()):
                 raise NotImplementedError("left / interior padding masks are not supported by the HIP path")
         T = B * q_len

@@ -55,7 +55,12 @@ class Node:
         return f"<Node {self.tag!r} attrib={self.attrib!r} children={len(self.children)}>"
 
 
-_REF = re.compile(r"&(#x[0-9A-Fa-f]+|#[0-9]+|[A-Za-z_][-A-Za-z0-9_.]*);")
+# XML 1.0 (5th edition) Name: what libxml2 reads behind an '&' before it looks for the ';'
+_NS = ":A-Za-z_\u00C0-\u00D6\u00D8-\u00F6\u00F8-\u02FF\u0370-\u037D\u037F-\u1FFF\u200C\u200D\u2070-\u218F\u2C00-\u2FEF\u3001-\uD7FF" \
+      "\uF900-\uFDCF\uFDF0-\uFFFD\U00010000-\U000EFFFF"
+_ENTNAME = f"[{_NS}][-.0-9\u00B7\u0300-\u036F\u203F\u2040{_NS}]*"
+_REF = re.compile(rf"&(#x[0-9A-Fa-f]+|#[0-9]+|{_ENTNAME});")
+_UNTERMINATED = re.compile(rf"&(#x[0-9A-Fa-f]+|#[0-9]+|#x?;?|{_ENTNAME})")
 
 
 class _State:
@@ -81,8 +86,13 @@ def unescape(s: str, state: Optional[_State] = None) -> str:
         out.append(s[i:j])
         m = _REF.match(s, j)
         if not m:
-            state.broken = True   # bare '&' -> dropped
-            i = j + 1
+            # An unterminated reference.  libxml2's recovering parser has already CONSUMED what it recognised of it when it
+            # misses the ';': `&name` (an XML Name: "c&d e" -> "c e", "x &amp y" -> "x  y"), `&#` + decimal digits
+            # ("x&#12y" -> "xy"), `&#x` + hex digits ("x&#x4g;" -> "xg;") are dropped whole; an '&' that starts none of
+            # these ("p & q", "x&1y", "x&;y") is dropped alone.  (Pinned against libxml2: tests/golden/pml_recover.json.)
+            state.broken = True
+            mu = _UNTERMINATED.match(s, j)
+            i = mu.end() if mu else j + 1
             continue
         body = m.group(1)
         if body.startswith("#x"):
@@ -132,8 +142,8 @@ def fromstring(src: str) -> Node:
             return
         text = "".join(buf)
         buf = []
-        if not stack:
-            return  # text outside the root element is ignored
+        if not stack or not text:
+            return  # text outside the root element is ignored; a run that recovery reduced to nothing is no text node
         if last is not None:
             last.tail = (last.tail or "") + text
         else:
@@ -168,36 +178,78 @@ def fromstring(src: str) -> Node:
             j = src.find(">", i)
             i = n if j < 0 else j + 1
         elif nxt == "/":
+            # libxml2's recovering parser lets ANY end tag close the innermost open element (a mismatched name is an error it
+            # reports and walks over: "<b>x</c>y</b>z" -> <b>x</b>, tail "y", and the second end tag closes the parent); what
+            # follows the root element's end is ignored.  (tests/golden/pml_recover.json)
+            # An end tag whose name cannot be read ("</#", "</<") closes the innermost element just the same, and the input goes
+            # on right behind the "</"; behind a readable name blanks and the '>' are consumed when they are there.
             m = _NAME.match(src, i + 2)
-            j = src.find(">", i)
-            j = n - 1 if j < 0 else j
-            if m:
-                name = m.group(0)
-                depth = next((d for d in range(len(stack) - 1, -1, -1) if stack[d].tag == name), None)
-                if depth is not None:
-                    flush()
-                    closed = stack[depth]
-                    if depth != len(stack) - 1:
-                        state.broken = True  # elements left open inside: closed here (mismatched nesting)
-                    del stack[depth:]
-                    last = closed if stack else None
-                else:
-                    state.broken = True  # stray end tag -> ignored
-            i = j + 1
+            k = m.end() if m else i + 2
+            while k < n and src[k] in " \t\r\n":
+                k += 1
+            if k < n and src[k] == ">":
+                k += 1
+            else:
+                state.broken = True
+            if stack:
+                flush()
+                closed = stack.pop()
+                if m is None or closed.tag != m.group(0):
+                    state.broken = True
+                last = closed if stack else None
+                if not stack:
+                    break                                   # the root element is closed: the rest of the input is ignored
+            else:
+                state.broken = True
+            i = k
         elif _NAME_START.match(nxt or " "):
+            # Start tag, as xmlParseStartTag recovers: attributes need whitespace in front of them and a quoted value; a name
+            # without '= value' is dropped and the tag goes on; anything else where an attribute, '>' or '/>' should stand ends
+            # the tag THERE -- the element is created with the attributes read so far, closed at once, and what follows is
+            # parsed as content ("<b x='1'y='2'>t" -> <b x="1"/> then the text "y='2'>t"; "<b/ >t" -> <b/> then "/ >t").
             m = _NAME.match(src, i + 1)
             name = m.group(0)
             k = m.end()
             attrib: Dict[str, str] = {}
+            opened, selfclose = False, False
             while True:
-                am = _ATTR.match(src, k)
-                if not am:
+                k0 = k
+                while k < n and src[k] in " \t\r\n":
+                    k += 1
+                if k < n and src[k] == ">":
+                    opened, k = True, k + 1
                     break
-                attrib[am.group(1)] = unescape(am.group(3) if am.group(3) is not None else am.group(4), state)
+                if src.startswith("/>", k):
+                    opened, selfclose, k = True, True, k + 2
+                    break
+                am = _NAME.match(src, k) if k > k0 else None
+                if am is None:
+                    break                                   # no whitespace / no attribute name: the tag ends here, unfinished
                 k = am.end()
-            j = src.find(">", k)
-            j = n - 1 if j < 0 else j
-            selfclose = src[j - 1] == "/" if j > k - 1 else False
+                while k < n and src[k] in " \t\r\n":
+                    k += 1
+                if k >= n or src[k] != "=":
+                    state.broken = True                     # attribute without a value: dropped, the tag goes on
+                    continue
+                k += 1
+                while k < n and src[k] in " \t\r\n":
+                    k += 1
+                if k < n and src[k] in "\"'":
+                    q = src.find(src[k], k + 1)
+                    lt = src.find("<", k + 1)
+                    if lt >= 0 and (q < 0 or lt < q):
+                        # '<' inside an attribute value: the value ends in front of it and so does the tag (unfinished)
+                        if am.group(0) not in attrib:
+                            attrib[am.group(0)] = unescape(src[k + 1:lt], state)
+                        k = lt
+                        break
+                    if q < 0:
+                        break
+                    if am.group(0) not in attrib:
+                        attrib[am.group(0)] = unescape(src[k + 1:q], state)
+                    k = q + 1
+                else:
+                    break                                   # unquoted value: the tag ends behind the '='
             flush()
             node = Node(name, attrib)
             if stack:
@@ -205,14 +257,20 @@ def fromstring(src: str) -> Node:
             elif root is None:
                 root = node
             else:
-                i = j + 1
-                continue  # content after the root element is ignored
-            if selfclose:
+                break  # content after the root element is ignored
+            if not opened:
+                state.broken = True
+                last = node if stack else None              # created and closed at once
+                if not stack:
+                    break
+            elif selfclose:
                 last = node if stack else None
+                if not stack:
+                    break
             else:
                 stack.append(node)
                 last = None
-            i = j + 1
+            i = k
         else:
             state.broken = True
             i += 1  # stray '<' -> dropped (libxml2 recovery)

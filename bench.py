@@ -1064,7 +1064,20 @@ def main():
                          past_key_values=past8, use_cache=True)
                 past8, tok8 = o8.past_key_values, int(torch.argmax(o8.logits[0, -1]))
             torch.cuda.synchronize(); dt8 = time.perf_counter() - t0
+        # ... and the device-side greedy loop (what GenerationEngine.generate runs; the fp16 figure is `decode_device_loop`)
+        loop8, loop8_rate = lm8.hf_model.greedy_loop(past8, tok8, max(pos8) + 2 + 64, 4 * 32), None
+        if loop8 is not None:
+            for _ in range(32):
+                loop8.enqueue()
+            loop8.token(31)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(64):
+                loop8.enqueue()
+            loop8.token(95)
+            loop8_rate = 64 / (time.perf_counter() - t0)
+            del loop8
         result["int8_weights"] = {"ttft_ms": sorted(ts8[2:])[len(ts8[2:]) // 2], "decode_tokens_per_s": 32 / dt8,
+                                  "decode_device_loop_tokens_per_s": loop8_rate,
                                   "mode": "llm_int8" if lm8.hf_model.llm_int8 else "weight_only",
                                   "outlier_columns_last_layer": outl,
                                   "what": "load_in_8bit=True: LLM.int8() as published (row-wise absmax int8 weights, vector-wise "

@@ -264,6 +264,9 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
  *              The products run on the int8 MFMA (v_mfma_i32_16x16x64_i8, int32 sums: igemmlt's arithmetic, exact for any K).
  *   x_codes8   (optional, with x_scale, M <= 64) the codes as the int8 operand image pc_quant_act_i8 / pc_rmsnorm_quant_i8 write
  *              next to the fp16 codes plane: the K loop then reads it instead of xf_hi (half the activation bytes, no packing)
+ *   row_max_out, flags_out, out_threshold   (PC_GEMM_EPI_SILU, M <= 16) what pc_gemm_q8's down_proj form reads instead of running a
+ *              quantiser launch: per output pair-tile and row the largest |fp16 value| below out_threshold, [N/32][16] floats, and one
+ *              flag byte per intermediate feature holding an entry at or above it (set-only: the buffer must be zero)
  *   flags, x_raw, w_codes_t, ldt, row_perm   the outlier correction computed INSIDE the launch (M <= 64): the flag bytes of
  *              pc_quant_act_i8 (>= 16384 bytes, zero behind K), the fp16 activations (fragment plane), the transposed int8 weight
  *              codes [K][ldt] (original row order) and, for q|k|v, the image-row -> original-row permutation
@@ -291,9 +294,51 @@ typedef struct pc_gemm_args {
     int32_t B, H, Hkv, D, q_len, past_len, cap;
     const int32_t* past_len_dev; void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_base;
     const void* x_codes8;
+    float* row_max_out; void* flags_out; float out_threshold;
 } pc_gemm_args;
 int pc_gemm(const pc_gemm_args* args, void* stream);
 int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
+/* pc_gemm_q8 -- LLM.int8 projection of M <= 16 rows with the vector-wise activation quantiser INSIDE the launch
+ *   (csrc/pc_gemm_q8.hip).  Same arithmetic as pc_rmsnorm_quant_i8 / pc_quant_act_i8 followed by pc_gemm with x_scale + flags
+ *   (bitsandbytes Linear8bitLt as demo.py:27-29 loads it; llama2.py:345-347, :405, :242 are the projections), without the
+ *   quantiser launches: codes, row scales and outlier flags are derived by every workgroup of the projection itself.
+ *   wf, w_scale, w_codes_t, ldt, row_perm   the int8 weight image, its scales, the transposed codes (outlier correction) and, for
+ *              q|k|v, the image-row -> original-row permutation: as in pc_gemm_args
+ *   threshold  the outlier threshold (6.0; <= 0: no outlier columns)
+ *   source     (x, norm_weight, eps): the fp32 residual stream, RMSNorm folded in (epilogues QKV_ROPE, SILU), K <= 6144; or
+ *              xf_hi: the fp16 activations as a fragment plane [1][K/32][64][8] (epilogues ADD, STORE), K <= 6144; or
+ *              xf_hi + row_max [row_max_units][16] + flags_in [>= 16384 bytes, zero behind K] (epilogue ADD, any K <= 16384):
+ *              the producer already left the per-tile row maxima and the outlier-column flags (row_max_out / flags_out of the
+ *              launch with the SiLU epilogue); K is then cut into kslices (1..8) workgroup slices of ks_tiles (2, 4, 8) output
+ *              tiles with the reduction inside the launch (ks_scratch >= pc_gemm_skinny_ks_scratch_bytes(N, kslices), ks_counters:
+ *              ceil(N/16/ks_tiles) zeroed uint32 words; as PC_GEMM_EPI_ADD with ks_counters in pc_gemm).  M <= 4 with kslices = 1
+ *              and ks_tiles 1 or 2 (decode): the rows' codes are staged once in LDS, every workgroup keeps all of K, no scratch
+ *   outputs    y / ldy (STORE, ADD), of_hi (+ optional of_lo) fragment planes (SILU), the q|k|v fields (QKV_ROPE) as in pc_gemm_args
+ *   row_max_out, flags_out   (SILU) per output pair-tile and row the largest |fp16 value| below the threshold, [N/32][16] floats, and
+ *              one flag byte per intermediate feature holding an entry at or above it (set-only: the buffer must be zero)
+ *   flags_clear, clear_bytes   a flag buffer this launch zeroes on the side (a multiple of 16 bytes) -- the o_proj launch clears
+ *              the buffer the following SiLU launch sets; the down_proj form clears the first quantiser's of the next layer
+ *   dbg_codes, dbg_scale, dbg_flags   (tests) workgroup 0 writes its operand image [K/64][64][16] int8, x_scale [M] and the K flag bytes */
+typedef struct pc_gemm_q8_args {
+    uint32_t struct_bytes;
+    int32_t epilogue;
+    const void* wf; const float* w_scale; const void* w_codes_t; int64_t ldt; const int32_t* row_perm;
+    float threshold;
+    const float* x; const void* norm_weight; float eps;
+    const void* xf_hi;
+    const float* row_max; int32_t row_max_units; const void* flags_in;
+    int32_t M, N, K;
+    float* y; int64_t ldy; void* of_hi; void* of_lo;
+    float* row_max_out; void* flags_out;
+    void* flags_clear; int32_t clear_bytes;
+    int32_t kslices, ks_tiles; void* ks_scratch; int64_t ks_scratch_bytes; void* ks_counters;
+    const float* cs; void* q_hi; void* q_lo; int64_t q_token_stride; void* k_arena; void* v_arena;
+    int64_t arena_batch_stride, arena_head_stride;
+    int32_t B, H, Hkv, D, q_len, past_len, cap;
+    const int32_t* past_len_dev; void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_base;
+    void* dbg_codes; float* dbg_scale; void* dbg_flags;
+} pc_gemm_q8_args;
+int pc_gemm_q8(const pc_gemm_q8_args* args, void* stream);
 /* pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes;
  *   optional prologue x += slabs[0] + ... + slabs[nslabs-1] (each [rows][hidden], the residual adds of
  *   llama2.py:638 / :644 fed by a K-sliced pc_gemm), written back to x in place. */

@@ -344,6 +344,9 @@ PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
         PC_REQUIRE(N % 64 == 0 && a->of_hi && a->of_lo, PC_ERR_ARG, "pc_gemm: the SiLU epilogue needs N = 2*inter with inter%%32==0 and output planes");
         p.npairs = N / 32;          // inter / 16
         p.KSo = (N / 2) / 32;       // k-steps of the consumer (down_proj, K = inter)
+        PC_REQUIRE((a->row_max_out == nullptr) == (a->flags_out == nullptr) && (!a->row_max_out || M <= 16), PC_ERR_ARG,
+                   "pc_gemm: row_max_out and flags_out go together (M <= 16)");
+        p.pmax_out = a->row_max_out; p.oflags_out = (unsigned char*)a->flags_out; p.thr_out = a->out_threshold;
         return launch_MT(EPI_SILU, p, choose_T(p.npairs), p.npairs, s);
     }
     if (epi == PC_GEMM_EPI_GELU) {

@@ -94,6 +94,10 @@ struct GemmParams {
     // code plane xf_hi), cbt = the int8 weight codes transposed [K][ldt] in ORIGINAL row order, row_perm = image row -> original
     // row (q|k|v's rotary permutation) or null
     const unsigned char* oflags; const _Float16* xraw; const signed char* cbt; int64_t ldt; const int32_t* row_perm;
+    // EPI_SILU as the PRODUCER of an LLM.int8 projection input quantised inside its consumer (pc_gemm_q8.hip): per output tile
+    // and row the largest |fp16(silu(g) * u)| below the outlier threshold, pmax_out[unit][16], and one flag byte per feature
+    // holding an entry at or above it (set-only; the buffer is zero when the launch starts)
+    float* pmax_out; unsigned char* oflags_out; float thr_out;
     RopeEpi rope;
     // K split inside a workgroup: the four waves dispatched first (one per SIMD, the OLDER wave of each SIMD) win the arbitration
     // for the CU's memory pipe against their younger SIMD partners and finish an equal share ~30 % earlier; the younger half
@@ -410,7 +414,7 @@ template <int EPI>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, int row, int unit, int g, int slice,
                                               bool fused_corr = false, f4 fused_cv = f4{0.f, 0.f, 0.f, 0.f},
                                               f4 fused_cu = f4{0.f, 0.f, 0.f, 0.f}, bool have_old = false,
-                                              f4 old_pre = f4{0.f, 0.f, 0.f, 0.f}) {
+                                              f4 old_pre = f4{0.f, 0.f, 0.f, 0.f}, bool have_xs = false, float xs_in = 0.f) {
     const int nunits = (EPI == EPI_SILU) ? p.npairs : p.ntiles;
     if (p.wscale && unit < nunits) {        // int8 weights: per-output-feature scale (linear, so K-sliced partials scale too)
         const f4 sv = *(const f4*)(p.wscale + unit * 16 + g * 4);
@@ -420,14 +424,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
             u[0] *= su[0]; u[1] *= su[1]; u[2] *= su[2]; u[3] *= su[3];
         }
     }
-    if (p.xscale && unit < nunits && row < p.M) {
-        const float xs = p.xscale[row];
+    if ((p.xscale || have_xs) && unit < nunits && row < p.M) {
+        const float xs = have_xs ? xs_in : p.xscale[row];      // (have_xs: the row scale was computed inside this launch)
         v[0] *= xs; v[1] *= xs; v[2] *= xs; v[3] *= xs;
         if (EPI == EPI_SILU) { u[0] *= xs; u[1] *= xs; u[2] *= xs; u[3] *= xs; }
         if (fused_corr) {                   // the correction was accumulated inside this launch
             v[0] += fused_cv[0]; v[1] += fused_cv[1]; v[2] += fused_cv[2]; v[3] += fused_cv[3];
             if (EPI == EPI_SILU) { u[0] += fused_cu[0]; u[1] += fused_cu[1]; u[2] += fused_cu[2]; u[3] += fused_cu[3]; }
-        } else if (*p.corr_has) {
+        } else if (p.corr_has && *p.corr_has) {
             const f4 cv = *(const f4*)(p.corr + (int64_t)row * p.ldc + unit * 16 + g * 4);
             v[0] += cv[0]; v[1] += cv[1]; v[2] += cv[2]; v[3] += cv[3];
             if (EPI == EPI_SILU) {
@@ -449,7 +453,19 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 v, f4 u, i
             }
             const int64_t off = frag_off(row, j0, p.KSo);
             *(h4*)(p.of_hi + off) = hi;
-            *(h4*)(p.of_lo + off) = lo;
+            if (p.of_lo) *(h4*)(p.of_lo + off) = lo;
+            if (p.pmax_out) {                   // (the four lanes of a row enter together: same row, same unit)
+                float mxl = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = fabsf((float)hi[r]);
+                    if (p.thr_out > 0.f && f >= p.thr_out) p.oflags_out[j0 + r] = 1;
+                    else mxl = fmaxf(mxl, f);
+                }
+                mxl = fmaxf(mxl, __shfl_xor(mxl, 16));
+                mxl = fmaxf(mxl, __shfl_xor(mxl, 32));
+                if (g == 0) p.pmax_out[unit * 16 + row] = mxl;
+            }
         } else if (EPI == EPI_GELU) {
             // nn.GELU() (falcon.py:726, exact erf form) of the reduced tile, as split-precision planes for dense_4h_to_h
             h4 hi, lo;

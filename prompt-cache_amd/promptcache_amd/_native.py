@@ -77,13 +77,36 @@ class GemmArgs(C.Structure):
                 ("arena_batch_stride", _i64), ("arena_head_stride", _i64),
                 ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
                 ("past_len_dev", _vp), ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64),
-                ("lo_base", _i32), ("x_codes8", _vp)]
+                ("lo_base", _i32), ("x_codes8", _vp),
+                ("row_max_out", _vp), ("flags_out", _vp), ("out_threshold", _f32)]
+
+
+class GemmQ8Args(C.Structure):
+    """``pc_gemm_q8_args`` of include/promptcache_hip.h (field for field)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("epilogue", _i32),
+                ("wf", _vp), ("w_scale", _vp), ("w_codes_t", _vp), ("ldt", _i64), ("row_perm", _vp),
+                ("threshold", _f32),
+                ("x", _vp), ("norm_weight", _vp), ("eps", _f32),
+                ("xf_hi", _vp),
+                ("row_max", _vp), ("row_max_units", _i32), ("flags_in", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32),
+                ("y", _vp), ("ldy", _i64), ("of_hi", _vp), ("of_lo", _vp),
+                ("row_max_out", _vp), ("flags_out", _vp),
+                ("flags_clear", _vp), ("clear_bytes", _i32),
+                ("kslices", _i32), ("ks_tiles", _i32), ("ks_scratch", _vp), ("ks_scratch_bytes", _i64), ("ks_counters", _vp),
+                ("cs", _vp), ("q_hi", _vp), ("q_lo", _vp), ("q_token_stride", _i64), ("k_arena", _vp), ("v_arena", _vp),
+                ("arena_batch_stride", _i64), ("arena_head_stride", _i64),
+                ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
+                ("past_len_dev", _vp), ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64),
+                ("lo_base", _i32),
+                ("dbg_codes", _vp), ("dbg_scale", _vp), ("dbg_flags", _vp)]
 
 
 # name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one
 SIGNATURES = {
     "pc_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "pc_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "pc_gemm_q8": (C.c_int, [C.POINTER(GemmQ8Args), _vp]),
     "pc_dev_gemm_trace": (C.c_int, [_vp]),
     "pc_dev_attn_trace": (C.c_int, [_vp]),
     "pc_gemm_skinny_ks_scratch_bytes": (C.c_int64, [_i32, _i32]),
@@ -645,10 +668,12 @@ def quant_act_i8(x, frag: bool, T: int, K: int, codes, x_scale, flags_set, flags
 
 
 def gemm_skinny_a8c(wf8, w_scale, xq, zeros, x_scale, flags, x_raw, w_codes_t, M: int, N: int, K: int, epilogue: int, y=None,
-                    ldy: int = 0, of_hi=None, of_lo=None, stream: Optional[int] = None, codes8=None) -> None:
-    """LLM.int8 projection over the code plane ``xq`` with the outlier correction inside the launch (``flags``: >= 16384 bytes)."""
+                    ldy: int = 0, of_hi=None, of_lo=None, stream: Optional[int] = None, codes8=None, row_max_out=None, flags_out=None) -> None:
+    """LLM.int8 projection over the code plane ``xq`` with the outlier correction inside the launch (``flags``: >= 16384 bytes).
+    ``row_max_out`` / ``flags_out`` (SiLU epilogue, M <= 16): the per-tile row maxima and outlier flags ``gemm_q8``'s down_proj form reads."""
     _gemm(stream, epilogue=epilogue, wf=wf8, w_scale=w_scale, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, flags=flags, x_raw=x_raw,
-          w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi, of_lo=of_lo)
+          w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), M=M, N=N, K=K, y=y, ldy=ldy, of_hi=of_hi, of_lo=of_lo, row_max_out=row_max_out,
+          flags_out=flags_out, out_threshold=LLM_INT8_THRESHOLD if row_max_out is not None else 0.0)
 
 
 def gemm_qkv_rope_a8c(wf8_perm, w_scale_perm, xq, zeros, x_scale, flags, x_raw, w_codes_t, row_perm, M, K, cs, q_hi, q_lo, q_ts,
@@ -657,6 +682,22 @@ def gemm_qkv_rope_a8c(wf8_perm, w_scale_perm, xq, zeros, x_scale, flags, x_raw, 
     _gemm(stream, wf=wf8_perm, w_scale=w_scale_perm, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, flags=flags, x_raw=x_raw,
           w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), row_perm=row_perm, M=M, K=K,
           **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
+
+
+def gemm_q8(stream=None, **f) -> None:
+    """One ``pc_gemm_q8`` call (LLM.int8 projection of <= 16 rows, activation quantiser inside the launch): keyword = field of
+    ``pc_gemm_q8_args``; tensors become pointers, everything else 0 / NULL.  ``qkv=dict(...)`` takes ``_qkv_fields``' arguments."""
+    a = GemmQ8Args()
+    a.struct_bytes = C.sizeof(GemmQ8Args)
+    a.kslices, a.lo_base, a.threshold = 1, -1, LLM_INT8_THRESHOLD
+    for k, v in f.items():
+        if v is None:
+            continue
+        setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    if f.get("w_codes_t") is not None and "ldt" not in f:
+        a.ldt = f["w_codes_t"].stride(-2)
+    rc = load().pc_gemm_q8(C.byref(a), current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_q8")
 
 
 def rmsnorm_quant_i8(x, norm_weight, eps: float, T: int, hidden: int, x_hi, codes, x_scale, flags_set, flags_clear=None,

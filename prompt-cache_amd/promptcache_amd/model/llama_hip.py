@@ -368,6 +368,16 @@ class LlamaHIP:
             # scans a whole row, 32 bytes per thread
             self._i8_flags = torch.zeros((4, max(kmax, 16384)), dtype=torch.uint8, device=dev)
             self.i8_fused_corr = os.environ.get("PC_INT8_FUSED_CORR", "1") != "0"
+            # <= 16 rows (the cached step, decode): the activation quantisers run INSIDE the projections (pc_gemm_q8): six launches
+            # per layer instead of ten.  PC_INT8_INLAUNCH=0: round 4's separate quantiser launches.  PC_Q8_DOWN="tiles,slices" of the
+            # K-sliced down_proj (2 / 4 / 8 output tiles per workgroup, 1..8 slices)
+            self.i8_inlaunch = os.environ.get("PC_INT8_INLAUNCH", "1") != "0" and c.hidden_size <= 6144 and \
+                self.H * self.D <= 6144 and c.intermediate_size <= 16384
+            self.q8_down = tuple(int(v) for v in os.environ.get("PC_Q8_DOWN", "4,4").split(","))
+            self.q8_down_small = tuple(int(v) for v in os.environ.get("PC_Q8_DOWN_SMALL", "1,1").split(","))   # <= 4 rows (decode)
+            self.q8_p_max_rows = int(os.environ.get("PC_Q8_P_MAX_ROWS", "4"))
+            self._q8_flags = torch.zeros(16384, dtype=torch.uint8, device=dev)
+            self._q8_pmax = torch.zeros((c.intermediate_size // 16, 16), dtype=torch.float32, device=dev)
             self._i8_zero = torch.zeros(((self.SKINNY_MAX_ROWS + 15) // 16) * 16 * kmax, dtype=self.dtype, device=dev)
             self.fuse_norm = False                        # activations are quantised between the norm and the projection
             self.batch_invariant = False                  # the fp16 outlier columns are chosen over ALL rows of a call
@@ -811,10 +821,43 @@ class LlamaHIP:
         # Outlier flags are set-only and slot s is cleared by the quantiser of slot s - 1: a pass that stopped behind a
         # layer's q|k|v (kv_only encodes) left slot 0 set, and this pass's first quantiser would OR onto it -- results would
         # depend on the call history.  One memset node (graph-capturable) makes every forward start clean.
-        self._i8_flags[0].zero_()
-        if self.i8_fused_corr:
+        q8_all = self.i8_inlaunch and T <= self.q8_p_max_rows          # every quantiser inside its projection
+        q8_down = self.i8_inlaunch and self.i8_fused_corr and T <= 16    # at least down_proj's
+        if not q8_all:
+            self._i8_flags[0].zero_()
+        if q8_all:
+            # every projection derives its input's codes / row scales / outlier flags itself (csrc/pc_gemm_q8.hip): q|k|v and gate|up
+            # from the fp32 residual stream (RMSNorm folded in), o_proj from the attention's fp16 plane, down_proj from the plane, the
+            # per-tile row maxima and the flag bytes gate|up's SiLU epilogue leaves (the o_proj launch zeroes those flag bytes)
+            qf, pm = self._q8_flags, self._q8_pmax
+            sc, ctr = self._ks_buffers(hid)
+            for li, lw in enumerate(layers):
+                kp, vp = arena.k_plane(li), arena.v_plane(li)
+                kvlo, lo_base = tail(li)
+                lo4 = (None, None, 0, 0) if not kvlo else kvlo[:4]
+                n.gemm_q8(epilogue=n.EPI_QKV_ROPE, wf=lw["wqkv_f"], w_scale=lw["wqkv_s"], w_codes_t=lw["wqkv_t8"], row_perm=self._qkv_perm_i32,
+                          x=x, norm_weight=lw["ln1"], eps=eps, M=T, K=hid, cs=cs, q_hi=q16, q_lo=q16l, q_token_stride=H * D, k_arena=kp,
+                          v_arena=vp, arena_batch_stride=arena.batch_stride, arena_head_stride=arena.head_stride, B=B, H=H, Hkv=Hkv, D=D,
+                          q_len=q_len, past_len=past_len, cap=arena.cap, past_len_dev=past_dev, k_lo=lo4[0], v_lo=lo4[1],
+                          lo_batch_stride=lo4[2], lo_head_stride=lo4[3], lo_base=lo_base)
+                n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                           B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                           q_lo=q16l, kv_lo=kvlo,
+                           gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
+                n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wo_f"], w_scale=lw["wo_s"], w_codes_t=lw["wo_t8"], xf_hi=ah, M=T, N=hid, K=H * D,
+                          y=x, ldy=hid, flags_clear=qf, clear_bytes=qf.numel())
+                n.gemm_q8(epilogue=n.EPI_SILU, wf=lw["wgu_f"], w_scale=lw["wgu_s"], w_codes_t=lw["wgu_t8"], x=x, norm_weight=lw["ln2"],
+                          eps=eps, M=T, N=2 * inter, K=hid, of_hi=ch, row_max_out=pm, flags_out=qf)
+                dn = self.q8_down_small if T <= 4 else self.q8_down
+                n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wdown_f"], w_scale=lw["wdown_s"], w_codes_t=lw["wdown_t8"], xf_hi=ch, row_max=pm,
+                          row_max_units=inter // 16, flags_in=qf, M=T, N=hid, K=inter, y=x, ldy=hid, ks_tiles=dn[0],
+                          kslices=dn[1], ks_scratch=sc, ks_scratch_bytes=sc.numel() * 4, ks_counters=ctr)
+            layers = []
+        elif self.i8_fused_corr:
             # the outlier correction runs INSIDE the projection launches (pc_gemm_*_a8c): 10 launches per layer instead of 14
             fl = self._i8_flags
+            pm = self._q8_pmax
+            ksc, kctr = self._ks_buffers(hid) if q8_down else (None, None)
 
             def quant(slot, act_hi, K, buf, norm=None):
                 codes, xs = buf[0], buf[1]
@@ -839,8 +882,17 @@ class LlamaHIP:
                 n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid,
                                   codes8=a8)
                 cd, xs = quant(2, xh, hid, bufs[2], norm=(x, lw["ln2"]))
+                # (more than q8_p_max_rows rows: the quantisers of q|k|v, o_proj and gate|up stay launches -- a 12-row prologue in
+                # every workgroup costs more vector ALU time than the launch it saves -- but down_proj reads what this SiLU
+                # epilogue leaves: flag slot 3 was zeroed by the quantiser above, slot 0 is zeroed by the down_proj launch)
                 n.gemm_skinny_a8c(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, fl[2], xh, lw["wgu_t8"], T, 2 * inter, hid, n.EPI_SILU,
-                                  of_hi=ch, of_lo=cl, codes8=x8)
+                                  of_hi=ch, of_lo=cl, codes8=x8, row_max_out=pm if q8_down else None, flags_out=fl[3] if q8_down else None)
+                if q8_down:
+                    n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wdown_f"], w_scale=lw["wdown_s"], w_codes_t=lw["wdown_t8"], xf_hi=ch, row_max=pm,
+                              row_max_units=inter // 16, flags_in=fl[3], M=T, N=hid, K=inter, y=x, ldy=hid, ks_tiles=self.q8_down[0],
+                              kslices=self.q8_down[1], ks_scratch=ksc, ks_scratch_bytes=ksc.numel() * 4, ks_counters=kctr,
+                              flags_clear=fl[0], clear_bytes=16384)
+                    continue
                 cd, xs = quant(3, ch, inter, bufs[3])
                 n.gemm_skinny_a8c(lw["wdown_f"], lw["wdown_s"], cd, zero, xs, fl[3], ch, lw["wdown_t8"], T, hid, inter, n.EPI_ADD,
                                   y=x, ldy=hid, codes8=c8)

@@ -23,3 +23,24 @@ for i in range(8):
     ids, pos, _, cache = eng.process(prompt)
     o = lm8(input_ids=torch.tensor([ids], device="cuda"), position_ids=torch.tensor([pos], device="cuda"), past_key_values=cache, use_cache=True)
     torch.cuda.synchronize(); print(f"ttft {i}: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
+if os.environ.get("PC_I8_DECODE", "1") == "1":
+    past, tok = o.past_key_values, int(torch.argmax(o.logits[0, -1]))
+    for phase in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(32):
+            o = lm8(input_ids=torch.tensor([[tok]], device="cuda"), position_ids=torch.tensor([[max(pos) + 2 + phase * 32 + i]], device="cuda"),
+                    past_key_values=past, use_cache=True)
+            past, tok = o.past_key_values, int(torch.argmax(o.logits[0, -1]))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"decode phase {phase}: {32 / dt:.1f} tok/s ({dt / 32 * 1e3:.3f} ms/token)", flush=True)
+    loop = lm8.hf_model.greedy_loop(past, tok, max(pos) + 2 + 64, 128)
+    if loop is not None:
+        for _ in range(32):
+            loop.enqueue()
+        loop.token(31)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(64):
+            loop.enqueue()
+        loop.token(95)
+        dt = time.perf_counter() - t0
+        print(f"decode device loop: {64 / dt:.1f} tok/s ({dt / 64 * 1e3:.3f} ms/token)", flush=True)

@@ -175,6 +175,12 @@ int pc_rope_append(const void* q, int64_t q_batch_stride, int64_t q_token_stride
  *              rows [0, past_len) of `k` / `v` hold exactly what pc_kv_gather would have left there.  Rows from past_len on
  *              (this pass's own) are read from `k` / `v` as always.  Implemented by the streaming kernel of <= 32-row passes
  *              (tail mode or >= 256 keys), the tail-mode 64-row kernel, and the ring kernel (33..512 split-precision rows, D = 128)
+ *   defer_merge, nsplit_out   optional (B = 1, no counters): a launch of <= 16 query rows that splits the keys (2..8 splits) LEAVES
+ *              its partials for a consumer that merges them in its own prologue (pc_gemm_q8 part_o: the o_proj of an LLM.int8
+ *              decode step) instead of running the merge launch: part_o fp32 [H * nsplit * q_len][D] at the start of the
+ *              workspace, part_ml (running maximum in log2 units, denominator) [H * nsplit * q_len][2] right behind;
+ *              slot = (h * nsplit + split) * q_len + row.  *nsplit_out (a HOST word, written before pc_attn returns) = the
+ *              partials per row, or 1 when this launch shape merged as usual and the output planes are final
  * ------------------------------------------------------------------------------------------- */
 int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t q_len, int32_t kv_len_max);
 
@@ -194,6 +200,7 @@ typedef struct pc_attn_args {
     uint32_t* counters;
     const void* prefix_k; const void* prefix_v; const void* prefix_k_lo; const void* prefix_v_lo; int64_t prefix_head_stride;
     const pc_kv_row* gather_rows; int32_t gather_k_plane, gather_v_plane;
+    int32_t defer_merge; int32_t* nsplit_out;
 } pc_attn_args;
 int pc_attn(const pc_attn_args* args, void* stream);
 /* 1 when pc_attn would run `args` (gather_rows ignored) on a kernel that implements gather_rows, else 0 */
@@ -313,6 +320,9 @@ int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
  *              tiles with the reduction inside the launch (ks_scratch >= pc_gemm_skinny_ks_scratch_bytes(N, kslices), ks_counters:
  *              ceil(N/16/ks_tiles) zeroed uint32 words; as PC_GEMM_EPI_ADD with ks_counters in pc_gemm).  M <= 4 with kslices = 1
  *              and ks_tiles 1 or 2 (decode): the rows' codes are staged once in LDS, every workgroup keeps all of K, no scratch
+ *              part_o, part_ml, part_nsplit, part_head_dim (epilogue ADD, M = 1, K = H * part_head_dim <= 4096): the split-KV partials a
+ *              pc_attn launch with defer_merge left (2..8 per row) -- the o_proj of a decode step merges them in its prologue
+ *              with attn_combine_kernel's arithmetic (same bits), and the merge launch disappears
  *   outputs    y / ldy (STORE, ADD), of_hi (+ optional of_lo) fragment planes (SILU), the q|k|v fields (QKV_ROPE) as in pc_gemm_args
  *   row_max_out, flags_out   (SILU) per output pair-tile and row the largest |fp16 value| below the threshold, [N/32][16] floats, and
  *              one flag byte per intermediate feature holding an entry at or above it (set-only: the buffer must be zero)
@@ -337,6 +347,7 @@ typedef struct pc_gemm_q8_args {
     int32_t B, H, Hkv, D, q_len, past_len, cap;
     const int32_t* past_len_dev; void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_base;
     void* dbg_codes; float* dbg_scale; void* dbg_flags;
+    const float* part_o; const float* part_ml; int32_t part_nsplit, part_head_dim;
 } pc_gemm_q8_args;
 int pc_gemm_q8(const pc_gemm_q8_args* args, void* stream);
 /* pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes;

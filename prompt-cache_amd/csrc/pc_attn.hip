@@ -1209,8 +1209,8 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float w = s < nsplit ? exp2f(mv[s] - mstar) : 0.f;
-        den += w * lv[s];
-        num += w * ov[s];
+        den = __builtin_fmaf(w, lv[s], den);         // (explicit: pc_gemm_q8.hip's consumer-side merge forms the same bits)
+        num = __builtin_fmaf(w, ov[s], num);
     }
     const float v = num / den;
     if (of_hi) {
@@ -1343,7 +1343,11 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(kThreads), 0, stream, p);
     int rc = pc_check_launch("attn_fwd_kernel");
     if (rc != PC_OK) return rc;
-    if (p.nsplit > 1) {
+    // defer_merge: the <= 16-row streaming kernel leaves its partials (part_o [B*H*nsplit*q_len][D], part_ml behind them, at the
+    // start of the workspace) to a consumer that merges them in its own prologue; every other shape merges as usual and says so
+    const bool deferred = p.defer_merge && p.small && !ring && p.nsplit > 1 && p.nsplit <= 8 && B == 1 && !p.out_lo;
+    if (p.nsplit_out) *p.nsplit_out = deferred ? p.nsplit : 1;
+    if (p.nsplit > 1 && !deferred) {
 #define PC_COMBINE(NSV)                                                                                         \
         do {                                                                                                    \
             if (p.q_len >= 64)                                                                                  \
@@ -1397,7 +1401,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   const void* k_lo, const void* v_lo, int64_t lo_bs, int64_t lo_hs, int32_t lo_row0, void* stream,
                   const int32_t* past_lens = nullptr, uint32_t* counters = nullptr, const void* pre_k = nullptr,
                   const void* pre_v = nullptr, const void* pre_k_lo = nullptr, const void* pre_v_lo = nullptr, int64_t pre_hs = 0,
-                  const pc_kv_row* gather_rows = nullptr, int32_t g_kplane = 0, int32_t g_vplane = 0, int* gather_ok = nullptr) {
+                  const pc_kv_row* gather_rows = nullptr, int32_t g_kplane = 0, int32_t g_vplane = 0, int* gather_ok = nullptr,
+                  int32_t defer_merge = 0, int32_t* nsplit_out = nullptr) {
     // gather_ok != NULL: dry run -- *gather_ok = whether this launch shape would take gather_rows; nothing is launched
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");
@@ -1419,6 +1424,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
     p.past_len_dev = past_len_dev;
     p.past_lens = past_lens;
     p.counters = counters;
+    p.defer_merge = defer_merge; p.nsplit_out = nsplit_out;
+    if (nsplit_out) *nsplit_out = 1;
     p.formal_handoff = pc_formal_handoff();
     p.pre_k = (const _Float16*)pre_k; p.pre_v = (const _Float16*)pre_v;
     p.pre_k_lo = (const _Float16*)pre_k_lo; p.pre_v_lo = (const _Float16*)pre_v_lo; p.pre_hs = pre_hs;
@@ -1505,6 +1512,7 @@ PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {
                    "pc_attn: lo_row0 must be -1 (= past_len), -2 (= past_len_dev[1]) or lie in [0, past_len] of a host past_len");
     }
     PC_REQUIRE(!a->counters || ((uintptr_t)a->counters & 3) == 0, PC_ERR_ARG, "pc_attn: counters not 4-byte aligned");
+    PC_REQUIRE(!a->defer_merge || (a->nsplit_out && !a->counters), PC_ERR_ARG, "pc_attn: defer_merge needs nsplit_out and excludes counters");
     if (a->prefix_k) {
         PC_REQUIRE(a->prefix_v && a->past_lens && a->prefix_head_stride % 8 == 0 && (a->q_lo || a->q_len > 16), PC_ERR_ARG,
                    "pc_attn: a shared prefix needs prefix_v, past_lens, a 16-byte aligned head stride and the many-row kernel");
@@ -1516,7 +1524,8 @@ PC_EXPORT int pc_attn(const pc_attn_args* a, void* stream) {
                          a->softmax_scale, a->workspace, a->workspace_bytes, a->past_len_dev, a->out_frag_hi, a->out_frag_lo,
                          a->key_pos, a->key_pos_batch_stride, a->slopes_log2, a->out_lo, a->k_lo, a->v_lo, a->lo_batch_stride,
                          a->lo_head_stride, a->lo_row0, stream, a->past_lens, a->counters, a->prefix_k, a->prefix_v,
-                         a->prefix_k_lo, a->prefix_v_lo, a->prefix_head_stride, a->gather_rows, a->gather_k_plane, a->gather_v_plane);
+                         a->prefix_k_lo, a->prefix_v_lo, a->prefix_head_stride, a->gather_rows, a->gather_k_plane, a->gather_v_plane, nullptr,
+                         a->defer_merge, a->nsplit_out);
 }
 
 // Whether pc_attn would run this launch shape on a kernel that implements gather_rows (the field itself is ignored here).

@@ -55,6 +55,8 @@ struct AttnParams {
     int32_t small;          // attn_small_kernel launch (host-side dispatch flag)
     int32_t formal_handoff; // fused merge: acq_rel arrival (the C++-memory-model form, env PC_FORMAL_HANDOFF=1) instead of relaxed + vmcnt(0)
     int32_t xcd_remap, nqblk, nbatch;
+    int32_t defer_merge;    // (host) leave the split-KV partials in the workspace: the consumer merges them (pc_gemm_q8 part_o)
+    int32_t* nsplit_out;    // (host) where pc_attn reports how many partials per row it left (1: the output planes are final)
     float scale_log2;
 };
 

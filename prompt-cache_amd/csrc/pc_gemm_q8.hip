@@ -40,7 +40,52 @@ struct Q8Params {
     unsigned char* flags_clear; int32_t clear_bytes;   // a flag buffer this launch zeroes (a multiple of 16 bytes)
     float* slabs; uint32_t* counters; int32_t formal;  // F form: in-launch K reduction (pc_gemm_ks.hip)
     signed char* dbg_codes; float* dbg_scale; unsigned char* dbg_flags;   // tests: workgroup 0's codes image / scales / flags
+    // P form, source "partials" (M = 1): the split-KV partials pc_attn left (defer_merge) are merged in the prologue
+    const float* part_o; const float* part_ml; int32_t part_nsplit, part_D;
 };
+
+// One 8-feature chunk of the merged attention output of ONE query row (q_len = 1, B = 1) from the split-KV partials, exactly as
+// attn_combine_kernel (pc_attn.hip) merges them: out = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s in split order, fp16 hi part.
+constexpr int kPartNS = 8;
+struct PartLoads { float mv[kPartNS], lv[kPartNS]; f4 oa[kPartNS], ob[kPartNS]; };
+__device__ __forceinline__ void part_issue(const Q8Params& qp, int k0, PartLoads& L) {
+    const int D = qp.part_D, ns = qp.part_nsplit;
+    const int h = k0 / D, d0 = k0 - h * D;
+#pragma unroll
+    for (int s = 0; s < kPartNS; ++s) {
+        const int sc = s < ns ? s : ns - 1;                                    // clamped re-read instead of a branch around the loads
+        const int64_t slot = (int64_t)h * ns + sc;
+        const float2 ml = *(const float2*)(qp.part_ml + slot * 2);
+        L.mv[s] = s < ns ? ml.x : -1.0e30f;
+        L.lv[s] = ml.y;
+        L.oa[s] = *(const f4*)(qp.part_o + slot * D + d0);
+        L.ob[s] = *(const f4*)(qp.part_o + slot * D + d0 + 4);
+    }
+}
+__device__ __forceinline__ h8 part_merge(const Q8Params& qp, const PartLoads& L) {
+    const int ns = qp.part_nsplit;
+    float mstar = -1.0e30f;
+#pragma unroll
+    for (int s = 0; s < kPartNS; ++s) mstar = fmaxf(mstar, L.mv[s]);
+    float num[8], den = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) num[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < kPartNS; ++s) {
+        const float w = s < ns ? exp2f(L.mv[s] - mstar) : 0.f;
+        den = __builtin_fmaf(w, L.lv[s], den);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) num[e] = __builtin_fmaf(w, e < 4 ? L.oa[s][e] : L.ob[s][e - 4], num[e]);
+    }
+    h8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 vh, vl;
+        pc_split(num[e] / den, vh, vl);
+        out[e] = vh;
+    }
+    return out;
+}
 
 __device__ __forceinline__ int nz4(uint32_t w) {
     return ((w & 0xffu) ? 1 : 0) + ((w & 0xff00u) ? 1 : 0) + ((w & 0xff0000u) ? 1 : 0) + ((w >> 24) ? 1 : 0);
@@ -176,9 +221,13 @@ __device__ __forceinline__ bool q8_correction(const GemmParams& p, const uint32_
 template <int TT> struct Q8Depth { static constexpr int NW = TT == 1 ? 8 : (TT == 2 ? 4 : (TT <= 6 ? 2 : 1)); };
 
 // RI: prologue passes (two rows each): 2 for M <= 4 (decode; both K-loop buffers are then in flight across the prologue), 8 for M <= 16
-template <int T, int EPI, bool NORM, int G, int RI>
+// SRC: 0 the fp16 plane, 1 the fp32 residual stream under an RMSNorm, 2 pc_attn's split-KV partials of one row (M = 1)
+template <int T, int EPI, int SRC, int G, int RI>
 __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
     const GemmParams& p = qp.g;
+    constexpr bool NORM = SRC == 1, PART = SRC == 2;
+    constexpr int GP = (G + 1) / 2;                      // PART: chunks per thread (all 512 threads on the one row)
+    static_assert(!PART || (RI == 2 && GP == 1), "the partials source is for one row of K <= 4096");
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
     constexpr int TPI = (EPI == EPI_SILU) ? 2 : 1;
     constexpr int kRT = (TT < 8) ? TT : 8;
@@ -233,10 +282,14 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
             } else {
                 h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 hv[it][k] = z;
-                if (row < M && i < nv) hv[it][k] = *(const h8*)(p.xf_hi + frag_off(row, i * 8, KS));
+                if constexpr (!PART) {
+                    if (row < M && i < nv) hv[it][k] = *(const h8*)(p.xf_hi + frag_off(row, i * 8, KS));
+                }
             }
         }
     }
+    [[maybe_unused]] PartLoads pl;
+    if constexpr (PART) part_issue(qp, (tid < nv ? tid : nv - 1) * 8, pl);
     if constexpr (NORM) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
@@ -334,6 +387,30 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
             }
         }
     }
+    if constexpr (PART) {
+        // ---- 3'. / 4'. one row, one chunk per thread: merge, flags, the row maximum over the eight waves, codes ----
+        const h8 hp = part_merge(qp, pl);
+        float mx = 0.f;
+        if (tid < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = fabsf((float)hp[e]);
+                if (f >= thr) lflag[tid * 8 + e] = 1;
+                else mx = fmaxf(mx, f);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) lredq[wave][0] = mx;
+        lds_barrier();
+        float sca = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) sca = fmaxf(sca, lredq[w][0]);
+        const float inv = sca > 0.f ? 127.0f / sca : 0.f;
+        if (tid == 0) lxs[0] = sca / 127.0f;
+        if (tid < nv) *(u32x2*)(img + img_off(0, tid * 8)) = quant8(hp, inv, thr);
+        lds_barrier();
+    } else {
     // ---- 3. outlier flags + row maxima without the outliers (quant_act_kernel) ----
 #pragma unroll
     for (int it = 0; it < RI; ++it) {
@@ -378,6 +455,7 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
         }
     }
     lds_barrier();
+    }
     if (qp.dbg_codes && bx == 0) {                       // tests: what this workgroup computed
         for (int i = tid; i < K * 4; i += kThreads) ((uint32_t*)qp.dbg_codes)[i] = ((const uint32_t*)img)[i];
         for (int i = tid; i < K; i += kThreads) qp.dbg_flags[i] = lflag[i];
@@ -454,6 +532,10 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
             _Float16 vh, vl;
             pc_split(v, vh, vl);
             return vh;
+        } else if constexpr (PART) {
+            PartLoads L;
+            part_issue(qp, k & ~7, L);
+            return part_merge(qp, L)[k & 7];
         } else {
             return p.xf_hi[frag_off(row, k, KS)];
         }
@@ -945,7 +1027,7 @@ int launch_q8c(const Q8Params& qp, hipStream_t s) {
     return pc_check_launch("gemm_q8c_kernel");
 }
 
-template <int T, int EPI, bool NORM, int G, int RI>
+template <int T, int EPI, int SRC, int G, int RI>
 int launch_q8p_one(const Q8Params& qp, int units, int K, hipStream_t s) {
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
     constexpr int kRT = (TT < 8) ? TT : 8;
@@ -953,17 +1035,20 @@ int launch_q8p_one(const Q8Params& qp, int units, int K, hipStream_t s) {
     constexpr size_t kLdsMax = 160 * 1024;
     const size_t lds = (size_t)K * 16 + (size_t)G * 2048;
     PC_REQUIRE(lds + kStatic <= kLdsMax, PC_ERR_ARG, "pc_gemm_q8: K = %d with %d weight tiles per workgroup does not fit the LDS", K, TT);
-    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_q8p_kernel<T, EPI, NORM, G, RI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_q8p_kernel<T, EPI, SRC, G, RI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)(kLdsMax - kStatic));
     (void)attr;
-    hipLaunchKernelGGL((gemm_q8p_kernel<T, EPI, NORM, G, RI>), dim3(pc_ceil_div(units, T)), dim3(kThreads), lds, s, qp);
+    hipLaunchKernelGGL((gemm_q8p_kernel<T, EPI, SRC, G, RI>), dim3(pc_ceil_div(units, T)), dim3(kThreads), lds, s, qp);
     return pc_check_launch("gemm_q8p_kernel");
 }
 
 template <int T, int EPI, bool NORM>
 int launch_q8p_g(const Q8Params& qp, int units, int K, hipStream_t s) {
-    if (qp.g.M <= 4) return K <= 4096 ? launch_q8p_one<T, EPI, NORM, 2, 2>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM, 3, 2>(qp, units, K, s);
-    return K <= 4096 ? launch_q8p_one<T, EPI, NORM, 2, kQ8RI>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM, 3, kQ8RI>(qp, units, K, s);
+    if constexpr (!NORM && EPI == EPI_ADD) {
+        if (qp.part_o) return launch_q8p_one<T, EPI, 2, 2, 2>(qp, units, K, s);           // (pc_gemm_q8 checked: M = 1, K <= 4096)
+    }
+    if (qp.g.M <= 4) return K <= 4096 ? launch_q8p_one<T, EPI, NORM ? 1 : 0, 2, 2>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM ? 1 : 0, 3, 2>(qp, units, K, s);
+    return K <= 4096 ? launch_q8p_one<T, EPI, NORM ? 1 : 0, 2, kQ8RI>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM ? 1 : 0, 3, kQ8RI>(qp, units, K, s);
 }
 
 template <int EPI, bool NORM, int kMaxT>
@@ -999,9 +1084,13 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
                "pc_gemm_q8: need 1 <= M <= 16, N %% 16 == 0, K %% 64 == 0");
     PC_REQUIRE(a->wf && a->w_scale && ((uintptr_t)a->w_scale & 15) == 0 && a->w_codes_t && a->ldt >= N && (!qkv || a->row_perm), PC_ERR_ARG,
                "pc_gemm_q8: needs the int8 weight image, 16-byte aligned w_scale, w_codes_t (ldt >= N) (and row_perm for q|k|v)");
-    const bool norm = a->x != nullptr, fform = a->row_max != nullptr;
-    PC_REQUIRE(norm ? (a->norm_weight && !a->xf_hi && !fform) : (a->xf_hi != nullptr), PC_ERR_ARG,
-               "pc_gemm_q8: pass either (x, norm_weight) or the fp16 activation plane xf_hi");
+    const bool norm = a->x != nullptr, fform = a->row_max != nullptr, part = a->part_o != nullptr;
+    PC_REQUIRE(norm ? (a->norm_weight && !a->xf_hi && !fform && !part) : ((a->xf_hi != nullptr) != part), PC_ERR_ARG,
+               "pc_gemm_q8: pass exactly one of (x, norm_weight), the fp16 activation plane xf_hi, or pc_attn's partials part_o");
+    PC_REQUIRE(!part || (a->part_ml && M == 1 && K <= 4096 && epi == PC_GEMM_EPI_ADD && !fform && a->part_nsplit >= 2 && a->part_nsplit <= kPartNS &&
+                         a->part_head_dim > 0 && a->part_head_dim % 8 == 0 && K % a->part_head_dim == 0 &&
+                         (((uintptr_t)a->part_o | (uintptr_t)a->part_ml) & 15) == 0), PC_ERR_ARG,
+               "pc_gemm_q8: part_o (pc_attn defer_merge) needs part_ml, M = 1, K = H * part_head_dim <= 4096, 2..8 partials, residual-add epilogue");
     PC_REQUIRE(!a->flags_clear || (a->clear_bytes > 0 && a->clear_bytes % 16 == 0 && ((uintptr_t)a->flags_clear & 15) == 0), PC_ERR_ARG,
                "pc_gemm_q8: flags_clear needs a 16-byte aligned buffer and a multiple of 16 bytes");
     hipStream_t s = (hipStream_t)stream;
@@ -1017,6 +1106,7 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
     qp.threshold = a->threshold;
     qp.flags_clear = (unsigned char*)a->flags_clear; qp.clear_bytes = a->clear_bytes;
     qp.dbg_codes = (signed char*)a->dbg_codes; qp.dbg_scale = a->dbg_scale; qp.dbg_flags = (unsigned char*)a->dbg_flags;
+    qp.part_o = a->part_o; qp.part_ml = a->part_ml; qp.part_nsplit = a->part_nsplit; qp.part_D = a->part_head_dim;
     PC_REQUIRE(!a->dbg_codes || (a->dbg_scale && a->dbg_flags && !fform), PC_ERR_ARG, "pc_gemm_q8: dbg_codes goes with dbg_scale and dbg_flags (P form)");
 
     if (fform) {

@@ -32,7 +32,8 @@ class AttnArgs(C.Structure):
                 ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64), ("lo_row0", _i32),
                 ("counters", _vp),
                 ("prefix_k", _vp), ("prefix_v", _vp), ("prefix_k_lo", _vp), ("prefix_v_lo", _vp), ("prefix_head_stride", _i64),
-                ("gather_rows", _vp), ("gather_k_plane", _i32), ("gather_v_plane", _i32)]
+                ("gather_rows", _vp), ("gather_k_plane", _i32), ("gather_v_plane", _i32),
+                ("defer_merge", _i32), ("nsplit_out", _vp)]
 
 
 class KvSeg(C.Structure):
@@ -99,7 +100,8 @@ class GemmQ8Args(C.Structure):
                 ("B", _i32), ("H", _i32), ("Hkv", _i32), ("D", _i32), ("q_len", _i32), ("past_len", _i32), ("cap", _i32),
                 ("past_len_dev", _vp), ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64),
                 ("lo_base", _i32),
-                ("dbg_codes", _vp), ("dbg_scale", _vp), ("dbg_flags", _vp)]
+                ("dbg_codes", _vp), ("dbg_scale", _vp), ("dbg_flags", _vp),
+                ("part_o", _vp), ("part_ml", _vp), ("part_nsplit", _i32), ("part_head_dim", _i32)]
 
 
 # name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one
@@ -296,8 +298,11 @@ def attn_gather_ok(*args, **kw) -> bool:
 
 def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale,
              workspace=None, past_len_dev=None, out_frag=None, q_lo=None, stream: Optional[int] = None,
-             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None, prefix=None, gather=None) -> None:
+             alibi=None, out_lo=None, kv_lo=None, past_lens=None, counters=None, prefix=None, gather=None,
+             defer_merge: bool = False) -> int:
     """The attention of one layer through ``pc_attn`` (struct entry; every option is a field).
+    ``defer_merge``: a split-KV launch of <= 16 rows leaves its partials in ``workspace`` for ``gemm_q8(part=...)``; returns the
+    partials per row (1: merged as usual, the output planes are final).
     ``past_lens`` (device int32 [B]): one past length per batch row (``past_len`` = their maximum).
     ``out_frag=(hi, lo)``: write split-precision fragment planes for the o_proj launch instead of ``out``.
     ``alibi=(key_pos fp32 [B, stride], slopes_log2 fp32 [H])``: MPT's additive position bias.
@@ -310,8 +315,12 @@ def attn_fwd(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q
     read from where the table (``kv_row_table``) says they lie and written to ``k`` / ``v`` unless they are there already."""
     a = _attn_args(q, q_bs, q_ts, k, v, kv_bs, kv_hs, out, o_bs, o_ts, B, H, Hkv, D, q_len, past_len, scale, workspace,
                    past_len_dev, out_frag, q_lo, alibi, out_lo, kv_lo, past_lens, counters, prefix, gather)
+    ns = C.c_int32(1)
+    if defer_merge:
+        a.defer_merge, a.nsplit_out = 1, C.addressof(ns)
     rc = load().pc_attn(C.byref(a), current_stream() if stream is None else stream)
     check(rc, "pc_attn")
+    return int(ns.value)
 
 
 EPI_STORE, EPI_ADD, EPI_SILU, EPI_GELU = 0, 1, 2, 4

@@ -376,6 +376,7 @@ class LlamaHIP:
             self.q8_down = tuple(int(v) for v in os.environ.get("PC_Q8_DOWN", "4,4").split(","))
             self.q8_down_small = tuple(int(v) for v in os.environ.get("PC_Q8_DOWN_SMALL", "1,1").split(","))   # <= 4 rows (decode)
             self.q8_p_max_rows = int(os.environ.get("PC_Q8_P_MAX_ROWS", "4"))
+            self.q8_defer_merge = os.environ.get("PC_Q8_DEFER_MERGE", "1") != "0"
             self._q8_flags = torch.zeros(16384, dtype=torch.uint8, device=dev)
             self._q8_pmax = torch.zeros((c.intermediate_size // 16, 16), dtype=torch.float32, device=dev)
             self._i8_zero = torch.zeros(((self.SKINNY_MAX_ROWS + 15) // 16) * 16 * kmax, dtype=self.dtype, device=dev)
@@ -840,12 +841,16 @@ class LlamaHIP:
                           v_arena=vp, arena_batch_stride=arena.batch_stride, arena_head_stride=arena.head_stride, B=B, H=H, Hkv=Hkv, D=D,
                           q_len=q_len, past_len=past_len, cap=arena.cap, past_len_dev=past_dev, k_lo=lo4[0], v_lo=lo4[1],
                           lo_batch_stride=lo4[2], lo_head_stride=lo4[3], lo_base=lo_base)
-                n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
-                           B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                           q_lo=q16l, kv_lo=kvlo,
-                           gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
-                n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wo_f"], w_scale=lw["wo_s"], w_codes_t=lw["wo_t8"], xf_hi=ah, M=T, N=hid, K=H * D,
-                          y=x, ldy=hid, flags_clear=qf, clear_bytes=qf.numel())
+                # (one row -- a decode step: the attention leaves its split-KV partials in `ws` and the o_proj launch merges them in
+                # its prologue; the merge launch, 4.8 us of a 75 us layer, disappears)
+                ns = n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                                B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                                q_lo=q16l, kv_lo=kvlo,
+                                gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv),
+                                defer_merge=self.q8_defer_merge and T == 1 and H * D <= 4096)
+                src = dict(xf_hi=ah) if ns <= 1 else dict(part_o=ws, part_ml=ws[H * ns * D:], part_nsplit=ns, part_head_dim=D)
+                n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wo_f"], w_scale=lw["wo_s"], w_codes_t=lw["wo_t8"], M=T, N=hid, K=H * D,
+                          y=x, ldy=hid, flags_clear=qf, clear_bytes=qf.numel(), **src)
                 n.gemm_q8(epilogue=n.EPI_SILU, wf=lw["wgu_f"], w_scale=lw["wgu_s"], w_codes_t=lw["wgu_t8"], x=x, norm_weight=lw["ln2"],
                           eps=eps, M=T, N=2 * inter, K=hid, of_hi=ch, row_max_out=pm, flags_out=qf)
                 dn = self.q8_down_small if T <= 4 else self.q8_down

@@ -224,3 +224,44 @@ def test_down_proj_form_matches_the_quantiser_launch_plus_pc_gemm_and_the_oracle
         assert np.abs(y_new.cpu().numpy()[:, :N] - ref).max() < 3e-5 * scale
         # the summation order differs from the one-workgroup-per-tile launch (slices, then the correction per slice): fp32 rounding only
         assert float((y_new - y_old).abs().max()) < 2e-4 * scale
+
+
+@pytest.mark.parametrize("S,nout", [(1800, 0), (1800, 3), (300, 1), (5000, 0)])
+def test_o_proj_merges_the_attention_partials_itself_bit_for_bit(S, nout):
+    """A decode step: pc_attn(defer_merge) leaves the split-KV partials, pc_gemm_q8(part_o) merges them in its prologue -- the same bits
+    as attn_combine_kernel + the fp16-plane source."""
+    n = _n()
+    rng = np.random.default_rng(S + nout)
+    H, Hkv, D, K, N = 32, 32, 128, 4096, 4096
+    q = torch.from_numpy((rng.standard_normal((1, H * D)) * (3.0 if nout else 1.0)).astype(np.float16)).to(DEV)
+    ql = torch.zeros_like(q)
+    kv = torch.from_numpy(rng.standard_normal((1, 2, Hkv, S + 8, D)).astype(np.float16)).to(DEV)
+    if nout:                                               # a few large value entries: |merged output| >= 6 in some columns
+        kv[0, 1, :, :, :nout] *= 40.0
+    w = (0.03 * rng.standard_normal((N, K))).astype(np.float32)
+    qw, sc = n.quantize_rows_int8(torch.from_numpy(w).to(DEV))
+    wf8, qt = n.to_weight_frags_i8(qw), qw.t().contiguous()
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, 1, S + 1), 4) // 4, dtype=torch.float32, device=DEV)
+    scale = 1.0 / np.sqrt(D)
+    cap = S + 8
+    args = (q, H * D, H * D, kv[:, 0], kv[:, 1], 2 * Hkv * cap * D, cap * D, None, 0, 0, 1, H, Hkv, D, 1, S, scale, ws)
+    ah, al = (torch.zeros((1, K // 32, 64, 8), dtype=torch.float16, device=DEV) for _ in range(2))
+    assert n.attn_fwd(*args, out_frag=(ah, al), q_lo=ql) == 1
+    base = torch.from_numpy(rng.standard_normal((1, N)).astype(np.float32)).to(DEV)
+    y_a = base.clone()
+    dsa = torch.zeros(16, dtype=torch.float32, device=DEV)
+    dca, dfa = torch.zeros((K // 64, 64, 16), dtype=torch.int8, device=DEV), torch.zeros(K, dtype=torch.uint8, device=DEV)
+    n.gemm_q8(epilogue=n.EPI_ADD, wf=wf8, w_scale=sc, w_codes_t=qt, xf_hi=ah, M=1, N=N, K=K, y=y_a, ldy=N, dbg_codes=dca, dbg_scale=dsa, dbg_flags=dfa)
+    ah2, al2 = torch.zeros_like(ah), torch.zeros_like(al)
+    ns = n.attn_fwd(*args, out_frag=(ah2, al2), q_lo=ql, defer_merge=True)
+    assert 2 <= ns <= 8 and float(ah2.abs().max()) == 0.0      # (no merge ran)
+    y_b = base.clone()
+    dsb = torch.zeros(16, dtype=torch.float32, device=DEV)
+    dcb, dfb = torch.zeros_like(dca), torch.zeros_like(dfa)
+    n.gemm_q8(epilogue=n.EPI_ADD, wf=wf8, w_scale=sc, w_codes_t=qt, part_o=ws, part_ml=ws[H * ns * D:], part_nsplit=ns, part_head_dim=D,
+              M=1, N=N, K=K, y=y_b, ldy=N, dbg_codes=dcb, dbg_scale=dsb, dbg_flags=dfb)
+    torch.cuda.synchronize()
+    assert int(dfa.sum()) >= (1 if nout else 0)
+    assert torch.equal(dfa, dfb) and torch.equal(dsa, dsb)
+    assert np.array_equal(_image_to_rows(dca.cpu().numpy(), 1, K), _image_to_rows(dcb.cpu().numpy(), 1, K))
+    assert torch.equal(y_a, y_b)

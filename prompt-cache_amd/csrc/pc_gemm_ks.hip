@@ -38,7 +38,9 @@ struct KsParams {
     int32_t formal;          // acq_rel arrival (PC_FORMAL_HANDOFF=1) instead of relaxed + vmcnt(0)
 };
 
-template <int T, int U>
+// DB: the K loop keeps TWO blocks of U k-steps in flight (block b + 1 is requested before block b is consumed, block b + 2 into
+// b's registers right after), addresses as a wave-uniform base + one 32-bit lane offset per k-step (pc_gemm_q8.hip's loop)
+template <int T, int U, bool DB = false>
 __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams kp) {
     const GemmParams& p = kp.g;
     __shared__ __attribute__((aligned(16))) float red_raw[kWaves * T * 64 * 4];
@@ -68,9 +70,68 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
         const int unit = bx * T + tw < p.ntiles ? bx * T + tw : p.ntiles - 1;
         yold = *(const f4*)(p.y + (int64_t)(m < p.M ? m : p.M - 1) * p.ldy + unit * 16 + g * 4);
     }
+    if constexpr (DB) {
+        const char* wt[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) wt[t] = (const char*)p.wf + (int64_t)tile[t] * KS * 1024;
+        const char* xhb = (const char*)p.xf_hi;
+        const char* xlb = (const char*)p.xf_lo;
+        h8 wA[U][T], wB[U][T], hA[U], hB[U], lA[U], lB[U];
+        const bool rok = row_ok[0];
+        auto issue = [&](h8 (&w)[U][T], h8 (&xh)[U], h8 (&xl)[U], int kb) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int k = kb + u < ks1 ? kb + u : ks1 - 1;
+                k = k < 0 ? 0 : k;
+                const uint32_t voff = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) w[u][t] = __builtin_bit_cast(h8, __builtin_nontemporal_load((const u32x4*)(wt[t] + voff)));
+                h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                xh[u] = z; xl[u] = z;
+                if (rok) {
+                    xh[u] = *(const h8*)(xhb + voff);
+                    xl[u] = *(const h8*)(xlb + voff);
+                }
+            }
+        };
+        auto consume = [&](const h8 (&w)[U][T], const h8 (&xh)[U], const h8 (&xl)[U], int kb) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (kb + u >= ks1) continue;             // (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], xh[u], acc[0][t], 0, 0, 0);
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u][t], xl[u], acc[0][t], 0, 0, 0);
+                }
+            }
+        };
+        const int nb = (ks1 - ks0 + U - 1) / U;
+        issue(wA, hA, lA, ks0);
+        if (nb > 1) issue(wB, hB, lB, ks0 + U);
+        int b = 0;
+        bool done = false;
+        while (b + 2 < nb) {
+            consume(wA, hA, lA, ks0 + b * U);
+            issue(wA, hA, lA, ks0 + (b + 2) * U);
+            if (!(b + 3 < nb)) {
+                consume(wB, hB, lB, ks0 + (b + 1) * U);
+                consume(wA, hA, lA, ks0 + (b + 2) * U);
+                done = true;
+                break;
+            }
+            consume(wB, hB, lB, ks0 + (b + 1) * U);
+            issue(wB, hB, lB, ks0 + (b + 3) * U);
+            b += 2;
+        }
+        if (!done) {
+            if (b < nb) consume(wA, hA, lA, ks0 + b * U);
+            if (b + 1 < nb) consume(wB, hB, lB, ks0 + (b + 1) * U);
+        }
+    } else {
     int ks = ks0;
     for (; ks + U <= ks1; ks += U) k_block<1, T, true, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
     if (ks < ks1) k_block<1, T, true, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+    }
 
     // ---- the eight waves' K shares through LDS, fixed order; wave t then holds this workgroup's partial of tile t ----
 #pragma unroll
@@ -133,10 +194,10 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
     tile_epilogue<EPI_ADD>(p, r, zero, m, my_tile, g, 0, false, zero, zero, true, yold);
 }
 
-template <int T, int U>
+template <int T, int U, bool DB = false>
 int launch_ks(const KsParams& kp, hipStream_t s) {
     const dim3 grid(pc_ceil_div(kp.g.ntiles, T), kp.g.kslices);
-    hipLaunchKernelGGL((gemm_skinny_ks_kernel<T, U>), grid, dim3(kThreads), 0, s, kp);
+    hipLaunchKernelGGL((gemm_skinny_ks_kernel<T, U, DB>), grid, dim3(kThreads), 0, s, kp);
     return pc_check_launch("gemm_skinny_ks_kernel");
 }
 
@@ -167,6 +228,16 @@ int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M
     kp.slabs = (float*)scratch; kp.counters = (uint32_t*)counters; kp.formal = pc_formal_handoff();
     // k-steps per block: a wave's K share is K / 32 / (8 kslices) k-steps -- keep the whole share in flight where it fits
     const int share = pc_ceil_div(pc_ceil_div(K / 32, kslices), kWaves);
+    static const int db = [] { const char* e = getenv("PC_KS_DB"); return e ? atoi(e) : 0; }();
+    if (db) {                                            // two blocks in flight (PC_KS_DB=1: A/B against the single-block loop)
+        switch (tiles_per_wg) {
+            case 1: return launch_ks<1, 4, true>(kp, s);
+            case 2: return launch_ks<2, 3, true>(kp, s);
+            case 4: return launch_ks<4, 2, true>(kp, s);
+            case 8: return launch_ks<8, 1, true>(kp, s);
+            default: break;
+        }
+    }
     switch (tiles_per_wg) {
         case 1: return share > 8 ? launch_ks<1, 16>(kp, s) : launch_ks<1, 8>(kp, s);
         case 2: return share > 8 ? launch_ks<2, 12>(kp, s) : launch_ks<2, 8>(kp, s);

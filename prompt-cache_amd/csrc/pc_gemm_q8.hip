@@ -25,6 +25,7 @@
 //       slices in order, adds the residual stream and stores.
 // The outlier correction (fp16 part of the decomposition) runs inside both forms exactly as in gemm_skinny_body (pc_gemm_skinny.h).
 #include "pc_gemm_skinny.h"
+#include "pc_part_merge.h"
 
 using namespace pcg;
 
@@ -41,51 +42,9 @@ struct Q8Params {
     float* slabs; uint32_t* counters; int32_t formal;  // F form: in-launch K reduction (pc_gemm_ks.hip)
     signed char* dbg_codes; float* dbg_scale; unsigned char* dbg_flags;   // tests: workgroup 0's codes image / scales / flags
     // P form, source "partials" (M = 1): the split-KV partials pc_attn left (defer_merge) are merged in the prologue
-    const float* part_o; const float* part_ml; int32_t part_nsplit, part_D;
+    pcm::PartSrc part;
 };
-
-// One 8-feature chunk of the merged attention output of ONE query row (q_len = 1, B = 1) from the split-KV partials, exactly as
-// attn_combine_kernel (pc_attn.hip) merges them: out = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s in split order, fp16 hi part.
-constexpr int kPartNS = 8;
-struct PartLoads { float mv[kPartNS], lv[kPartNS]; f4 oa[kPartNS], ob[kPartNS]; };
-__device__ __forceinline__ void part_issue(const Q8Params& qp, int k0, PartLoads& L) {
-    const int D = qp.part_D, ns = qp.part_nsplit;
-    const int h = k0 / D, d0 = k0 - h * D;
-#pragma unroll
-    for (int s = 0; s < kPartNS; ++s) {
-        const int sc = s < ns ? s : ns - 1;                                    // clamped re-read instead of a branch around the loads
-        const int64_t slot = (int64_t)h * ns + sc;
-        const float2 ml = *(const float2*)(qp.part_ml + slot * 2);
-        L.mv[s] = s < ns ? ml.x : -1.0e30f;
-        L.lv[s] = ml.y;
-        L.oa[s] = *(const f4*)(qp.part_o + slot * D + d0);
-        L.ob[s] = *(const f4*)(qp.part_o + slot * D + d0 + 4);
-    }
-}
-__device__ __forceinline__ h8 part_merge(const Q8Params& qp, const PartLoads& L) {
-    const int ns = qp.part_nsplit;
-    float mstar = -1.0e30f;
-#pragma unroll
-    for (int s = 0; s < kPartNS; ++s) mstar = fmaxf(mstar, L.mv[s]);
-    float num[8], den = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) num[e] = 0.f;
-#pragma unroll
-    for (int s = 0; s < kPartNS; ++s) {
-        const float w = s < ns ? exp2f(L.mv[s] - mstar) : 0.f;
-        den = __builtin_fmaf(w, L.lv[s], den);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) num[e] = __builtin_fmaf(w, e < 4 ? L.oa[s][e] : L.ob[s][e - 4], num[e]);
-    }
-    h8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        _Float16 vh, vl;
-        pc_split(num[e] / den, vh, vl);
-        out[e] = vh;
-    }
-    return out;
-}
+using pcm::PartLoads;
 
 __device__ __forceinline__ int nz4(uint32_t w) {
     return ((w & 0xffu) ? 1 : 0) + ((w & 0xff00u) ? 1 : 0) + ((w & 0xff0000u) ? 1 : 0) + ((w >> 24) ? 1 : 0);
@@ -289,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
         }
     }
     [[maybe_unused]] PartLoads pl;
-    if constexpr (PART) part_issue(qp, (tid < nv ? tid : nv - 1) * 8, pl);
+    if constexpr (PART) pcm::part_issue(qp.part, 0, (tid < nv ? tid : nv - 1) * 8, pl);
     if constexpr (NORM) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
@@ -389,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
     }
     if constexpr (PART) {
         // ---- 3'. / 4'. one row, one chunk per thread: merge, flags, the row maximum over the eight waves, codes ----
-        const h8 hp = part_merge(qp, pl);
+        const h8 hp = __builtin_bit_cast(h8, pcm::part_merge(qp.part, pl));
         float mx = 0.f;
         if (tid < nv) {
 #pragma unroll
@@ -534,8 +493,8 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
             return vh;
         } else if constexpr (PART) {
             PartLoads L;
-            part_issue(qp, k & ~7, L);
-            return part_merge(qp, L)[k & 7];
+            pcm::part_issue(qp.part, 0, k & ~7, L);
+            return pcm::part_merge(qp.part, L)[k & 7];
         } else {
             return p.xf_hi[frag_off(row, k, KS)];
         }
@@ -1045,7 +1004,7 @@ int launch_q8p_one(const Q8Params& qp, int units, int K, hipStream_t s) {
 template <int T, int EPI, bool NORM>
 int launch_q8p_g(const Q8Params& qp, int units, int K, hipStream_t s) {
     if constexpr (!NORM && EPI == EPI_ADD) {
-        if (qp.part_o) return launch_q8p_one<T, EPI, 2, 2, 2>(qp, units, K, s);           // (pc_gemm_q8 checked: M = 1, K <= 4096)
+        if (qp.part.part_o) return launch_q8p_one<T, EPI, 2, 2, 2>(qp, units, K, s);           // (pc_gemm_q8 checked: M = 1, K <= 4096)
     }
     if (qp.g.M <= 4) return K <= 4096 ? launch_q8p_one<T, EPI, NORM ? 1 : 0, 2, 2>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM ? 1 : 0, 3, 2>(qp, units, K, s);
     return K <= 4096 ? launch_q8p_one<T, EPI, NORM ? 1 : 0, 2, kQ8RI>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM ? 1 : 0, 3, kQ8RI>(qp, units, K, s);
@@ -1087,7 +1046,7 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
     const bool norm = a->x != nullptr, fform = a->row_max != nullptr, part = a->part_o != nullptr;
     PC_REQUIRE(norm ? (a->norm_weight && !a->xf_hi && !fform && !part) : ((a->xf_hi != nullptr) != part), PC_ERR_ARG,
                "pc_gemm_q8: pass exactly one of (x, norm_weight), the fp16 activation plane xf_hi, or pc_attn's partials part_o");
-    PC_REQUIRE(!part || (a->part_ml && M == 1 && K <= 4096 && epi == PC_GEMM_EPI_ADD && !fform && a->part_nsplit >= 2 && a->part_nsplit <= kPartNS &&
+    PC_REQUIRE(!part || (a->part_ml && M == 1 && K <= 4096 && epi == PC_GEMM_EPI_ADD && !fform && a->part_nsplit >= 2 && a->part_nsplit <= pcm::kPartNS &&
                          a->part_head_dim > 0 && a->part_head_dim % 8 == 0 && K % a->part_head_dim == 0 &&
                          (((uintptr_t)a->part_o | (uintptr_t)a->part_ml) & 15) == 0), PC_ERR_ARG,
                "pc_gemm_q8: part_o (pc_attn defer_merge) needs part_ml, M = 1, K = H * part_head_dim <= 4096, 2..8 partials, residual-add epilogue");
@@ -1106,7 +1065,7 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
     qp.threshold = a->threshold;
     qp.flags_clear = (unsigned char*)a->flags_clear; qp.clear_bytes = a->clear_bytes;
     qp.dbg_codes = (signed char*)a->dbg_codes; qp.dbg_scale = a->dbg_scale; qp.dbg_flags = (unsigned char*)a->dbg_flags;
-    qp.part_o = a->part_o; qp.part_ml = a->part_ml; qp.part_nsplit = a->part_nsplit; qp.part_D = a->part_head_dim;
+    qp.part.part_o = a->part_o; qp.part.part_ml = a->part_ml; qp.part.nsplit = a->part_nsplit; qp.part.D = a->part_head_dim; qp.part.q_len = 1;
     PC_REQUIRE(!a->dbg_codes || (a->dbg_scale && a->dbg_flags && !fform), PC_ERR_ARG, "pc_gemm_q8: dbg_codes goes with dbg_scale and dbg_flags (P form)");
 
     if (fform) {

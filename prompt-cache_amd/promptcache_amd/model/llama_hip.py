@@ -808,22 +808,24 @@ class LlamaHIP:
         ah, al, aq = planes(H * D, 3)
         ch, cl, cq = planes(inter, 3)
         zero = self._i8_zero
-        has = torch.zeros(4, dtype=torch.int32, device=dev)
+        q8_all = self.i8_inlaunch and T <= self.q8_p_max_rows          # every quantiser inside its projection
+        q8_down = self.i8_inlaunch and self.i8_fused_corr and T <= 16    # at least down_proj's
+        # (the correction-has words of the two-launch forms: one fill node per forward, not needed when the projections quantise)
+        has = None if q8_all else torch.zeros(4, dtype=torch.int32, device=dev)
 
         def image8(k):        # the int8 MFMA's operand image of a code plane (pc_quant_act_i8 codes8; K % 64 == 0 with int8 weights)
             return torch.empty((mt, k // 64, 64, 16), dtype=torch.int8, device=dev)
 
         x8, a8, c8 = image8(hid), image8(H * D), image8(inter)
-        bufs = [(xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, W), dtype=f32, device=dev), has[0:1], x8),
-                (aq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[1:2], a8),
-                (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3], x8),
-                (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4], c8)]
+        bufs = None if q8_all else \
+            [(xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, W), dtype=f32, device=dev), has[0:1], x8),
+             (aq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[1:2], a8),
+             (xq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, 2 * inter), dtype=f32, device=dev), has[2:3], x8),
+             (cq, torch.empty(T, dtype=f32, device=dev), torch.empty((T, hid), dtype=f32, device=dev), has[3:4], c8)]
         layers = self.layers if num_layers is None else self.layers[:num_layers]
         # Outlier flags are set-only and slot s is cleared by the quantiser of slot s - 1: a pass that stopped behind a
         # layer's q|k|v (kv_only encodes) left slot 0 set, and this pass's first quantiser would OR onto it -- results would
         # depend on the call history.  One memset node (graph-capturable) makes every forward start clean.
-        q8_all = self.i8_inlaunch and T <= self.q8_p_max_rows          # every quantiser inside its projection
-        q8_down = self.i8_inlaunch and self.i8_fused_corr and T <= 16    # at least down_proj's
         if not q8_all:
             self._i8_flags[0].zero_()
         if q8_all:

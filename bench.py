@@ -1082,7 +1082,11 @@ def main():
                                   "outlier_columns_last_layer": outl,
                                   "what": "load_in_8bit=True: LLM.int8() as published (row-wise absmax int8 weights, vector-wise "
                                           "int8 activations, fp16 outlier columns at |x| >= 6), lm_head fp16; module KV from the "
-                                          "fp16 engine; PC_INT8_WEIGHT_ONLY=1 selects round 1's weight-only mode"}
+                                          "fp16 engine; the activation quantisers run inside the projection launches (pc_gemm_q8: "
+                                          "all four at <= 4 rows, down_proj's at 5..16 rows; PC_INT8_INLAUNCH=0: round 4's quantiser "
+                                          "launches); decode_tokens_per_s steps through lm() with a host argmax, "
+                                          "decode_device_loop_tokens_per_s is GreedyLoop (compare decode_device_loop); "
+                                          "PC_INT8_WEIGHT_ONLY=1 selects round 1's weight-only mode"}
         del lm8, o8, past8, cache8
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

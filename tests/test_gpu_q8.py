@@ -265,3 +265,41 @@ def test_o_proj_merges_the_attention_partials_itself_bit_for_bit(S, nout):
     assert torch.equal(dfa, dfb) and torch.equal(dsa, dsb)
     assert np.array_equal(_image_to_rows(dca.cpu().numpy(), 1, K), _image_to_rows(dcb.cpu().numpy(), 1, K))
     assert torch.equal(y_a, y_b)
+
+
+def test_7b_shape_int8_stack_inlaunch_quantisers_equal_the_quantiser_launches():
+    """Three layers of the 7b shape, load_in_8bit: the cached step (12 rows: quantiser launches + the F form for down_proj), a 3-row
+    step and decode steps (1 row: every quantiser inside its projection, the attention's partials merged by o_proj) against round 4's
+    path (PC_INT8_INLAUNCH=0: a quantiser launch in front of every projection).  The P forms are bit-identical; the K-sliced / compact
+    down_proj forms add their slices in another order (fp32 rounding)."""
+    import dataclasses
+    from promptcache_amd.model import Llama2
+    from promptcache_amd.model.config import SHAPES
+    from promptcache_amd.model.weights import random_weights_device
+    shape = dataclasses.replace(SHAPES["llama2-7b"], num_hidden_layers=3, vocab_size=4096)
+    w = random_weights_device(shape, DEV, torch.float16, seed=5)
+    w["embed"][:, [7, 300, 2049]] *= 40.0                 # outlier feature channels: flagged columns on every layer's q|k|v and gate|up input
+    lm = Llama2(name="q8-7b", shape=shape, weights=w, device=DEV, load_in_8bit=True)
+    m = lm.hf_model
+    assert m.llm_int8 and m.i8_inlaunch
+    g = torch.Generator().manual_seed(3)
+    S = 700
+    ids = torch.randint(0, shape.vocab_size, (1, S), generator=g).to(DEV)
+    out0 = lm(input_ids=ids, position_ids=torch.arange(S, device=DEV)[None], use_cache=True)     # many-row path: fills the arena
+    results = {}
+    for mode in (True, False):
+        m.i8_inlaunch = mode
+        m._graphs.clear()
+        past = out0.past_key_values
+        logs = []
+        pos = S
+        for rows in (12, 3, 1, 1):
+            step = torch.randint(0, shape.vocab_size, (1, rows), generator=torch.Generator().manual_seed(rows + pos)).to(DEV)
+            o = lm(input_ids=step, position_ids=torch.arange(pos, pos + rows, device=DEV)[None], past_key_values=past, use_cache=True)
+            logs.append(o.logits[0].float().cpu().numpy())
+            past = o.past_key_values
+            pos += rows
+        results[mode] = logs                               # (the next mode starts from out0's views again: rows S.. are rewritten)
+    for a, b in zip(results[True], results[False]):
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() < 2e-3 * max(1.0, np.abs(b).max()), np.abs(a - b).max()

@@ -305,6 +305,13 @@ typedef struct pc_gemm_args {
 } pc_gemm_args;
 int pc_gemm(const pc_gemm_args* args, void* stream);
 int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
+/* pc_gemm_part -- o_proj + residual (llama2.py:405, :638) of a ONE-ROW forward (a decode step) on the attention's split-KV
+ *   PARTIALS: y[0][n] += sum_k merged[k] W[n][k], where merged = the H * D values attn_combine_kernel would have produced from
+ *   part_o / part_ml (pc_attn with defer_merge: nsplit = *nsplit_out in 2..8, layout there), split into fp16 hi + lo as pc_attn's
+ *   fragment planes hold them.  wf: the fp16 fragment image of W [N][K = H * D <= 4096].  Bit-identical to pc_attn + its merge
+ *   launch + pc_gemm(PC_GEMM_EPI_ADD) on the merged planes; one launch less per layer and decode step (csrc/pc_gemm_part.hip). */
+int pc_gemm_part(const void* wf, const float* part_o, const float* part_ml, int32_t nsplit, int32_t H, int32_t D, int32_t N, float* y,
+                 void* stream);
 /* pc_gemm_q8 -- LLM.int8 projection of M <= 16 rows with the vector-wise activation quantiser INSIDE the launch
  *   (csrc/pc_gemm_q8.hip).  Same arithmetic as pc_rmsnorm_quant_i8 / pc_quant_act_i8 followed by pc_gemm with x_scale + flags
  *   (bitsandbytes Linear8bitLt as demo.py:27-29 loads it; llama2.py:345-347, :405, :242 are the projections), without the

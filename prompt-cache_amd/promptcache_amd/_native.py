@@ -109,6 +109,7 @@ SIGNATURES = {
     "pc_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "pc_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "pc_gemm_q8": (C.c_int, [C.POINTER(GemmQ8Args), _vp]),
+    "pc_gemm_part": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pc_dev_gemm_trace": (C.c_int, [_vp]),
     "pc_dev_attn_trace": (C.c_int, [_vp]),
     "pc_gemm_skinny_ks_scratch_bytes": (C.c_int64, [_i32, _i32]),
@@ -691,6 +692,13 @@ def gemm_qkv_rope_a8c(wf8_perm, w_scale_perm, xq, zeros, x_scale, flags, x_raw, 
     _gemm(stream, wf=wf8_perm, w_scale=w_scale_perm, xf_hi=xq, xf_lo=zeros, x_scale=x_scale, x_codes8=codes8, flags=flags, x_raw=x_raw,
           w_codes_t=w_codes_t, ldt=w_codes_t.stride(-2), row_perm=row_perm, M=M, K=K,
           **_qkv_fields(cs, q_hi, q_lo, q_ts, k_arena, v_arena, a_bs, a_hs, B, H, Hkv, D, q_len, past_len, cap, past_len_dev, kv_lo, lo_base))
+
+
+def gemm_part(wf, part_o, part_ml, nsplit: int, H: int, D: int, N: int, y, stream: Optional[int] = None) -> None:
+    """o_proj + residual of a one-row step on the split-KV partials ``attn_fwd(defer_merge=True)`` left (``nsplit`` per head)."""
+    rc = load().pc_gemm_part(wf.data_ptr(), part_o.data_ptr(), part_ml.data_ptr(), nsplit, H, D, N, y.data_ptr(),
+                             current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_part")
 
 
 def gemm_q8(stream=None, **f) -> None:

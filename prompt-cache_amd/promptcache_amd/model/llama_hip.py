@@ -275,6 +275,7 @@ class LlamaHIP:
         # attention reads residual tiles): decode logits 5e-5 from the oracle instead of 2-4e-3 -- both far inside the
         # 1e-2 bar -- for ~5 % of the decode rate.  Opt-in (PC_DECODE_TAIL=1 or model.decode_tail = True).
         self.decode_tail = os.environ.get("PC_DECODE_TAIL", "0") == "1"
+        self.defer_merge = os.environ.get("PC_DEFER_MERGE", "1") != "0"    # one-row steps: o_proj merges the attention's partials
         # arrival counters of the single-launch split-KV merge (pc_attn `counters`: zero now, every launch leaves them zero).
         # Opt-in (PC_ATTN_FUSED=1): measured on MI355X the in-launch hand-off (write-through partials, drain, arrival counter,
         # the last arriver's read-back: ~4.5 us on the critical path) costs what the second launch costs -- persona step 3.922 /
@@ -1034,10 +1035,16 @@ class LlamaHIP:
                                      arena.head_stride, B, H, Hkv, D, q_len, past_len, arena.cap, past_dev,
                                      kv_lo=kvlo and kvlo[:4], wscale=lw["wqkv_s"], lo_base=lo_base, rows_dev=rows_dev)
             qkv_done = False
-            n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
-                       B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
-                       q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
-                       gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
+            # (one row -- a decode step: the attention leaves its split-KV partials and o_proj merges them in its prologue,
+            # pc_gemm_part; PC_DEFER_MERGE=0 keeps the merge launch)
+            # (rows_dev: a one-row graph has one live row)
+            part_ok = self.defer_merge and T == 1 and B == 1 and H * D <= 4096 and lw["wo_s"] is None and not chain and \
+                self._attn_counters is None
+            ns = n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
+                            B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
+                            q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
+                            gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv),
+                            defer_merge=part_ok)
             if chain:
                 nxt = None
                 if li + 1 < len(layers):
@@ -1054,7 +1061,9 @@ class LlamaHIP:
                     continue
                 except RuntimeError:
                     chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
-            if self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 16:      # (the in-launch K reduction: one row tile)
+            if ns > 1:
+                n.gemm_part(lw["wo_f"], ws, ws[H * ns * D:], ns, H, D, hid, x)
+            elif self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 16:      # (the in-launch K reduction: one row tile)
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr, rows_dev=rows_dev)
             else:

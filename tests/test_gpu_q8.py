@@ -303,3 +303,36 @@ def test_7b_shape_int8_stack_inlaunch_quantisers_equal_the_quantiser_launches():
     for a, b in zip(results[True], results[False]):
         assert np.isfinite(a).all()
         assert np.abs(a - b).max() < 2e-3 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("S,H,D", [(1800, 32, 128), (300, 32, 128), (5000, 16, 128), (900, 8, 64)])
+def test_fp16_o_proj_merges_the_attention_partials_itself_bit_for_bit(S, H, D):
+    """pc_gemm_part (a decode step of the fp16 model): pc_attn(defer_merge) + o_proj on the partials = pc_attn + merge launch + pc_gemm."""
+    n = _n()
+    rng = np.random.default_rng(S + H)
+    Hkv, K, N = H, H * D, 4096 if H * D >= 2048 else 512
+    q = torch.from_numpy(rng.standard_normal((1, K)).astype(np.float16)).to(DEV)
+    ql = torch.from_numpy((rng.standard_normal((1, K)) * 1e-3).astype(np.float16)).to(DEV)
+    cap = S + 8
+    kv = torch.from_numpy(rng.standard_normal((1, 2, Hkv, cap, D)).astype(np.float16)).to(DEV)
+    w = torch.from_numpy((0.03 * rng.standard_normal((N, K))).astype(np.float16)).to(DEV)
+    wf = n.to_weight_frags(w)
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, 1, S + 1), 4) // 4, dtype=torch.float32, device=DEV)
+    args = (q, K, K, kv[:, 0], kv[:, 1], 2 * Hkv * cap * D, cap * D, None, 0, 0, 1, H, Hkv, D, 1, S, 1.0 / np.sqrt(D), ws)
+    ah, al = (torch.zeros((1, K // 32, 64, 8), dtype=torch.float16, device=DEV) for _ in range(2))
+    assert n.attn_fwd(*args, out_frag=(ah, al), q_lo=ql) == 1
+    base = torch.from_numpy(rng.standard_normal((1, N)).astype(np.float32)).to(DEV)
+    y_a = base.clone()
+    n.gemm_skinny(wf, ah, al, 1, N, K, n.EPI_ADD, y=y_a, ldy=N)
+    ah2, al2 = torch.zeros_like(ah), torch.zeros_like(al)
+    ns = n.attn_fwd(*args, out_frag=(ah2, al2), q_lo=ql, defer_merge=True)
+    if ns == 1:                                            # (a launch shape without key splits merges nothing: planes final)
+        assert torch.equal(ah, ah2)
+        return
+    assert 2 <= ns <= 8 and float(ah2.abs().max()) == 0.0
+    y_b = base.clone()
+    n.gemm_part(wf, ws, ws[H * ns * D:], ns, H, D, N, y_b)
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_b), float((y_a - y_b).abs().max())
+    ref = base.cpu().numpy() + (n.from_act_frags(ah, 1).float().cpu().numpy() + n.from_act_frags(al, 1).float().cpu().numpy()) @ w.float().cpu().numpy().T
+    assert np.abs(y_b.cpu().numpy() - ref).max() < 1e-3

@@ -724,7 +724,7 @@ def test_trunk_pass_on_the_row_split_stack_stores_the_module_kv_of_the_many_row_
     assert worst < 4e-3 and moved < 0.02
 
 
-@pytest.mark.parametrize("family", ["llama", "falcon"])
+@pytest.mark.parametrize("family", ["llama", "falcon", "llama_int8"])
 def test_device_greedy_loop_equals_stepping_through_the_model(family):
     """GenerationEngine's device-side greedy loop (one hipGraph replay per token: forward + argmax + state advance, no host
     round trip) must emit exactly the tokens of the per-step path (lm() call + host argmax), including across an arena
@@ -735,6 +735,10 @@ def test_device_greedy_loop_equals_stepping_through_the_model(family):
     from promptcache_amd.model.weights import make_falcon_weights_np, make_weights_np
     if family == "falcon":
         lm = Falcon(name="x", shape=FALCON_SHAPES["falcon-mid"], weights=make_falcon_weights_np(FALCON_SHAPES["falcon-mid"], 4, 3.0), device="cuda:0")
+    elif family == "llama_int8":
+        # load_in_8bit: the one-row steps run pc_gemm_q8 (quantisers inside the projections, o_proj on the attention's partials)
+        lm = Llama2(name="x", shape=SHAPES["mid64_gqa"], weights=make_weights_np(SHAPES["mid64_gqa"], 4, 1.0), device="cuda:0", load_in_8bit=True)
+        assert lm.hf_model.llm_int8 and lm.hf_model.i8_inlaunch
     else:
         lm = Llama2(name="x", shape=SHAPES["mid_gqa"], weights=make_weights_np(SHAPES["mid_gqa"], 4, 3.0), device="cuda:0")
     sp, pp = synth.flat_docs("gl", 12, (40, 33), 9, seed=6)

@@ -990,7 +990,14 @@ def main():
                 loop.enqueue()
             last = loop.token(3 * nstep - 1)
             dtl = time.perf_counter() - t0
+            # a decode step against the HBM roof: every weight byte once (lm_head included) + the K/V rows behind the token once
+            cfd = lm.hf_model.config
+            layer_w = cfd.num_hidden_layers * (cfd.hidden_size * (lm.hf_model.H + 2 * Hkv) * D + lm.hf_model.H * D * cfd.hidden_size +
+                                               3 * cfd.hidden_size * cfd.intermediate_size)
+            dec_bytes = 2 * layer_w + 2 * cfd.vocab_size * cfd.hidden_size + (S + q + 5 * nstep) * 2 * L * Hkv * D * 2
+            result["decode_bytes"] = {"layer_weight_params": layer_w, "fp16_bytes_per_token": dec_bytes}
             result["decode_device_loop"] = {"tokens_per_s": 2 * nstep / dtl, "ms_per_token": dtl / (2 * nstep) * 1e3,
+                                            "hbm_frac": dec_bytes / (dtl / (2 * nstep)) / 1e9 / HBM_PEAK_GBS,
                                             "kv_len": S + q + 5 * nstep, "last_token": last,
                                             "how": "GreedyLoop: one hipGraph replay per token (forward + pc_greedy_advance), no "
                                                    "host round trip; what GenerationEngine.generate uses for greedy decoding"}
@@ -1076,8 +1083,14 @@ def main():
             loop8.token(95)
             loop8_rate = 64 / (time.perf_counter() - t0)
             del loop8
+        # (int8 images: half the layer-weight bytes; lm_head and K/V stay fp16 -- the fraction is lower than fp16's although the
+        # step is faster: what is left is per-launch fixed cost, not bytes)
+        db = result.get("decode_bytes")
+        i8_bytes = None if db is None else db["fp16_bytes_per_token"] - db["layer_weight_params"]
         result["int8_weights"] = {"ttft_ms": sorted(ts8[2:])[len(ts8[2:]) // 2], "decode_tokens_per_s": 32 / dt8,
                                   "decode_device_loop_tokens_per_s": loop8_rate,
+                                  "decode_device_loop_hbm_frac": None if (loop8_rate is None or i8_bytes is None) else
+                                  i8_bytes * loop8_rate / 1e9 / HBM_PEAK_GBS,
                                   "mode": "llm_int8" if lm8.hf_model.llm_int8 else "weight_only",
                                   "outlier_columns_last_layer": outl,
                                   "what": "load_in_8bit=True: LLM.int8() as published (row-wise absmax int8 weights, vector-wise "

@@ -330,6 +330,11 @@ int pc_gemm_part(const void* wf, const float* part_o, const float* part_ml, int3
  *              part_o, part_ml, part_nsplit, part_head_dim (epilogue ADD, M = 1, K = H * part_head_dim <= 4096): the split-KV partials a
  *              pc_attn launch with defer_merge left (2..8 per row) -- the o_proj of a decode step merges them in its prologue
  *              with attn_combine_kernel's arithmetic (same bits), and the merge launch disappears
+ *              xf_hi + x_codes8, x_scale, x_flags (epilogues QKV_ROPE, SILU, ADD; K <= 6144): what a quantiser launch left
+ *              (pc_quant_act_i8 / pc_rmsnorm_quant_i8: fp16 plane, codes8 operand image, row scales, >= 16384 flag bytes) -- no quantiser
+ *              arithmetic in this launch, but this file's K loop (image copied to LDS once, activation operands read from there, two
+ *              weight blocks in flight); bit-identical to pc_gemm with x_scale + flags.  The form of 5..16 rows, where quantising all
+ *              rows in every workgroup costs more than the launch
  *   outputs    y / ldy (STORE, ADD), of_hi (+ optional of_lo) fragment planes (SILU), the q|k|v fields (QKV_ROPE) as in pc_gemm_args
  *   row_max_out, flags_out   (SILU) per output pair-tile and row the largest |fp16 value| below the threshold, [N/32][16] floats, and
  *              one flag byte per intermediate feature holding an entry at or above it (set-only: the buffer must be zero)
@@ -355,6 +360,7 @@ typedef struct pc_gemm_q8_args {
     const int32_t* past_len_dev; void* k_lo; void* v_lo; int64_t lo_batch_stride, lo_head_stride; int32_t lo_base;
     void* dbg_codes; float* dbg_scale; void* dbg_flags;
     const float* part_o; const float* part_ml; int32_t part_nsplit, part_head_dim;
+    const void* x_codes8; const float* x_scale; const void* x_flags;
 } pc_gemm_q8_args;
 int pc_gemm_q8(const pc_gemm_q8_args* args, void* stream);
 /* pc_rmsnorm_frag -- LlamaRMSNorm (llama2.py:103-108) on the fp32 residual stream, output as fragment planes;

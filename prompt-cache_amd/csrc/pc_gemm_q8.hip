@@ -43,6 +43,8 @@ struct Q8Params {
     signed char* dbg_codes; float* dbg_scale; unsigned char* dbg_flags;   // tests: workgroup 0's codes image / scales / flags
     // P form, source "partials" (M = 1): the split-KV partials pc_attn left (defer_merge) are merged in the prologue
     pcm::PartSrc part;
+    // P form, source "image" (5..16 rows): a quantiser launch left the codes as the operand image, the row scales and the flag bytes
+    const signed char* img8; const float* img_scale; const unsigned char* img_flags;
 };
 using pcm::PartLoads;
 
@@ -180,11 +182,13 @@ __device__ __forceinline__ bool q8_correction(const GemmParams& p, const uint32_
 template <int TT> struct Q8Depth { static constexpr int NW = TT == 1 ? 8 : (TT == 2 ? 4 : (TT <= 6 ? 2 : 1)); };
 
 // RI: prologue passes (two rows each): 2 for M <= 4 (decode; both K-loop buffers are then in flight across the prologue), 8 for M <= 16
-// SRC: 0 the fp16 plane, 1 the fp32 residual stream under an RMSNorm, 2 pc_attn's split-KV partials of one row (M = 1)
+// SRC: 0 the fp16 plane, 1 the fp32 residual stream under an RMSNorm, 2 pc_attn's split-KV partials of one row (M = 1),
+// 3 the operand image + scales + flags of a quantiser launch (pc_quant_act_i8 / pc_rmsnorm_quant_i8 codes8): copied into LDS, no
+// quantiser arithmetic here -- the K loop of this file (activation operands from LDS, two blocks in flight) for 5..16 rows
 template <int T, int EPI, int SRC, int G, int RI>
 __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
     const GemmParams& p = qp.g;
-    constexpr bool NORM = SRC == 1, PART = SRC == 2;
+    constexpr bool NORM = SRC == 1, PART = SRC == 2, IMG = SRC == 3;
     constexpr int GP = (G + 1) / 2;                      // PART: chunks per thread (all 512 threads on the one row)
     static_assert(!PART || (RI == 2 && GP == 1), "the partials source is for one row of K <= 4096");
     constexpr int TT = (EPI == EPI_SILU) ? 2 * T : T;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
             } else {
                 h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 hv[it][k] = z;
-                if constexpr (!PART) {
+                if constexpr (!PART && !IMG) {
                     if (row < M && i < nv) hv[it][k] = *(const h8*)(p.xf_hi + frag_off(row, i * 8, KS));
                 }
             }
@@ -249,6 +253,17 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
     }
     [[maybe_unused]] PartLoads pl;
     if constexpr (PART) pcm::part_issue(qp.part, 0, (tid < nv ? tid : nv - 1) * 8, pl);
+    [[maybe_unused]] u32x4 ci[IMG ? 4 * G : 1];          // IMG: this thread's 16-byte entries of the image (K entries), its flag dwords
+    [[maybe_unused]] uint32_t cf[IMG ? G : 1];
+    if constexpr (IMG) {
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) {
+            const int e = tid + j * kThreads;
+            ci[j] = ((const u32x4*)qp.img8)[e < K ? e : K - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) cf[j] = ((const uint32_t*)qp.img_flags)[tid * G + j];
+    }
     if constexpr (NORM) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
@@ -291,7 +306,18 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
         yold = *(const f4*)(p.y + (int64_t)(m < M ? m : M - 1) * p.ldy + unit * 16 + g * 4);
     }
     // the flag bytes start at zero; a flag buffer of the NEXT producer is cleared by the whole grid on the side
-    for (int i = tid; i < G * 512; i += kThreads) ((uint32_t*)lflag)[i] = 0u;
+    if constexpr (IMG) {
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) {
+            const int e = tid + j * kThreads;
+            if (e < K) ((u32x4*)img)[e] = ci[j];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) ((uint32_t*)lflag)[tid * G + j] = cf[j];
+        if (tid < M) lxs[tid] = qp.img_scale[tid];
+    } else {
+        for (int i = tid; i < G * 512; i += kThreads) ((uint32_t*)lflag)[i] = 0u;
+    }
     if (qp.flags_clear) {
         const u32x4 z4 = {0u, 0u, 0u, 0u};
         for (int i = bx * kThreads + tid; i < (qp.clear_bytes >> 4); i += gridDim.x * kThreads) ((u32x4*)qp.flags_clear)[i] = z4;
@@ -346,7 +372,9 @@ __global__ __launch_bounds__(kThreads) void gemm_q8p_kernel(const Q8Params qp) {
             }
         }
     }
-    if constexpr (PART) {
+    if constexpr (IMG) {
+        // (image, flags and scales are in LDS behind the barrier above)
+    } else if constexpr (PART) {
         // ---- 3'. / 4'. one row, one chunk per thread: merge, flags, the row maximum over the eight waves, codes ----
         const h8 hp = __builtin_bit_cast(h8, pcm::part_merge(qp.part, pl));
         float mx = 0.f;
@@ -1006,6 +1034,9 @@ int launch_q8p_g(const Q8Params& qp, int units, int K, hipStream_t s) {
     if constexpr (!NORM && EPI == EPI_ADD) {
         if (qp.part.part_o) return launch_q8p_one<T, EPI, 2, 2, 2>(qp, units, K, s);           // (pc_gemm_q8 checked: M = 1, K <= 4096)
     }
+    if constexpr (EPI != EPI_STORE) {
+        if (qp.img8) return K <= 4096 ? launch_q8p_one<T, EPI, 3, 2, 2>(qp, units, K, s) : launch_q8p_one<T, EPI, 3, 3, 2>(qp, units, K, s);
+    }
     if (qp.g.M <= 4) return K <= 4096 ? launch_q8p_one<T, EPI, NORM ? 1 : 0, 2, 2>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM ? 1 : 0, 3, 2>(qp, units, K, s);
     return K <= 4096 ? launch_q8p_one<T, EPI, NORM ? 1 : 0, 2, kQ8RI>(qp, units, K, s) : launch_q8p_one<T, EPI, NORM ? 1 : 0, 3, kQ8RI>(qp, units, K, s);
 }
@@ -1043,9 +1074,12 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
                "pc_gemm_q8: need 1 <= M <= 16, N %% 16 == 0, K %% 64 == 0");
     PC_REQUIRE(a->wf && a->w_scale && ((uintptr_t)a->w_scale & 15) == 0 && a->w_codes_t && a->ldt >= N && (!qkv || a->row_perm), PC_ERR_ARG,
                "pc_gemm_q8: needs the int8 weight image, 16-byte aligned w_scale, w_codes_t (ldt >= N) (and row_perm for q|k|v)");
-    const bool norm = a->x != nullptr, fform = a->row_max != nullptr, part = a->part_o != nullptr;
-    PC_REQUIRE(norm ? (a->norm_weight && !a->xf_hi && !fform && !part) : ((a->xf_hi != nullptr) != part), PC_ERR_ARG,
+    const bool norm = a->x != nullptr, fform = a->row_max != nullptr, part = a->part_o != nullptr, image = a->x_codes8 != nullptr;
+    PC_REQUIRE(norm ? (a->norm_weight && !a->xf_hi && !fform && !part && !image) : ((a->xf_hi != nullptr) != part), PC_ERR_ARG,
                "pc_gemm_q8: pass exactly one of (x, norm_weight), the fp16 activation plane xf_hi, or pc_attn's partials part_o");
+    PC_REQUIRE(!image || (a->xf_hi && a->x_scale && a->x_flags && !fform && !part && epi != PC_GEMM_EPI_STORE &&
+                          (((uintptr_t)a->x_codes8 | (uintptr_t)a->x_flags) & 15) == 0), PC_ERR_ARG,
+               "pc_gemm_q8: x_codes8 (a quantiser launch's operand image) goes with xf_hi (the fp16 plane), x_scale, x_flags (>= 16384 bytes), 16-byte aligned");
     PC_REQUIRE(!part || (a->part_ml && M == 1 && K <= 4096 && epi == PC_GEMM_EPI_ADD && !fform && a->part_nsplit >= 2 && a->part_nsplit <= pcm::kPartNS &&
                          a->part_head_dim > 0 && a->part_head_dim % 8 == 0 && K % a->part_head_dim == 0 &&
                          (((uintptr_t)a->part_o | (uintptr_t)a->part_ml) & 15) == 0), PC_ERR_ARG,
@@ -1065,6 +1099,7 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
     qp.threshold = a->threshold;
     qp.flags_clear = (unsigned char*)a->flags_clear; qp.clear_bytes = a->clear_bytes;
     qp.dbg_codes = (signed char*)a->dbg_codes; qp.dbg_scale = a->dbg_scale; qp.dbg_flags = (unsigned char*)a->dbg_flags;
+    qp.img8 = (const signed char*)a->x_codes8; qp.img_scale = a->x_scale; qp.img_flags = (const unsigned char*)a->x_flags;
     qp.part.part_o = a->part_o; qp.part.part_ml = a->part_ml; qp.part.nsplit = a->part_nsplit; qp.part.D = a->part_head_dim; qp.part.q_len = 1;
     PC_REQUIRE(!a->dbg_codes || (a->dbg_scale && a->dbg_flags && !fform), PC_ERR_ARG, "pc_gemm_q8: dbg_codes goes with dbg_scale and dbg_flags (P form)");
 
@@ -1100,7 +1135,7 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
     // ---- P form ----
     PC_REQUIRE(K <= 6144, PC_ERR_ARG, "pc_gemm_q8: the in-launch quantiser stages K <= 6144 features in LDS (K = %d)", K);
     if (qkv) {
-        PC_REQUIRE(norm, PC_ERR_ARG, "pc_gemm_q8: q|k|v takes the fused-RMSNorm source");
+        PC_REQUIRE(norm || image, PC_ERR_ARG, "pc_gemm_q8: q|k|v takes the fused-RMSNorm source or a quantiser launch's image");
         PC_REQUIRE(M == a->B * a->q_len && a->D % 16 == 0 && a->H > 0 && a->Hkv > 0, PC_ERR_ARG, "pc_gemm_q8: bad q|k|v shape");
         PC_REQUIRE(a->cs && a->q_hi && a->q_lo && a->k_arena && a->v_arena, PC_ERR_ARG, "pc_gemm_q8: null q|k|v pointer");
         PC_REQUIRE((int64_t)a->past_len + a->q_len <= a->cap, PC_ERR_BOUNDS,
@@ -1119,7 +1154,7 @@ PC_EXPORT int pc_gemm_q8(const pc_gemm_q8_args* a, void* stream) {
         return launch_q8p<EPI_ROPE, true, 4>(qp, choose_T(p.ntiles), p.ntiles, K, s);
     }
     if (epi == PC_GEMM_EPI_SILU) {
-        PC_REQUIRE(norm && N % 64 == 0 && a->of_hi, PC_ERR_ARG, "pc_gemm_q8: the SiLU epilogue takes the fused-RMSNorm source, N = 2*inter (inter %% 32 == 0), of_hi");
+        PC_REQUIRE((norm || image) && N % 64 == 0 && a->of_hi, PC_ERR_ARG, "pc_gemm_q8: the SiLU epilogue takes the fused-RMSNorm source, N = 2*inter (inter %% 32 == 0), of_hi");
         PC_REQUIRE((a->row_max_out == nullptr) == (a->flags_out == nullptr), PC_ERR_ARG, "pc_gemm_q8: row_max_out and flags_out go together");
         p.npairs = N / 32; p.KSo = (N / 2) / 32;
         return launch_q8p<EPI_SILU, true, 4>(qp, choose_T(p.npairs), p.npairs, K, s);

@@ -101,7 +101,8 @@ class GemmQ8Args(C.Structure):
                 ("past_len_dev", _vp), ("k_lo", _vp), ("v_lo", _vp), ("lo_batch_stride", _i64), ("lo_head_stride", _i64),
                 ("lo_base", _i32),
                 ("dbg_codes", _vp), ("dbg_scale", _vp), ("dbg_flags", _vp),
-                ("part_o", _vp), ("part_ml", _vp), ("part_nsplit", _i32), ("part_head_dim", _i32)]
+                ("part_o", _vp), ("part_ml", _vp), ("part_nsplit", _i32), ("part_head_dim", _i32),
+                ("x_codes8", _vp), ("x_scale", _vp), ("x_flags", _vp)]
 
 
 # name -> (restype, argtypes); mirrors include/promptcache_hip.h one to one

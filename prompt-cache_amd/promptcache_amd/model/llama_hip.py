@@ -378,6 +378,7 @@ class LlamaHIP:
             self.q8_down_small = tuple(int(v) for v in os.environ.get("PC_Q8_DOWN_SMALL", "1,1").split(","))   # <= 4 rows (decode)
             self.q8_p_max_rows = int(os.environ.get("PC_Q8_P_MAX_ROWS", "4"))
             self.q8_defer_merge = os.environ.get("PC_Q8_DEFER_MERGE", "1") != "0"
+            self.q8_image = os.environ.get("PC_Q8_IMAGE", "1") != "0"    # 5..16 rows: pc_gemm_q8 on the quantiser launches' images
             self._q8_flags = torch.zeros(16384, dtype=torch.uint8, device=dev)
             self._q8_pmax = torch.zeros((c.intermediate_size // 16, 16), dtype=torch.float32, device=dev)
             self._i8_zero = torch.zeros(((self.SKINNY_MAX_ROWS + 15) // 16) * 16 * kmax, dtype=self.dtype, device=dev)
@@ -866,6 +867,7 @@ class LlamaHIP:
             fl = self._i8_flags
             pm = self._q8_pmax
             ksc, kctr = self._ks_buffers(hid) if q8_down else (None, None)
+            q8_img = q8_down and self.q8_image and hid <= 6144
 
             def quant(slot, act_hi, K, buf, norm=None):
                 codes, xs = buf[0], buf[1]
@@ -879,22 +881,40 @@ class LlamaHIP:
                 kp, vp = arena.k_plane(li), arena.v_plane(li)
                 kvlo, lo_base = tail(li)
                 cd, xs = quant(0, xh, hid, bufs[0], norm=(x, lw["ln1"]))
-                n.gemm_qkv_rope_a8c(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, fl[0], xh, lw["wqkv_t8"], self._qkv_perm_i32, T, hid, cs,
-                                    q16, q16l, H * D, kp, vp, arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len,
-                                    arena.cap, past_dev, kv_lo=kvlo and kvlo[:4], lo_base=lo_base, codes8=x8)
+                if q8_img:
+                    # (5..16 rows: the quantiser stays a launch, but the projection is pc_gemm_q8's -- the image copied to LDS once,
+                    # activation operands read from there, two weight blocks in flight; same bits as pc_gemm with x_scale + flags)
+                    lo4 = (None, None, 0, 0) if not kvlo else kvlo[:4]
+                    n.gemm_q8(epilogue=n.EPI_QKV_ROPE, wf=lw["wqkv_f"], w_scale=lw["wqkv_s"], w_codes_t=lw["wqkv_t8"], row_perm=self._qkv_perm_i32,
+                              xf_hi=xh, x_codes8=x8, x_scale=xs, x_flags=fl[0], M=T, K=hid, cs=cs, q_hi=q16, q_lo=q16l, q_token_stride=H * D,
+                              k_arena=kp, v_arena=vp, arena_batch_stride=arena.batch_stride, arena_head_stride=arena.head_stride, B=B, H=H,
+                              Hkv=Hkv, D=D, q_len=q_len, past_len=past_len, cap=arena.cap, past_len_dev=past_dev, k_lo=lo4[0], v_lo=lo4[1],
+                              lo_batch_stride=lo4[2], lo_head_stride=lo4[3], lo_base=lo_base)
+                else:
+                    n.gemm_qkv_rope_a8c(lw["wqkv_f"], lw["wqkv_s"], cd, zero, xs, fl[0], xh, lw["wqkv_t8"], self._qkv_perm_i32, T, hid, cs,
+                                        q16, q16l, H * D, kp, vp, arena.batch_stride, arena.head_stride, B, H, Hkv, D, q_len, past_len,
+                                        arena.cap, past_dev, kv_lo=kvlo and kvlo[:4], lo_base=lo_base, codes8=x8)
                 n.attn_fwd(q16, q_len * H * D, H * D, kp, vp, arena.batch_stride, arena.head_stride, None, 0, 0,
                            B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                            q_lo=q16l, kv_lo=kvlo,
                            gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
                 cd, xs = quant(1, ah, H * D, bufs[1])
-                n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid,
-                                  codes8=a8)
+                if q8_img and H * D <= 6144:
+                    n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wo_f"], w_scale=lw["wo_s"], w_codes_t=lw["wo_t8"], xf_hi=ah, x_codes8=a8, x_scale=xs,
+                              x_flags=fl[1], M=T, N=hid, K=H * D, y=x, ldy=hid)
+                else:
+                    n.gemm_skinny_a8c(lw["wo_f"], lw["wo_s"], cd, zero, xs, fl[1], ah, lw["wo_t8"], T, hid, H * D, n.EPI_ADD, y=x, ldy=hid,
+                                      codes8=a8)
                 cd, xs = quant(2, xh, hid, bufs[2], norm=(x, lw["ln2"]))
                 # (more than q8_p_max_rows rows: the quantisers of q|k|v, o_proj and gate|up stay launches -- a 12-row prologue in
                 # every workgroup costs more vector ALU time than the launch it saves -- but down_proj reads what this SiLU
                 # epilogue leaves: flag slot 3 was zeroed by the quantiser above, slot 0 is zeroed by the down_proj launch)
-                n.gemm_skinny_a8c(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, fl[2], xh, lw["wgu_t8"], T, 2 * inter, hid, n.EPI_SILU,
-                                  of_hi=ch, of_lo=cl, codes8=x8, row_max_out=pm if q8_down else None, flags_out=fl[3] if q8_down else None)
+                if q8_img:
+                    n.gemm_q8(epilogue=n.EPI_SILU, wf=lw["wgu_f"], w_scale=lw["wgu_s"], w_codes_t=lw["wgu_t8"], xf_hi=xh, x_codes8=x8, x_scale=xs,
+                              x_flags=fl[2], M=T, N=2 * inter, K=hid, of_hi=ch, of_lo=cl, row_max_out=pm, flags_out=fl[3])
+                else:
+                    n.gemm_skinny_a8c(lw["wgu_f"], lw["wgu_s"], cd, zero, xs, fl[2], xh, lw["wgu_t8"], T, 2 * inter, hid, n.EPI_SILU,
+                                      of_hi=ch, of_lo=cl, codes8=x8, row_max_out=pm if q8_down else None, flags_out=fl[3] if q8_down else None)
                 if q8_down:
                     n.gemm_q8(epilogue=n.EPI_ADD, wf=lw["wdown_f"], w_scale=lw["wdown_s"], w_codes_t=lw["wdown_t8"], xf_hi=ch, row_max=pm,
                               row_max_units=inter // 16, flags_in=fl[3], M=T, N=hid, K=inter, y=x, ldy=hid, ks_tiles=self.q8_down[0],

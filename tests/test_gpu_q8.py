@@ -336,3 +336,72 @@ def test_fp16_o_proj_merges_the_attention_partials_itself_bit_for_bit(S, H, D):
     assert torch.equal(y_a, y_b), float((y_a - y_b).abs().max())
     ref = base.cpu().numpy() + (n.from_act_frags(ah, 1).float().cpu().numpy() + n.from_act_frags(al, 1).float().cpu().numpy()) @ w.float().cpu().numpy().T
     assert np.abs(y_b.cpu().numpy() - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("T,nout", [(12, 0), (12, 4), (16, 30), (5, 1)])
+def test_image_source_equals_pc_gemm_on_the_quantiser_outputs_bit_for_bit(T, nout):
+    """5..16 rows: the quantiser stays a launch, pc_gemm_q8 takes its operand image / scales / flags (x_codes8) -- residual add, SiLU and
+    q|k|v epilogues against pc_gemm with x_scale + flags."""
+    n = _n()
+    rng = np.random.default_rng(77 + T + nout)
+    K, inter = 2048, 1408
+    x = _acts(rng, T, K, nout)
+    hi, _ = n.to_act_frags(torch.from_numpy(x).to(DEV))
+    codes, zero = torch.empty_like(hi), torch.zeros_like(hi)
+    xs = torch.empty(T, dtype=torch.float32, device=DEV)
+    flags = torch.zeros((2, 16384), dtype=torch.uint8, device=DEV)
+    c8 = torch.zeros((1, K // 64, 64, 16), dtype=torch.int8, device=DEV)
+    n.quant_act_i8(hi, True, T, K, codes, xs, flags[0], flags[1], codes8=c8)
+    # residual add
+    N = 1024
+    w = (0.03 * rng.standard_normal((N, K))).astype(np.float32)
+    q, sc = n.quantize_rows_int8(torch.from_numpy(w).to(DEV))
+    wf8, qt = n.to_weight_frags_i8(q), q.t().contiguous()
+    base = torch.from_numpy(rng.standard_normal((T, N)).astype(np.float32)).to(DEV)
+    y_a, y_b = base.clone(), base.clone()
+    n.gemm_skinny_a8c(wf8, sc, codes, zero, xs, flags[0], hi, qt, T, N, K, n.EPI_ADD, y=y_a, ldy=N, codes8=c8)
+    n.gemm_q8(epilogue=n.EPI_ADD, wf=wf8, w_scale=sc, w_codes_t=qt, xf_hi=hi, x_codes8=c8, x_scale=xs, x_flags=flags[0], M=T, N=N, K=K, y=y_b, ldy=N)
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_b)
+    # gate|up + SiLU (+ what it leaves for down_proj)
+    w = (0.2 * rng.standard_normal((2 * inter, K))).astype(np.float32)
+    q, sc = n.quantize_rows_int8(torch.from_numpy(w).to(DEV))
+    wf8, qt = n.to_weight_frags_i8(q), q.t().contiguous()
+    oshape = (1, inter // 32, 64, 8)
+    oh_a, ol_a, oh_b, ol_b = (torch.zeros(oshape, dtype=torch.float16, device=DEV) for _ in range(4))
+    pm_a, pm_b = (torch.zeros((inter // 16, 16), dtype=torch.float32, device=DEV) for _ in range(2))
+    fo_a, fo_b = (torch.zeros(16384, dtype=torch.uint8, device=DEV) for _ in range(2))
+    n.gemm_skinny_a8c(wf8, sc, codes, zero, xs, flags[0], hi, qt, T, 2 * inter, K, n.EPI_SILU, of_hi=oh_a, of_lo=ol_a, codes8=c8, row_max_out=pm_a,
+                      flags_out=fo_a)
+    n.gemm_q8(epilogue=n.EPI_SILU, wf=wf8, w_scale=sc, w_codes_t=qt, xf_hi=hi, x_codes8=c8, x_scale=xs, x_flags=flags[0], M=T, N=2 * inter, K=K,
+              of_hi=oh_b, of_lo=ol_b, row_max_out=pm_b, flags_out=fo_b)
+    torch.cuda.synchronize()
+    assert torch.equal(oh_a, oh_b) and torch.equal(ol_a, ol_b) and torch.equal(pm_a[:, :T], pm_b[:, :T]) and torch.equal(fo_a, fo_b)
+    # q|k|v + RoPE + append
+    B, H, Hkv, D, q_len, past = 1, 8, 4, 128, T, 9
+    W = (H + 2 * Hkv) * D
+    wq = (0.05 * rng.standard_normal((W, K))).astype(np.float32)
+    perm = n.qkv_rope_row_perm(H + 2 * Hkv, D).to(DEV)
+    qq, scq = n.quantize_rows_int8(torch.from_numpy(wq).to(DEV))
+    wf8p, scp, qtt = n.to_weight_frags_i8(qq[perm].contiguous()), scq[perm].contiguous(), qq.t().contiguous()
+    perm32 = perm.to(torch.int32)
+    cs = torch.empty((T, D // 2, 2), dtype=torch.float32, device=DEV)
+    pos = torch.from_numpy(rng.integers(0, 2000, size=T).astype(np.int32)).to(DEV)
+    inv = torch.from_numpy((1.0 / (10000.0 ** (np.arange(0, D, 2, dtype=np.float64) / D))).astype(np.float32)).to(DEV)
+    n.rope_table(pos, inv, cs, T, D)
+    cap = past + q_len + 2
+    outs = []
+    for new in (False, True):
+        arena = torch.zeros((B, 2, Hkv, cap, D), dtype=torch.float16, device=DEV)
+        qh = torch.zeros((T, H * D), dtype=torch.float16, device=DEV); ql = torch.zeros_like(qh)
+        if new:
+            n.gemm_q8(epilogue=n.EPI_QKV_ROPE, wf=wf8p, w_scale=scp, w_codes_t=qtt, row_perm=perm32, xf_hi=hi, x_codes8=c8, x_scale=xs,
+                      x_flags=flags[0], M=T, K=K, cs=cs, q_hi=qh, q_lo=ql, q_token_stride=H * D, k_arena=arena[:, 0], v_arena=arena[:, 1],
+                      arena_batch_stride=2 * Hkv * cap * D, arena_head_stride=cap * D, B=B, H=H, Hkv=Hkv, D=D, q_len=q_len, past_len=past, cap=cap)
+        else:
+            n.gemm_qkv_rope_a8c(wf8p, scp, codes, zero, xs, flags[0], hi, qtt, perm32, T, K, cs, qh, ql, H * D, arena[:, 0], arena[:, 1],
+                                2 * Hkv * cap * D, cap * D, B, H, Hkv, D, q_len, past, cap, codes8=c8)
+        torch.cuda.synchronize()
+        outs.append((qh, ql, arena))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

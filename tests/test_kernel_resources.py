@@ -24,10 +24,10 @@ def test_kernel_count_and_the_hot_path_kernels_are_there():
     rows = _rows()
     names = [r["demangled"] for r in rows]
     # round 2 shipped 748 instantiations of the weight-streaming template alone
-    # (round 5: + 8 gemm_dense_kernel<.., LO8> and 4 quant_rows_kernel instantiations; + 50 gemm_q8p_kernel, 3 gemm_q8f_kernel and 4 gemm_q8c_kernel:
+    # (round 5: + 8 gemm_dense_kernel<.., LO8> and 4 quant_rows_kernel instantiations; + 70 gemm_q8p_kernel, 3 gemm_q8f_kernel and 4 gemm_q8c_kernel:
     # the LLM.int8 projections with the quantiser inside, csrc/pc_gemm_q8.hip)
-    assert len(rows) <= 700, len(rows)
-    for must in ("kv_copy_kernel", "attn_small_kernel<128, false, 0, false, 1>", "attn_small_kernel<128, false, 0, true, 1>", "attn_small_kernel<128, false, 0, true, 2>", "kv_row_table_kernel", "pca::attn_ring_kernel<true, false, false>", "pca::attn_ring_kernel<true, false, true>", "gemm_skinny_ks_kernel", "gemm_q8p_kernel<3, 2, 1, 2, 2>", "gemm_q8p_kernel<3, 3, 1, 2, 2>", "gemm_q8p_kernel<1, 1, 0, 2, 2>", "gemm_q8p_kernel<1, 1, 2, 2, 2>", "gemm_q8p_kernel<3, 2, 1, 2, 8>", "gemm_q8f_kernel<4, 2>", "gemm_q8c_kernel<1, 11>", "gemm_part_kernel",
+    assert len(rows) <= 725, len(rows)
+    for must in ("kv_copy_kernel", "attn_small_kernel<128, false, 0, false, 1>", "attn_small_kernel<128, false, 0, true, 1>", "attn_small_kernel<128, false, 0, true, 2>", "kv_row_table_kernel", "pca::attn_ring_kernel<true, false, false>", "pca::attn_ring_kernel<true, false, true>", "gemm_skinny_ks_kernel", "gemm_q8p_kernel<3, 2, 1, 2, 2>", "gemm_q8p_kernel<3, 3, 1, 2, 2>", "gemm_q8p_kernel<1, 1, 0, 2, 2>", "gemm_q8p_kernel<1, 1, 2, 2, 2>", "gemm_q8p_kernel<3, 2, 1, 2, 8>", "gemm_q8f_kernel<4, 2>", "gemm_q8c_kernel<1, 11>", "gemm_part_kernel", "gemm_q8p_kernel<3, 2, 3, 2, 2>", "gemm_q8p_kernel<1, 1, 3, 2, 2>",
                  "pcg::gemm_rows_kernel<4, 3, 2, true,", "pcg::gemm_rows_kernel<8, 2, 2, true, 3, 3, 2, 768>", "gemm_dense_kernel<2, 2, true, false, false>", "gemm_dense_kernel<2, 3, false, false, true>", "rope_append_kernel"):
         assert any(must in n for n in names), must
     # register budgets the launch bounds promise: 512-thread kernels at most 256 registers, 768-thread ones 168, 1024-thread ones 128

@@ -235,7 +235,8 @@ int pc_embed_gather(const void* table, const int64_t* ids, void* out, int32_t n_
  *   epilogue   PC_GEMM_EPI_STORE     y[m][n]  = sum_k X[m][k] W[n][k]   fp32 [M][ldy]; kslices > 1: the K axis is also split
  *                                    across workgroups, slice s writes its partial sums to y + s*M*ldy (slabs [kslices][M][ldy];
  *                                    pc_rmsnorm_frag adds them to the residual stream in fixed order)
- *              PC_GEMM_EPI_ADD       y[m][n] += ...   fp32 residual stream, in place.  With ks_counters (M <= 16, fp16 weights):
+ *              PC_GEMM_EPI_ADD       y[m][n] += ...   fp32 residual stream, in place.  With ks_counters (M <= 32, fp16 weights;
+ *                                    17..32 rows: ks_tiles 1, 2 or 4 and twice the scratch bytes):
  *                                    K is cut into `kslices` (1..8) slices that run as separate workgroups of `ks_tiles`
  *                                    (1, 2, 4, 8) output tiles each, and the partial tiles are added INSIDE the launch -- every
  *                                    workgroup writes its partial through to ks_scratch (>= pc_gemm_skinny_ks_scratch_bytes(N,

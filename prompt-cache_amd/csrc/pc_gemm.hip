@@ -274,8 +274,8 @@ PC_EXPORT int pc_gemm(const pc_gemm_args* a, void* stream) {
 
     // ---- residual add with K split across workgroups and the reduction inside the launch (pc_gemm_ks.hip) ----
     if (epi == PC_GEMM_EPI_ADD && a->ks_counters) {
-        PC_REQUIRE(!a->w_scale && !norm && a->xf_lo && M <= 16, PC_ERR_ARG,
-                   "pc_gemm: the in-launch K reduction takes fp16 weights, both activation planes, M <= 16");
+        PC_REQUIRE(!a->w_scale && !norm && a->xf_lo && M <= 32, PC_ERR_ARG,
+                   "pc_gemm: the in-launch K reduction takes fp16 weights, both activation planes, M <= 32");
         return launch_skinny_ks(a->wf, a->xf_hi, a->xf_lo, M, N, K, a->y, a->ldy, kslices, a->ks_tiles, a->ks_scratch,
                                 a->ks_scratch_bytes, a->ks_counters, a->rows_dev, s);
     }

@@ -40,12 +40,16 @@ struct KsParams {
 
 // DB: the K loop keeps TWO blocks of U k-steps in flight (block b + 1 is requested before block b is consumed, block b + 2 into
 // b's registers right after), addresses as a wave-uniform base + one 32-bit lane offset per k-step (pc_gemm_q8.hip's loop)
-template <int T, int U, bool DB = false>
+// MT: row tiles (1: M <= 16; 2: M <= 32 -- the 17..32-row questions of BASELINE config 3 keep their K slices and the in-launch residual
+// add instead of leaving slabs to a pc_rmsnorm_frag launch); an item = (row tile a, weight tile t), MT * T <= 8 items, one per wave
+template <int T, int U, bool DB = false, int MT = 1>
 __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams kp) {
     const GemmParams& p = kp.g;
-    __shared__ __attribute__((aligned(16))) float red_raw[kWaves * T * 64 * 4];
+    static_assert(MT * T <= kWaves && (!DB || MT == 1), "one wave per (row tile, weight tile) item");
+    constexpr int NI = MT * T;
+    __shared__ __attribute__((aligned(16))) float red_raw[kWaves * NI * 64 * 4];
     __shared__ int s_last;
-    float (*red)[T][64][4] = (float (*)[T][64][4])red_raw;
+    float (*red)[NI][64][4] = (float (*)[NI][64][4])red_raw;
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = blockIdx.x, by = blockIdx.y, KS = p.KS, S = p.kslices;
@@ -53,22 +57,29 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
     wave_k_range<false>(p, by, wave, ks0, ks1);
     int tile[T];
     wg_tiles<T, EPI_ADD>(p, bx, tile);
-    f4 acc[1][T];
+    f4 acc[MT][T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[0][t] = z; }
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int t = 0; t < T; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[a][t] = z; }
     const _Float16* wbase[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) wbase[t] = p.wf + ((int64_t)tile[t] * KS * 64 + lane) * 8;
     const _Float16* xh_base = p.xf_hi + lane * 8;
     const _Float16* xl_base = p.xf_lo + lane * 8;
-    bool row_ok[1];
-    row_ok[0] = m < (p.m_dev ? (*p.m_dev < p.M ? *p.m_dev : p.M) : p.M);
+    bool row_ok[MT];
+    const int rows_live = p.m_dev ? (*p.m_dev < p.M ? *p.m_dev : p.M) : p.M;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) row_ok[a] = a * 16 + m < rows_live;
+    // this wave's item: row tile ia, weight tile it (waves behind the items repeat the last one and store nothing)
+    const int item = wave < NI ? wave : NI - 1;
+    const int ia = item / T, it = item - ia * T;
+    const int my_row = ia * 16 + m;
     // the residual tile the last arriver will add to, fetched now (clamped, unconditional; written by that lane only)
     f4 yold;
     {
-        const int tw = wave < T ? wave : T - 1;
-        const int unit = bx * T + tw < p.ntiles ? bx * T + tw : p.ntiles - 1;
-        yold = *(const f4*)(p.y + (int64_t)(m < p.M ? m : p.M - 1) * p.ldy + unit * 16 + g * 4);
+        const int unit = bx * T + it < p.ntiles ? bx * T + it : p.ntiles - 1;
+        yold = *(const f4*)(p.y + (int64_t)(my_row < p.M ? my_row : p.M - 1) * p.ldy + unit * 16 + g * 4);
     }
     if constexpr (DB) {
         const char* wt[T];
@@ -129,26 +140,30 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
         }
     } else {
     int ks = ks0;
-    for (; ks + U <= ks1; ks += U) k_block<1, T, true, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
-    if (ks < ks1) k_block<1, T, true, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
+    for (; ks + U <= ks1; ks += U) k_block<MT, T, true, U, false>(wbase, xh_base, xl_base, KS, ks, U, row_ok, acc);
+    if (ks < ks1) k_block<MT, T, true, U, true>(wbase, xh_base, xl_base, KS, ks, ks1 - ks, row_ok, acc);
     }
 
     // ---- the eight waves' K shares through LDS, fixed order; wave t then holds this workgroup's partial of tile t ----
 #pragma unroll
-    for (int t = 0; t < T; ++t) *(f4*)red[wave][t][lane] = acc[0][t];
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int t = 0; t < T; ++t) *(f4*)red[wave][a * T + t][lane] = acc[a][t];
     lds_barrier();
     f4 v = {0.f, 0.f, 0.f, 0.f};
-    const bool mine = wave < T && bx * T + wave < p.ntiles;          // (clamped duplicate tiles are not stored)
-    if (wave < T) {
+    const bool mine = wave < NI && bx * T + it < p.ntiles;           // (clamped duplicate tiles are not stored)
+    if (wave < NI) {
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
             const f4 x = *(const f4*)red[w][wave][lane];
             v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
         }
     }
-    const int my_tile = bx * T + wave;
+    const int my_tile = bx * T + it;
+    const int64_t slab_tiles = (int64_t)MT * p.ntiles;               // partial tiles per slice: [row tile][weight tile]
+    const int64_t my_slot = (int64_t)ia * p.ntiles + my_tile;
     if (mine) {
-        float* dst = kp.slabs + (((int64_t)by * p.ntiles + my_tile) * 64 + lane) * 4;
+        float* dst = kp.slabs + (((int64_t)by * slab_tiles + my_slot) * 64 + lane) * 4;
         st_wt2(dst, v[0], v[1]);
         st_wt2(dst + 2, v[2], v[3]);
     }
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
 #pragma unroll
     for (int s = 0; s < kMaxSlices; ++s) {
         const int sc = s < S ? s : S - 1;                             // clamped re-read instead of a branch around the loads
-        const float* src = kp.slabs + (((int64_t)sc * p.ntiles + my_tile) * 64 + lane) * 4;
+        const float* src = kp.slabs + (((int64_t)sc * slab_tiles + my_slot) * 64 + lane) * 4;
         a[s] = ld_wt2(src);
         b[s] = ld_wt2(src + 2);
     }
@@ -191,13 +206,13 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_ks_kernel(const KsParams
     for (int s = 0; s < kMaxSlices; ++s)
         if (s < S) { r[0] += a[s].x; r[1] += a[s].y; r[2] += b[s].x; r[3] += b[s].y; }
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    tile_epilogue<EPI_ADD>(p, r, zero, m, my_tile, g, 0, false, zero, zero, true, yold);
+    tile_epilogue<EPI_ADD>(p, r, zero, my_row, my_tile, g, 0, false, zero, zero, true, yold);
 }
 
-template <int T, int U, bool DB = false>
+template <int T, int U, bool DB = false, int MT = 1>
 int launch_ks(const KsParams& kp, hipStream_t s) {
     const dim3 grid(pc_ceil_div(kp.g.ntiles, T), kp.g.kslices);
-    hipLaunchKernelGGL((gemm_skinny_ks_kernel<T, U, DB>), grid, dim3(kThreads), 0, s, kp);
+    hipLaunchKernelGGL((gemm_skinny_ks_kernel<T, U, DB, MT>), grid, dim3(kThreads), 0, s, kp);
     return pc_check_launch("gemm_skinny_ks_kernel");
 }
 
@@ -216,11 +231,12 @@ namespace pcg {
 int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M, int N, int K, float* y, int64_t ldy, int kslices,
                      int tiles_per_wg, void* scratch, int64_t scratch_bytes, void* counters, const int32_t* rows_dev, hipStream_t s) {
     PC_REQUIRE(wf && xf_hi && xf_lo && y && scratch && counters, PC_ERR_ARG, "pc_gemm (ks): null pointer");
-    PC_REQUIRE(M > 0 && M <= 16 && N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0 && ldy >= N && ldy % 4 == 0, PC_ERR_ARG,
-               "pc_gemm (ks): need 1 <= M <= 16, N %% 16 == 0, K %% 32 == 0");
+    PC_REQUIRE(M > 0 && M <= 32 && N > 0 && N % 16 == 0 && K > 0 && K % 32 == 0 && ldy >= N && ldy % 4 == 0, PC_ERR_ARG,
+               "pc_gemm (ks): need 1 <= M <= 32, N %% 16 == 0, K %% 32 == 0");
     PC_REQUIRE(kslices >= 1 && kslices <= kMaxSlices, PC_ERR_ARG, "pc_gemm (ks): kslices %d outside 1..8", kslices);
-    PC_REQUIRE(scratch_bytes >= pc_gemm_skinny_ks_scratch_bytes(N, kslices) && ((uintptr_t)scratch & 15) == 0, PC_ERR_WORKSPACE,
-               "pc_gemm (ks): scratch too small or misaligned");
+    const int mt = M > 16 ? 2 : 1;
+    PC_REQUIRE(scratch_bytes >= mt * pc_gemm_skinny_ks_scratch_bytes(N, kslices) && ((uintptr_t)scratch & 15) == 0, PC_ERR_WORKSPACE,
+               "pc_gemm (ks): scratch too small (17..32 rows: twice pc_gemm_skinny_ks_scratch_bytes) or misaligned");
     KsParams kp;
     memset(&kp, 0, sizeof(kp));
     kp.g.wf = (const _Float16*)wf; kp.g.xf_hi = (const _Float16*)xf_hi; kp.g.xf_lo = (const _Float16*)xf_lo;
@@ -229,6 +245,16 @@ int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M
     // k-steps per block: a wave's K share is K / 32 / (8 kslices) k-steps -- keep the whole share in flight where it fits
     const int share = pc_ceil_div(pc_ceil_div(K / 32, kslices), kWaves);
     static const int db = [] { const char* e = getenv("PC_KS_DB"); return e ? atoi(e) : 0; }();
+    if (mt == 2) {                                       // two row tiles: at most four weight tiles per workgroup
+        switch (tiles_per_wg) {
+            case 1: return share > 4 ? launch_ks<1, 8, false, 2>(kp, s) : launch_ks<1, 4, false, 2>(kp, s);
+            case 2: return share > 4 ? launch_ks<2, 6, false, 2>(kp, s) : launch_ks<2, 4, false, 2>(kp, s);
+            case 4: return launch_ks<4, 2, false, 2>(kp, s);
+            default: break;
+        }
+        pc_set_error("pc_gemm (ks): 17..32 rows take ks_tiles 1, 2 or 4 (got %d)", tiles_per_wg);
+        return PC_ERR_ARG;
+    }
     if (db) {                                            // two blocks in flight (PC_KS_DB=1: A/B against the single-block loop)
         switch (tiles_per_wg) {
             case 1: return launch_ks<1, 4, true>(kp, s);

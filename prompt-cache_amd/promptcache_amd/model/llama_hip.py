@@ -1083,14 +1083,14 @@ class LlamaHIP:
                     chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
             if ns > 1:
                 n.gemm_part(lw["wo_f"], ws, ws[H * ns * D:], ns, H, D, hid, x)
-            elif self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 16:      # (the in-launch K reduction: one row tile)
+            elif self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 32 and (T <= 16 or self.ks_o[1] <= 4):   # (in-launch K reduction)
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr, rows_dev=rows_dev)
             else:
                 n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"], rows_dev=rows_dev)  # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
                                wscale=lw["wgu_s"], rows_dev=rows_dev)
-            if self.ks_down and lw["wdown_s"] is None and self.ks_min_rows <= T <= 16 and inter >= 2 * hid:
+            if self.ks_down and lw["wdown_s"] is None and self.ks_min_rows <= T <= 32 and (T <= 16 or self.ks_down[1] <= 4) and inter >= 2 * hid:
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, x, hid, self.ks_down[1], self.ks_down[0], sc, ctr, rows_dev=rows_dev)
             else:

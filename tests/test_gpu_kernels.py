@@ -597,7 +597,10 @@ def test_gemm_skinny_k_slices(M, N, K, kq):
 
 
 @pytest.mark.parametrize("M,N,K,S,T", [(12, 4096, 4096, 4, 4), (12, 4096, 11008, 8, 8), (12, 4096, 11008, 2, 1), (1, 4096, 11008, 4, 2),
-                                       (16, 5120, 13824, 8, 4), (3, 64, 96, 2, 1), (7, 80, 1376, 3, 2), (12, 4096, 4096, 1, 1)])
+                                       (16, 5120, 13824, 8, 4), (3, 64, 96, 2, 1), (7, 80, 1376, 3, 2), (12, 4096, 4096, 1, 1),
+                                       # (17..32 rows: two row tiles per workgroup -- the questions of BASELINE config 3)
+                                       (26, 4096, 11008, 2, 2), (32, 4096, 4096, 4, 4), (17, 4096, 4096, 1, 1), (22, 5120, 13824, 4, 2),
+                                       (31, 80, 1376, 3, 1)])
 def test_gemm_skinny_ks_in_launch_reduction(M, N, K, S, T):
     """pc_gemm_skinny_ks: K split across workgroups, partials added inside the launch by the last arriver -- against an fp64
     reference, bit-reproducible over repeated launches (slice-order sum whoever arrives last), counters back at zero."""
@@ -607,7 +610,7 @@ def test_gemm_skinny_ks_in_launch_reduction(M, N, K, S, T):
     x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
     wf = n.to_weight_frags(w)
     hi, lo = n.to_act_frags(x)
-    scratch = torch.full((n.gemm_skinny_ks_scratch_bytes(N, S) // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    scratch = torch.full(((2 if M > 16 else 1) * n.gemm_skinny_ks_scratch_bytes(N, S) // 4,), float("nan"), dtype=torch.float32, device=DEV)
     counters = torch.zeros((N // 16 + T - 1) // T, dtype=torch.int32, device=DEV)
     ref = (x.double() @ w.double().t()).float()
     tol = 2e-4 * float(ref.abs().max()) + 1e-5

@@ -139,33 +139,53 @@ __device__ __forceinline__ bool q8_correction(const GemmParams& p, const uint32_
 #pragma unroll
     for (int t = 0; t < TT; ++t) { f4 z = {0.f, 0.f, 0.f, 0.f}; iacc[t] = z; }
     const int nks = (total + 31) >> 5;
-    for (int sblk = wave; sblk < nks; sblk += kWaves) {
-        int cj[8];
-        bool okc[8];
+    // SETS column blocks per pass: every gather of both blocks is issued before the first MFMA (one memory round trip instead of one
+    // per block -- the random-init bench model flags ~460 columns of down_proj's input: 15 blocks, two per wave); the blocks enter the
+    // accumulators in the same order as one at a time
+    constexpr int SETS = TT <= 4 ? 2 : 1;
+    for (int s0 = wave; s0 < nks; s0 += SETS * kWaves) {
+        int cj[SETS][8];
+        bool okc[SETS][8];
+        h8 xb[SETS], cb[SETS];
+        signed char qb[SETS][TT][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = sblk * 32 + g * 8 + e;
-            okc[e] = j < total;
-            cj[e] = cols[okc[e] ? j : 0];
-        }
-        h8 xb, cb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ok = okc[e] && row_ok;
-            xb[e] = ok ? xraw(m, cj[e]) : (_Float16)0;
-            cb[e] = ok ? code(m, cj[e]) : (_Float16)0;
-        }
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            h8 wa, qa;
+        for (int z = 0; z < SETS; ++z) {
+            const int sblk = s0 + z * kWaves;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float q = okc[e] ? (float)p.cbt[(int64_t)cj[e] * p.ldt + nra[t]] : 0.f;
-                qa[e] = (_Float16)q;
-                wa[e] = (_Float16)(q * wsa[t]);
+                const int j = sblk * 32 + g * 8 + e;
+                okc[z][e] = sblk < nks && j < total;
+                cj[z][e] = cols[okc[z][e] ? j : 0];
             }
-            cacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, cacc[t], 0, 0, 0);
-            iacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, cb, iacc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int z = 0; z < SETS; ++z) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = okc[z][e] && row_ok;
+                xb[z][e] = ok ? xraw(m, cj[z][e]) : (_Float16)0;
+                cb[z][e] = ok ? code(m, cj[z][e]) : (_Float16)0;
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qb[z][t][e] = okc[z][e] ? p.cbt[(int64_t)cj[z][e] * p.ldt + nra[t]] : (signed char)0;
+        }
+#pragma unroll
+        for (int z = 0; z < SETS; ++z) {
+            if (s0 + z * kWaves >= nks) continue;        // (wave-uniform)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                h8 wa, qa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float q = (float)qb[z][t][e];
+                    qa[e] = (_Float16)q;
+                    wa[e] = (_Float16)(q * wsa[t]);
+                }
+                cacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[z], cacc[t], 0, 0, 0);
+                iacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, cb[z], iacc[t], 0, 0, 0);
+            }
         }
     }
 #pragma unroll

@@ -314,7 +314,7 @@ int64_t pc_gemm_skinny_ks_scratch_bytes(int32_t N, int32_t kslices);
 int pc_gemm_part(const void* wf, const float* part_o, const float* part_ml, int32_t nsplit, int32_t H, int32_t D, int32_t N, float* y,
                  void* stream);
 /* pc_gemm_q8 -- LLM.int8 projection of M <= 16 rows with the vector-wise activation quantiser INSIDE the launch
- *   (csrc/pc_gemm_q8.hip).  Same arithmetic as pc_rmsnorm_quant_i8 / pc_quant_act_i8 followed by pc_gemm with x_scale + flags
+ *   (csrc/pc_gemm_q8.h).  Same arithmetic as pc_rmsnorm_quant_i8 / pc_quant_act_i8 followed by pc_gemm with x_scale + flags
  *   (bitsandbytes Linear8bitLt as demo.py:27-29 loads it; llama2.py:345-347, :405, :242 are the projections), without the
  *   quantiser launches: codes, row scales and outlier flags are derived by every workgroup of the projection itself.
  *   wf, w_scale, w_codes_t, ldt, row_perm   the int8 weight image, its scales, the transposed codes (outlier correction) and, for

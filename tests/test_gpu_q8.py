@@ -1,4 +1,4 @@
-"""pc_gemm_q8 (csrc/pc_gemm_q8.hip): LLM.int8 projections of <= 16 rows with the activation quantiser inside the launch, against
+"""pc_gemm_q8 (csrc/pc_gemm_q8.h): LLM.int8 projections of <= 16 rows with the activation quantiser inside the launch, against
 the stand-alone quantisers + pc_gemm (bit for bit where the summation order is the same) and against oracle/llmint8_oracle.py --
 the published algorithm behind the reference's ``load_in_8bit=True`` (demo.py:27-29)."""
 import numpy as np

@@ -34,7 +34,7 @@ if os.environ.get("PC_I8_DECODE", "1") == "1":
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"decode phase {phase}: {32 / dt:.1f} tok/s ({dt / 32 * 1e3:.3f} ms/token)", flush=True)
     loop = lm8.hf_model.greedy_loop(past, tok, max(pos) + 2 + 64, 128)
-    if loop is not None:
+    if loop is not None and os.environ.get("PC_I8_LOOP", "1") == "1":
         for _ in range(32):
             loop.enqueue()
         loop.token(31)

@@ -2,7 +2,7 @@
 gemm_skinny_ks_kernel (down_proj of the timed step: partial tiles written through, arrival counter, last arriver adds them in
 slice order) and the split-KV merge inside attn_small_kernel (pc_attn `counters`).  Both publish with agent-scope atomic stores
 + `s_waitcnt vmcnt(0)` + a relaxed arrival counter (pc_gemm_ks.hip: the hand-off contract).  A lost or stale partial would show
-as a wrong word once in many launches, so: 1e5 launches each, under UNEVEN load (a copy stream hammering HBM and the L2s next to
+as a wrong word once in many launches, so: 1e5 launches each (2e4 for the int8 down_proj form of pc_gemm_q8, which carries the same hand-off), under UNEVEN load (a copy stream hammering HBM and the L2s next to
 them), the consumer's caches warm, EVERY output word compared with the first launch's."""
 import os
 
@@ -104,6 +104,67 @@ def test_k_reduction_inside_the_launch_1e5_launches_bit_stable(formal):
         os.environ["PC_FORMAL_HANDOFF"] = "0"
         outs[0].copy_(y0)
         n.gemm_skinny_ks(wf, hi, lo, M, N, K, outs[0], N, slices, tiles, scratch, counters)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int32), ref[0].view(torch.int32))
+
+
+def test_int8_down_proj_k_reduction_inside_the_launch_bit_stable(formal):
+    """pc_gemm_q8's F form (down_proj of the LLM.int8 cached step as it is dispatched: 4 tiles x 4 slices, the quantiser and the outlier
+    correction inside, round 5): the same hand-off as gemm_skinny_ks_kernel in its own kernel -- same stress, a fifth of the launches."""
+    n = _n()
+    rng = np.random.default_rng(43)
+    M, N, K, tiles, slices = 12, 4096, 11008, 4, 4
+    x = np.clip(rng.standard_normal((M, K)).astype(np.float32) * 1.5, -5.9, 5.9)
+    cols = rng.permutation(K)[:200]
+    x[rng.integers(0, M, size=200), cols] = 9.0                         # flagged columns in every K slice: the correction runs
+    x = x.astype(np.float16).astype(np.float32)
+    w = (0.03 * rng.standard_normal((N, K))).astype(np.float32)
+    q, sc = n.quantize_rows_int8(torch.from_numpy(w).to(DEV))
+    wf8, qt = n.to_weight_frags_i8(q), q.t().contiguous()
+    hi, _ = n.to_act_frags(torch.from_numpy(x).to(DEV))
+    outl = np.abs(x) >= 6.0
+    pm = np.zeros((K // 16, 16), dtype=np.float32)
+    pm[:, :M] = np.where(outl, 0.0, np.abs(x)).reshape(M, K // 16, 16).max(axis=2).T
+    pmd = torch.from_numpy(pm).to(DEV)
+    fl = torch.zeros(16384, dtype=torch.uint8, device=DEV)
+    fl[:K] = torch.from_numpy(outl.any(axis=0).astype(np.uint8)).to(DEV)
+    y0 = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV)
+    scratch = torch.empty(n.gemm_skinny_ks_scratch_bytes(N, 8) // 4, dtype=torch.float32, device=DEV)
+    counters = torch.zeros(N // 16, dtype=torch.int32, device=DEV)
+    outs = torch.empty((PER_GRAPH, M, N), dtype=torch.float32, device=DEV)
+
+    def one(dst):
+        dst.copy_(y0)
+        n.gemm_q8(epilogue=n.EPI_ADD, wf=wf8, w_scale=sc, w_codes_t=qt, xf_hi=hi, row_max=pmd, row_max_units=K // 16, flags_in=fl, M=M, N=N, K=K,
+                  y=dst, ldy=N, ks_tiles=tiles, kslices=slices, ks_scratch=scratch, ks_scratch_bytes=scratch.numel() * 4, ks_counters=counters)
+
+    def body():
+        for j in range(PER_GRAPH):
+            one(outs[j])
+
+    body()
+    torch.cuda.synchronize()
+    ref = outs[0:1].clone()
+    from oracle import int8_oracle as io
+    from oracle import llmint8_oracle as lo
+    qo, so = io.quantize_rows_int8(w)
+    exact = y0.cpu().numpy() + lo.linear(x, qo, so)
+    assert np.abs(ref[0].cpu().numpy() - exact).max() < 3e-5 * max(1.0, np.abs(exact).max())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    global LAUNCHES
+    keep, LAUNCHES = LAUNCHES, max(PER_GRAPH, LAUNCHES // 5)
+    try:
+        with _Load() as load:
+            bad = _replay_and_count(g, outs, ref.expand_as(outs), load)
+    finally:
+        LAUNCHES = keep
+    assert bad == 0, f"{bad} words differed"
+    assert int(counters.abs().sum()) == 0
+    if formal:
+        os.environ["PC_FORMAL_HANDOFF"] = "0"
+        one(outs[0])
         torch.cuda.synchronize()
         assert torch.equal(outs[0].view(torch.int32), ref[0].view(torch.int32))
 

@@ -267,7 +267,8 @@ def test_o_proj_merges_the_attention_partials_itself_bit_for_bit(S, nout):
     assert torch.equal(y_a, y_b)
 
 
-def test_7b_shape_int8_stack_inlaunch_quantisers_equal_the_quantiser_launches():
+@pytest.mark.parametrize("shape_name,layers", [("llama2-7b", 3), ("llama2-13b", 2)])
+def test_7b_shape_int8_stack_inlaunch_quantisers_equal_the_quantiser_launches(shape_name, layers):
     """Three layers of the 7b shape, load_in_8bit: the cached step (12 rows: quantiser launches + the F form for down_proj), a 3-row
     step and decode steps (1 row: every quantiser inside its projection, the attention's partials merged by o_proj) against round 4's
     path (PC_INT8_INLAUNCH=0: a quantiser launch in front of every projection).  The P forms are bit-identical; the K-sliced / compact
@@ -276,7 +277,8 @@ def test_7b_shape_int8_stack_inlaunch_quantisers_equal_the_quantiser_launches():
     from promptcache_amd.model import Llama2
     from promptcache_amd.model.config import SHAPES
     from promptcache_amd.model.weights import random_weights_device
-    shape = dataclasses.replace(SHAPES["llama2-7b"], num_hidden_layers=3, vocab_size=4096)
+    # (13b: hidden 5120 -- three chunks per thread in the P form, K = 13824 in the F / C forms, H * D > 4096: o_proj reads the merged plane)
+    shape = dataclasses.replace(SHAPES[shape_name], num_hidden_layers=layers, vocab_size=4096)
     w = random_weights_device(shape, DEV, torch.float16, seed=5)
     w["embed"][:, [7, 300, 2049]] *= 40.0                 # outlier feature channels: flagged columns on every layer's q|k|v and gate|up input
     lm = Llama2(name="q8-7b", shape=shape, weights=w, device=DEV, load_in_8bit=True)

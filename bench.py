@@ -134,6 +134,41 @@ def cpu_baseline_and_parity(lm, eng, prompt, ids, pos, k_layers: int, repeats: i
     return base, parity
 
 
+def compact_summary(result: dict) -> dict:
+    """Every leg's headline value in <= 1500 characters, as the LAST key of the JSON line (the driver's record keeps the tail of
+    stdout: the legs' full objects above scroll out of it).  Recipe the legs mirror: /root/reference/eval.py:172-219."""
+    def g(path, nd=None):
+        x = result
+        for k in path.split("."):
+            if not isinstance(x, dict) or k not in x or x[k] is None:
+                return None
+            x = x[k]
+        return round(x, nd) if (nd is not None and isinstance(x, float)) else x
+    s = {"ttft_ms": g("ms_per_step", 3), "tok_s": g("value", 0), "step_hbm_frac": g("roofline_step.frac", 3),
+         "kernel_frac": g("roofline.frac", 3), "gather_GBs": g("roofline_gather.achieved", 0),
+         "nocache_ttft_ms": g("no_cache.ttft_ms", 2),
+         "decode_tok_s": g("decode.tokens_per_s", 1), "decode_loop_tok_s": g("decode_device_loop.tokens_per_s", 1),
+         "decode_loop_hbm_frac": g("decode_device_loop.hbm_frac", 3),
+         "encode_tok_s": g("encode.tokens_per_s", 0), "encode_frac": g("encode.roofline.frac", 3),
+         "library_tok_s": g("encode_library.tokens_per_s", 0),
+         "parity_dlogit": g("parity.max_abs_dlogit", 6), "cpu_tok_s": g("cpu_baseline.value", 0)}
+    i8 = result.get("int8_weights")
+    if isinstance(i8, dict):
+        s["int8"] = {"ttft_ms": g("int8_weights.ttft_ms", 3), "loop_tok_s": g("int8_weights.decode_device_loop_tokens_per_s", 1),
+                     "outlier_cols": g("int8_weights.outlier_columns_last_layer.down_proj_in")}
+        if isinstance(i8.get("trained_like"), dict):
+            s["int8"]["trained_like"] = {"ttft_ms": g("int8_weights.trained_like.ttft_ms", 3),
+                                         "loop_tok_s": g("int8_weights.trained_like.decode_device_loop_tokens_per_s", 1),
+                                         "outlier_cols": g("int8_weights.trained_like.outlier_cols")}
+    cf = result.get("configs")
+    if isinstance(cf, dict):
+        s["configs"] = {k: [round(v["ms_per_step"], 3), round(v["frac"], 3)] for k, v in cf.items()
+                        if isinstance(v, dict) and "ms_per_step" in v}
+        s["c4_attn_frac"] = g("configs.4.roofline_attention.frac", 4)
+        s["c4_attn_us"] = g("configs.4.roofline_attention.avg_launch_us", 1)
+    return {k: v for k, v in s.items() if v is not None}
+
+
 def _pmc_traffic(kernel_key: str, signature: str):
     """HBM bytes per launch from the committed PMC summary (profiles/pmc_traffic.json, written by tools/pmc_traffic.py from
     separate rocprofv3 --pmc passes: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  None unless the summary was taken on exactly
@@ -1111,6 +1146,7 @@ def main():
         torch.cuda.empty_cache()
         result["configs"] = configs_leg(device, world, rank, barrier, lm)
     if rank == 0:
+        result["summary"] = compact_summary(result)     # LAST key: the tail of the line is what the driver's record keeps
         print(json.dumps(result))
     if world > 1:
         barrier()                      # the other ranks wait for rank 0's (untimed) context legs before tearing down

@@ -532,6 +532,9 @@ def recover_goldens():
                 "<a><_ x='1'y='2'>t</_>u</a>", "<a><_ x=1>t</_>u</a>", "<a>q<_ x</a>", "<a><b/ >t</a>", "<a><b / >t</a>",
                 "<r><a b=\"x<y\">t</a>u</r>", "<a><\u00e9<_>&lt;</c></a>", "<a b='1' c=\"2\"  d = '3' >t</a>",
                 ]
+    # round 6: character references outside XML's Char production are dropped (and count as the first error)
+    extra = ["<r>a&#12;b&#0;c</r>", "<r>x&#x110000;y</r>", "<r>x&#xD800;y &lt; z</r>", "<r>x&#xFFFE;y</r>", "<r>a&#9;b&#10;c&#13;d</r>",
+             "<r>x&#99999999999;y</r>", "<r>p&#1;q &amp; r</r>", "<r a='u&#0;v'>t</r>"]
 
     def dump(e):
         return {"tag": e.tag, "attrib": dict(e.attrib), "text": e.text, "tail": e.tail, "children": [dump(c) for c in e]}
@@ -540,14 +543,14 @@ def recover_goldens():
     rnd = random.Random(20260929)                 # + 150 random malformed snippets (seeded; generated here)
     alphabet = ["word ", " ", "\n  ", "&amp;", "&lt;=", "R&D ", "a<b ", "x > y ", "<module name=\"m\">", "</module>", "<union>", "</union>",
                 "<parameter name='p' length=\"3\"/>", "\"q\" ", "it's ", "</x>", "<m n=v>", "\u00e9 ", "&#233;", "&nbsp;", "</>", "<b/ >", "&#12", "&x"]
-    while len(snippets) < 64 + 150:
+    while len(snippets) < 64 + 150:      # (64 hand-written + 150 random; `extra` goes behind them so the random ones stay as they were)
         cand = "<schema name='s'>" + "".join(rnd.choice(alphabet) for _ in range(rnd.randint(2, 10))) + "</schema>"
         try:
             ET.fromstring(ref_shim.libxml2_recover(cand))
         except Exception:  # noqa: BLE001  (libxml2 kept a duplicate attribute or produced nothing: not a tree to compare)
             continue
         snippets.append(cand)
-    return [{"src": s, "tree": dump(ET.fromstring(ref_shim.libxml2_recover(s)))} for s in snippets]
+    return [{"src": s, "tree": dump(ET.fromstring(ref_shim.libxml2_recover(s)))} for s in snippets + extra]
 
 
 def model_golden(pc, case: str, shape_name: str, seed: int, scale: float, schema_text: str, prompt_text: str,
@@ -691,9 +694,18 @@ def write_manifest():
     for fn in sorted(glob.glob(os.path.join(GOLD, "*.npz"))):
         with np.load(fn, allow_pickle=False) as z:
             man[os.path.basename(fn)] = sorted(z.files)
+    man["_provenance"] = {
+        "model fixtures (*.npz)": "captured from the imported reference (promptcache/ + its patched llama2.py / falcon.py / mpt.py) "
+                                  "running on CPU in the build container, seeded random-init weights, stand-in tokenizer",
+        "pml_layout.json, pml_recover.json, pml/*.xml": "the reference's schema.py / prompt.py run over an lxml STAND-IN "
+            "(oracle/ref_shim.py: xml.etree.ElementTree + the system libxml2.so.2 through ctypes, XML_PARSE_RECOVER) because lxml "
+            "is not installed in the image: libxml2's recovery behaviour is the real one (lxml wraps the same library), the tree "
+            "API between it and the reference is the builder's -- a real-lxml pin is not possible offline",
+        "LLM.int8": "no fixture: bitsandbytes==0.41.1 (requirements.txt) is absent and has no CPU path; oracle/llmint8_oracle.py "
+                    "restates the published algorithm (parity unpinned for that mode)"}
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(man, f, indent=1, sort_keys=True)
-    print(f"[golden] manifest: {len(man)} fixtures")
+    print(f"[golden] manifest: {len(man) - 1} fixtures")
 
 
 SAMPLING_CASES = [

@@ -156,11 +156,14 @@ class StagedKV(Sequence):
 
     def __init__(self, arena: KVArena, length: int, batched: bool = True):
         self.arena = arena
+        self._arena: Optional[KVArena] = None      # the arena once an entry was replaced (see __setitem__)
         self.length = length
         self._batched = batched
         self._items: Optional[list] = None
 
     def _look(self) -> list:
+        if self._items is not None and self.arena is None:
+            return self._items
         a = self.arena
         if a.pending is not None:
             a.materialize()
@@ -173,13 +176,22 @@ class StagedKV(Sequence):
         return self._items
 
     def __len__(self):
-        return self.arena.L
+        return self._live_arena.L
 
     def __getitem__(self, i):
         return self._look()[i]
 
     def __setitem__(self, i, v):
+        # an assigned entry is foreign data: from here on the model must not take the arena shortcut (`.arena` reads as None and
+        # arena_from_past() inspects the items -- a replaced layer fails its stride test and the whole list is copied into a
+        # fresh arena, replaced entries included)
         self._look()[i] = v
+        if self.arena is not None:
+            self._arena, self.arena = self.arena, None
+
+    @property
+    def _live_arena(self) -> KVArena:
+        return self.arena if self.arena is not None else self._arena
 
     def __iter__(self):
         return iter(self._look())
@@ -204,11 +216,12 @@ class StagedKV(Sequence):
         return (list, (self._look(),))       # pickles as the plain list of views it stands for
 
     def __repr__(self):
-        return f"StagedKV(layers={self.arena.L}, length={self.length}, pending={self.arena.pending is not None})"
+        a = self._live_arena
+        return f"StagedKV(layers={a.L}, length={self.length}, pending={a.pending is not None}, replaced={self.arena is None})"
 
     def unbatched(self) -> "StagedKV":
         """``[Hkv, length, D]`` views: what ``CacheEngine.process`` returns (``cache_engine.py:161-165``)."""
-        return StagedKV(self.arena, self.length, batched=False)
+        return StagedKV(self._live_arena, self.length, batched=False)
 
 
 def arena_from_past(past, n_layers: int, n_kv_heads: int, head_dim: int) -> Optional[Tuple[KVArena, int]]:

@@ -85,7 +85,7 @@ class _InputBlock:
         self._busy = True
 
 
-_GRAPH_RNG_PRIMED = False
+_GRAPH_RNG_PRIMED: dict = {}
 
 
 def prime_graph_capture(device) -> None:
@@ -95,16 +95,18 @@ def prime_graph_capture(device) -> None:
     ``capture_begin`` ("Inplace update to inference tensor outside InferenceMode").  So the first capture of the process is a
     trivial one taken with inference mode switched off (once, ~1 ms) -- and KEPT: torch frees those words again when the last
     registered graph dies and would re-allocate them under whatever mode the next capture runs in."""
-    global _GRAPH_RNG_PRIMED
-    if _GRAPH_RNG_PRIMED is not False:
+    # (the capture state is per DEVICE: one primed graph per device index this process drives)
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _GRAPH_RNG_PRIMED:
         return
-    with torch.inference_mode(False):
-        t = torch.zeros(8, device=device)
+    with torch.inference_mode(False), torch.cuda.device(idx):
+        t = torch.zeros(8, device=torch.device("cuda", idx))
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             t.add_(1.0)
-    _GRAPH_RNG_PRIMED = (g, t)
+    _GRAPH_RNG_PRIMED[idx] = (g, t)
 
 
 def lw0_fp16(layers) -> bool:
@@ -1083,14 +1085,14 @@ class LlamaHIP:
                     chain = self.use_chain = False       # no instantiation for this shape: nothing was launched
             if ns > 1:
                 n.gemm_part(lw["wo_f"], ws, ws[H * ns * D:], ns, H, D, hid, x)
-            elif self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 32 and (T <= 16 or self.ks_o[1] <= 4):   # (in-launch K reduction)
+            elif self.ks_o and lw["wo_s"] is None and self.ks_min_rows <= T <= 32 and (T <= 16 or (self.ks_o[1] <= 4 and self.ks_o[0] in (1, 2, 4))):   # (in-launch K reduction)
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wo_f"], ah, al, T, hid, H * D, x, hid, self.ks_o[1], self.ks_o[0], sc, ctr, rows_dev=rows_dev)
             else:
                 n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_ADD, y=x, ldy=hid, wscale=lw["wo_s"], rows_dev=rows_dev)  # x += attn @ Wo^T
             n.gemm_skinny_norm(lw["wgu_f"], x, lw["ln2"], eps, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl,
                                wscale=lw["wgu_s"], rows_dev=rows_dev)
-            if self.ks_down and lw["wdown_s"] is None and self.ks_min_rows <= T <= 32 and (T <= 16 or self.ks_down[1] <= 4) and inter >= 2 * hid:
+            if self.ks_down and lw["wdown_s"] is None and self.ks_min_rows <= T <= 32 and (T <= 16 or (self.ks_down[1] <= 4 and self.ks_down[0] in (1, 2, 4))) and inter >= 2 * hid:
                 sc, ctr = self._ks_buffers(hid)
                 n.gemm_skinny_ks(lw["wdown_f"], ch, cl, T, hid, inter, x, hid, self.ks_down[1], self.ks_down[0], sc, ctr, rows_dev=rows_dev)
             else:

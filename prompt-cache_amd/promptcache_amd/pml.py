@@ -297,7 +297,14 @@ class Module(Element):
                 # them with a ValueError, i.e. the reference cannot load a schema with a comment or foreign tag among a module's
                 # children -- and neither does this loader (pinned by tests/golden/pml_layout.json: syn:comment_module,
                 # syn:unknown_tag and the two benchmark/schema/test files that carry comments).
-                child = TokenSequence(cursor, pml_xml.tostring(e).encode("ascii", "xmlcharrefreplace"), lm, max_tokens=max_tokens)
+                # Raised HERE, with the text the reference's (slow, transformers 4.34) tokenizer gives, so that the outcome does not
+                # depend on the tokenizer behind `lm.encode` (HF fast tokenizers raise TypeError for bytes, a custom LM might
+                # silently tokenize them); the cause names what is wrong with the schema.
+                data = pml_xml.tostring(e).encode("ascii", "xmlcharrefreplace")
+                raise ValueError(f"Input {data!r} is not valid. Should be a string, a list/tuple of strings or a list/tuple of "
+                                 f"integers.") from ValueError(
+                    "XML comment or unknown tag among a module's children: the reference hands its serialised BYTES to the "
+                    "tokenizer (schema.py:362-363) and cannot load such a schema; remove it or make it a <module>")
             self.children.append(child)
             cursor += len(child)
             cursor = self._text(cursor, e.tail, lm, max_tokens)

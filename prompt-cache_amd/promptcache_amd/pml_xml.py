@@ -95,10 +95,14 @@ def unescape(s: str, state: Optional[_State] = None) -> str:
             i = mu.end() if mu else j + 1
             continue
         body = m.group(1)
-        if body.startswith("#x"):
-            out.append(chr(int(body[2:], 16)))
-        elif body.startswith("#"):
-            out.append(chr(int(body[1:])))
+        if body.startswith("#"):
+            # a character reference outside XML's Char production (&#0; &#12; &#xD800; &#xFFFE; &#x110000; ...) is an error
+            # to libxml2: the recovering parser drops it and is "broken" from there on (tests/golden/pml_recover.json)
+            cp = int(body[2:], 16) if body.startswith("#x") else int(body[1:])
+            if cp in (0x9, 0xA, 0xD) or 0x20 <= cp <= 0xD7FF or 0xE000 <= cp <= 0xFFFD or 0x10000 <= cp <= 0x10FFFF:
+                out.append(chr(cp))
+            else:
+                state.broken = True
         elif body in _ENTITIES:
             if not state.broken:
                 out.append(_ENTITIES[body])

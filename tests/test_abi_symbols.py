@@ -74,7 +74,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     from promptcache_amd import _native
     src = tmp_path / "layout.c"
     structs = (("pc_attn_args", _native.AttnArgs), ("pc_gemm_args", _native.GemmArgs), ("pc_dense_qkv_args", _native.DenseQkvArgs),
-               ("pc_kv_seg", _native.KvSeg), ("pc_kv_row", _native.KvRow))
+               ("pc_kv_seg", _native.KvSeg), ("pc_kv_row", _native.KvRow), ("pc_gemm_q8_args", _native.GemmQ8Args))
     body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/promptcache_hip.h"', 'int main(void) {']
     for st, cls in structs:
         body.append(f'  printf("{st} %zu\\n", sizeof({st}));')

@@ -43,3 +43,19 @@ def test_staged_views_answer_every_read_accessor():
     assert w[0] == ("k", "v") and len(w) == 3
     # a sequence consumer that is not written for this class
     assert len(torch.nn.utils.rnn.pad_sequence([t[0][0, 0] for t in fresh()], batch_first=True)) == 3
+
+
+def test_assigned_entry_switches_the_arena_shortcut_off():
+    """ADVICE r5: ``past[i] = (K, V)`` used to change only the lazily built view list while the model kept reading ``.arena``;
+    now a replaced entry makes the object foreign data: ``arena_from_past`` no longer returns the aliasing arena (the model then
+    copies the items -- the replacement included -- into a fresh one)."""
+    from promptcache_amd.model.kv_arena import KVArena, arena_from_past
+    a = KVArena(1, 2, 4, 64, 32, "cpu")
+    v = a.views(10)
+    assert arena_from_past(v, 2, 4, 32)[0] is a
+    k1 = torch.ones(1, 4, 10, 32, dtype=torch.float16)
+    v[1] = (k1, k1.clone())
+    v[1] = (k1, k1.clone())                  # (a second assignment must not lose the arena behind len() / repr())
+    assert v.arena is None and arena_from_past(v, 2, 4, 32) is None
+    assert len(v) == 2 and v[1][0] is k1 and "replaced=True" in repr(v)
+    assert v[0][0].data_ptr() == a.buf[:, 0, 0].data_ptr()      # untouched layers still alias the arena's rows

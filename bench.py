@@ -393,8 +393,12 @@ def attn_many_roofline(lm, q_len: int, S: int):
     avg = sum(us[staging]) / len(us[staging])
     flops = 4.0 * H * D * q_len * (S + (q_len + 1) / 2)
     kv_bytes = 2 * Hkv * S * D * 2
-    res = {"kernel": ("attn_ring_kernel<KVLO, GATHER> (stages while it reads: pc_attn gather_rows)" if staging else "attn_ring_kernel<KVLO>") +
-                     " + attn_combine_kernel (pc_attn, > 64 split-precision rows; pc_attn_ring.hip)",
+    wide = S >= int(os.environ.get("PC_ATTN_WIDE_MIN", "6144")) and q_len >= int(os.environ.get("PC_ATTN_WIDE_MIN_ROWS", "128")) \
+        and os.environ.get("PC_ATTN_NO_WIDE") != "1"
+    res = {"kernel": (("attn_wide_kernel<GATHER, R> over the staged keys (all query rows of a head per workgroup, key slices; "
+                       "pc_attn_wide.hip) + attn_ring_kernel<KVLO> over the pass's own rows" if wide else "attn_ring_kernel<KVLO, GATHER>") +
+                      (" (stages while it reads: pc_attn gather_rows)" if staging else "")) +
+                     " + attn_combine_kernel (pc_attn, > 64 split-precision rows): ALL launches of one pc_attn call inside the events",
            "staging": staging, "bound": "mfma", "achieved": flops / (avg * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "executed_frac": 2 * flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
            "traffic": _pmc_traffic("attn_ring_staging", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[0] if staging else None,

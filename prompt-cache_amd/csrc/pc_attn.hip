@@ -1315,7 +1315,7 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     }
     if (ring) {
         // > 64 split-precision rows at head_dim 128: 128 rows per workgroup, tiles by LDS-DMA (pc_attn_ring.hip)
-        const int rrc = launch_attn_ring(p, B, stream);
+        const int rrc = p.wide ? launch_attn_wide(p, stream) : launch_attn_ring(p, B, stream);
         if (rrc != PC_OK) return rrc;
     } else if (p.small && p.rows) {       // stage while reading (pc_attn gather_rows)
         if (p.key_pos) hipLaunchKernelGGL((attn_small_kernel<D, true, 0, true>), grid, dim3(kThreads), 0, stream, p);
@@ -1383,6 +1383,10 @@ PC_EXPORT int64_t pc_attn_workspace_bytes(int32_t B, int32_t H, int32_t D, int32
     // passes of <= 16 rows may take attn_small_kernel: one partial per workgroup (+ the tail's)
     if (q_len <= 2 * kSmallQ && ns < small_nstream(B, H) + 1) ns = small_nstream(B, H) + 1;   // (17..32 rows: two row tiles per wave)
     if (D == 128 && q_len >= ring_min_rows()) { const int nr = ring_nsplit(B, H, q_len, kv_len_max); ns = ns > nr ? ns : nr; }   // (pc_attn_ring.hip)
+    if (D == 128 && B == 1 && q_len >= ring_min_rows() && kv_len_max - q_len >= wide_min_keys()) {      // (pc_attn_wide.hip: staged keys = kv_len - q_len)
+        const int nw = wide_nsplit(H, q_len, kv_len_max - q_len) + 1;
+        ns = ns > nw ? ns : nw;
+    }
     if (ns <= 1) return 0;
     return (int64_t)B * H * ns * q_len * (D + 2) * (int64_t)sizeof(float);
 }
@@ -1465,6 +1469,8 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                "pc_attn: gather_rows must be 16-byte aligned, planes non-negative");
     p.rows = gather_rows; p.g_kplane = g_kplane; p.g_vplane = g_vplane;
     if (ring_eligible(p, D)) p.nsplit = ring_nsplit(B, H, q_len, past_len + q_len);
+    p.wide = 0; p.wide_nsplit = 0; p.own_only = 0;
+    if (!small && wide_eligible(p, D, B)) { p.wide = 1; p.nsplit = wide_nsplit(H, q_len, past_len) + 1; }
     if (p.tail && !small) {
         p.nsplit = tail_stream_splits(B, H, past_len);
         // one more split for the tail workgroup -- taken from the streaming splits when the total would cross into the

@@ -55,6 +55,9 @@ struct AttnParams {
     int32_t small;          // attn_small_kernel launch (host-side dispatch flag)
     int32_t formal_handoff; // fused merge: acq_rel arrival (the C++-memory-model form, env PC_FORMAL_HANDOFF=1) instead of relaxed + vmcnt(0)
     int32_t xcd_remap, nqblk, nbatch;
+    // (host) the staged keys go to attn_wide_kernel in `nsplit - 1` slices, the keys this pass appended to attn_ring_kernel in its
+    // own_only mode as partial nsplit - 1 (pc_attn_wide.hip)
+    int32_t wide, wide_nsplit, own_only;
     int32_t defer_merge;    // (host) leave the split-KV partials in the workspace: the consumer merges them (pc_gemm_q8 part_o)
     int32_t* nsplit_out;    // (host) where pc_attn reports how many partials per row it left (1: the output planes are final)
     float scale_log2;
@@ -101,10 +104,37 @@ __device__ __forceinline__ void glds16_nt(const _Float16* g, char* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// (hi, lo) fp16 pair planes of two fp32 values: hi = fp16(e), lo = fp16(e - hi), packed two per register.  The residual is ONE
+// v_fma_mix per value (f16 source widened inside the fma, result rounded to f16 into the low / high half) instead of
+// v_cvt_f32_f16 + v_sub_f32 + v_cvt_f16_f32 + a pack -- the softmax is a third of this kernel's issue slots.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float e0, float e1, uint32_t& hi, uint32_t& lo) {
+    const h2 hh = {(_Float16)e0, (_Float16)e1};
+    hi = __builtin_bit_cast(uint32_t, hh);
+    uint32_t d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(d) : "v"(hi), "v"(e0), "v"(e1));
+    lo = d;
+}
+
+// LDS-DMA issued as raw instructions: 16 bytes per lane from `g` to LDS byte address `lds_addr` + 16 * lane.  The builtin form
+// makes hipcc wait vmcnt(0) in front of every ds_read_b64_tr_b16 that follows (it cannot tell the transposing reads from
+// the buffer the DMA is filling), which would serialise the ring; here the waits are the explicit ones in the ring loop.
+__device__ __forceinline__ void glds16_raw(const _Float16* g, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");   // (m0: no other instruction of this kernel uses it; checked in the ISA)
+}
+
 // the many-row ring kernel (pc_attn_ring.hip): 128 query rows per workgroup, K / V tiles by LDS-DMA
 bool ring_eligible(const AttnParams& p, int D);
 int ring_min_rows();
 int ring_nsplit(int B, int H, int q_len, int kv_len);
 int launch_attn_ring(const AttnParams& p, int B, hipStream_t stream);
+// a long question over a long staged cache (pc_attn_wide.hip): all query rows of a head per workgroup, slices of the staged keys
+bool wide_eligible(const AttnParams& p, int D, int B);
+int wide_nsplit(int H, int q_len, int past_len);
+int wide_min_keys();
+int launch_attn_wide(const AttnParams& p, hipStream_t stream);
 
 }  // namespace pca

@@ -37,8 +37,6 @@
 namespace pca {
 namespace {
 
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int RD = 128;                 // head dim
 constexpr int RKS = RD / 32, RDB = RD / 16, RCPR = RD / 8;
 constexpr int kRingThreads = 512, kRingQB = 128;
@@ -47,27 +45,6 @@ constexpr int kStage = 4 * kPlane;      // 64 KiB
 
 // one region of the key walk (all workgroup-uniform): keys [a, e) are rows of k / v indexed BY KEY (bases are pre-shifted);
 // lo != 0: every key of the region has a residual row in kl / vl
-// (hi, lo) fp16 pair planes of two fp32 values: hi = fp16(e), lo = fp16(e - hi), packed two per register.  The residual is ONE
-// v_fma_mix per value (f16 source widened inside the fma, result rounded to f16 into the low / high half) instead of
-// v_cvt_f32_f16 + v_sub_f32 + v_cvt_f16_f32 + a pack -- the softmax is a third of this kernel's issue slots.
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair(float e0, float e1, uint32_t& hi, uint32_t& lo) {
-    const h2 hh = {(_Float16)e0, (_Float16)e1};
-    hi = __builtin_bit_cast(uint32_t, hh);
-    uint32_t d;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(d) : "v"(hi), "v"(e0), "v"(e1));
-    lo = d;
-}
-
-// LDS-DMA issued as raw instructions: 16 bytes per lane from `g` to LDS byte address `lds_addr` + 16 * lane.  The builtin form
-// makes hipcc wait vmcnt(0) in front of every ds_read_b64_tr_b16 that follows (it cannot tell the transposing reads from
-// the buffer the DMA is filling), which would serialise the ring; here the waits are the explicit ones in the ring loop.
-__device__ __forceinline__ void glds16_raw(const _Float16* g, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");   // (m0: no other instruction of this kernel uses it; checked in the ISA)
-}
-
 struct Region { const _Float16* k; const _Float16* v; const _Float16* kl; const _Float16* vl; int a, e, lo; };
 
 // GATHER (pc_attn gather_rows; B = 1, no shared prefix): STAGE WHILE READING, as attn_small_kernel does for short prompts.  Keys of
@@ -87,22 +64,25 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int qblk, h, b, split;
+    // own_only (launch_attn_wide, pc_attn_wide.hip): one workgroup per (q-block, head) walks the keys THIS PASS appended,
+    // [past_len, kv_len), and leaves the result as partial nsplit - 1 of nsplit (the staged keys are the wide kernel's slices)
+    const int gns = p.own_only ? 1 : p.nsplit;
     if (p.xcd_remap) {
         // 1-D grid, XCD-aware (see attn_fwd_kernel): heads are dealt to XCDs, an XCD walks the q-blocks of one head after
         // another, heaviest first, so that head's K / V is served from that XCD's L2
         // (with KV splits a "pair" is (batch row, head, split): its q-blocks stream the same key range)
         const int nqb = p.nqblk, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int npairs = p.H * p.nbatch * p.nsplit;
+        const int npairs = p.H * p.nbatch * gns;
         const int per_xcd = (npairs + 7) >> 3;
         const int pair = (slot / nqb) * 8 + xcd;
         if (slot / nqb >= per_xcd || pair >= npairs) return;
         qblk = nqb - 1 - (slot % nqb);
-        const int bh = pair / p.nsplit;
-        split = pair - bh * p.nsplit;
+        const int bh = pair / gns;
+        split = pair - bh * gns;
         b = bh / p.H; h = bh - b * p.H;
     } else {
         qblk = blockIdx.x; h = blockIdx.y;
-        b = blockIdx.z / p.nsplit; split = blockIdx.z - b * p.nsplit;
+        b = blockIdx.z / gns; split = blockIdx.z - b * gns;
     }
     const int hkv = h / (p.H / p.Hkv);
     const int q_len = p.q_len;
@@ -116,9 +96,10 @@ __global__ __launch_bounds__(kRingThreads) void attn_ring_kernel(const AttnParam
     const int kv_len = past_len + q_len;
 
     // this split's key range clipped by what the workgroup can causally see
-    int kps = (kv_len + p.nsplit - 1) / p.nsplit;
+    int kps = (kv_len + gns - 1) / gns;
     kps = (kps + kTK - 1) / kTK * kTK;
-    const int ks0 = split * kps;
+    const int ks0 = p.own_only ? past_len : split * kps;
+    if (p.own_only) split = p.nsplit - 1;
     const int wg_rows_end = (qblk * kRingQB + kRingQB < q_len) ? qblk * kRingQB + kRingQB : q_len;
     int kend = ks0 + kps;
     kend = kend < kv_len ? kend : kv_len;
@@ -766,8 +747,9 @@ int launch_attn_ring(const AttnParams& p0, int B, hipStream_t stream) {
     p.nqblk = pc_ceil_div(p.q_len, kRingQB);
     p.nbatch = B;
     p.xcd_remap = (p.nqblk >= 2 && !no_remap) ? 1 : 0;
-    dim3 grid(p.nqblk, p.H, B * p.nsplit);
-    if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B * p.nsplit + 7) / 8), 1, 1);
+    const int gns = p.own_only ? 1 : p.nsplit;
+    dim3 grid(p.nqblk, p.H, B * gns);
+    if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B * gns + 7) / 8), 1, 1);
     const dim3 block(kRingThreads);
     if (p.pre_k) {
         if (p.k_lo) hipLaunchKernelGGL((attn_ring_kernel<true, true>), grid, block, 0, stream, p);

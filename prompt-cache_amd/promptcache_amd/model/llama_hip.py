@@ -1473,7 +1473,8 @@ class LlamaHIP:
                        B, H, Hkv, D, q_len, past_len, self.softmax_scale, ws, past_len_dev=past_dev, out_frag=(ah, al),
                        q_lo=q16l, kv_lo=kvlo, counters=self._counters_for(B, H),
                        gather=None if self._gather is None else (self._gather, li * 2 * Hkv, (li * 2 + 1) * Hkv))
-            n.gemm_skinny(lw["wo_f"], ah, al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
+            mid_skip = self.mid_lo_skip if (T > self.SKINNY_MAX_ROWS and self._lo_mode != 3) else ()      # (precision audit: tools/plane_audit.py)
+            n.gemm_skinny(lw["wo_f"], ah, None if "o" in mid_skip else al, T, hid, H * D, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wo_s"])                                                    # attn @ Wo^T
             n.rmsnorm_frag(x, lw["ln2"], xh, xl, T, hid, eps, slabs, KQ)                       # x += ...; norm
             # (an encode pass on this stack follows the many-row stack's plane policy: dense_lo_skip; PC_MID_LO_SKIP=gu extends it to
@@ -1481,7 +1482,7 @@ class LlamaHIP:
             gu_lo = None if (T > self.SKINNY_MAX_ROWS and ((self._lo_mode == 3 and "gu" in self.dense_lo_skip) or
                                                            (self._lo_mode != 3 and "gu" in self.mid_lo_skip))) else xl
             n.gemm_skinny(lw["wgu_f"], xh, gu_lo, T, 2 * inter, hid, n.EPI_SILU, of_hi=ch, of_lo=cl, wscale=lw["wgu_s"])  # silu(g)*u
-            n.gemm_skinny(lw["wdown_f"], ch, cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
+            n.gemm_skinny(lw["wdown_f"], ch, None if "down" in mid_skip else cl, T, hid, inter, n.EPI_STORE, y=slabs, ldy=hid, kslices=KQ,
                           wscale=lw["wdown_s"])                                                 # act @ Wd^T
             pending = KQ
         V = c.vocab_size

@@ -5,6 +5,7 @@ config 4's shape (13b heads, 259 new rows over 8 258 staged keys: the ring kerne
 rows + 259 new ones against ``LlamaOracle.forward`` on oracle-staged random K/V.  The oracle only pays for the new rows, so these
 sizes cost it seconds."""
 import dataclasses
+import os
 import time
 
 import numpy as np
@@ -27,7 +28,10 @@ def _f16(a):
 
 
 @pytest.mark.parametrize("H,Hkv,D,q_len,past,stage_while_reading", [
-    (40, 40, 128, 259, 8258, False),      # BASELINE config 4: the ring kernel, 3 q-blocks x KV splits, residual tiles for the pass's own rows
+    (40, 40, 128, 259, 8258, False),      # BASELINE config 4: the wide kernel over the staged keys (17 row groups per workgroup, 6 key slices) + the ring kernel over the pass's own rows (residual tiles)
+    (40, 40, 128, 259, 8258, True),       # ... the same launch reading the staged rows from one module store and staging them (config 4's first forward)
+    (8, 2, 128, 130, 6200, True),         # wide kernel, grouped-query heads (4 per kv head: one writer each), 9 row groups = 2 + 1 + ... + 1, last tile partial
+    (4, 4, 128, 300, 6200, False),        # wide kernel, two q-blocks (19 row groups = 10 + 9)
     (32, 32, 128, 14, 4390, False),       # BASELINE config 2: <= 16 rows over the game prompt's staged keys (fp32 tail workgroup)
     (32, 32, 128, 14, 4390, True),        # ... the same launch reading the staged rows from module stores and staging them
     (32, 32, 128, 12, 1725, True),        # the headline step's attention
@@ -51,6 +55,8 @@ def test_attention_at_baseline_sizes_vs_pinned_oracle(H, Hkv, D, q_len, past, st
     gather = None
     if stage_while_reading:
         lens = [306, 2, 2, 2, 2, 76] + [800] * 5 if past == 4390 else [275, 1, 1, 1, 1, 1, 84, 1, 1, 174, 1, 1, 256, 1, 1, 155, 1, 1, 267, 1, 1, 265, 1, 1, 232]
+        if past > 5000:
+            lens = [258, past - 258 - 3001, 3000, 1]           # (config 4's schema: system blurb | one long context module | ...)
         assert sum(lens) == past
         offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(int)
         stores = [torch.stack([_f16(k_st[:, o:o + ln]), _f16(v_st[:, o:o + ln])]).unsqueeze(0).contiguous() for o, ln in zip(offs, lens)]   # [1][2][Hkv][len][D]
@@ -124,3 +130,32 @@ def test_13b_stack_at_config4_size_vs_llama_oracle():
     print(f"[13b x {L} layers, S={S} q={q}] max|dlogit| vs LlamaOracle = {err:.2e}, appended K rows {kerr:.2e} "
           f"(max|logit| {np.abs(logits).max():.2f}; oracle {time.perf_counter() - t0:.0f} s)")
     assert err < 1e-2 and kerr < 4e-3
+
+
+def test_wide_and_ring_paths_agree_at_config4_size():
+    """The same launch through the wide staged-key kernel (+ own rows + merge) and through the ring kernel alone (PC_ATTN_NO_WIDE=1):
+    two summation orders of the same split-precision arithmetic -- they agree to fp32 rounding, and both leave identical K / V."""
+    n = _n()
+    H = Hkv = 40; D = 128; q_len, past = 259, 8258
+    g = torch.Generator(device=DEV).manual_seed(7)
+    cap = past + q_len + 9
+    arena = torch.stack([0.7 * torch.randn((Hkv, cap, D), device=DEV, generator=g), torch.randn((Hkv, cap, D), device=DEV, generator=g)]).half()
+    q = torch.randn((q_len, H * D), device=DEV, generator=g)
+    qh = q.half(); ql = (q - qh.float()).half()
+    lo = (torch.randn((2, 1, Hkv, q_len, D), device=DEV, generator=g) * 2 ** -12).half()
+    ws = torch.empty(max(n.attn_workspace_bytes(1, H, D, q_len, past + q_len), 4) // 4, dtype=torch.float32, device=DEV)
+    outs = []
+    for no_wide in ("0", "1"):
+        os.environ["PC_ATTN_NO_WIDE"] = no_wide
+        try:
+            mt = (q_len + 15) // 16
+            oh = torch.full((mt, H * D // 32, 64, 8), float("nan"), dtype=torch.float16, device=DEV); ol = torch.full_like(oh, float("nan"))
+            n.attn_fwd(qh, q_len * H * D, H * D, arena[0].unsqueeze(0), arena[1].unsqueeze(0), 2 * Hkv * cap * D, cap * D, None, 0, 0,
+                       1, H, Hkv, D, q_len, past, 1.0 / np.sqrt(D), ws, out_frag=(oh, ol), q_lo=ql,
+                       kv_lo=(lo[0], lo[1], Hkv * q_len * D, q_len * D, -1))
+            torch.cuda.synchronize()
+            outs.append((n.from_act_frags(oh, q_len).float() + n.from_act_frags(ol, q_len).float()).cpu().numpy())
+        finally:
+            os.environ.pop("PC_ATTN_NO_WIDE", None)
+    assert np.isfinite(outs[0]).all() and np.isfinite(outs[1]).all()
+    assert np.abs(outs[0] - outs[1]).max() < 2e-6, np.abs(outs[0] - outs[1]).max()

@@ -1302,6 +1302,8 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
     dim3 grid(p.nqblk, p.H, B * p.nsplit);
     if (p.xcd_remap) grid = dim3(8 * p.nqblk * ((p.H * B + 7) / 8), 1, 1);
     const bool ring = D == 128 && ring_eligible(p, D);      // (attn_fwd_impl chose p.nsplit for it)
+#ifdef PC_DEV_SWEEPS      // (the merge inside the launch: built, bit-reproducible, and no faster than the second launch in three rounds of
+                          // measurements -- dev builds only; the product library ignores `counters` and merges in a second launch)
     if (!ring && p.small && p.counters) {
         // one launch: the last-arriving workgroup of each head merges the partials (no attn_combine_kernel)
 #define PC_SMALL_FUSED(NSV)                                                                                          \
@@ -1313,6 +1315,9 @@ int launch_attn(const AttnParams& p0, int B, hipStream_t stream) {
 #undef PC_SMALL_FUSED
         return pc_check_launch("attn_small_kernel");
     }
+#else
+    p.counters = nullptr;
+#endif
     if (ring) {
         // > 64 split-precision rows at head_dim 128: 128 rows per workgroup, tiles by LDS-DMA (pc_attn_ring.hip)
         const int rrc = p.wide ? launch_attn_wide(p, stream) : launch_attn_ring(p, B, stream);
@@ -1407,6 +1412,9 @@ int attn_fwd_impl(const void* q, const void* q_lo, int64_t q_batch_stride, int64
                   const void* pre_v = nullptr, const void* pre_k_lo = nullptr, const void* pre_v_lo = nullptr, int64_t pre_hs = 0,
                   const pc_kv_row* gather_rows = nullptr, int32_t g_kplane = 0, int32_t g_vplane = 0, int* gather_ok = nullptr,
                   int32_t defer_merge = 0, int32_t* nsplit_out = nullptr) {
+#ifndef PC_DEV_SWEEPS
+    counters = nullptr;       // (the in-launch merge exists in dev builds only: the product merges in a second launch, bit for bit the same)
+#endif
     // gather_ok != NULL: dry run -- *gather_ok = whether this launch shape would take gather_rows; nothing is launched
     PC_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len >= 0 && past_len >= 0, PC_ERR_ARG,
                "pc_attn_fwd: bad sizes");

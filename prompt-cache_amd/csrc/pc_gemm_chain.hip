@@ -1,3 +1,5 @@
+#ifdef PC_DEV_SWEEPS      // (dev builds only: see pc_dev.h)
+#include "pc_dev.h"
 // pc_gemm_chain: the projections between two attention calls of a <= 16-row forward as ONE persistent launch (opt-in,
 // PC_CHAIN=1).  Kernel templates shared with the stand-alone launches: pc_gemm_skinny.h.
 #include "pc_gemm_skinny.h"
@@ -263,3 +265,5 @@ PC_EXPORT int pc_gemm_chain(const void* wo_f, const void* attn_hi, const void* a
     pc_set_error("pc_gemm_chain: no instantiation for these tile widths (o/down %d, gate|up %d, q|k|v %d)", to, tg, tq);
     return PC_ERR_ARG;
 }
+
+#endif  // PC_DEV_SWEEPS

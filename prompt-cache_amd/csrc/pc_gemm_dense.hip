@@ -40,6 +40,9 @@
 #include <type_traits>
 
 #include "pc_common.h"
+#ifdef PC_DEV_SWEEPS
+#include "pc_dev.h"
+#endif
 
 namespace {
 
@@ -828,12 +831,17 @@ int launch_dense(DenseParams& p, hipStream_t s, int kslices = 1) {
     }
 #endif
     if (p.xl8) {
+#ifdef PC_DEV_SWEEPS
         if constexpr (EPI == EPI_GELU) {               // (no caller: the Falcon / MPT stacks keep the fp16 residual plane)
             pc_set_error("pc_gemm_dense_lo8: no GELU instantiation");
             return PC_ERR_ARG;
         } else {
             hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false, false, true>), grid, block, 0, s, p);
         }
+#else
+        pc_set_error("pc_gemm_dense: the int8 residual plane (x_lo8) needs a -DPC_DEV_SWEEPS build (csrc/pc_dev.h)");
+        return PC_ERR_ARG;
+#endif
     } else if (p.xl) hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, true, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_dense_kernel<WM, EPI, false, false>), grid, block, 0, s, p);
     return pc_check_launch("gemm_dense_kernel");
@@ -965,6 +973,7 @@ PC_EXPORT int pc_gemm_dense_ws(const void* x_hi, const void* x_lo, int64_t ldx, 
                            out_lo, ldo, stream, workspace, ws_bytes);
 }
 
+#ifdef PC_DEV_SWEEPS      // (dev builds only: see pc_dev.h)
 // pc_gemm_dense with the residual activation plane as int8 codes (pc_quant_rows_i8) against an int8 image of the weights: the
 // second plane's product runs on v_mfma_i32_32x32x32_i8 at twice the fp16 MFMA rate (include/promptcache_hip.h).
 PC_EXPORT int pc_gemm_dense_lo8(const void* x_hi, int64_t ldx, const void* x_lo8, const float* x_lo8_scale, int64_t ldx8, const void* w,
@@ -975,6 +984,7 @@ PC_EXPORT int pc_gemm_dense_lo8(const void* x_hi, int64_t ldx, const void* x_lo8
     return gemm_dense_impl(x_hi, nullptr, ldx, w, ldw, nullptr, nullptr, nullptr, 0, nullptr, M, N, K, epilogue, y, ldy, out_hi, out_lo,
                            ldo, stream, workspace, ws_bytes, &lo8);
 }
+#endif  // PC_DEV_SWEEPS
 
 // The fused q|k|v projection of a many-row pass at head_dim 128 (include/promptcache_hip.h: pc_dense_qkv_args): projection,
 // RoPE at the supplied positions, rotated q as hi / lo planes, rotated k and v appended to the arena (+ residual planes) -- the

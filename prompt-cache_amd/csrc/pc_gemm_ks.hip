@@ -244,7 +244,9 @@ int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M
     kp.slabs = (float*)scratch; kp.counters = (uint32_t*)counters; kp.formal = pc_formal_handoff();
     // k-steps per block: a wave's K share is K / 32 / (8 kslices) k-steps -- keep the whole share in flight where it fits
     const int share = pc_ceil_div(pc_ceil_div(K / 32, kslices), kWaves);
+#ifdef PC_DEV_SWEEPS      // (two blocks in flight: measured no gain, profiles/r05_ks_db_ab.txt -- dev builds only)
     static const int db = [] { const char* e = getenv("PC_KS_DB"); return e ? atoi(e) : 0; }();
+#endif
     if (mt == 2) {                                       // two row tiles: at most four weight tiles per workgroup
         switch (tiles_per_wg) {
             case 1: return share > 4 ? launch_ks<1, 8, false, 2>(kp, s) : launch_ks<1, 4, false, 2>(kp, s);
@@ -255,6 +257,7 @@ int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M
         pc_set_error("pc_gemm (ks): 17..32 rows take ks_tiles 1, 2 or 4 (got %d)", tiles_per_wg);
         return PC_ERR_ARG;
     }
+#ifdef PC_DEV_SWEEPS
     if (db) {                                            // two blocks in flight (PC_KS_DB=1: A/B against the single-block loop)
         switch (tiles_per_wg) {
             case 1: return launch_ks<1, 4, true>(kp, s);
@@ -264,6 +267,7 @@ int launch_skinny_ks(const void* wf, const void* xf_hi, const void* xf_lo, int M
             default: break;
         }
     }
+#endif
     switch (tiles_per_wg) {
         case 1: return share > 8 ? launch_ks<1, 16>(kp, s) : launch_ks<1, 8>(kp, s);
         case 2: return share > 8 ? launch_ks<2, 12>(kp, s) : launch_ks<2, 8>(kp, s);

@@ -1043,5 +1043,24 @@ int choose_T(int units);
             default: return launch_T<MTV, EPI_GELU>(p, T, units, s);                      \
         }                                                                                 \
     }
+// the same dispatcher over TWO translation units (the one-row-tile regime is the longest compile of the library: its epilogues with
+// an output plane on one side, the residual-stream ones on the other)
+#define PC_SKINNY_MT_DEFINE_A(NAME, MTV)                                                  \
+    int NAME(int epi, const GemmParams& p, int T, int units, hipStream_t s) {             \
+        switch (epi) {                                                                    \
+            case EPI_SILU: return launch_T<MTV, EPI_SILU>(p, T, units, s);                \
+            default: return launch_T<MTV, EPI_ROPE>(p, T, units, s);                      \
+        }                                                                                 \
+    }
+#define PC_SKINNY_MT_DEFINE_B(NAME, NAME_A, MTV)                                          \
+    int NAME_A(int epi, const GemmParams& p, int T, int units, hipStream_t s);            \
+    int NAME(int epi, const GemmParams& p, int T, int units, hipStream_t s) {             \
+        switch (epi) {                                                                    \
+            case EPI_STORE: return launch_T<MTV, EPI_STORE>(p, T, units, s);              \
+            case EPI_ADD: return launch_T<MTV, EPI_ADD>(p, T, units, s);                  \
+            case EPI_SILU: case EPI_ROPE: return NAME_A(epi, p, T, units, s);             \
+            default: return launch_T<MTV, EPI_GELU>(p, T, units, s);                      \
+        }                                                                                 \
+    }
 
 }  // namespace pcg

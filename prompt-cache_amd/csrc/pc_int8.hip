@@ -26,6 +26,9 @@
 #include <hip/hip_fp16.h>
 
 #include "pc_common.h"
+#ifdef PC_DEV_SWEEPS
+#include "pc_dev.h"
+#endif
 
 namespace {
 
@@ -414,6 +417,7 @@ PC_EXPORT int pc_outlier_corr(const void* flags, int32_t K, const void* x, const
     return pc_check_launch("outlier_corr_kernel");
 }
 
+#ifdef PC_DEV_SWEEPS      // (dev builds only: see pc_dev.h)
 PC_EXPORT int pc_quant_rows_i8(const void* x, int64_t ldx, int32_t M, int32_t K, void* codes, int64_t ld8, float* scale, void* stream) {
     PC_REQUIRE(x && codes && scale && M > 0 && K > 0 && K % 8 == 0 && ldx >= K && ldx % 8 == 0 && ld8 >= K && ld8 % 8 == 0 &&
                ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 7) == 0, PC_ERR_ARG,
@@ -431,3 +435,4 @@ PC_EXPORT int pc_quant_rows_i8(const void* x, int64_t ldx, int32_t M, int32_t K,
     }
     return pc_check_launch("quant_rows_kernel");
 }
+#endif  // PC_DEV_SWEEPS

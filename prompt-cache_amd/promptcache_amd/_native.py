@@ -149,16 +149,21 @@ SIGNATURES = {
     "pc_outlier_corr": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_dense_a8": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pc_gemm_dense": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "pc_gemm_dense_qkv_rope": (C.c_int, [_vp, _vp]),
+    "pc_gemm_dense_ws": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
+}
+
+# Entry points of -DPC_DEV_SWEEPS builds only (csrc/pc_dev.h: measured negative results kept for A/B; not in the product library
+# and not part of include/promptcache_hip.h): bound when the loaded library has them.
+DEV_SIGNATURES = {
     "pc_chain_sync_words": (C.c_int32, []),
     "pc_chain_sync_err_word": (C.c_int32, []),
     "pc_gemm_chain": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64,
                                 _i32, _vp, _vp]),
-    "pc_gemm_dense_qkv_rope": (C.c_int, [_vp, _vp]),
     "pc_quant_rows_i8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_dense_lo8": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp,
                                     _i64, _vp, _i64, _vp]),
-    "pc_gemm_dense_ws": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
 
@@ -181,8 +186,25 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DEV_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+def has(name: str) -> bool:
+    """Whether the loaded library exports ``name`` (the dev-only entry points of csrc/pc_dev.h exist in -DPC_DEV_SWEEPS builds)."""
+    return hasattr(load(), name)
+
+
+def _dev(name: str):
+    fn = getattr(load(), name, None)
+    if fn is None:
+        raise RuntimeError(f"{name} exists only in a dev build of the library: PC_BUILD_FLAGS=-DPC_DEV_SWEEPS python __graft_entry__.py --force")
+    return fn
 
 
 def check(rc: int, what: str) -> None:
@@ -591,7 +613,7 @@ def gemm_dense(x_hi, x_lo, w, M: int, N: int, K: int, epilogue: int, y=None, out
 def quant_rows_i8(x_lo, M: int, K: int, codes, scale, stream: Optional[int] = None) -> None:
     """A residual activation plane fp16 ``[M, K]`` -> row-wise absmax int8 codes ``codes [M, K]`` + ``scale [M]`` fp32
     (``pc_quant_rows_i8``): the second operand plane of ``gemm_dense(..., lo8=...)``."""
-    rc = load().pc_quant_rows_i8(x_lo.data_ptr(), x_lo.stride(-2), M, K, codes.data_ptr(), codes.stride(-2), scale.data_ptr(),
+    rc = _dev("pc_quant_rows_i8")(x_lo.data_ptr(), x_lo.stride(-2), M, K, codes.data_ptr(), codes.stride(-2), scale.data_ptr(),
                                  current_stream() if stream is None else stream)
     check(rc, "pc_quant_rows_i8")
 
@@ -600,7 +622,7 @@ def gemm_dense_lo8(x_hi, x_lo8, x_lo8_scale, w, w8, w8_scale, M: int, N: int, K:
                    workspace=None, stream: Optional[int] = None) -> None:
     """``gemm_dense`` with the residual activation plane on the int8 MFMA (``pc_gemm_dense_lo8``): ``x_lo8`` int8 ``[M, K]`` +
     ``x_lo8_scale [M]`` from ``quant_rows_i8``, ``w8`` int8 ``[N, K]`` + ``w8_scale [N]`` from ``quantize_rows_int8(w)``."""
-    rc = load().pc_gemm_dense_lo8(x_hi.data_ptr(), x_hi.stride(-2), x_lo8.data_ptr(), x_lo8_scale.data_ptr(), x_lo8.stride(-2),
+    rc = _dev("pc_gemm_dense_lo8")(x_hi.data_ptr(), x_hi.stride(-2), x_lo8.data_ptr(), x_lo8_scale.data_ptr(), x_lo8.stride(-2),
                                   w.data_ptr(), w.stride(-2), w8.data_ptr(), w8_scale.data_ptr(), w8.stride(-2), M, N, K, epilogue,
                                   _ptr(y), 0 if y is None else y.stride(-2), _ptr(out_hi), _ptr(out_lo),
                                   0 if out_hi is None else out_hi.stride(-2), _ptr(workspace),
@@ -629,12 +651,12 @@ def gemm_dense_qkv_rope(x_hi, x_lo, w, K: int, cs, q_hi, q_lo, q_ts: int, k_aren
 def chain_sync_state(device) -> "torch.Tensor":
     """Zeroed sync state of pc_gemm_chain (owned by the launches afterwards; one per stream of chained launches)."""
     import torch
-    return torch.zeros(load().pc_chain_sync_words(), dtype=torch.int32, device=device)
+    return torch.zeros(_dev("pc_chain_sync_words")(), dtype=torch.int32, device=device)
 
 
 def chain_sync_error(state) -> int:
     """Non-zero: an in-kernel wait of pc_gemm_chain timed out (synchronises)."""
-    return int(state[load().pc_chain_sync_err_word()].item())
+    return int(state[_dev("pc_chain_sync_err_word")()].item())
 
 
 def gemm_chain(wo_f, attn_hi, attn_lo, attn_width: int, x, M: int, hidden: int, wgu_f, ln2, eps: float, inter: int, act_hi, act_lo,
@@ -644,7 +666,7 @@ def gemm_chain(wo_f, attn_hi, attn_lo, attn_width: int, x, M: int, hidden: int, 
     past_len_dev=None, kv_lo=None (k_lo, v_lo, bs, hs), lo_base=-1) or None."""
     q = qkv or {}
     lo = q.get("kv_lo") or (None, None, 0, 0)
-    rc = load().pc_gemm_chain(wo_f.data_ptr(), attn_hi.data_ptr(), attn_lo.data_ptr(), attn_width, x.data_ptr(), M, hidden,
+    rc = _dev("pc_gemm_chain")(wo_f.data_ptr(), attn_hi.data_ptr(), attn_lo.data_ptr(), attn_width, x.data_ptr(), M, hidden,
                               wgu_f.data_ptr(), ln2.data_ptr(), eps, inter, act_hi.data_ptr(), act_lo.data_ptr(),
                               wdown_f.data_ptr(), _ptr(q.get("wqkv_f")), _ptr(q.get("ln1")), _ptr(q.get("cs")),
                               _ptr(q.get("q_hi")), _ptr(q.get("q_lo")), q.get("q_ts", 0), _ptr(q.get("k_arena")),

@@ -238,7 +238,7 @@ class LlamaHIP:
         self.kslices = 4        # K-slices of the o_proj / down_proj launches (see _forward_skinny)
         # pc_gemm_chain (one persistent launch for o_proj -> gate|up -> down -> next q|k|v): correct and bit-identical, but
         # measured SLOWER than the four launches on MI355X (106-121 vs 88 us per layer, profiles/r02_chain_trace.txt): opt-in
-        self.use_chain = os.environ.get("PC_CHAIN", "0") == "1"
+        self.use_chain = os.environ.get("PC_CHAIN", "0") == "1" and _native.has("pc_gemm_chain")      # (dev builds only: csrc/pc_dev.h)
         self._chain_sync = None
         # split-precision activations in the many-row path (see _forward_dense_split); PC_FAST_DENSE=1 trades the
         # full-depth parity for 2x fewer GEMM flops
@@ -266,7 +266,7 @@ class LlamaHIP:
         # ~75 % of the matrix peak at the clock the chip holds under this load), the persona encode 101.9 -> 104.2 k tok/s, full-depth
         # parity unchanged at 7b (5.1e-3) and 3.3e-3 instead of 2.0e-3 at 13b -- for 6.7 GB of int8 weight images at 7b.  Not worth a
         # second weight image by default: OPT-IN (PC_DENSE_LO8=1).
-        self.dense_lo8 = os.environ.get("PC_DENSE_LO8", "0") == "1"
+        self.dense_lo8 = os.environ.get("PC_DENSE_LO8", "0") == "1" and _native.has("pc_gemm_dense_lo8")      # (dev builds only: csrc/pc_dev.h)
         self.encode_mid = os.environ.get("PC_ENC_MID", "1") != "0"    # encode passes of 65..512 rows on the row-split stack
         # keep the fp16 residuals of the K / V rows appended behind a staged cache -- the prompt's own tokens and every
         # decoded token -- in the arena's residual tail and feed them to the attention (the reference keeps those rows in

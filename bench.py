@@ -1139,20 +1139,25 @@ def main():
         del lm8
         torch.cuda.empty_cache()
         # ... and with an outlier profile closer to a trained model's: N(0, 0.02) init leaves ~460 of down_proj's 11 008 input columns
-        # above the LLM.int8 threshold (the cost of the fp16 correction scales with them), a trained Llama carries a handful of massive
-        # hidden channels instead.  Same recipe as tests/test_gpu_fullsize.py::test_full_depth_7b_with_outlier_feature_channels: six
-        # channels of the embedding scaled 60 x (after RMSNorm ~24 against ~0.4 for the rest).
+        # above the LLM.int8 threshold (silu(g) * u with g, u ~ N(0, 1.3): the cost of the fp16 correction scales with them), a trained
+        # Llama carries a handful of massive hidden channels instead.  Recipe: six channels of the embedding scaled 60 x (after RMSNorm
+        # ~24 against ~0.4 for the rest, as tests/test_gpu_fullsize.py::test_full_depth_7b_with_outlier_feature_channels builds: six
+        # flagged columns on every q|k|v / gate|up input) and the gate / up weights halved (g, u ~ N(0, 0.6): the MLP's intermediate
+        # activations stay under the threshold but for the columns the massive channels drive).  Synthetic either way: no checkpoint here.
         from promptcache_amd.model.config import SHAPES as _SH
         from promptcache_amd.model.weights import random_weights_device as _rw
         _shape8 = _SH[args.model]
         _w8 = _rw(_shape8, device, torch.float16, 0)
         _w8["embed"][:, [7, 300, 1021, 2049, 3000, 4000]] *= 60.0
+        for _k in list(_w8):
+            if _k.endswith((".gate", ".up")):
+                _w8[_k] *= 0.5
         lm8t = Llama2(name=args.model + "-outlier-channels", shape=_shape8, weights=_w8, device=device, load_in_8bit=True)
         del _w8
         i8t = int8_leg(lm8t)
         i8t["outlier_cols"] = (i8t["outlier_columns_last_layer"] or {}).get("down_proj_in")
-        i8t["what"] = ("the same leg on a model with six 60 x hidden channels (a trained-like outlier profile: a handful of flagged "
-                       "columns per projection input instead of ~460 on down_proj's)")
+        i8t["what"] = ("the same leg on a model with six 60 x hidden channels and halved gate / up weights (a trained-like outlier profile: "
+                       "a handful of flagged columns per projection input instead of ~460 on down_proj's)")
         del lm8t
         torch.cuda.empty_cache()
         i8["trained_like"] = i8t

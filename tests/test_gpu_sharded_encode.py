@@ -144,3 +144,30 @@ def _two_ranks(backend):
     print(f"[sharded encode, 2 ranks, {backend}] passes per rank {passes}, max|dKV| vs solo {max(r[3] for r in res):.2e}, "
           f"max|dlogit| {max(r[4] for r in res):.2e}")
     assert all(r[0] in (0, 1) for r in res) and all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_py_two_ranks_on_one_gpu_plumbing():
+    """VERDICT r5, Next 8: the driver's ``--gpus N`` launch of bench.py has never run on hardware (no multi-GPU box was granted).  This
+    runs the SAME command line the driver uses -- ``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`` -- with
+    both ranks on cuda:0 and gloo in place of RCCL (bench.py's test hooks), at the mid model shape: the rendezvous, the barriers, the
+    max-over-ranks timing, the sharded schema encode + module-KV exchange of the `encode` and `encode_library` legs and the one JSON
+    line of rank 0 are exercised end to end, so that the first real 8-GPU run cannot fail in plumbing rather than in RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PC_BENCH_SAME_DEVICE="1", PC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--model", "mid", "--max-ctx", "2048", "--no-context", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line, the other rank nothing
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    enc, lib = d["encode"], d["encode_library"]
+    assert enc["sharded_over"] == 2 and len(enc["per_rank_computed_tokens"]) == 2 and min(enc["per_rank_computed_tokens"]) > 0
+    assert enc["library_identical_on_all_ranks"] is True and enc["exchange"]["bytes_received_per_rank_max"] > 0
+    assert lib["sharded_over"] == 2 and lib["tokens_per_s"] > 0
+    assert list(d)[-1] == "summary"

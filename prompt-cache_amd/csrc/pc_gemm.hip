@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void rmsnorm_frag_kernel(float* __restrict__ x
         // CH slabs at a time: all of their loads are issued before the first add (clamped, unconditional), so a chunk
         // costs one L2 round trip instead of one per slab (one workgroup per row: with 12..64 rows nothing else hides
         // the latency -- 6.5 -> ~4 us per launch at 22 rows); the adds keep the fixed slab order
-        constexpr int CH = G <= 2 ? 4 : (G <= 4 ? 3 : 1);     // (6 slabs at hidden 5120: two round trips instead of three)
+        constexpr int CH = G <= 4 ? 4 : 1;     // (4 slabs -- the 65..512-row stack at every hidden size up to 8192 -- in ONE round trip; 6 slabs at hidden 5120: two)
         for (int s0 = 0; s0 < nslabs; s0 += CH) {
             f4 c[CH][G], d[CH][G];
 #pragma unroll

@@ -300,33 +300,34 @@ __global__ __launch_bounds__(kWThreads) void attn_wide_kernel(const AttnParams p
     };
     auto pv_unit = [&](const _Float16* Vl, auto g0i, auto ngi, const h8 (&pb)[2][2], const h8 (&pbl)[2][2]) {
         constexpr int G0 = decltype(g0i)::value, NG = decltype(ngi)::value;
-        h4 va[2][2][4];
+        // register sets of V^T fragments: the next pair of head-dim blocks is read while this one is multiplied; a ONE-group unit
+        // multiplies a pair in 8 MFMAs (128 cycles: half an LDS round trip) and reads two pairs ahead where the registers allow
+        // (R < 3: 94.7 -> 92.0 us at 130 rows, profiles/r06_variants.txt)
+        constexpr int NS = (NG == 1 && R < 3) ? 3 : 2;
+        h4 va[NS][2][4];
         // V^T fragment of head-dim block db, key step t: row t * 32 + gq * 4 + (n >> 2) of the plane, 8 bytes at column
         // (db * 32 + (n & 3) * 8 + 32 (row & 7)) mod 256 -- one per-lane row base (opaque per unit: see qk_unit) and a column that
         // walks 32 bytes per block; the key step and the second half of the fragment are immediate offsets
         int vb = v_rowb;
         asm volatile("" : "+v"(vb));
         const char* const vrow_p = (const char*)Vl + vb;
-        auto load_v = [&](int db, int set) {
-            const char* q = vrow_p + ((v_colb + db * 32) & 255);
+        auto load_pair = [&](int dp) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                va[set][db & 1][2 * t] = lds_tr_read((const _Float16*)(q + t * 32 * D * 2));
-                va[set][db & 1][2 * t + 1] = lds_tr_read((const _Float16*)(q + t * 32 * D * 2 + 16 * D * 2));
+            for (int d = 0; d < 2; ++d) {
+                const char* q = vrow_p + ((v_colb + (2 * dp + d) * 32) & 255);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    va[dp % NS][d][2 * t] = lds_tr_read((const _Float16*)(q + t * 32 * D * 2));
+                    va[dp % NS][d][2 * t + 1] = lds_tr_read((const _Float16*)(q + t * 32 * D * 2 + 16 * D * 2));
+                }
             }
         };
-        // head-dim blocks in PAIRS: the 8 NG MFMAs of a pair walk its 2 NG accumulators in turn, and the fragments of the next pair
-        // are read while this one is multiplied
-        load_v(0, 0);
-        load_v(1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 2);
+        // head-dim blocks in PAIRS: the 8 NG MFMAs of a pair walk its 2 NG accumulators in turn
+#pragma unroll
+        for (int dp = 0; dp < NS - 1; ++dp) { load_pair(dp); __builtin_amdgcn_sched_group_barrier(0x100, 8, 2); }
 #pragma unroll
         for (int dp = 0; dp < DB / 2; ++dp) {
-            if (dp + 1 < DB / 2) {
-                load_v(2 * dp + 2, (dp + 1) & 1);
-                load_v(2 * dp + 3, (dp + 1) & 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 2);
-            }
+            if (dp + NS - 1 < DB / 2) { load_pair(dp + NS - 1); __builtin_amdgcn_sched_group_barrier(0x100, 8, 2); }
 #if PC_WIDE_EXP != 1
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -336,12 +337,12 @@ __global__ __launch_bounds__(kWThreads) void attn_wide_kernel(const AttnParams p
                     for (int u = 0; u < NG; ++u)
 #pragma unroll
                         for (int d = 0; d < 2; ++d) {
-                            const h4 lo = va[dp & 1][d][2 * t], hi = va[dp & 1][d][2 * t + 1];
+                            const h4 lo = va[dp % NS][d][2 * t], hi = va[dp % NS][d][2 * t + 1];
                             const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             o[G0 + u][2 * dp + d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pl_ ? pbl[u][t] : pb[u][t], o[G0 + u][2 * dp + d], 0, 0, 0);
                         }
 #else
-            asm volatile("" :: "v"(va[dp & 1][0][0]), "v"(va[dp & 1][0][3]), "v"(va[dp & 1][1][0]), "v"(va[dp & 1][1][3]));
+            asm volatile("" :: "v"(va[dp % NS][0][0]), "v"(va[dp % NS][0][3]), "v"(va[dp % NS][1][0]), "v"(va[dp % NS][1][3]));
 #endif
             __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 2);
         }

@@ -23,7 +23,9 @@ constexpr int kStageWaves = 4;
 
 
 // SW staging waves, KCV k-steps per stage, PDV activation prefetch distance, LB launch bound (0 / -1 / 0: the defaults)
-template <int TT, int EPI, int MTW, bool TWO, int SW = kStageWaves, int KCV = 0, int PDV = -1, int LB = 0>
+// NSD > 0: the staging waves move the stages HBM -> LDS by LDS-DMA (`global_load_lds`, no registers in between) through a ring of
+// NSD stages instead of three register sets and two LDS buffers
+template <int TT, int EPI, int MTW, bool TWO, int SW = kStageWaves, int KCV = 0, int PDV = -1, int LB = 0, int NSD = 0>
 __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_kernel(const GemmParams p) {
     constexpr int T = (EPI == EPI_SILU) ? TT / 2 : TT;   // output units (tiles, or gate/up pairs) per workgroup
     constexpr int KC = KCV ? KCV : (TT <= 4) ? 8 : 4;    // k-steps per stage
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
     constexpr int FPW = F / SW;
     constexpr int PD = PDV >= 0 ? PDV : (MTW == 2) ? 3 : 1, NX = PD + 1;  // activation prefetch distance (k-steps) / register sets
     static_assert(F % SW == 0 && KC % NX == 0, "stage must split evenly over the staging waves");
-    __shared__ __attribute__((aligned(16))) _Float16 wbuf[2][F][64][8];
+    constexpr int NB = NSD ? NSD : 2;                    // LDS stages
+    __shared__ __attribute__((aligned(16))) _Float16 wbuf[NB][F][64][8];
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,6 +71,44 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
             kst[i] = kk;
             src[i] = p.wf + (((int64_t)tile * KS + kq0 + kk) * 64 + lane) * 8;
         }
+        if constexpr (NSD > 0) {
+            // Ring of NSD stages: stage st lives in slot st % NSD.  Compute waves pass barrier #st when they are done with
+            // stage st-1, so after it slot (st-1) % NSD is free: that is where stage st+NSD-1 goes.  Before barrier #st this
+            // wave's DMAs of stage st must have landed: all but the NSD-2 stages issued after it (vmcnt counts in order).
+            // K-steps of the last stage past the end of the K range re-read the last valid one; the compute waves skip them.
+            const uint32_t w0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&wbuf[0][0][0][0];
+            auto issue = [&](int st, int slot) __attribute__((always_inline)) {
+                const int se = st < nst ? st : nst - 1;
+#pragma unroll
+                for (int i = 0; i < FPW; ++i) {
+                    const int kabs = kq0 + se * KC + kst[i];
+                    const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);
+                    const _Float16* g = src[i] + ((int64_t)se * KC - back) * 512;
+                    const uint32_t dst = w0 + (uint32_t)((slot * F + sidx + SW * i) * 1024);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(dst) : "memory");
+                }
+            };
+            int slot = 0;
+            for (int st = 0; st < NSD - 1 && st < nst; ++st) { issue(st, slot); slot = slot + 1 == NSD ? 0 : slot + 1; }
+            for (int st = 0; st < nst; ++st) {
+                const int ahead = nst - 1 - st < NSD - 2 ? nst - 1 - st : NSD - 2;   // stages issued behind st: they may stay in flight
+#pragma unroll
+                for (int r = 0; r <= NSD - 2; ++r)
+                    if (ahead == r) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(r * FPW) : "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (st + NSD - 1 < nst) {
+                    issue(st + NSD - 1, slot);
+                    slot = slot + 1 == NSD ? 0 : slot + 1;
+                }
+            }
+            return;
+        }
+        // (dev timing probes, tools/rows_exp.sh: -DPC_ROWS_EXP=2 streams nothing, =1 computes nothing, =3 loads no activations)
+#if defined(PC_ROWS_EXP) && PC_ROWS_EXP == 2
+#define PC_ROWS_STAGE_SRC(dst, ptr) { (void)(ptr); dst = h8{1, 1, 1, 1, 1, 1, 1, 1}; }
+#else
+#define PC_ROWS_STAGE_SRC(dst, ptr) dst = ldg_h8_nt(ptr);
+#endif
         h8 r0[FPW], r1[FPW], r2[FPW];
         const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         // loads of stage st into a register set; k-steps past the end of the K range re-read the last valid
@@ -78,7 +119,7 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
             _Pragma("unroll") for (int i = 0; i < FPW; ++i) {                                 \
                 const int kabs = kq0 + se * KC + kst[i];                                      \
                 const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);                           \
-                R[i] = ldg_h8_nt(src[i] + ((int64_t)se * KC - back) * 512);                   \
+                PC_ROWS_STAGE_SRC(R[i], src[i] + ((int64_t)se * KC - back) * 512)            \
             }                                                                                 \
         }
 #define PC_STAGE_WRITE(R, ST)                                                                 \
@@ -111,6 +152,7 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
         }
 #undef PC_STAGE_LOAD
 #undef PC_STAGE_WRITE
+#undef PC_ROWS_STAGE_SRC
         return;
     }
 
@@ -149,25 +191,36 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
             }
         }
     }
+    int slot = 0;
     for (int st = 0; st < nst; ++st) {
-        lds_barrier();                                   // stage st is in wbuf[st & 1]
-        const _Float16* wst = &wbuf[st & 1][0][lane][0];
+        lds_barrier();                                   // stage st is in wbuf[st & 1] (ring: wbuf[st % NSD])
+        const _Float16* wst = &wbuf[NSD ? slot : (st & 1)][0][lane][0];
+        if (NSD) slot = slot + 1 == NSD ? 0 : slot + 1;
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             // prefetch the activation fragments PD k-steps ahead (clamped at the end of the K range)
             const int kn = kseq(st * KC + j + PD);
 #pragma unroll
             for (int a = 0; a < MTW; ++a) {
+#if defined(PC_ROWS_EXP) && PC_ROWS_EXP == 3
+                (void)kn;
+#else
                 xs[(j + PD) % NX][a] = ldg_h8(xa[a] + (int64_t)kn * 512);
                 if (TWO) xsl[(j + PD) % NX][a] = ldg_h8(xa[a] + lo_delta + (int64_t)kn * 512);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead of this k-step's MFMAs (see k_block)
             h8 w[TT];
 #pragma unroll
             for (int t = 0; t < TT; ++t) w[t] = *(const h8*)(wst + (j * TT + t) * 512);
+            const bool kok = !NSD || st * KC + j <= klast;   // (ring stages hold re-read k-steps behind the end of the K range, not zeros)
 #pragma unroll
             for (int a = 0; a < MTW; ++a) {
-                if (a < nva) {
+#if defined(PC_ROWS_EXP) && PC_ROWS_EXP == 1
+                if (a < nva && p.M < 0) {
+#else
+                if (a < nva && kok) {
+#endif
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
                         acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], xs[j % NX][a], acc[a][t], 0, 0, 0);
@@ -235,6 +288,18 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
             GemmParams pz = p;
             pz.zrows = nz == 1 ? 0 : 16 * pc_ceil_div(mt, 2);
             const int rw = pc_ceil_div(pc_ceil_div(mt, nz), 2);
+#ifdef PC_DEV_SWEEPS
+            // (LDS-DMA ring staging, round 6: the same time as register staging in the step -- config 4 21.96 / 21.93 ms against
+            // 21.93 / 21.83 -- because a CU's weight stream is capped near 13.5 GB/s whatever is in flight; profiles/r06_variants.txt r6s)
+            static const int ring = [] { const char* e = getenv("PC_ROWS_RING"); return e ? atoi(e) : 0; }();
+            if (ring == 6)
+                hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768, 6>), dim3(pc_ceil_div(units, TV), p.kslices, nz),
+                                   dim3((rw + 3) * 64), 0, s, pz);
+            else if (ring == 3)
+                hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 6, 2, 768, 3>), dim3(pc_ceil_div(units, TV), p.kslices, nz),
+                                   dim3((rw + 3) * 64), 0, s, pz);
+            else
+#endif
             hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768>), dim3(pc_ceil_div(units, TV), p.kslices, nz),
                                dim3((rw + 3) * 64), 0, s, pz);
             return pc_check_launch("gemm_rows_kernel");

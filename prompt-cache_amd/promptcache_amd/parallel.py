@@ -20,7 +20,7 @@ encode overlaps the exchange of schema k with the encode of schema k + 1 (``Cach
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -156,14 +156,16 @@ def carve(sizes: Sequence[int], dtype, device, align: int = 8) -> Tuple[torch.Te
 
 
 def exchange_slabs(mine: torch.Tensor, sizes_by_rank: Sequence[Sequence[int]], rank: int, world: int, device, dtype=None,
-                   group=None, async_op: bool = False):
+                   group=None, async_op: bool = False, rank_map: Optional[Sequence[int]] = None):
     """Every rank contributes one slab laid out by ``carve(sizes_by_rank[rank])``; returns ``(views_by_rank, handles)``:
     ``views_by_rank[r]`` = the flat per-segment views of rank r's slab (this rank's own slab is ``mine`` itself, the
     others are received at their exact size: nothing is padded, nothing is re-packed).  ONE grouped point-to-point
     step: this rank's slab goes to every peer and every non-empty peer slab is received, all in one
     ``batch_isend_irecv`` (RCCL: one ncclGroup -- the G - 1 sends leave over G - 1 links concurrently; the peers are
     walked starting behind this rank so that no two ranks open with the same destination).  ``async_op``: return the
-    pending work handles instead of waiting -- the caller keeps computing and waits before the segments are read."""
+    pending work handles instead of waiting -- the caller keeps computing and waits before the segments are read.
+    ``rank_map`` (tests): logical rank -> rank of the process group, so that a one-GPU box can run the grouped send / recv
+    on RCCL as a loop onto itself (``tests/test_gpu_sharded_encode.py``)."""
     import torch.distributed as dist
     dtype = dtype or mine.dtype
     views_by_rank = []
@@ -176,6 +178,9 @@ def exchange_slabs(mine: torch.Tensor, sizes_by_rank: Sequence[Sequence[int]], r
         views_by_rank.append(views)
         slabs.append(slab)
     glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    if rank_map is not None:
+        inner = glob
+        glob = lambda r: inner(rank_map[r])  # noqa: E731
     ops = []
     for d in range(1, world):
         src = (rank - d) % world                     # receive from the rank d places behind, send to the one d ahead

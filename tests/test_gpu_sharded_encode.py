@@ -224,3 +224,26 @@ def test_exchange_slabs_runs_on_rccl_as_a_self_loop():
     p.join(timeout=60)
     assert res[0] == "ok", res[1]
     assert p.exitcode == 0
+
+
+def test_bench_py_collectives_run_on_rccl_with_one_rank():
+    """bench.py's own collectives -- the ``device_id`` form of ``init_process_group("nccl")``, the barriers around the timed region, the
+    MAX / MIN / SUM all-reduces on device tensors behind it -- executed by RCCL: the driver's launch line with one rank and
+    ``PC_BENCH_FORCE_DIST=1`` (a one-rank group instead of none).  Together with the two-rank gloo run above and the self-loop
+    exchange this is everything of ``--gpus N`` a one-GPU box can execute on the real backend."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    env.pop("PC_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--model", "mid", "--max-ctx", "2048", "--no-context", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and list(d)[-1] == "summary"
+    assert d["encode"]["per_rank_computed_tokens"] == [d["encode"]["computed_tokens"]]

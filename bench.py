@@ -401,8 +401,8 @@ def attn_many_roofline(lm, q_len: int, S: int):
                      " + attn_combine_kernel (pc_attn, > 64 split-precision rows): ALL launches of one pc_attn call inside the events",
            "staging": staging, "bound": "mfma", "achieved": flops / (avg * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "executed_frac": 2 * flops / (avg * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
-           "traffic": _pmc_traffic("attn_ring_staging", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[0] if staging else None,
-           "traffic_source": _pmc_traffic("attn_ring_staging", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[1] if staging else None,
+           "traffic": _pmc_traffic("attn_wide_staging" if wide else "attn_ring_staging", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[0] if staging else None,
+           "traffic_source": _pmc_traffic("attn_wide_staging" if wide else "attn_ring_staging", f"H={H},Hkv={Hkv},D={D},q={q_len},S={S}")[1] if staging else None,
            "algorithmic_flops_per_launch": flops, "avg_launch_us": avg, "min_launch_us": us[staging][0],
            "launches_timed": len(us[staging]), "launches_per_step": m.L, "q_len": q_len, "staged_keys": S,
            "hbm_bytes_per_launch_algorithmic": (2 if staging else 1) * kv_bytes,

@@ -19,9 +19,10 @@ env = dict(os.environ, TMPDIR="/tmp")
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(OUT, ctr)
-    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable,
-                    os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-context", "--no-cpu-baseline",
-                    "--no-library"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if "--reuse" not in sys.argv:                       # (--reuse: only re-read the CSVs of an earlier run)
+        subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable,
+                        os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-context", "--no-cpu-baseline",
+                        "--no-library"], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -70,17 +71,26 @@ if "--config4" in sys.argv:
     v4 = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(OUT, "c4_" + ctr)
-        subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable,
-                        os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
-                       cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if "--reuse" not in sys.argv:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable,
+                            os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                           cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
-        xs = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "attn_ring_kernel<true, false, true>" in r["Kernel_Name"]]
-        v4[ctr] = sum(xs) / len(xs) if xs else None
-    if v4["FETCH_SIZE"] is not None and v4["WRITE_SIZE"] is not None:
-        tab["attn_ring_staging"] = {"signature": "H=40,Hkv=40,D=128,q=259,S=8258",
-                                    "hbm_bytes_per_launch": int((2 * v4["FETCH_SIZE"] + v4["WRITE_SIZE"]) * 1024),
+        rows_ = list(csv.DictReader(open(f)))
+        # round 6: the wide staged-key kernel (staging variant) + the ring kernel over the pass's own rows (split merge not included)
+        per = {}
+        # (the own-rows launch is told from the schema encode's ring launches of the same run by its grid: 40 heads x 3 blocks of 128 rows x 512 threads)
+        for sub, grid in (("attn_wide_kernel<true", None), ("attn_ring_kernel<", str(40 * 3 * 512))):
+            xs = [float(r["Counter_Value"]) for r in rows_ if sub in r["Kernel_Name"] and (grid is None or r["Grid_Size"] == grid)]
+            per[sub] = sum(xs) / len(xs) if xs else None
+        v4[ctr] = per
+    if all(v4[c][k] is not None for c in v4 for k in v4[c]):
+        tot = {c: sum(v4[c].values()) for c in v4}
+        tab["attn_wide_staging"] = {"signature": "H=40,Hkv=40,D=128,q=259,S=8258",
+                                    "hbm_bytes_per_launch": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024),
+                                    "parts_KiB": v4,
                                     "source": src.replace("bench.py --no-context", "bench.py --config 4") +
-                                    " (attn_ring_kernel<true, false, true> = pc_attn gather_rows at > 32 rows; the split merge not included)"}
+                                    " (attn_wide_kernel<true, 3> over the staged keys, staging them as they pass, + attn_ring_kernel over the pass's own rows = one pc_attn call; the split merge not included)"}
 # keep entries of earlier rounds that this run did not re-measure (e.g. attn_cached: the copy-first step)
 try:
     old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

@@ -5,6 +5,10 @@
 //                        profiles/r05_variants.txt r5j)
 //   pc_gemm_dense_lo8    the residual activation plane of the many-row projections on the int8 MFMA: +2 % encode throughput for
 //                        6.7 GB of int8 weight images at 7b (profiles/r05_dense_lo8_ab.txt)
+//   pc_gemm_part_rows    o_proj of a 2..16-row cached step on the attention's split-KV partials, K sliced across workgroups (round 6,
+//                        VERDICT r5 Next 2's second half): correct and deterministic, and SLOWER than merge launch + o_proj -- 19.1 us
+//                        against 4.7 + 10.0 at the persona shape: every workgroup pulls 256 KiB of fp32 partials next to its 128 KiB
+//                        of weights (profiles/r06_variants.txt r6t)
 #pragma once
 #include <stdint.h>
 #ifdef __cplusplus
@@ -28,6 +32,19 @@ int pc_gemm_dense_lo8(const void* x_hi, int64_t ldx, const void* x_lo8, const fl
                       int64_t ldw, const void* w8, const float* w8_scale, int64_t ldw8, int32_t M, int32_t N, int32_t K,
                       int32_t epilogue, float* y, int64_t ldy, void* out_hi, void* out_lo, int64_t ldo, void* workspace,
                       int64_t workspace_bytes, void* stream);
+
+/* pc_gemm_part_rows -- the same for M = 1..16 rows (the cached prefill of a short question; llama2.py:405, :638 behind :368-398):
+ *   y[m][n] += sum_k merged[m][k] W[n][k].  part_o / part_ml as pc_attn(defer_merge) left them for q_len = M rows (pad rows of a
+ *   captured graph included; rows_dev, optional: the number of live rows on the device -- rows behind it are not stored).  K = H * D is
+ *   cut into kslices (2, 4 or 8) slices across workgroups of kslices output tiles each, added inside the launch in slice order
+ *   (deterministic): scratch >= pc_gemm_skinny_ks_scratch_bytes(N, kslices) bytes, counters = N / 16 / kslices zeroed uint32 words
+ *   that every launch leaves zero (pc_gemm's ks_scratch / ks_counters may be shared: launches of one stream).  Every lane merges the
+ *   operand fragments it multiplies itself (attn_combine_kernel's arithmetic): no merge launch, no activation plane, no activation
+ *   load in the K loop.  Differs from the three-launch form only in the fp32 summation order (csrc/pc_gemm_part.hip).
+ *   Measured slower than the merge launch + pc_gemm (see the head of this file). */
+int pc_gemm_part_rows(const void* wf, const float* part_o, const float* part_ml, int32_t nsplit, int32_t H, int32_t D, int32_t N, int32_t M,
+                      const int32_t* rows_dev, float* y, int64_t ldy, int32_t kslices, void* scratch, int64_t scratch_bytes, void* counters,
+                      void* stream);
 
 /* ---- pc_gemm_chain: the projections between two attention calls of a <= 16-row forward as ONE persistent launch --------
  *   phase 0  x += attn @ Wo^T                                   o_proj + residual        llama2.py:405, :638

@@ -18,17 +18,6 @@ using namespace pcg;
 
 namespace {
 
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) uint32_t gu32;
-__device__ __forceinline__ void st_wt2(float* p, float a, float b) {
-    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
-    __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_wt2(const float* p) {
-    const unsigned long long x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32)));
-}
-
 constexpr int kMaxSlices = 8;
 
 struct KsParams {

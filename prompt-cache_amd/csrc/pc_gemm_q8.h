@@ -80,16 +80,7 @@ __device__ __forceinline__ int img_off(int row, int k) {
     return (((c >> 3) * 64 + (c & 3) * 16 + row) << 4) + (((c >> 2) & 1) << 3) + (k & 7);
 }
 
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) uint32_t gu32;
-__device__ __forceinline__ void st_wt2(float* p, float a, float b) {
-    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
-    __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_wt2(const float* p) {
-    const unsigned long long x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32)));
-}
+// (st_wt2 / ld_wt2, the write-through hand-off helpers: pc_gemm_skinny.h)
 
 // ---- the outlier correction of one workgroup's tiles (gemm_skinny_body's, with the flags / operands behind accessors) ----
 // corr[t][n] = sum over the flagged columns k of  X[t][k] * fp16(CB[n][k] * s[n])  -  CA[t][k] * CB[n][k] * xs[t] * s[n].

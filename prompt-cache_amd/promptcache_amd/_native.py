@@ -162,6 +162,7 @@ DEV_SIGNATURES = {
                                 _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64,
                                 _i32, _vp, _vp]),
     "pc_quant_rows_i8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "pc_gemm_part_rows": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "pc_gemm_dense_lo8": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp,
                                     _i64, _vp, _i64, _vp]),
 }
@@ -722,6 +723,17 @@ def gemm_part(wf, part_o, part_ml, nsplit: int, H: int, D: int, N: int, y, strea
     rc = load().pc_gemm_part(wf.data_ptr(), part_o.data_ptr(), part_ml.data_ptr(), nsplit, H, D, N, y.data_ptr(),
                              current_stream() if stream is None else stream)
     check(rc, "pc_gemm_part")
+
+
+def gemm_part_rows(wf, part_o, part_ml, nsplit: int, H: int, D: int, N: int, M: int, y, ldy: int, kslices: int, scratch, counters,
+                   rows_dev=None, stream: Optional[int] = None) -> None:
+    """o_proj + residual of a 1..16-row step on the split-KV partials ``attn_fwd(defer_merge=True)`` left for ``q_len = M`` rows: K cut
+    into ``kslices`` workgroup slices, reduced inside the launch (``pc_gemm_part_rows``; -DPC_DEV_SWEEPS builds only: measured slower than the merge launch + o_proj)."""
+    rc = _dev("pc_gemm_part_rows")(wf.data_ptr(), part_o.data_ptr(), part_ml.data_ptr(), nsplit, H, D, N, M,
+                                  None if rows_dev is None else rows_dev.data_ptr(), y.data_ptr(), ldy, kslices, scratch.data_ptr(),
+                                  scratch.numel() * scratch.element_size(), counters.data_ptr(),
+                                  current_stream() if stream is None else stream)
+    check(rc, "pc_gemm_part_rows")
 
 
 def gemm_q8(stream=None, **f) -> None:

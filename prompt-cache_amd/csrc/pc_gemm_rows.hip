@@ -25,7 +25,11 @@ constexpr int kStageWaves = 4;
 // SW staging waves, KCV k-steps per stage, PDV activation prefetch distance, LB launch bound (0 / -1 / 0: the defaults)
 // NSD > 0: the staging waves move the stages HBM -> LDS by LDS-DMA (`global_load_lds`, no registers in between) through a ring of
 // NSD stages instead of three register sets and two LDS buffers
-template <int TT, int EPI, int MTW, bool TWO, int SW = kStageWaves, int KCV = 0, int PDV = -1, int LB = 0, int NSD = 0>
+// XT (with NSD): an ODD number of row tiles leaves the last one to the staging waves -- with LDS-DMA staging they hold no weight
+// registers and issue a handful of instructions per stage, so each multiplies that row tile against a third of the workgroup's weight
+// tiles.  (Otherwise the odd tile is a ninth compute wave on the SIMD that already runs two: 5 row tiles against 4 on the others --
+// 259 rows = 17 tiles cost 8 % more than 256.)
+template <int TT, int EPI, int MTW, bool TWO, int SW = kStageWaves, int KCV = 0, int PDV = -1, int LB = 0, int NSD = 0, bool XT = false>
 __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_kernel(const GemmParams p) {
     constexpr int T = (EPI == EPI_SILU) ? TT / 2 : TT;   // output units (tiles, or gate/up pairs) per workgroup
     constexpr int KC = KCV ? KCV : (TT <= 4) ? 8 : 4;    // k-steps per stage
@@ -34,7 +38,9 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
     constexpr int PD = PDV >= 0 ? PDV : (MTW == 2) ? 3 : 1, NX = PD + 1;  // activation prefetch distance (k-steps) / register sets
     static_assert(F % SW == 0 && KC % NX == 0, "stage must split evenly over the staging waves");
     constexpr int NB = NSD ? NSD : 2;                    // LDS stages
-    __shared__ __attribute__((aligned(16))) _Float16 wbuf[NB][F][64][8];
+    constexpr int FA = XT ? 2 * KC : 0;                  // (XT) the odd row tile's activation fragments of a stage, hi then lo, behind the weights
+    static_assert(!XT || FA % SW == 0, "the activation fragments split evenly over the staging waves");
+    __shared__ __attribute__((aligned(16))) _Float16 wbuf[NB][F + FA][64][8];
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,7 +51,8 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
     // shorter second block of a two-block launch one compute wave fewer than the host launched: a fourth wave then took the
     // staging branch of a three-wave staging split and wrote fragment slot 24 of a 24-slot stage -- M = 321..336, 385..400,
     // 449..464.)  A compute wave whose rows all lie behind Mz only keeps the barriers: nva <= 0, nothing stored.
-    const int RW = ((p.zrows ? p.zrows : p.M) + 16 * MTW - 1) / (16 * MTW);
+    static_assert(!XT || (NSD > 0 && MTW == 2 && TWO), "the staging waves take the odd row tile of a two-plane, two-tiles-per-wave launch with ring staging");
+    const int RW = XT ? ((p.M + 15) >> 4) / MTW : ((p.zrows ? p.zrows : p.M) + 16 * MTW - 1) / (16 * MTW);   // (XT: one block, odd tile count)
     const int KS = p.KS;
     const int ksq = (KS + p.kslices - 1) / p.kslices;
     const int kq0 = blockIdx.y * ksq;
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
 
     if (wave >= RW) {
         // ---------------- staging wave ----------------
-        if (nst <= 0) return;                            // empty K slice (kslices > k-steps): nothing to stream
+        if (nst <= 0 && !XT) return;                     // empty K slice (kslices > k-steps): nothing to stream
         const int sidx = wave - RW;
         const _Float16* src[FPW];
         int kst[FPW];
@@ -84,10 +91,11 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
                     const int kabs = kq0 + se * KC + kst[i];
                     const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);
                     const _Float16* g = src[i] + ((int64_t)se * KC - back) * 512;
-                    const uint32_t dst = w0 + (uint32_t)((slot * F + sidx + SW * i) * 1024);
+                    const uint32_t dst = w0 + (uint32_t)((slot * (F + FA) + sidx + SW * i) * 1024);
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(dst) : "memory");
                 }
             };
+            if constexpr (!XT) {
             int slot = 0;
             for (int st = 0; st < NSD - 1 && st < nst; ++st) { issue(st, slot); slot = slot + 1 == NSD ? 0 : slot + 1; }
             for (int st = 0; st < nst; ++st) {
@@ -100,6 +108,77 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
                     issue(st + NSD - 1, slot);
                     slot = slot + 1 == NSD ? 0 : slot + 1;
                 }
+            }
+            } else {
+            // ---- XT: stream AND multiply the odd last row tile against this wave's share of the weight tiles ----
+            // units (tiles, or gate/up pairs) sidx, sidx + SW, ...  The row tile's activation fragments travel with the stage: 2 KC more
+            // 1-KiB DMAs behind the weights (hi plane, then lo), shared by the three waves -- every vector-memory operation of this
+            // wave is an LDS-DMA under the counted waits below, the operands are LDS reads.
+            constexpr int NU = (T + SW - 1) / SW;        // units per staging wave, at most
+            constexpr int TPU = (EPI == EPI_SILU) ? 2 : 1;
+            constexpr int APW = FA / SW;                 // activation fragments per staging wave and stage
+            constexpr int OPS = FPW + APW;               // DMA instructions per wave and stage
+            const int xt_tile = MTW * RW;                // (row0 = 0: one block)
+            const _Float16* xa = p.xf_hi + (((int64_t)xt_tile * KS + kq0) * 64 + lane) * 8;
+            const int64_t lo_delta = p.xf_lo - p.xf_hi;
+            const int klast = kq1 - 1 - kq0;
+            f4 acc[NU][TPU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+#pragma unroll
+                for (int q = 0; q < TPU; ++q) { f4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][q] = z; }
+            auto issue_all = [&](int st, int slot) __attribute__((always_inline)) {
+                issue(st, slot);
+#pragma unroll
+                for (int i = 0; i < APW; ++i) {
+                    const int a = sidx + SW * i, pl = a / KC, kk = a - pl * KC;
+                    const int kn = st * KC + kk < klast ? st * KC + kk : klast;
+                    const _Float16* g = xa + (pl ? lo_delta : 0) + (int64_t)kn * 512;
+                    const uint32_t dst = w0 + (uint32_t)((slot * (F + FA) + F + a) * 1024);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+                }
+            };
+            int slot = 0, rslot = 0;
+            for (int st = 0; st < NSD - 1 && st < nst; ++st) { issue_all(st, slot); slot = slot + 1 == NSD ? 0 : slot + 1; }
+            for (int st = 0; st < nst; ++st) {
+                const int ahead = nst - 1 - st < NSD - 2 ? nst - 1 - st : NSD - 2;
+#pragma unroll
+                for (int r = 0; r <= NSD - 2; ++r)
+                    if (ahead == r) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(r * OPS) : "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (st + NSD - 1 < nst) {
+                    issue_all(st + NSD - 1, slot);
+                    slot = slot + 1 == NSD ? 0 : slot + 1;
+                }
+                const _Float16* wst = &wbuf[rslot][0][lane][0];
+                rslot = rslot + 1 == NSD ? 0 : rslot + 1;
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    if (st * KC + j > klast) continue;                  // (wave-uniform: re-read k-steps behind the end of the K range)
+                    const h8 xh = *(const h8*)(wst + (F + j) * 512);
+                    const h8 xl = *(const h8*)(wst + (F + KC + j) * 512);
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        const int u = sidx + SW * i;
+                        if (u >= T) continue;
+#pragma unroll
+                        for (int q = 0; q < TPU; ++q) {
+                            const h8 w = *(const h8*)(wst + (j * TT + u + q * T) * 512);
+                            acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xh, acc[i][q], 0, 0, 0);
+                            acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xl, acc[i][q], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            const int lrow = xt_tile * 16 + m;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = sidx + SW * i;
+                if (u >= T) continue;
+                f4 uu = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_SILU) uu = acc[i][TPU - 1];
+                tile_epilogue<EPI>(p, acc[i][0], uu, lrow < Mz ? lrow : p.M, (int)blockIdx.x * T + u, g, (int)blockIdx.y);
+            }
             }
             return;
         }
@@ -300,6 +379,14 @@ int launch_rows(const GemmParams& p_in, int units, hipStream_t s) {
                                    dim3((rw + 3) * 64), 0, s, pz);
             else
 #endif
+            // an odd number of row tiles in one block (259 rows = 17 tiles): the odd tile goes to the three staging waves (XT: LDS-DMA
+            // ring of five 30-KiB stages) instead of a ninth compute wave on the SIMD that already runs two.  PC_ROWS_XT=0: off
+            static const bool xt_on = [] { const char* e = getenv("PC_ROWS_XT"); return !(e && e[0] == '0'); }();
+            if (xt_on && nz == 1 && (mt & 1) && mt >= 5) {
+                hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768, 5, true>), dim3(pc_ceil_div(units, TV), p.kslices, 1),
+                                   dim3((mt / 2 + 3) * 64), 0, s, pz);
+                return pc_check_launch("gemm_rows_kernel");
+            }
             hipLaunchKernelGGL((gemm_rows_kernel<8, EPI, 2, true, 3, 3, 2, 768>), dim3(pc_ceil_div(units, TV), p.kslices, nz),
                                dim3((rw + 3) * 64), 0, s, pz);
             return pc_check_launch("gemm_rows_kernel");

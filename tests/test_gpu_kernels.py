@@ -703,7 +703,10 @@ def test_gemm_qkv_rope_fused_equals_unfused(B, H, Hkv, D, q_len, past, hid):
                                       (96, 32000, 4096, 1), (70, 32, 64, 4),      # (70, ..., 4): two of the four K slices are empty
                                       # two row blocks whose SECOND block is a compute wave shorter than the first (21 / 25 / 29 row
                                       # tiles: M = 321..336, 385..400, 449..464) -- the launch and the kernel must agree on the wave split
-                                      (330, 4096, 4096, 2), (450, 5120, 13824, 4), (336, 4096, 11008, 3), (390, 2048, 1024, 1)])
+                                      (330, 4096, 4096, 2), (450, 5120, 13824, 4), (336, 4096, 11008, 3), (390, 2048, 1024, 1),
+                                      # an odd number of row tiles in one block: the last tile is multiplied by the staging waves (round 6, XT);
+                                      # K ranges that end inside a stage, more slices than stages
+                                      (225, 5120, 5120, 2), (257, 4096, 11008, 6), (273 - 16, 128, 224, 3), (81 + 16, 256, 96, 4)])
 def test_gemm_rows_store_add_slices(M, N, K, kq):
     n = _n()
     rng = np.random.default_rng(21)
@@ -726,7 +729,8 @@ def test_gemm_rows_store_add_slices(M, N, K, kq):
         assert (y2 - 7.0 - ref_hi).abs().max().item() < tol + 1e-5
 
 
-@pytest.mark.parametrize("M,inter,K", [(65, 11008, 4096), (259, 13824, 5120), (300, 64, 32), (128, 1376, 512), (512, 11008, 4096)])
+@pytest.mark.parametrize("M,inter,K", [(65, 11008, 4096), (259, 13824, 5120), (300, 64, 32), (128, 1376, 512), (512, 11008, 4096),
+                                       (225, 1376, 544), (97, 13824, 5120)])
 def test_gemm_rows_silu_epilogue(M, inter, K):
     n = _n()
     rng = np.random.default_rng(22)

@@ -6,7 +6,7 @@ mkdir -p $OUT
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc$i -o p -f csv -- python $R/tools/rows_one.py $1 $2 $3 $4 12 > $OUT/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc$i -o p -f csv -- python $R/tools/rows_one.py $1 $2 $3 $4 12 ${5:-1} > $OUT/pmc$i.log 2>&1
 done
 python3 - <<'PY'
 import csv,glob,os,collections

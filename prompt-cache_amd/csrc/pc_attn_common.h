@@ -123,7 +123,7 @@ __device__ __forceinline__ void split_pair(float e0, float e1, uint32_t& hi, uin
 // makes hipcc wait vmcnt(0) in front of every ds_read_b64_tr_b16 that follows (it cannot tell the transposing reads from
 // the buffer the DMA is filling), which would serialise the ring; here the waits are the explicit ones in the ring loop.
 __device__ __forceinline__ void glds16_raw(const _Float16* g, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");   // (m0: no other instruction of this kernel uses it; checked in the ISA)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
 }
 
 // the many-row ring kernel (pc_attn_ring.hip): 128 query rows per workgroup, K / V tiles by LDS-DMA

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
                     const int back = kabs < kq1 ? 0 : kabs - (kq1 - 1);
                     const _Float16* g = src[i] + ((int64_t)se * KC - back) * 512;
                     const uint32_t dst = w0 + (uint32_t)((slot * (F + FA) + sidx + SW * i) * 1024);
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(dst) : "memory");
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(dst) : "memory", "m0");
                 }
             };
             if constexpr (!XT) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(LB ? LB : (MTW == 2 ? 1024 : 768)) void gemm_rows_k
                     const int kn = st * KC + kk < klast ? st * KC + kk : klast;
                     const _Float16* g = xa + (pl ? lo_delta : 0) + (int64_t)kn * 512;
                     const uint32_t dst = w0 + (uint32_t)((slot * (F + FA) + F + a) * 1024);
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
                 }
             };
             int slot = 0, rslot = 0;
